@@ -1,0 +1,253 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by executing the REFERENCE's own function bodies.
+
+Runs only in the build container (needs /root/reference); the GPU box gets the
+fixtures, never the reference.  The reference modules cannot be imported whole
+(they need cv2 / dt_apriltags / matplotlib windows and src/EKF-SLAM.py runs broken
+module-level code), so the functions on the hot path are
+lifted with ``ast`` -- FunctionDef nodes plus the upper-case module constants --
+and executed unmodified against NumPy:
+
+  src/replay_no_ros.py : EKF_pose_estimation (:269-482), delta_phi (:250-266),
+                         displacement (:484-497), flags (:15-36)
+  src/EKF-SLAM.py      : predict (:29-56), update (:59-84), noise globals (:12-13)
+
+Fixtures hold inputs and the reference's outputs only (data, no source text).
+Usage:  python oracle/gen_golden.py [--ref /root/reference] [--out tests/golden]
+"""
+from __future__ import annotations
+
+import argparse
+import ast
+import os
+import sys
+from collections import defaultdict
+from types import SimpleNamespace
+from typing import Tuple
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+from oracle.ekf_oracle import synthetic_stream  # noqa: E402  (input generator only)
+
+
+def lift(path: str, func_names, const_pred):
+    tree = ast.parse(open(path).read())
+    keep = []
+    for node in tree.body:
+        if isinstance(node, ast.FunctionDef) and node.name in func_names:
+            keep.append(node)
+        elif isinstance(node, ast.Assign) and all(isinstance(t, ast.Name) and const_pred(t.id) for t in node.targets):
+            keep.append(node)
+    ns = {"np": np, "defaultdict": defaultdict, "Tuple": Tuple}
+    exec(compile(ast.Module(body=keep, type_ignores=[]), os.path.basename(path), "exec"), ns)
+    return ns
+
+
+def load_reference(ref_root: str):
+    slam = lift(os.path.join(ref_root, "src", "replay_no_ros.py"),
+                {"EKF_pose_estimation", "delta_phi", "displacement"}, str.isupper)
+    proto = lift(os.path.join(ref_root, "src", "EKF-SLAM.py"),
+                 {"predict", "update"}, lambda s: s in ("motion_noise", "observation_noise"))
+    return slam, proto
+
+
+def make_tag(tag_id, x_r, y_r, err):
+    # robot frame (x_r forward, y_r left) -> camera pose_t = [[-y_r],[h],[x_r]]  (replay_no_ros.py:321)
+    return SimpleNamespace(tag_id=int(tag_id), pose_R=np.eye(3),
+                           pose_t=np.array([[-y_r], [0.05], [x_r]]), pose_err=float(err))
+
+
+def replay_scenario(seed: int, steps: int, n_tags: int, big_turns: bool):
+    """A small world with progressively discovered tags, several frames per window."""
+    rng = np.random.default_rng(seed)
+    lm = np.stack([rng.uniform(-1.0, 1.0, n_tags), rng.uniform(-0.8, 1.2, n_tags)], axis=1)
+    tag_ids = rng.permutation(np.arange(20, 20 + 3 * n_tags))[:n_tags]
+    pose = np.zeros(3)
+    rec = dict(step=[], frame=[], tag_id=[], pose_t=[], err=[])
+    lin = np.zeros(steps)
+    ang = np.zeros(steps)
+    for k in range(steps):
+        lin[k] = rng.uniform(0.0, 0.08)
+        if k % 7 == 3:
+            ang[k] = rng.uniform(-0.009, 0.009)          # straight branch (:376)
+        elif big_turns:
+            ang[k] = rng.uniform(0.5, 0.9)               # crosses +-pi quickly -> theta wrap (:397)
+        else:
+            ang[k] = rng.uniform(-0.25, 0.35)
+        n_frames = int(rng.integers(0, 4))
+        th = pose[2]
+        for f in range(n_frames):
+            order = rng.permutation(n_tags)
+            for t in order:
+                if rng.random() < 0.45:
+                    continue
+                d = lm[t] - pose[0:2]
+                xr = np.cos(th) * d[0] + np.sin(th) * d[1] + rng.normal(0, 0.02)
+                yr = -np.sin(th) * d[0] + np.cos(th) * d[1] + rng.normal(0, 0.02)
+                # tags behind the robot give |bearing| near pi -> innovation wrap (:458)
+                rec["step"].append(k); rec["frame"].append(f); rec["tag_id"].append(tag_ids[t])
+                rec["pose_t"].append([-yr, 0.05, xr]); rec["err"].append(rng.uniform(1e-4, 1e-2))
+        # truth moves with the same kinematics, loosely (only inputs matter for parity)
+        if abs(ang[k]) > 1e-2:
+            r = lin[k] / ang[k]
+            pose = pose + np.array([-r * np.sin(th) + r * np.sin(th + ang[k]),
+                                    r * np.cos(th) - r * np.cos(th + ang[k]), ang[k]])
+        else:
+            pose = pose + np.array([lin[k] * np.cos(th), lin[k] * np.sin(th), 0.0])
+    out = {k: np.asarray(v) for k, v in rec.items()}
+    out["pose_t"] = out["pose_t"].reshape(-1, 3).astype(float)
+    return lin, ang, out
+
+
+def detections_for_step(rec, k):
+    sel = np.nonzero(rec["step"] == k)[0]
+    frames = {}
+    for i in sel:
+        frames.setdefault(int(rec["frame"][i]), []).append(
+            SimpleNamespace(tag_id=int(rec["tag_id"][i]), pose_R=np.eye(3),
+                            pose_t=rec["pose_t"][i].reshape(3, 1).copy(), pose_err=float(rec["err"][i])))
+    return [(float(k) + 0.1 * f, tags) for f, tags in sorted(frames.items())]
+
+
+def run_replay(slam, lin, ang, rec, flags):
+    saved = {k: slam[k] for k in flags}
+    slam.update(flags)
+    try:
+        mean = np.array([0.0, 0.0, 0.0])
+        cov = np.eye(3) * slam["MOTION_MODEL_VARIANCE"]          # replay_no_ros.py:69-70
+        tag_index = {}
+        means, covs, sizes, obs_idx = [], [], [], []
+        for k in range(len(lin)):
+            det = detections_for_step(rec, k)
+            mean, cov, tp = slam["EKF_pose_estimation"](ang[k], lin[k], mean.copy(), cov.copy(), 0.7, det, tag_index)
+            means.append(mean.copy()); covs.append(cov.copy()); sizes.append(len(mean))
+            obs_idx.append(list(tp.keys()))
+        nmax = max(sizes)
+        M = np.zeros((len(lin), nmax)); Pm = np.zeros((len(lin), nmax, nmax))
+        for k, (mu, P) in enumerate(zip(means, covs)):
+            M[k, :len(mu)] = mu; Pm[k, :len(mu), :len(mu)] = P
+        order = np.full((len(lin), 16), -1, dtype=np.int64)
+        for k, o in enumerate(obs_idx):
+            order[k, :len(o)] = o
+        ti = np.array(sorted(tag_index.items(), key=lambda kv: kv[1]), dtype=np.int64).reshape(-1, 2)
+        return dict(out_mean=M, out_cov=Pm, out_size=np.array(sizes), out_obs_order=order, out_tag_index=ti)
+    finally:
+        slam.update(saved)
+
+
+def tags_from_obs(idx, zr, zb):
+    tags = []
+    for i, r, b in zip(idx, zr, zb):
+        xr, yr = r * np.cos(b), r * np.sin(b)
+        tags.append(SimpleNamespace(tag_id=1000 + int(i), pose_R=np.eye(3),
+                                    pose_t=np.array([[-yr], [0.0], [xr]]), pose_err=0.0))
+    return tags
+
+
+def run_stream(slam, n_landmarks, steps, m, keep_every, rows_only=None):
+    """Synthetic stream of SURVEY 8(d) through the reference, god-mode style pre-sized state."""
+    mean0, diag0, lin, ang, idx, zr, zb = synthetic_stream(n_landmarks, steps, m, 0)
+    mean = mean0.copy(); cov = np.diag(diag0)
+    tag_index = {1000 + i: i for i in range(n_landmarks)}
+    means = np.zeros((steps, len(mean0)))
+    zr_eff = np.zeros_like(zr); zb_eff = np.zeros_like(zb)
+    kept, kept_steps, diags, fro = [], [], [], []
+    for k in range(steps):
+        det = [(float(k), tags_from_obs(idx[k], zr[k], zb[k]))]
+        mean, cov, tp = slam["EKF_pose_estimation"](ang[k], lin[k], mean, cov, 0.7, det, tag_index)
+        assert list(tp.keys()) == list(idx[k]), "gate dropped a synthetic observation"
+        # what the reference actually used after its pose_t round trip (:321-330)
+        zr_eff[k] = [tp[i][4] for i in idx[k]]; zb_eff[k] = [tp[i][5] for i in idx[k]]
+        means[k] = mean
+        diags.append(np.diag(cov).copy()); fro.append(np.linalg.norm(cov))
+        if (k + 1) % keep_every == 0 or k == steps - 1:
+            kept.append(cov.copy() if rows_only is None else cov[rows_only, :].copy()); kept_steps.append(k)
+    out = dict(n_landmarks=np.int64(n_landmarks), m=np.int64(m), lin=lin, ang=ang, idx=idx, zr=zr_eff, zb=zb_eff,
+               mean0=mean0, diag0=diag0, out_mean=means, out_diag=np.array(diags), out_fro=np.array(fro),
+               out_cov_steps=np.array(kept_steps), out_cov=np.array(kept))
+    if rows_only is not None:
+        out["out_cov_rows"] = np.asarray(rows_only)
+        out["out_cov_rowsum"] = cov.sum(axis=1)
+        out["out_cov_colsum"] = cov.sum(axis=0)
+    return out
+
+
+def run_proto(proto, seed, steps):
+    rng = np.random.default_rng(seed)
+    state = np.array([0.0, 0.0, 0.0]); cov = np.eye(3) * 0.1        # EKF-SLAM.py:8-9
+    lms = rng.uniform(-2, 2, (5, 2))
+    ctrl = np.zeros((steps, 2)); dts = np.zeros(steps); obs = np.zeros((steps, 2)); lmk = np.zeros((steps, 2))
+    s_pred = np.zeros((steps, 3)); p_pred = np.zeros((steps, 3, 3)); s_upd = np.zeros((steps, 3)); p_upd = np.zeros((steps, 3, 3))
+    for k in range(steps):
+        v = rng.uniform(0.0, 0.5)
+        om = 0.0 if k % 5 == 2 else (5e-7 if k % 5 == 4 else rng.uniform(-1.5, 1.5))
+        dt = rng.uniform(0.05, 0.8)
+        ctrl[k] = (v, om); dts[k] = dt
+        state, cov = proto["predict"](state, cov, (v, om), dt)
+        s_pred[k] = state; p_pred[k] = cov
+        lm = lms[k % 5]
+        d = lm - state[0:2]
+        z = (np.hypot(*d) + rng.normal(0, 0.05), np.arctan2(d[1], d[0]) - state[2] + rng.normal(0, 0.05) + (TWO_PI if k % 3 == 0 else 0))
+        obs[k] = z; lmk[k] = lm
+        state, cov = proto["update"](state, cov, z, lm)
+        s_upd[k] = state; p_upd[k] = cov
+    return dict(control=ctrl, dt=dts, observation=obs, landmark=lmk,
+                pred_state=s_pred, pred_cov=p_pred, upd_state=s_upd, upd_cov=p_upd)
+
+
+TWO_PI = 2 * np.pi
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--ref", default="/root/reference")
+    ap.add_argument("--out", default=os.path.join(os.path.dirname(HERE), "tests", "golden"))
+    args = ap.parse_args()
+    os.makedirs(args.out, exist_ok=True)
+    slam, proto = load_reference(args.ref)
+
+    def save(name, **arrs):
+        path = os.path.join(args.out, name + ".npz")
+        np.savez_compressed(path, **arrs)
+        print(f"{name}: {os.path.getsize(path) / 1024:.0f} KiB")
+
+    # 1. whole-function replay scenarios: association, gate, averaging, augmentation, both branches, wraps
+    base_flags = dict(ENABLE_MEASUREMENT_MODEL=True, ENABLE_CIRCULAR_INTERPOLATION=True, DISABLE_MOTION_MODEL=False)
+    variants = {
+        "replay_default": (dict(base_flags), False),
+        "replay_bigturns": (dict(base_flags), True),
+        "replay_no_measurement": (dict(base_flags, ENABLE_MEASUREMENT_MODEL=False), False),
+        "replay_no_motion": (dict(base_flags, DISABLE_MOTION_MODEL=True), False),
+        "replay_linear_interp": (dict(base_flags, ENABLE_CIRCULAR_INTERPOLATION=False), True),
+    }
+    for i, (name, (flags, big)) in enumerate(variants.items()):
+        lin, ang, rec = replay_scenario(100 + i, 40, 7, big)
+        out = run_replay(slam, lin, ang, rec, flags)
+        save(name, lin=lin, ang=ang, det_step=rec["step"], det_frame=rec["frame"], det_tag_id=rec["tag_id"],
+             det_pose_t=rec["pose_t"], det_err=rec["err"],
+             flag_measurement=np.bool_(flags["ENABLE_MEASUREMENT_MODEL"]),
+             flag_circular=np.bool_(flags["ENABLE_CIRCULAR_INTERPOLATION"]),
+             flag_no_motion=np.bool_(flags["DISABLE_MOTION_MODEL"]), **out)
+
+    # 2. synthetic stream: config 1 (N=20, 500 steps), N=50, N=500 (rows + sums only)
+    save("stream_n20_m8", **run_stream(slam, 20, 500, 8, keep_every=25))
+    save("stream_n20_m1", **run_stream(slam, 20, 100, 1, keep_every=25))
+    save("stream_n50_m8", **run_stream(slam, 50, 30, 8, keep_every=5))
+    rows = np.array([0, 1, 2, 3, 4, 17, 18, 101, 500, 501, 777, 1001, 1002])
+    save("stream_n500_m8", **run_stream(slam, 500, 6, 8, keep_every=3, rows_only=rows))
+
+    # 3. 3-state predict/update prototype
+    save("proto3", **run_proto(proto, 7, 60))
+
+    # 4. odometry scalars
+    rng = np.random.default_rng(11)
+    ticks = rng.integers(-500, 500, (64, 4))
+    dphi = np.array([[slam["delta_phi"](int(a), int(b), 135), slam["delta_phi"](int(c), int(d), 135)] for a, b, c, d in ticks])
+    disp = np.array([slam["displacement"](0.0318, 0.1, l, r) for l, r in dphi])
+    save("odometry", ticks=ticks, resolution=np.int64(135), wheel_radius=0.0318, baseline=0.1, dphi=dphi, disp=disp)
+
+
+if __name__ == "__main__":
+    main()
