@@ -1,0 +1,186 @@
+#!/usr/bin/env python3
+"""EKF-SLAM step throughput on MI355X (BASELINE.json metric: EKF update steps/sec at N landmarks).
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+Workload (config.workload): N = 2000 landmarks (n = 4003), m = 8 observations per step, B independent
+trajectories per GPU (default 32 = BASELINE config 4's per-GPU shard: 256 trajectories over 8 GPUs).
+Trajectories are sharded over ranks with no data-path collective (weak scaling: per-GPU work is
+fixed).  A bench "step" advances every trajectory of the rank by one EKF step (predict + sequential
+update); `value` = trajectory-steps per second over all ranks.  Inputs (the whole odometry+landmark
+stream) are resident in HBM before the timed region.  torch is used only for the cross-rank
+barrier / max-reduce (gloo); the product path is NumPy + ctypes -> HIP.
+
+The JSON line also carries
+  roofline      the covariance pass kernel: algorithmic bytes per launch (B * 16 n^2) / average launch
+                duration from HIP events on the kernel's own stream (a separate instrumented leg of K
+                steps so that event records do not perturb `value`)
+  cpu_baseline  the oracle's reference-shaped dense NumPy step timed on this box's host cores (rank 0,
+                N = 1 only, a bounded sample)
+  single_trajectory  BASELINE config 3 (B = 1) steps/s, rank 0, N = 1 only.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+
+
+def make_streams(sd_syn, traj_ids, n_landmarks, steps, m):
+    streams = [sd_syn.synthetic_stream(n_landmarks, steps, m, t) for t in traj_ids]
+    lin = np.stack([s[2] for s in streams], axis=1)
+    ang = np.stack([s[3] for s in streams], axis=1)
+    idx = np.stack([s[4] for s in streams], axis=1)
+    zr = np.stack([s[5] for s in streams], axis=1)
+    zb = np.stack([s[6] for s in streams], axis=1)
+    return streams, lin, ang, idx, zr, zb
+
+
+def time_filter(sd, sd_syn, device, traj_ids, n_landmarks, m, steps, warmup, barrier, profile_leg=True):
+    """Returns (seconds for `steps` steps on this rank, pass_ms_total, pass_launches, device_ms)."""
+    n = 3 + 2 * n_landmarks
+    total = warmup + steps + (steps if profile_leg else 0)
+    streams, lin, ang, idx, zr, zb = make_streams(sd_syn, traj_ids, n_landmarks, total, m)
+    f = sd.EkfSlam(n, batch=len(traj_ids), device=device)
+    for b, s in enumerate(streams):
+        f.set_state_diag(s[0], s[1], b)
+    f.stream_upload(lin, ang, idx, zr, zb)
+    f.stream_run(0, warmup)
+    f.sync()
+    barrier()
+    t0 = time.perf_counter()
+    f.timer_begin()
+    f.stream_run(warmup, steps)
+    dev_ms = f.timer_end()            # synchronises the stream
+    f.sync()
+    dt = time.perf_counter() - t0
+    barrier()
+    pass_ms, launches = 0.0, 0
+    if profile_leg:
+        f.profile_enable(True)
+        f.stream_run(warmup + steps, steps)
+        pass_ms, launches = f.profile_read()
+        f.profile_enable(False)
+    flags = [f.flags(b) for b in range(len(traj_ids))]
+    mu = f.mean(0)
+    assert not any(flags) and np.isfinite(mu).all(), "filter diverged during the benchmark"
+    f.close()
+    return dt, pass_ms, launches, dev_ms
+
+
+def cpu_baseline(n_landmarks, m, budget_s=25.0):
+    """Reference-shaped dense NumPy step (oracle/ekf_oracle.py::ekf_step_dense) on the host cores."""
+    from oracle import ekf_oracle as orc          # checker / baseline only
+    mean0, diag0, lin, ang, idx, zr, zb = orc.synthetic_stream(n_landmarks, 8, m, 0)
+    cfg = orc.EkfConfig()
+    mean, cov = mean0.copy(), np.diag(diag0)
+    times = []
+    t_all = time.perf_counter()
+    for k in range(8):
+        t0 = time.perf_counter()
+        mean, cov = orc.ekf_step_dense(mean, cov, lin[k], ang[k], idx[k], zr[k], zb[k], cfg)
+        times.append(time.perf_counter() - t0)
+        if time.perf_counter() - t_all > budget_s and len(times) >= 2:
+            break
+    try:
+        from threadpoolctl import threadpool_info
+        cores = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+    except Exception:
+        cores = os.cpu_count() or 1
+    med = float(np.median(times))
+    return {"value": 1.0 / med, "unit": "steps/s", "cores": int(cores), "kind": "port",
+            "sample": f"{len(times)} steps of N={n_landmarks}, m={m}, 1 trajectory, dense NumPy "
+                      f"(oracle.ekf_step_dense), median {med * 1e3:.0f} ms/step"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--landmarks", type=int, default=2000)
+    ap.add_argument("--obs", type=int, default=8)
+    ap.add_argument("--trajectories", type=int, default=32, help="trajectories per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-single", action="store_true")
+    args = ap.parse_args()
+
+    import slam_duckietown_amd.sharding as shard
+    grp = shard.RankGroup()
+    rank, local_rank, world = grp.rank, grp.local_rank, grp.world
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    barrier = grp.barrier
+
+    import slam_duckietown_amd as sd
+    import slam_duckietown_amd.synthetic as sd_syn
+    sd.load_library()
+
+    B = args.trajectories
+    n = 3 + 2 * args.landmarks
+    traj_ids = shard.shard_trajectories(B * world, world, rank)
+    dt, pass_ms, launches, dev_ms = time_filter(sd, sd_syn, local_rank, traj_ids, args.landmarks, args.obs,
+                                                args.steps, args.warmup, barrier)
+    dt = grp.max_over_ranks(dt)
+    total_units = grp.sum_over_ranks(len(traj_ids) * args.steps)
+
+    out = None
+    if rank == 0:
+        value = total_units / dt
+        alg_bytes = B * 16.0 * n * n                     # per pass launch: every trajectory's P read + written
+        avg_s = (pass_ms / max(launches, 1)) * 1e-3
+        achieved = alg_bytes / avg_s / 1e9 if avg_s > 0 else 0.0
+        out = {
+            "metric": "EKF update steps/sec", "value": value, "unit": "steps/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": f"N={args.landmarks} landmarks (n={n}), m={args.obs} obs/step, "
+                                   f"{B} trajectories/GPU x {world} GPU(s), fused predict+update step",
+                       "landmarks": args.landmarks, "state_dim": n, "obs_per_step": args.obs,
+                       "trajectories_per_gpu": B, "parallelism": f"trajectory-sharded x{world}, no collective"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "ekf::k_pass",
+                         "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_s * 1e3, "launches": launches},
+            "device_ms_per_step": dev_ms / args.steps,
+        }
+        traffic_file = os.path.join(ROOT, "profiles", "pass_traffic.json")
+        if os.path.exists(traffic_file):
+            try:
+                tr = json.load(open(traffic_file))
+                key = f"N{args.landmarks}_B{B}"
+                if key in tr:
+                    out["roofline"]["traffic"] = tr[key]["hbm_bytes_per_launch"]
+                    out["roofline"]["traffic_source"] = tr[key].get("source", "profiles/pass_traffic.json")
+            except Exception:
+                pass
+    if world == 1 and rank == 0:
+        if not args.no_single:
+            dt1, p1, l1, _ = time_filter(sd, sd_syn, local_rank, [0], args.landmarks, args.obs, args.steps,
+                                         args.warmup, lambda: None)
+            a1 = 16.0 * n * n / ((p1 / max(l1, 1)) * 1e-3) / 1e9 if p1 > 0 else 0.0
+            out["single_trajectory"] = {"workload": f"N={args.landmarks}, m={args.obs}, 1 trajectory (BASELINE config 3)",
+                                        "value": args.steps / dt1, "unit": "steps/s",
+                                        "pass_avg_launch_ms": p1 / max(l1, 1),
+                                        "pass_achieved_GBs": a1, "pass_frac_of_hbm_peak": a1 / HBM_PEAK_GBS}
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.landmarks, args.obs)
+    if rank == 0:
+        if "cpu_baseline" not in out:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    grp.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,112 @@
+/*
+ * ekfslam_hip.h -- C ABI of libekfslam_hip.so: the MI355X (gfx950) EKF-SLAM predict/update core.
+ *
+ * The reference (AHHHZ975/SLAM-Duckietown) has no FFI layer: its hot path is one Python
+ * function, EKF_pose_estimation (src/replay_no_ros.py:269-482), and src/ekf_bindings.py is an
+ * empty placeholder for "EKF bindings".  This header is what that placeholder would bind with
+ * ctypes.  Each entry point names the reference lines it replaces.  Plain pointers and sizes
+ * only; every function returns an int status (0 = EKF_OK) unless stated otherwise.
+ *
+ * State layout at this boundary is the reference's own (src/replay_no_ros.py:69-70, :341-360):
+ *   mu : (n,)   float64   [x, y, theta, l0x, l0y, ..., l(N-1)x, l(N-1)y],  n = 3 + 2N
+ *   P  : (n,n)  float64   row-major (NumPy C order)
+ * Device buffers are owned by the handle; host arrays are borrowed for the duration of a call.
+ * A handle is not thread-safe: one handle per device per host thread.
+ */
+#ifndef EKFSLAM_HIP_H
+#define EKFSLAM_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EKF_OK 0
+#define EKF_ERR_ARG (-1)      /* bad argument (message in ekf_last_error) */
+#define EKF_ERR_HIP (-2)      /* a HIP runtime call failed, or no gfx950 device */
+#define EKF_ERR_STATE (-3)    /* call not valid in the current state */
+
+#define EKF_MMAX 16           /* max landmarks per single device update pass (longer lists are split) */
+
+/* sticky per-trajectory flags, ekf_status_flags() */
+#define EKF_FLAG_NONFINITE 1u /* a non-finite mean entry was produced (q = 0 at :466-469, singular S at :473) */
+
+typedef struct ekf_handle ekf_handle;
+
+/* Module constants of src/replay_no_ros.py:15-31 and the literals at :289, :356, :376. */
+typedef struct ekf_config {
+  double motion_sigma;                /* MOTION_MODEL_VARIANCE       (:15)  default 0.1  */
+  double meas_sigma;                  /* MEASUREMENT_MODEL_VARIANCE  (:16)  default 0.7  */
+  double arc_threshold;               /* |ang| <= thr -> straight branch (:376) default 1e-2 */
+  double landmark_init_var;           /* new-landmark variance (:356-357)   default 1e4  */
+  int enable_measurement_model;       /* (:18)  default 1 */
+  int enable_circular_interpolation;  /* (:19)  default 1 */
+  int disable_motion_model;           /* (:28)  default 0 */
+  int reserved;
+} ekf_config;
+
+int ekf_config_default(ekf_config *cfg);
+
+/* Create a filter bank of `batch` independent trajectories on HIP device `device`, each with room
+ * for n_max = 3 + 2*N_max states.  All trajectories start as the reference does
+ * (src/replay_no_ros.py:69-70): n = 3, mu = 0, P = motion_sigma * I3.  Fails (EKF_ERR_HIP) when no
+ * gfx950 device is present: there is no CPU fallback. */
+int ekf_create(int device, int n_max, int batch, const ekf_config *cfg, ekf_handle **out);
+int ekf_destroy(ekf_handle *h);
+
+/* Whole state in / out for trajectory b (checkpoint, parity checks).  Blocking. */
+int ekf_upload_state(ekf_handle *h, int b, const double *mu, const double *P, int n);
+int ekf_upload_state_diag(ekf_handle *h, int b, const double *mu, const double *diagP, int n);
+int ekf_download_state(ekf_handle *h, int b, double *mu, double *P, int n);
+int ekf_download_mean(ekf_handle *h, int b, double *mu, int n);
+int ekf_state_size(ekf_handle *h, int b, int *n);
+
+/* State augmentation, src/replay_no_ros.py:341-360: append k landmarks (indices must continue the
+ * current count), mean = xy[2*i..], variance = landmark_init_var, zero cross terms. */
+int ekf_add_landmarks(ekf_handle *h, int b, int first_index, const double *xy, int k);
+
+/* predict(): src/replay_no_ros.py:368-430 for every trajectory (lin[b], ang[b]).  O(n) work. */
+int ekf_predict(ekf_handle *h, const double *lin, const double *ang);
+
+/* update(): src/replay_no_ros.py:436-480, sequential over idx[b*stride + 0..m[b]) in that order. */
+int ekf_update(ekf_handle *h, const int *idx, const double *range, const double *bearing,
+               const int *m, int stride);
+
+/* step() = predict + update fused into one pass over P (what EKF_pose_estimation does after
+ * association/augmentation, src/replay_no_ros.py:363-482).  Asynchronous on the handle's stream. */
+int ekf_step(ekf_handle *h, const double *lin, const double *ang, const int *idx,
+             const double *range, const double *bearing, const int *m, int stride);
+
+/* Streams of pre-uploaded inputs ([step][batch] and [step][batch][stride] arrays, stride <= EKF_MMAX).
+ * ekf_stream_upload copies and validates `steps` steps of inputs into HBM (blocking);
+ * ekf_stream_run enqueues steps [first, first+count) back to back (asynchronous);
+ * ekf_run_stream = upload + run all. */
+int ekf_stream_upload(ekf_handle *h, int steps, const double *lin, const double *ang, const int *idx,
+                      const double *range, const double *bearing, const int *m, int stride);
+int ekf_stream_run(ekf_handle *h, int first, int count);
+int ekf_run_stream(ekf_handle *h, int steps, const double *lin, const double *ang, const int *idx,
+                   const double *range, const double *bearing, const int *m, int stride);
+
+/* General dense propagation P <- F P F^T + Q (F, Q row-major n x n) on the fp64 MFMA path: the
+ * reference's literal G_F @ P @ G_F.T + F.T @ R @ F product (src/replay_no_ros.py:430) for an
+ * arbitrary Jacobian. */
+int ekf_predict_dense(ekf_handle *h, int b, const double *F, const double *Q);
+
+int ekf_sync(ekf_handle *h);
+int ekf_status_flags(ekf_handle *h, int b, unsigned *flags);
+
+/* Message of the last failure on this handle (h == NULL: last failure of ekf_create). */
+const char *ekf_last_error(ekf_handle *h);
+
+/* --- measurement hooks (HIP events on the handle's own stream) --- */
+int ekf_timer_begin(ekf_handle *h);
+int ekf_timer_end(ekf_handle *h, double *elapsed_ms);          /* synchronises */
+/* When enabled every launch of the covariance-pass kernel is bracketed by an event pair. */
+int ekf_profile_enable(ekf_handle *h, int on);
+int ekf_profile_read(ekf_handle *h, double *pass_ms_total, long long *pass_launches); /* and resets */
+/* Tuning knobs (rows per workgroup of the pass kernel etc.); name/value, unknown names fail. */
+int ekf_set_option(ekf_handle *h, const char *name, int value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,545 @@
+// C ABI of libekfslam_hip.so (include/ekfslam_hip.h): host-side orchestration of the HIP kernels.
+// No CPU fallback exists: every entry point needs a gfx950 device.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "ekf_device.h"
+
+namespace ekf {
+void launch_solve(hipStream_t, const double*, double*, const int*, const StepIn*, SolveOut*, unsigned*,
+                  const DeviceConfig&, int, long, int, int);
+void launch_panels(hipStream_t, int, const double*, double*, const int*, const SolveOut*, double*,
+                   double*, int, long, int, int);
+void launch_pass(hipStream_t, int, double*, const double*, const double*, const int*, const SolveOut*,
+                 int, long, int, int, int);
+void launch_predict_rc(hipStream_t, double*, const int*, const SolveOut*, int, long, int, int);
+void launch_add_landmarks(hipStream_t, double*, double*, int, int, int, double, const double*);
+void launch_fill_diag(hipStream_t, double*, int, int, const double*);
+int dense_propagate(hipStream_t, double* P, double* tmp, const double* F, const double* Q, int n, int ld);
+}  // namespace ekf
+
+using namespace ekf;
+
+static thread_local std::string g_create_error;
+constexpr int RING = 16;
+
+struct ekf_handle {
+  int device = 0, n_max = 0, ld = 0, batch = 0;
+  long pstride = 0;
+  ekf_config cfg{};
+  DeviceConfig dcfg{};
+  hipStream_t stream = nullptr;
+  double *dP = nullptr, *dmu = nullptr, *dV = nullptr, *dW = nullptr, *dscratch = nullptr;
+  int* dn = nullptr;
+  unsigned* dflags = nullptr;
+  SolveOut* dso = nullptr;
+  StepIn *d_ring = nullptr, *h_ring = nullptr;
+  hipEvent_t ring_ev[RING]{};
+  bool ring_used[RING]{};
+  int ring_pos = 0;
+  StepIn* d_stream = nullptr;
+  size_t stream_cap = 0;
+  int stream_steps = 0;
+  std::vector<int> stream_mhi;
+  double *dF = nullptr, *dQ = nullptr, *dTmp = nullptr;   // dense path, allocated on first use
+  std::vector<int> n;
+  hipEvent_t t0 = nullptr, t1 = nullptr;
+  bool profile = false;
+  std::vector<hipEvent_t> prof_pool;
+  size_t prof_used = 0;
+  int opt_rows_per_block = 0;     // 0 = auto
+  std::string err;
+};
+
+static int fail(ekf_handle* h, int code, const std::string& msg) {
+  if (h) h->err = msg; else g_create_error = msg;
+  return code;
+}
+
+#define HIP_TRY(h, expr)                                                                   \
+  do {                                                                                     \
+    hipError_t e_ = (expr);                                                                \
+    if (e_ != hipSuccess)                                                                  \
+      return fail(h, EKF_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));      \
+  } while (0)
+
+extern "C" int ekf_config_default(ekf_config* cfg) {
+  if (!cfg) return EKF_ERR_ARG;
+  cfg->motion_sigma = 0.1;
+  cfg->meas_sigma = 0.7;
+  cfg->arc_threshold = 1e-2;
+  cfg->landmark_init_var = 10000.0;
+  cfg->enable_measurement_model = 1;
+  cfg->enable_circular_interpolation = 1;
+  cfg->disable_motion_model = 0;
+  cfg->reserved = 0;
+  return EKF_OK;
+}
+
+extern "C" const char* ekf_last_error(ekf_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+static void free_all(ekf_handle* h) {
+  if (!h) return;
+  (void)hipSetDevice(h->device);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  void* ptrs[] = {h->dP, h->dmu, h->dV, h->dW, h->dscratch, h->dn, h->dflags, h->dso,
+                  h->d_ring, h->d_stream, h->dF, h->dQ, h->dTmp};
+  for (void* p : ptrs) if (p) (void)hipFree(p);
+  if (h->h_ring) (void)hipHostFree(h->h_ring);
+  for (auto& e : h->ring_ev) if (e) (void)hipEventDestroy(e);
+  for (auto& e : h->prof_pool) (void)hipEventDestroy(e);
+  if (h->t0) (void)hipEventDestroy(h->t0);
+  if (h->t1) (void)hipEventDestroy(h->t1);
+  if (h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+}
+
+extern "C" int ekf_create(int device, int n_max, int batch, const ekf_config* cfg, ekf_handle** out) {
+  if (!out) return fail(nullptr, EKF_ERR_ARG, "ekf_create: out is NULL");
+  *out = nullptr;
+  if (n_max < 3 || (n_max & 1) == 0) return fail(nullptr, EKF_ERR_ARG, "ekf_create: n_max must be 3 + 2*N");
+  if (batch < 1) return fail(nullptr, EKF_ERR_ARG, "ekf_create: batch must be >= 1");
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count <= 0)
+    return fail(nullptr, EKF_ERR_HIP, std::string("ekf_create: no HIP device (") + hipGetErrorString(e) +
+                                          "); this library has no CPU fallback");
+  if (device < 0 || device >= count) return fail(nullptr, EKF_ERR_ARG, "ekf_create: device index out of range");
+  hipDeviceProp_t prop;
+  if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess)
+    return fail(nullptr, EKF_ERR_HIP, std::string("hipGetDeviceProperties: ") + hipGetErrorString(e));
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(nullptr, EKF_ERR_HIP, std::string("ekf_create: device is ") + prop.gcnArchName +
+                                          ", kernels are built for gfx950 only");
+  ekf_handle* h = new ekf_handle();
+  h->device = device;
+  h->n_max = n_max;
+  h->ld = (n_max + 15) / 16 * 16;
+  h->batch = batch;
+  h->pstride = (long)h->ld * h->ld;
+  if (cfg) h->cfg = *cfg; else ekf_config_default(&h->cfg);
+  const double s = h->cfg.motion_sigma, q = h->cfg.meas_sigma;
+  h->dcfg.rd[0] = s * s;                        // src/replay_no_ros.py:421
+  h->dcfg.rd[1] = s * s;
+  h->dcfg.rd[2] = (s / 2) * (s / 2);
+  h->dcfg.qd[0] = q * q;                        // :438
+  h->dcfg.qd[1] = q * q;
+  h->dcfg.arc_threshold = h->cfg.arc_threshold;
+  h->dcfg.enable_measurement_model = h->cfg.enable_measurement_model;
+  h->dcfg.enable_circular_interpolation = h->cfg.enable_circular_interpolation;
+  h->dcfg.disable_motion_model = h->cfg.disable_motion_model;
+  h->n.assign(batch, 3);
+
+#define CREATE_TRY(expr)                                                                  \
+  do {                                                                                    \
+    hipError_t e2_ = (expr);                                                              \
+    if (e2_ != hipSuccess) {                                                              \
+      g_create_error = std::string(#expr) + ": " + hipGetErrorString(e2_);                \
+      free_all(h);                                                                        \
+      return EKF_ERR_HIP;                                                                 \
+    }                                                                                     \
+  } while (0)
+  CREATE_TRY(hipSetDevice(device));
+  CREATE_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+  const size_t ldz = (size_t)h->ld;
+  CREATE_TRY(hipMalloc(&h->dP, sizeof(double) * ldz * ldz * batch));
+  CREATE_TRY(hipMalloc(&h->dmu, sizeof(double) * ldz * batch));
+  CREATE_TRY(hipMalloc(&h->dV, sizeof(double) * ldz * (2 * MMAX + 2) * batch));
+  CREATE_TRY(hipMalloc(&h->dW, sizeof(double) * ldz * (2 * MMAX + 2) * batch));
+  CREATE_TRY(hipMalloc(&h->dscratch, sizeof(double) * ldz * 2));
+  CREATE_TRY(hipMalloc(&h->dn, sizeof(int) * batch));
+  CREATE_TRY(hipMalloc(&h->dflags, sizeof(unsigned) * batch));
+  CREATE_TRY(hipMalloc(&h->dso, sizeof(SolveOut) * batch));
+  CREATE_TRY(hipMalloc(&h->d_ring, sizeof(StepIn) * batch * RING));
+  CREATE_TRY(hipHostMalloc(&h->h_ring, sizeof(StepIn) * batch * RING, hipHostMallocDefault));
+  for (auto& ev : h->ring_ev) CREATE_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+  CREATE_TRY(hipEventCreate(&h->t0));
+  CREATE_TRY(hipEventCreate(&h->t1));
+  CREATE_TRY(hipMemsetAsync(h->dP, 0, sizeof(double) * ldz * ldz * batch, h->stream));
+  CREATE_TRY(hipMemsetAsync(h->dmu, 0, sizeof(double) * ldz * batch, h->stream));
+  CREATE_TRY(hipMemsetAsync(h->dV, 0, sizeof(double) * ldz * (2 * MMAX + 2) * batch, h->stream));
+  CREATE_TRY(hipMemsetAsync(h->dW, 0, sizeof(double) * ldz * (2 * MMAX + 2) * batch, h->stream));
+  CREATE_TRY(hipMemsetAsync(h->dflags, 0, sizeof(unsigned) * batch, h->stream));
+  CREATE_TRY(hipMemsetAsync(h->dso, 0, sizeof(SolveOut) * batch, h->stream));
+  // reference initial state (src/replay_no_ros.py:69-70): mu = 0, P = MOTION_MODEL_VARIANCE * I3
+  {
+    std::vector<double> p3(3 * 3, 0.0);
+    p3[0] = p3[4] = p3[8] = h->cfg.motion_sigma;
+    for (int b = 0; b < batch; ++b)
+      CREATE_TRY(hipMemcpy2DAsync(h->dP + (size_t)b * h->pstride, sizeof(double) * ldz, p3.data(),
+                                  sizeof(double) * 3, sizeof(double) * 3, 3, hipMemcpyHostToDevice, h->stream));
+    CREATE_TRY(hipMemcpyAsync(h->dn, h->n.data(), sizeof(int) * batch, hipMemcpyHostToDevice, h->stream));
+    CREATE_TRY(hipStreamSynchronize(h->stream));
+  }
+#undef CREATE_TRY
+  *out = h;
+  return EKF_OK;
+}
+
+extern "C" int ekf_destroy(ekf_handle* h) {
+  if (!h) return EKF_ERR_ARG;
+  free_all(h);
+  return EKF_OK;
+}
+
+static int check_b(ekf_handle* h, int b, const char* fn) {
+  if (!h) return EKF_ERR_ARG;
+  if (b < 0 || b >= h->batch) return fail(h, EKF_ERR_ARG, std::string(fn) + ": trajectory index out of range");
+  return EKF_OK;
+}
+
+static int set_size(ekf_handle* h, int b, int n) {
+  h->n[b] = n;
+  HIP_TRY(h, hipMemcpyAsync(h->dn + b, &h->n[b], sizeof(int), hipMemcpyHostToDevice, h->stream));
+  return EKF_OK;
+}
+
+extern "C" int ekf_upload_state(ekf_handle* h, int b, const double* mu, const double* P, int n) {
+  if (int rc = check_b(h, b, "ekf_upload_state")) return rc;
+  if (!mu || !P) return fail(h, EKF_ERR_ARG, "ekf_upload_state: NULL array");
+  if (n < 3 || (n & 1) == 0 || n > h->n_max) return fail(h, EKF_ERR_ARG, "ekf_upload_state: n must be 3+2N and <= n_max");
+  HIP_TRY(h, hipSetDevice(h->device));
+  HIP_TRY(h, hipMemcpy2DAsync(h->dP + (size_t)b * h->pstride, sizeof(double) * h->ld, P, sizeof(double) * n,
+                              sizeof(double) * n, n, hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(h, hipMemcpyAsync(h->dmu + (size_t)b * h->ld, mu, sizeof(double) * n, hipMemcpyHostToDevice, h->stream));
+  if (int rc = set_size(h, b, n)) return rc;
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return EKF_OK;
+}
+
+extern "C" int ekf_upload_state_diag(ekf_handle* h, int b, const double* mu, const double* diagP, int n) {
+  if (int rc = check_b(h, b, "ekf_upload_state_diag")) return rc;
+  if (!mu || !diagP) return fail(h, EKF_ERR_ARG, "ekf_upload_state_diag: NULL array");
+  if (n < 3 || (n & 1) == 0 || n > h->n_max) return fail(h, EKF_ERR_ARG, "ekf_upload_state_diag: n must be 3+2N and <= n_max");
+  HIP_TRY(h, hipSetDevice(h->device));
+  HIP_TRY(h, hipMemcpyAsync(h->dscratch, diagP, sizeof(double) * n, hipMemcpyHostToDevice, h->stream));
+  launch_fill_diag(h->stream, h->dP + (size_t)b * h->pstride, h->ld, n, h->dscratch);
+  HIP_TRY(h, hipGetLastError());
+  HIP_TRY(h, hipMemcpyAsync(h->dmu + (size_t)b * h->ld, mu, sizeof(double) * n, hipMemcpyHostToDevice, h->stream));
+  if (int rc = set_size(h, b, n)) return rc;
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return EKF_OK;
+}
+
+extern "C" int ekf_download_state(ekf_handle* h, int b, double* mu, double* P, int n) {
+  if (int rc = check_b(h, b, "ekf_download_state")) return rc;
+  if (n != h->n[b]) return fail(h, EKF_ERR_ARG, "ekf_download_state: n does not match the state size");
+  HIP_TRY(h, hipSetDevice(h->device));
+  if (P)
+    HIP_TRY(h, hipMemcpy2DAsync(P, sizeof(double) * n, h->dP + (size_t)b * h->pstride, sizeof(double) * h->ld,
+                                sizeof(double) * n, n, hipMemcpyDeviceToHost, h->stream));
+  if (mu)
+    HIP_TRY(h, hipMemcpyAsync(mu, h->dmu + (size_t)b * h->ld, sizeof(double) * n, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return EKF_OK;
+}
+
+extern "C" int ekf_download_mean(ekf_handle* h, int b, double* mu, int n) {
+  return ekf_download_state(h, b, mu, nullptr, n);
+}
+
+extern "C" int ekf_state_size(ekf_handle* h, int b, int* n) {
+  if (int rc = check_b(h, b, "ekf_state_size")) return rc;
+  if (!n) return fail(h, EKF_ERR_ARG, "ekf_state_size: NULL");
+  *n = h->n[b];
+  return EKF_OK;
+}
+
+extern "C" int ekf_add_landmarks(ekf_handle* h, int b, int first_index, const double* xy, int k) {
+  if (int rc = check_b(h, b, "ekf_add_landmarks")) return rc;
+  if (k <= 0) return EKF_OK;
+  if (!xy) return fail(h, EKF_ERR_ARG, "ekf_add_landmarks: NULL xy");
+  const int n_old = h->n[b], n_new = n_old + 2 * k;
+  if (first_index != (n_old - 3) / 2)
+    return fail(h, EKF_ERR_ARG, "ekf_add_landmarks: first_index must continue the landmark count (replay_no_ros.py:294-295)");
+  if (n_new > h->n_max) return fail(h, EKF_ERR_ARG, "ekf_add_landmarks: state would exceed n_max");
+  if (2 * k > 2 * h->ld) return fail(h, EKF_ERR_ARG, "ekf_add_landmarks: too many landmarks in one call");
+  HIP_TRY(h, hipSetDevice(h->device));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));   // xy is staged through a single scratch buffer
+  HIP_TRY(h, hipMemcpyAsync(h->dscratch, xy, sizeof(double) * 2 * k, hipMemcpyHostToDevice, h->stream));
+  launch_add_landmarks(h->stream, h->dP + (size_t)b * h->pstride, h->dmu + (size_t)b * h->ld, h->ld, n_old, n_new,
+                       h->cfg.landmark_init_var, h->dscratch);
+  HIP_TRY(h, hipGetLastError());
+  if (int rc = set_size(h, b, n_new)) return rc;
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return EKF_OK;
+}
+
+// ---- step machinery -------------------------------------------------------------------------
+static int cap_for(int m) { return m <= 1 ? 1 : m <= 2 ? 2 : m <= 4 ? 4 : m <= 8 ? 8 : 16; }
+
+static int auto_rows_per_block(const ekf_handle* h, int n_hi) {
+  if (h->opt_rows_per_block > 0) return h->opt_rows_per_block;
+  // aim for >= ~2048 workgroups over the whole batch, 16..128 rows each
+  const long col_blocks = (n_hi + 511) / 512;
+  long rpb = 128;
+  while (rpb > 16 && col_blocks * ((n_hi + rpb - 1) / rpb) * h->batch < 2048) rpb >>= 1;
+  return (int)rpb;
+}
+
+static int prof_event(ekf_handle* h, hipEvent_t* ev) {
+  if (h->prof_used == h->prof_pool.size()) {
+    hipEvent_t e;
+    HIP_TRY(h, hipEventCreate(&e));
+    h->prof_pool.push_back(e);
+  }
+  *ev = h->prof_pool[h->prof_used++];
+  return EKF_OK;
+}
+
+// Enqueue one device pass with inputs already at d_in (StepIn[batch]); m_hi = max m over the batch.
+static int enqueue_pass(ekf_handle* h, const StepIn* d_in, int m_hi) {
+  const int n_hi = *std::max_element(h->n.begin(), h->n.end());
+  const int mcap = cap_for(m_hi);
+  launch_solve(h->stream, h->dP, h->dmu, h->dn, d_in, h->dso, h->dflags, h->dcfg, h->ld, h->pstride, h->batch, mcap);
+  if (m_hi == 0) {
+    launch_predict_rc(h->stream, h->dP, h->dn, h->dso, h->ld, h->pstride, h->batch, n_hi);
+  } else {
+    launch_panels(h->stream, mcap, h->dP, h->dmu, h->dn, h->dso, h->dV, h->dW, h->ld, h->pstride, h->batch, n_hi);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (h->profile) {
+      if (int rc = prof_event(h, &e0)) return rc;
+      if (int rc = prof_event(h, &e1)) return rc;
+      HIP_TRY(h, hipEventRecord(e0, h->stream));
+    }
+    launch_pass(h->stream, mcap, h->dP, h->dV, h->dW, h->dn, h->dso, h->ld, h->pstride, h->batch, n_hi,
+                auto_rows_per_block(h, n_hi));
+    if (h->profile) HIP_TRY(h, hipEventRecord(e1, h->stream));
+  }
+  HIP_TRY(h, hipGetLastError());
+  return EKF_OK;
+}
+
+// Validate one trajectory's observation list and fill StepIn for pass `p` (landmarks [p*MMAX, ...)).
+static int fill_step(ekf_handle* h, StepIn& s, int b, double lin, double ang, int flags, const int* idx,
+                     const double* range, const double* bearing, int m, int p) {
+  s.lin = lin;
+  s.ang = ang;
+  s.flags = flags;
+  const int lo = p * MMAX, cnt = std::max(0, std::min(m - lo, MMAX));
+  s.m = cnt;
+  const int n_lm = (h->n[b] - 3) / 2;
+  for (int i = 0; i < cnt; ++i) {
+    const int id = idx[lo + i];
+    if (id < 0 || id >= n_lm) return fail(h, EKF_ERR_ARG, "landmark index outside the current state (add_landmarks first)");
+    for (int k = 0; k < i; ++k)
+      if (s.idx[k] == id) return fail(h, EKF_ERR_ARG, "duplicate landmark index in one update (the reference keys observations by index, replay_no_ros.py:312-313)");
+    s.idx[i] = id;
+    s.range[i] = range[lo + i];
+    s.bearing[i] = bearing[lo + i];
+  }
+  for (int i = cnt; i < MMAX; ++i) { s.idx[i] = 0; s.range[i] = 0.0; s.bearing[i] = 0.0; }
+  return EKF_OK;
+}
+
+static int do_step(ekf_handle* h, int base_flags, const double* lin, const double* ang, const int* idx,
+                   const double* range, const double* bearing, const int* m, int stride) {
+  if (!h) return EKF_ERR_ARG;
+  const bool upd = (base_flags & FLAG_UPDATE) != 0, pred = (base_flags & FLAG_PREDICT) != 0;
+  if (pred && (!lin || !ang)) return fail(h, EKF_ERR_ARG, "NULL lin/ang");
+  if (upd && (!m || stride < 0)) return fail(h, EKF_ERR_ARG, "NULL m / bad stride");
+  int m_hi = 0;
+  if (upd && h->cfg.enable_measurement_model)
+    for (int b = 0; b < h->batch; ++b) {
+      if (m[b] < 0 || m[b] > stride) return fail(h, EKF_ERR_ARG, "m[b] must be in [0, stride]");
+      m_hi = std::max(m_hi, m[b]);
+    }
+  if (m_hi > 0 && (!idx || !range || !bearing)) return fail(h, EKF_ERR_ARG, "NULL observation arrays");
+  HIP_TRY(h, hipSetDevice(h->device));
+  const int passes = std::max(1, (m_hi + MMAX - 1) / MMAX);
+  for (int p = 0; p < passes; ++p) {
+    const int slot = h->ring_pos;
+    h->ring_pos = (h->ring_pos + 1) % RING;
+    if (h->ring_used[slot]) HIP_TRY(h, hipEventSynchronize(h->ring_ev[slot]));
+    StepIn* hs = h->h_ring + (size_t)slot * h->batch;
+    StepIn* ds = h->d_ring + (size_t)slot * h->batch;
+    int flags = (upd ? FLAG_UPDATE : 0) | ((pred && p == 0) ? FLAG_PREDICT : 0);
+    int m_pass_hi = 0;
+    for (int b = 0; b < h->batch; ++b) {
+      const int mb = (upd && h->cfg.enable_measurement_model) ? m[b] : 0;
+      const long off = (long)b * stride;
+      if (int rc = fill_step(h, hs[b], b, pred ? lin[b] : 0.0, pred ? ang[b] : 0.0, flags,
+                             idx ? idx + off : nullptr, range ? range + off : nullptr,
+                             bearing ? bearing + off : nullptr, mb, p))
+        return rc;
+      m_pass_hi = std::max(m_pass_hi, hs[b].m);
+    }
+    HIP_TRY(h, hipMemcpyAsync(ds, hs, sizeof(StepIn) * h->batch, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipEventRecord(h->ring_ev[slot], h->stream));
+    h->ring_used[slot] = true;
+    if (int rc = enqueue_pass(h, ds, m_pass_hi)) return rc;
+  }
+  return EKF_OK;
+}
+
+extern "C" int ekf_predict(ekf_handle* h, const double* lin, const double* ang) {
+  return do_step(h, FLAG_PREDICT, lin, ang, nullptr, nullptr, nullptr, nullptr, 0);
+}
+
+extern "C" int ekf_update(ekf_handle* h, const int* idx, const double* range, const double* bearing,
+                          const int* m, int stride) {
+  return do_step(h, FLAG_UPDATE, nullptr, nullptr, idx, range, bearing, m, stride);
+}
+
+extern "C" int ekf_step(ekf_handle* h, const double* lin, const double* ang, const int* idx,
+                        const double* range, const double* bearing, const int* m, int stride) {
+  return do_step(h, FLAG_PREDICT | FLAG_UPDATE, lin, ang, idx, range, bearing, m, stride);
+}
+
+extern "C" int ekf_stream_upload(ekf_handle* h, int steps, const double* lin, const double* ang, const int* idx,
+                                 const double* range, const double* bearing, const int* m, int stride) {
+  if (!h) return EKF_ERR_ARG;
+  if (steps <= 0) return fail(h, EKF_ERR_ARG, "ekf_stream_upload: steps must be > 0");
+  if (!lin || !ang || !m || stride < 0) return fail(h, EKF_ERR_ARG, "ekf_stream_upload: NULL array");
+  if (stride > MMAX) return fail(h, EKF_ERR_ARG, "ekf_stream_upload: stride must be <= EKF_MMAX");
+  const size_t count = (size_t)steps * h->batch;
+  std::vector<StepIn> host(count);
+  h->stream_mhi.assign(steps, 0);
+  h->stream_steps = 0;
+  for (int k = 0; k < steps; ++k)
+    for (int b = 0; b < h->batch; ++b) {
+      const size_t e = (size_t)k * h->batch + b;
+      int mb = h->cfg.enable_measurement_model ? m[e] : 0;
+      if (mb < 0 || mb > stride) return fail(h, EKF_ERR_ARG, "ekf_stream_upload: m out of range");
+      if (mb > 0 && (!idx || !range || !bearing)) return fail(h, EKF_ERR_ARG, "ekf_stream_upload: NULL observation arrays");
+      if (int rc = fill_step(h, host[e], b, lin[e], ang[e], FLAG_PREDICT | FLAG_UPDATE,
+                             idx ? idx + e * stride : nullptr, range ? range + e * stride : nullptr,
+                             bearing ? bearing + e * stride : nullptr, mb, 0))
+        return rc;
+      h->stream_mhi[k] = std::max(h->stream_mhi[k], mb);
+    }
+  HIP_TRY(h, hipSetDevice(h->device));
+  if (h->stream_cap < count) {
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (h->d_stream) HIP_TRY(h, hipFree(h->d_stream));
+    h->d_stream = nullptr;
+    h->stream_cap = 0;
+    HIP_TRY(h, hipMalloc(&h->d_stream, sizeof(StepIn) * count));
+    h->stream_cap = count;
+  }
+  HIP_TRY(h, hipMemcpyAsync(h->d_stream, host.data(), sizeof(StepIn) * count, hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));      // inputs are resident in HBM from here on
+  h->stream_steps = steps;
+  return EKF_OK;
+}
+
+extern "C" int ekf_stream_run(ekf_handle* h, int first, int count) {
+  if (!h) return EKF_ERR_ARG;
+  if (first < 0 || count < 0 || first + count > h->stream_steps)
+    return fail(h, EKF_ERR_STATE, "ekf_stream_run: range outside the uploaded stream");
+  HIP_TRY(h, hipSetDevice(h->device));
+  for (int k = first; k < first + count; ++k)
+    if (int rc = enqueue_pass(h, h->d_stream + (size_t)k * h->batch, h->stream_mhi[k])) return rc;
+  return EKF_OK;
+}
+
+extern "C" int ekf_run_stream(ekf_handle* h, int steps, const double* lin, const double* ang, const int* idx,
+                              const double* range, const double* bearing, const int* m, int stride) {
+  if (!h) return EKF_ERR_ARG;
+  if (steps <= 0) return EKF_OK;
+  if (int rc = ekf_stream_upload(h, steps, lin, ang, idx, range, bearing, m, stride)) return rc;
+  return ekf_stream_run(h, 0, steps);
+}
+
+extern "C" int ekf_predict_dense(ekf_handle* h, int b, const double* F, const double* Q) {
+  if (int rc = check_b(h, b, "ekf_predict_dense")) return rc;
+  if (!F || !Q) return fail(h, EKF_ERR_ARG, "ekf_predict_dense: NULL matrix");
+  const int n = h->n[b];
+  const size_t bytes = sizeof(double) * (size_t)h->ld * h->ld;
+  HIP_TRY(h, hipSetDevice(h->device));
+  if (!h->dF) {
+    HIP_TRY(h, hipMalloc(&h->dF, bytes));
+    HIP_TRY(h, hipMalloc(&h->dQ, bytes));
+    HIP_TRY(h, hipMalloc(&h->dTmp, bytes));
+  }
+  HIP_TRY(h, hipMemsetAsync(h->dF, 0, bytes, h->stream));
+  HIP_TRY(h, hipMemcpy2DAsync(h->dF, sizeof(double) * h->ld, F, sizeof(double) * n, sizeof(double) * n, n,
+                              hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(h, hipMemcpy2DAsync(h->dQ, sizeof(double) * h->ld, Q, sizeof(double) * n, sizeof(double) * n, n,
+                              hipMemcpyHostToDevice, h->stream));
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (h->profile) {
+    if (int rc = prof_event(h, &e0)) return rc;
+    if (int rc = prof_event(h, &e1)) return rc;
+    HIP_TRY(h, hipEventRecord(e0, h->stream));
+  }
+  if (dense_propagate(h->stream, h->dP + (size_t)b * h->pstride, h->dTmp, h->dF, h->dQ, n, h->ld) != 0)
+    return fail(h, EKF_ERR_HIP, "ekf_predict_dense: launch failed");
+  if (h->profile) HIP_TRY(h, hipEventRecord(e1, h->stream));
+  HIP_TRY(h, hipGetLastError());
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return EKF_OK;
+}
+
+extern "C" int ekf_sync(ekf_handle* h) {
+  if (!h) return EKF_ERR_ARG;
+  HIP_TRY(h, hipSetDevice(h->device));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return EKF_OK;
+}
+
+extern "C" int ekf_status_flags(ekf_handle* h, int b, unsigned* flags) {
+  if (int rc = check_b(h, b, "ekf_status_flags")) return rc;
+  if (!flags) return fail(h, EKF_ERR_ARG, "ekf_status_flags: NULL");
+  HIP_TRY(h, hipSetDevice(h->device));
+  HIP_TRY(h, hipMemcpyAsync(flags, h->dflags + b, sizeof(unsigned), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return EKF_OK;
+}
+
+extern "C" int ekf_timer_begin(ekf_handle* h) {
+  if (!h) return EKF_ERR_ARG;
+  HIP_TRY(h, hipSetDevice(h->device));
+  HIP_TRY(h, hipEventRecord(h->t0, h->stream));
+  return EKF_OK;
+}
+
+extern "C" int ekf_timer_end(ekf_handle* h, double* elapsed_ms) {
+  if (!h || !elapsed_ms) return EKF_ERR_ARG;
+  HIP_TRY(h, hipSetDevice(h->device));
+  HIP_TRY(h, hipEventRecord(h->t1, h->stream));
+  HIP_TRY(h, hipEventSynchronize(h->t1));
+  float ms = 0.f;
+  HIP_TRY(h, hipEventElapsedTime(&ms, h->t0, h->t1));
+  *elapsed_ms = ms;
+  return EKF_OK;
+}
+
+extern "C" int ekf_profile_enable(ekf_handle* h, int on) {
+  if (!h) return EKF_ERR_ARG;
+  HIP_TRY(h, hipSetDevice(h->device));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  h->profile = on != 0;
+  h->prof_used = 0;
+  return EKF_OK;
+}
+
+extern "C" int ekf_profile_read(ekf_handle* h, double* pass_ms_total, long long* pass_launches) {
+  if (!h || !pass_ms_total || !pass_launches) return EKF_ERR_ARG;
+  HIP_TRY(h, hipSetDevice(h->device));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  double total = 0.0;
+  for (size_t i = 0; i + 1 < h->prof_used; i += 2) {
+    float ms = 0.f;
+    HIP_TRY(h, hipEventElapsedTime(&ms, h->prof_pool[i], h->prof_pool[i + 1]));
+    total += ms;
+  }
+  *pass_ms_total = total;
+  *pass_launches = (long long)(h->prof_used / 2);
+  h->prof_used = 0;
+  return EKF_OK;
+}
+
+extern "C" int ekf_set_option(ekf_handle* h, const char* name, int value) {
+  if (!h || !name) return EKF_ERR_ARG;
+  if (std::strcmp(name, "pass_rows_per_block") == 0) {
+    if (value < 0 || value > 4096) return fail(h, EKF_ERR_ARG, "pass_rows_per_block out of range");
+    h->opt_rows_per_block = value;
+    return EKF_OK;
+  }
+  return fail(h, EKF_ERR_ARG, std::string("unknown option ") + name);
+}

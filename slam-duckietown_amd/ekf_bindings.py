@@ -1,0 +1,459 @@
+"""ctypes bindings of libekfslam_hip.so -- the module the reference's empty ``src/ekf_bindings.py`` stands for.
+
+Call surface:
+
+* ``EKF_pose_estimation(ang, lin, mean, cov, delta_t, detections, TAG_INDEX)``
+  drop-in for ``src/replay_no_ros.py:269-482`` (same arguments, same return triple, ``TAG_INDEX``
+  mutated the same way).  Association stays on the host (``frontend.associate``); augmentation,
+  prediction and the sequential update run on the GPU.
+* ``EkfSlam(n_max, batch=1, ...)`` with ``predict / update / step / run_stream`` keeps the state
+  resident in HBM -- this is the fast path.
+* ``predict(state, covariance, control, dt)`` / ``update(state, covariance, observation,
+  landmark_pos)``: the 3-state prototype surface of ``src/EKF-SLAM.py:29-84``.
+
+There is NO CPU fallback: if the shared library or a gfx950 device is missing, calls raise
+``EkfError``.  Host code is NumPy + ctypes only (no PyTorch, no CuPy).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import dataclasses
+import os
+import subprocess
+import warnings
+from typing import Optional, Sequence
+
+import numpy as np
+
+from .frontend import associate
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_NAME = "libekfslam_hip.so"
+EKF_MMAX = 16
+EKF_FLAG_NONFINITE = 1
+
+
+class EkfError(RuntimeError):
+    """A C-ABI call returned a non-zero status (message from ``ekf_last_error``)."""
+
+
+class _CConfig(C.Structure):
+    _fields_ = [("motion_sigma", C.c_double), ("meas_sigma", C.c_double), ("arc_threshold", C.c_double),
+                ("landmark_init_var", C.c_double), ("enable_measurement_model", C.c_int),
+                ("enable_circular_interpolation", C.c_int), ("disable_motion_model", C.c_int),
+                ("reserved", C.c_int)]
+
+
+@dataclasses.dataclass
+class EkfConfig:
+    """The reference's module constants (src/replay_no_ros.py:15-36) as explicit fields."""
+    motion_sigma: float = 0.1                  # MOTION_MODEL_VARIANCE
+    meas_sigma: float = 0.7                    # MEASUREMENT_MODEL_VARIANCE
+    arc_threshold: float = 1e-2                # :376
+    landmark_init_var: float = 10000.0         # :356
+    enable_measurement_model: bool = True      # ENABLE_MEASUREMENT_MODEL
+    enable_circular_interpolation: bool = True  # ENABLE_CIRCULAR_INTERPOLATION
+    disable_motion_model: bool = False         # DISABLE_MOTION_MODEL
+    gate_range: float = 1.5                    # :289 (host side)
+    ignore_tags: tuple = ()                    # IGNORE_TAGS (host side)
+
+    def _c(self) -> _CConfig:
+        return _CConfig(self.motion_sigma, self.meas_sigma, self.arc_threshold, self.landmark_init_var,
+                        int(self.enable_measurement_model), int(self.enable_circular_interpolation),
+                        int(self.disable_motion_model), 0)
+
+
+def library_path() -> str:
+    return os.path.join(_HERE, _LIB_NAME)
+
+
+def build_library(force: bool = False) -> str:
+    """Compile the HIP sources for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    path = library_path()
+    srcdir = os.path.join(_HERE, "csrc")
+    if force:
+        subprocess.run(["make", "-C", srcdir, "clean"], check=True, stdout=subprocess.DEVNULL)
+    subprocess.run(["make", "-C", srcdir, "-j4"], check=True, stdout=subprocess.DEVNULL)
+    if not os.path.exists(path):
+        raise EkfError("build did not produce " + path)
+    return path
+
+
+_lib = None
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int)
+
+# name -> (restype, argtypes): every symbol include/ekfslam_hip.h declares
+ABI = {
+    "ekf_config_default": (C.c_int, [C.POINTER(_CConfig)]),
+    "ekf_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(_CConfig), C.POINTER(C.c_void_p)]),
+    "ekf_destroy": (C.c_int, [C.c_void_p]),
+    "ekf_upload_state": (C.c_int, [C.c_void_p, C.c_int, _dp, _dp, C.c_int]),
+    "ekf_upload_state_diag": (C.c_int, [C.c_void_p, C.c_int, _dp, _dp, C.c_int]),
+    "ekf_download_state": (C.c_int, [C.c_void_p, C.c_int, _dp, _dp, C.c_int]),
+    "ekf_download_mean": (C.c_int, [C.c_void_p, C.c_int, _dp, C.c_int]),
+    "ekf_state_size": (C.c_int, [C.c_void_p, C.c_int, _ip]),
+    "ekf_add_landmarks": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _dp, C.c_int]),
+    "ekf_predict": (C.c_int, [C.c_void_p, _dp, _dp]),
+    "ekf_update": (C.c_int, [C.c_void_p, _ip, _dp, _dp, _ip, C.c_int]),
+    "ekf_step": (C.c_int, [C.c_void_p, _dp, _dp, _ip, _dp, _dp, _ip, C.c_int]),
+    "ekf_stream_upload": (C.c_int, [C.c_void_p, C.c_int, _dp, _dp, _ip, _dp, _dp, _ip, C.c_int]),
+    "ekf_stream_run": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "ekf_run_stream": (C.c_int, [C.c_void_p, C.c_int, _dp, _dp, _ip, _dp, _dp, _ip, C.c_int]),
+    "ekf_predict_dense": (C.c_int, [C.c_void_p, C.c_int, _dp, _dp]),
+    "ekf_sync": (C.c_int, [C.c_void_p]),
+    "ekf_status_flags": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_uint)]),
+    "ekf_last_error": (C.c_char_p, [C.c_void_p]),
+    "ekf_timer_begin": (C.c_int, [C.c_void_p]),
+    "ekf_timer_end": (C.c_int, [C.c_void_p, _dp]),
+    "ekf_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
+    "ekf_profile_read": (C.c_int, [C.c_void_p, _dp, C.POINTER(C.c_longlong)]),
+    "ekf_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
+}
+
+
+def load_library():
+    """dlopen the in-tree library and type every entry point.  Raises EkfError if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if not os.path.exists(path):
+        raise EkfError(f"{path} not found: build it with __graft_entry__.build() or `make -C "
+                       f"{os.path.join(_HERE, 'csrc')}` -- there is no CPU fallback")
+    try:
+        lib = C.CDLL(path)
+    except OSError as e:
+        raise EkfError(f"cannot load {path}: {e}") from e
+    for name, (res, args) in ABI.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def _f64(a, shape=None):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if shape is not None and a.shape != tuple(shape):
+        raise ValueError(f"expected shape {shape}, got {a.shape}")
+    return a
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def _p(a, typ=_dp):
+    return a.ctypes.data_as(typ)
+
+
+class EkfSlam:
+    """A bank of ``batch`` independent EKF-SLAM filters resident on one MI355X.
+
+    State per trajectory: ``mu`` (3+2N,) and ``P`` (3+2N, 3+2N) float64 in HBM.  All stepping calls
+    are asynchronous on the handle's stream; ``mean()/covariance()/sync()`` block.
+    """
+
+    def __init__(self, n_max: int, batch: int = 1, device: int = 0, config: Optional[EkfConfig] = None):
+        self._lib = load_library()
+        self.config = config or EkfConfig()
+        self.n_max = int(n_max)
+        self.batch = int(batch)
+        self._h = C.c_void_p()
+        cc = self.config._c()
+        rc = self._lib.ekf_create(int(device), self.n_max, self.batch, C.byref(cc), C.byref(self._h))
+        if rc != 0:
+            msg = self._lib.ekf_last_error(None).decode()
+            self._h = C.c_void_p()
+            raise EkfError(f"ekf_create failed ({rc}): {msg}")
+
+    # -- plumbing ------------------------------------------------------------------------------
+    def _check(self, rc: int):
+        if rc != 0:
+            raise EkfError(f"status {rc}: {self._lib.ekf_last_error(self._h).decode()}")
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._lib.ekf_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _per_traj(self, x, name):
+        a = np.atleast_1d(np.asarray(x, dtype=np.float64))
+        if a.shape == (1,) and self.batch > 1:
+            a = np.repeat(a, self.batch)
+        if a.shape != (self.batch,):
+            raise ValueError(f"{name}: expected {self.batch} values")
+        return np.ascontiguousarray(a)
+
+    def _obs(self, idx, ranges, bearings):
+        """Normalise observations to padded [batch, stride] arrays + m[batch]."""
+        if self.batch == 1 and (len(idx) == 0 or np.isscalar(idx[0]) or np.ndim(idx[0]) == 0):
+            idx, ranges, bearings = [idx], [ranges], [bearings]
+        if len(idx) != self.batch:
+            raise ValueError("observations: one list per trajectory expected")
+        m = np.array([len(i) for i in idx], dtype=np.int32)
+        stride = max(1, int(m.max()) if len(m) else 1)
+        I = np.zeros((self.batch, stride), dtype=np.int32)
+        R = np.zeros((self.batch, stride))
+        B = np.zeros((self.batch, stride))
+        for b in range(self.batch):
+            if len(ranges[b]) != m[b] or len(bearings[b]) != m[b]:
+                raise ValueError("idx / ranges / bearings lengths differ")
+            I[b, :m[b]] = idx[b]
+            R[b, :m[b]] = ranges[b]
+            B[b, :m[b]] = bearings[b]
+        return I, R, B, m, stride
+
+    # -- state ---------------------------------------------------------------------------------
+    def size(self, b: int = 0) -> int:
+        n = C.c_int()
+        self._check(self._lib.ekf_state_size(self._h, b, C.byref(n)))
+        return n.value
+
+    def set_state(self, mean, cov, b: int = 0):
+        mean = _f64(mean)
+        n = mean.shape[0]
+        cov = _f64(cov, (n, n))
+        self._check(self._lib.ekf_upload_state(self._h, b, _p(mean), _p(cov), n))
+
+    def set_state_diag(self, mean, diag, b: int = 0):
+        """P = diag(diag): avoids shipping a dense n x n host matrix for block-diagonal starts."""
+        mean = _f64(mean)
+        n = mean.shape[0]
+        diag = _f64(diag, (n,))
+        self._check(self._lib.ekf_upload_state_diag(self._h, b, _p(mean), _p(diag), n))
+
+    def mean(self, b: int = 0) -> np.ndarray:
+        n = self.size(b)
+        out = np.empty(n)
+        self._check(self._lib.ekf_download_mean(self._h, b, _p(out), n))
+        return out
+
+    def covariance(self, b: int = 0) -> np.ndarray:
+        n = self.size(b)
+        out = np.empty((n, n))
+        self._check(self._lib.ekf_download_state(self._h, b, None, _p(out), n))
+        return out
+
+    def state(self, b: int = 0):
+        n = self.size(b)
+        mu, P = np.empty(n), np.empty((n, n))
+        self._check(self._lib.ekf_download_state(self._h, b, _p(mu), _p(P), n))
+        return mu, P
+
+    def add_landmarks(self, xy, b: int = 0):
+        """Append landmarks with world guesses xy (k,2): variance landmark_init_var, zero cross terms."""
+        xy = _f64(xy).reshape(-1, 2)
+        first = (self.size(b) - 3) // 2
+        self._check(self._lib.ekf_add_landmarks(self._h, b, first, _p(xy), xy.shape[0]))
+
+    def flags(self, b: int = 0) -> int:
+        f = C.c_uint()
+        self._check(self._lib.ekf_status_flags(self._h, b, C.byref(f)))
+        return f.value
+
+    def sync(self):
+        self._check(self._lib.ekf_sync(self._h))
+
+    # -- the EKF ---------------------------------------------------------------------------------
+    def predict(self, lin, ang):
+        """Motion model + P <- G_F P G_F^T + F^T R F  (src/replay_no_ros.py:368-430)."""
+        lin, ang = self._per_traj(lin, "lin"), self._per_traj(ang, "ang")
+        self._check(self._lib.ekf_predict(self._h, _p(lin), _p(ang)))
+
+    def update(self, idx, ranges, bearings):
+        """Sequential range/bearing updates in the given order (src/replay_no_ros.py:436-480)."""
+        I, R, B, m, stride = self._obs(idx, ranges, bearings)
+        self._check(self._lib.ekf_update(self._h, _p(I, _ip), _p(R), _p(B), _p(m, _ip), stride))
+
+    def step(self, lin, ang, idx, ranges, bearings):
+        """predict + update in one fused pass over P."""
+        lin, ang = self._per_traj(lin, "lin"), self._per_traj(ang, "ang")
+        I, R, B, m, stride = self._obs(idx, ranges, bearings)
+        self._check(self._lib.ekf_step(self._h, _p(lin), _p(ang), _p(I, _ip), _p(R), _p(B), _p(m, _ip), stride))
+
+    def stream_upload(self, lin, ang, idx, ranges, bearings, m=None) -> int:
+        """Copy a whole input stream into HBM (blocking).  Returns the number of steps.
+
+        lin, ang: [steps, batch]; idx, ranges, bearings: [steps, batch, stride]; m: [steps, batch]
+        (default: every step observes ``stride`` landmarks).
+        """
+        lin = _f64(lin).reshape(-1, self.batch)
+        steps = lin.shape[0]
+        ang = _f64(ang).reshape(steps, self.batch)
+        idx = _i32(idx).reshape(steps, self.batch, -1)
+        stride = idx.shape[2]
+        ranges = _f64(ranges).reshape(steps, self.batch, stride)
+        bearings = _f64(bearings).reshape(steps, self.batch, stride)
+        m = np.full((steps, self.batch), stride, dtype=np.int32) if m is None else _i32(m).reshape(steps, self.batch)
+        self._check(self._lib.ekf_stream_upload(self._h, steps, _p(lin), _p(ang), _p(idx, _ip), _p(ranges),
+                                                _p(bearings), _p(m, _ip), stride))
+        return steps
+
+    def stream_run(self, first: int, count: int):
+        """Enqueue steps [first, first+count) of the uploaded stream (asynchronous)."""
+        self._check(self._lib.ekf_stream_run(self._h, int(first), int(count)))
+
+    def run_stream(self, lin, ang, idx, ranges, bearings, m=None):
+        """stream_upload + stream_run of every step."""
+        steps = self.stream_upload(lin, ang, idx, ranges, bearings, m)
+        self.stream_run(0, steps)
+
+    def predict_dense(self, F, Q, b: int = 0):
+        """P <- F P F^T + Q for a general dense Jacobian (fp64 MFMA GEMMs)."""
+        n = self.size(b)
+        F, Q = _f64(F, (n, n)), _f64(Q, (n, n))
+        self._check(self._lib.ekf_predict_dense(self._h, b, _p(F), _p(Q)))
+
+    # -- measurement hooks ---------------------------------------------------------------------
+    def timer_begin(self):
+        self._check(self._lib.ekf_timer_begin(self._h))
+
+    def timer_end(self) -> float:
+        ms = C.c_double()
+        self._check(self._lib.ekf_timer_end(self._h, C.byref(ms)))
+        return ms.value
+
+    def profile_enable(self, on: bool = True):
+        self._check(self._lib.ekf_profile_enable(self._h, int(on)))
+
+    def profile_read(self):
+        ms, cnt = C.c_double(), C.c_longlong()
+        self._check(self._lib.ekf_profile_read(self._h, C.byref(ms), C.byref(cnt)))
+        return ms.value, cnt.value
+
+    def set_option(self, name: str, value: int):
+        self._check(self._lib.ekf_set_option(self._h, name.encode(), int(value)))
+
+
+# ------------------------------------------------------------------------------------------------
+# Drop-in for the reference function
+# ------------------------------------------------------------------------------------------------
+class _DropInState:
+    """Device state kept between EKF_pose_estimation calls so the covariance need not be re-uploaded
+    when the caller passes back exactly what the previous call returned (the reference loop does,
+    src/replay_no_ros.py:229-237)."""
+    filt: Optional[EkfSlam] = None
+    mean: Optional[np.ndarray] = None
+    cov: Optional[np.ndarray] = None
+    sample: Optional[np.ndarray] = None
+
+
+_drop = _DropInState()
+DROP_IN_CONFIG = EkfConfig()      # edit like the reference's module constants
+DROP_IN_ALWAYS_UPLOAD = False     # True: never trust array identity
+DROP_IN_MIN_CAPACITY = 203        # n_max of the first handle (100 landmarks); grows by doubling
+
+
+def _cov_sample(cov: np.ndarray) -> np.ndarray:
+    return np.concatenate([np.diag(cov), cov[:3].ravel(), cov[:, :3].ravel()])
+
+
+def EKF_pose_estimation(angular_displacement, linear_displacement, motion_model_mean, motion_model_covariance,
+                        delta_t, timestamp_detectedTags_pair_list, TAG_INDEX):
+    """Drop-in for ``EKF_pose_estimation`` (src/replay_no_ros.py:269-482).
+
+    Same arguments (``delta_t`` accepted and unused, like :274), same return triple
+    ``(mean, covariance, tags_positions)``; ``TAG_INDEX`` is mutated in place (:295).
+    Raises ``KeyError`` like :359 when a newly indexed tag has no measurement this window.
+    """
+    cfg = DROP_IN_CONFIG
+    mean_in = np.asarray(motion_model_mean, dtype=np.float64)
+    cov_in = np.asarray(motion_model_covariance, dtype=np.float64)
+    tags_positions = associate(timestamp_detectedTags_pair_list, TAG_INDEX, mean_in,
+                               cfg.gate_range, cfg.ignore_tags)
+    n_old = mean_in.shape[0]
+    n_new = max(n_old, 3 + 2 * len(TAG_INDEX))
+    new_xy = []
+    for i in range(n_old, n_new, 2):                      # :355-360
+        j = (i - 3) // 2
+        new_xy.append((tags_positions[j][0], tags_positions[j][1]))   # KeyError like the reference
+
+    d = _drop
+    resident = (not DROP_IN_ALWAYS_UPLOAD and d.filt is not None and d.mean is motion_model_mean
+                and d.cov is motion_model_covariance and d.filt.size() == n_old
+                and np.array_equal(d.sample, _cov_sample(cov_in)) and np.array_equal(d.mean, mean_in))
+    if d.filt is None or d.filt.n_max < n_new or d.filt.config != cfg:
+        cap = max(DROP_IN_MIN_CAPACITY, n_new if d.filt is None else max(n_new, 2 * d.filt.n_max - 3))
+        cap |= 1
+        if d.filt is not None:
+            d.filt.close()
+        d.filt = EkfSlam(cap, 1, 0, dataclasses.replace(cfg))
+        resident = False
+    f = d.filt
+    if not resident:
+        f.set_state(mean_in, cov_in)
+    if new_xy:
+        f.add_landmarks(np.array(new_xy))
+    idx = list(tags_positions.keys())
+    f.step(linear_displacement, angular_displacement, idx,
+           [tags_positions[k][4] for k in idx], [tags_positions[k][5] for k in idx])
+    mean, cov = f.state()
+    if f.flags() & EKF_FLAG_NONFINITE:
+        warnings.warn("EKF_pose_estimation: non-finite state (q == 0 or singular S)", RuntimeWarning)
+    d.mean, d.cov, d.sample = mean, cov, _cov_sample(cov)
+    return mean, cov, tags_positions
+
+
+# ------------------------------------------------------------------------------------------------
+# 3-state prototype surface (src/EKF-SLAM.py:29-84)
+# ------------------------------------------------------------------------------------------------
+motion_noise = np.diag([0.1, 0.1, np.radians(5)])      # EKF-SLAM.py:12
+observation_noise = np.diag([0.5, 0.5])                # EKF-SLAM.py:13
+_proto = {}
+
+
+def _proto_filter(kind: str) -> EkfSlam:
+    if kind not in _proto:
+        cfg = EkfConfig(meas_sigma=float(np.sqrt(observation_noise[0, 0])))
+        _proto[kind] = EkfSlam(3 if kind == "predict" else 5, 1, 0, cfg)
+    return _proto[kind]
+
+
+def predict(state, covariance, control, dt):
+    """3-state EKF prediction, ``src/EKF-SLAM.py:29-56``: arc motion for |omega| > 1e-6, theta wrapped
+    with atan2(sin, cos), straight-line Jacobian F, ``covariance <- F P F^T + motion_noise`` on the GPU
+    (general dense path)."""
+    v, omega = control
+    state = np.asarray(state, dtype=np.float64)
+    theta = state[2]
+    if abs(omega) > 1e-6:
+        dx = -v / omega * np.sin(theta) + v / omega * np.sin(theta + omega * dt)
+        dy = v / omega * np.cos(theta) - v / omega * np.cos(theta + omega * dt)
+        dth = omega * dt
+    else:
+        dx, dy, dth = v * np.cos(theta) * dt, v * np.sin(theta) * dt, 0.0
+    new_state = state + np.array([dx, dy, dth])
+    new_state[2] = np.arctan2(np.sin(new_state[2]), np.cos(new_state[2]))
+    F = np.array([[1.0, 0.0, -v * dt * np.sin(theta)], [0.0, 1.0, v * dt * np.cos(theta)], [0.0, 0.0, 1.0]])
+    f = _proto_filter("predict")
+    f.set_state(new_state, covariance)
+    f.predict_dense(F, motion_noise)
+    return new_state, f.covariance()
+
+
+def update(state, covariance, observation, landmark_pos):
+    """3-state EKF update against a known landmark, ``src/EKF-SLAM.py:59-84``.  Runs the device update
+    on [x, y, theta, lx, ly] with a zero-covariance landmark block, which reduces to the 2x3 H of :67-70
+    (observation noise diag(0.5, 0.5), :13)."""
+    f = _proto_filter("update")
+    mu = np.concatenate([np.asarray(state, dtype=np.float64)[:3], np.asarray(landmark_pos, dtype=np.float64)[:2]])
+    P = np.zeros((5, 5))
+    P[:3, :3] = covariance
+    f.set_state(mu, P)
+    f.update([0], [float(observation[0])], [float(observation[1])])
+    mu2, P2 = f.state()
+    return mu2[:3].copy(), P2[:3, :3].copy()

@@ -1,0 +1,81 @@
+"""Multi-GPU plumbing: one process per GPU, trajectories sharded over ranks, NO data-path collective.
+
+Independent trajectories (Monte-Carlo replicas) are closed systems (nothing in
+src/replay_no_ros.py:269-482 couples two filter instances), so the only cross-rank traffic is the
+benchmark's barrier and the max-over-ranks of the elapsed time.  That control traffic goes over
+torch.distributed's gloo backend on the host; RCCL/xGMI are not involved.
+"""
+from __future__ import annotations
+
+import os
+from typing import Callable, List, Optional
+
+
+def shard_trajectories(total: int, world_size: int, rank: int) -> List[int]:
+    """Contiguous block partition of trajectory ids [0, total) over ranks; sizes differ by at most 1."""
+    if world_size < 1 or not 0 <= rank < world_size:
+        raise ValueError("bad rank / world size")
+    base, extra = divmod(total, world_size)
+    lo = rank * base + min(rank, extra)
+    return list(range(lo, lo + base + (1 if rank < extra else 0)))
+
+
+class RankGroup:
+    """Rank bookkeeping from the torchrun environment (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*)."""
+
+    def __init__(self, env=None):
+        env = os.environ if env is None else env
+        self.rank = int(env.get("RANK", "0"))
+        self.local_rank = int(env.get("LOCAL_RANK", "0"))
+        self.world = int(env.get("WORLD_SIZE", "1"))
+        self._dist = None
+        if self.world > 1:
+            import torch.distributed as dist
+            if "MASTER_ADDR" not in env:
+                os.environ["MASTER_ADDR"] = "127.0.0.1"
+            if not dist.is_initialized():
+                dist.init_process_group(backend="gloo", rank=self.rank, world_size=self.world)
+            self._dist = dist
+
+    def barrier(self):
+        if self._dist is not None:
+            self._dist.barrier()
+
+    def max_over_ranks(self, x: float) -> float:
+        if self._dist is None:
+            return float(x)
+        import torch
+        t = torch.tensor([float(x)], dtype=torch.float64)
+        self._dist.all_reduce(t, op=self._dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def sum_over_ranks(self, x: float) -> float:
+        if self._dist is None:
+            return float(x)
+        import torch
+        t = torch.tensor([float(x)], dtype=torch.float64)
+        self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM)
+        return float(t.item())
+
+    def close(self):
+        if self._dist is not None:
+            self._dist.barrier()
+            self._dist.destroy_process_group()
+            self._dist = None
+
+
+def timed_region(group: RankGroup, run: Callable[[], None], sync: Callable[[], None], clock) -> float:
+    """barrier + device sync on both sides of `run`; returns the MAX elapsed seconds over ranks."""
+    sync()
+    group.barrier()
+    t0 = clock()
+    run()
+    sync()
+    dt = clock() - t0
+    group.barrier()
+    return group.max_over_ranks(dt)
+
+
+def aggregate_steps_per_second(units_this_rank: float, group: RankGroup, seconds_max: float) -> float:
+    """Whole-job throughput: units processed by all ranks / max-over-ranks time."""
+    return group.sum_over_ranks(units_this_rank) / seconds_max

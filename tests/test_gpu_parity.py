@@ -1,0 +1,339 @@
+"""GPU parity: the HIP path (through the C ABI) against the pinned oracle and the golden vectors.
+
+Bar (BASELINE.json north_star): state and covariance within 1e-6 relative Frobenius norm of the
+reference NumPy path on identical inputs.  REL_TOL is that bar; TIGHT is what fp64 kernels are
+expected to reach and is asserted too so that a regression shows long before the bar.
+"""
+import numpy as np
+import pytest
+
+from oracle import ekf_oracle as orc
+from tests import golden_util as gu
+
+pytestmark = pytest.mark.gpu
+
+REL_TOL = 1e-6
+TIGHT = 1e-9
+
+
+@pytest.fixture(scope="module")
+def sd():
+    import slam_duckietown_amd as sd
+    sd.load_library()          # fails loudly if the HIP library is not built
+    return sd
+
+
+def close(a, b, tol=TIGHT):
+    r = orc.rel_fro(a, b)
+    assert r < REL_TOL, f"rel Frobenius {r:.3e} exceeds the 1e-6 bar"
+    assert r < tol, f"rel Frobenius {r:.3e} exceeds the expected {tol:g}"
+
+
+# ---------------------------------------------------------------------------------------------
+# golden vectors produced by the reference itself
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("case", ["stream_n20_m8", "stream_n20_m1", "stream_n50_m8"])
+def test_stream_golden_every_step(sd, case):
+    g = gu.load(case)
+    n = len(g["mean0"])
+    kept = {int(s): i for i, s in enumerate(g["out_cov_steps"])}
+    with sd.EkfSlam(n) as f:
+        f.set_state_diag(g["mean0"], g["diag0"])
+        for k in range(len(g["lin"])):
+            f.step(g["lin"][k], g["ang"][k], g["idx"][k], g["zr"][k], g["zb"][k])
+            close(f.mean(), g["out_mean"][k])
+            if k in kept:
+                close(f.covariance(), g["out_cov"][kept[k]])
+        assert f.flags() == 0
+
+
+def test_stream_golden_n500(sd):
+    g = gu.load("stream_n500_m8")
+    n = len(g["mean0"])
+    kept = {int(s): i for i, s in enumerate(g["out_cov_steps"])}
+    rows = g["out_cov_rows"]
+    with sd.EkfSlam(n) as f:
+        f.set_state_diag(g["mean0"], g["diag0"])
+        for k in range(len(g["lin"])):
+            f.step(g["lin"][k], g["ang"][k], g["idx"][k], g["zr"][k], g["zb"][k])
+            mu, P = f.state()
+            close(mu, g["out_mean"][k])
+            close(np.diag(P), g["out_diag"][k])
+            assert abs(np.linalg.norm(P) - g["out_fro"][k]) < TIGHT * g["out_fro"][k]
+            if k in kept:
+                close(P[rows, :], g["out_cov"][kept[k]])
+        close(P.sum(axis=1), g["out_cov_rowsum"])
+        close(P.sum(axis=0), g["out_cov_colsum"])
+
+
+@pytest.mark.parametrize("case", gu.REPLAY_CASES)
+def test_drop_in_function_golden(sd, case):
+    """EKF_pose_estimation drop-in: association, gate, averaging, augmentation, flags, wraps."""
+    from slam_duckietown_amd import ekf_bindings as eb
+    g = gu.load(case)
+    eb.DROP_IN_CONFIG = sd.EkfConfig(enable_measurement_model=bool(g["flag_measurement"]),
+                                     enable_circular_interpolation=bool(g["flag_circular"]),
+                                     disable_motion_model=bool(g["flag_no_motion"]))
+    try:
+        mean = np.array([0.0, 0.0, 0.0])
+        cov = np.eye(3) * 0.1
+        tag_index = {}
+        for k in range(len(g["lin"])):
+            det = gu.detections_for_step(g, k)
+            mean, cov, tp = eb.EKF_pose_estimation(g["ang"][k], g["lin"][k], mean, cov, 0.7, det, tag_index)
+            n = int(g["out_size"][k])
+            assert mean.shape == (n,) and cov.shape == (n, n)
+            assert list(tp.keys()) == [i for i in g["out_obs_order"][k] if i >= 0]
+            close(mean, g["out_mean"][k, :n])
+            close(cov, g["out_cov"][k, :n, :n])
+        assert sorted(tag_index.items(), key=lambda kv: kv[1]) == [tuple(r) for r in g["out_tag_index"]]
+    finally:
+        eb.DROP_IN_CONFIG = sd.EkfConfig()
+
+
+def test_drop_in_fresh_arrays_are_uploaded(sd):
+    """A caller that passes arrays we did not return (or edits them) must not hit the resident state."""
+    from slam_duckietown_amd import ekf_bindings as eb
+    g = gu.load("replay_default")
+    mean = np.array([0.0, 0.0, 0.0])
+    cov = np.eye(3) * 0.1
+    ti = {}
+    ocfg = orc.EkfConfig()
+    omean, ocov, oti = mean.copy(), cov.copy(), {}
+    for k in range(12):
+        det = gu.detections_for_step(g, k)
+        mean, cov, _ = eb.EKF_pose_estimation(g["ang"][k], g["lin"][k], mean, cov, 0.7, det, ti)
+        omean, ocov, _ = orc.ekf_pose_estimation_dense(g["ang"][k], g["lin"][k], omean, ocov, 0.7, det, oti, ocfg)
+        if k % 3 == 0:             # perturb in place / rebind to copies: the wrapper must notice
+            mean = mean.copy()
+            cov = cov * 1.0
+            cov[0, 0] *= 1.5
+            ocov[0, 0] *= 1.5
+        close(mean, omean)
+        close(cov, ocov)
+
+
+def test_drop_in_keyerror_like_reference(sd):
+    """A TAG_INDEX larger than the state with no measurement for the new index: KeyError (:359)."""
+    from types import SimpleNamespace
+    from slam_duckietown_amd import ekf_bindings as eb
+    tag = SimpleNamespace(tag_id=5, pose_R=np.eye(3), pose_t=np.array([[0.1], [0.0], [0.7]]), pose_err=0.0)
+    with pytest.raises(KeyError):
+        eb.EKF_pose_estimation(0.0, 0.01, np.zeros(3), np.eye(3) * 0.1, 0.7, [(0.0, [tag])], {99: 0})
+
+
+# ---------------------------------------------------------------------------------------------
+# oracle on seeded inputs
+# ---------------------------------------------------------------------------------------------
+def test_config2_n500_fifty_steps_vs_dense(sd):
+    """BASELINE config 2: N=500, 1 trajectory, every step compared for 50 steps."""
+    N, steps, m = 500, 50, 8
+    mean0, diag0, lin, ang, idx, zr, zb = orc.synthetic_stream(N, steps, m, 0)
+    cfg = orc.EkfConfig()
+    om, oP = mean0.copy(), np.diag(diag0)
+    with sd.EkfSlam(len(mean0)) as f:
+        f.set_state_diag(mean0, diag0)
+        for k in range(steps):
+            f.step(lin[k], ang[k], idx[k], zr[k], zb[k])
+            om, oP = orc.ekf_step_dense(om, oP, lin[k], ang[k], idx[k], zr[k], zb[k], cfg)
+            mu, P = f.state()
+            close(mu, om)
+            close(P, oP)
+
+
+def test_config3_n2000_stream_vs_structured(sd):
+    """BASELINE config 3 size (n = 4003): 12 steps through run_stream vs the O(n^2) oracle, plus
+    size-independent properties (symmetry to rounding, variances never grow under updates)."""
+    N, steps, m = 2000, 12, 8
+    mean0, diag0, lin, ang, idx, zr, zb = orc.synthetic_stream(N, steps, m, 3)
+    cfg = orc.EkfConfig()
+    om, oP = mean0.copy(), np.diag(diag0)
+    for k in range(steps):
+        om, oP = orc.ekf_step_structured(om, oP, lin[k], ang[k], idx[k], zr[k], zb[k], cfg)
+    with sd.EkfSlam(len(mean0)) as f:
+        f.set_state_diag(mean0, diag0)
+        f.run_stream(lin, ang, idx, zr, zb)
+        mu, P = f.state()
+    close(mu, om)
+    close(P, oP)
+    assert np.abs(P - P.T).max() <= 1e-9 * np.abs(P).max()
+    d = np.diag(P)
+    assert (d[3:] <= diag0[3:] * (1 + 1e-12)).all() and (d > 0).all()
+
+
+def test_one_step_n2000_vs_dense(sd):
+    """One full-size step against the reference-shaped dense path (about 4 s of dgemm on the host)."""
+    N, m = 2000, 8
+    mean0, diag0, lin, ang, idx, zr, zb = orc.synthetic_stream(N, 2, m, 1)
+    cfg = orc.EkfConfig()
+    om, oP = orc.ekf_step_dense(mean0, np.diag(diag0), lin[0], ang[0], idx[0], zr[0], zb[0], cfg)
+    with sd.EkfSlam(len(mean0)) as f:
+        f.set_state_diag(mean0, diag0)
+        f.step(lin[0], ang[0], idx[0], zr[0], zb[0])
+        mu, P = f.state()
+    close(mu, om)
+    close(P, oP)
+
+
+def test_batched_trajectories_independent(sd):
+    """Each trajectory of a batch equals its own single-trajectory oracle run (different seeds, and
+    a different number of observations per trajectory per step)."""
+    N, steps, B = 60, 15, 5
+    cfg = orc.EkfConfig()
+    streams = [orc.synthetic_stream(N, steps, 8, t) for t in range(B)]
+    n = 3 + 2 * N
+    with sd.EkfSlam(n, batch=B) as f:
+        for b, s in enumerate(streams):
+            f.set_state_diag(s[0], s[1], b)
+        ref = [(s[0].copy(), np.diag(s[1])) for s in streams]
+        for k in range(steps):
+            mk = [(3 * b + k) % 9 for b in range(B)]           # 0..8 observations
+            f.step([s[2][k] for s in streams], [s[3][k] for s in streams],
+                   [s[4][k][:mk[b]] for b, s in enumerate(streams)],
+                   [s[5][k][:mk[b]] for b, s in enumerate(streams)],
+                   [s[6][k][:mk[b]] for b, s in enumerate(streams)])
+            for b, s in enumerate(streams):
+                ref[b] = orc.ekf_step_dense(ref[b][0], ref[b][1], s[2][k], s[3][k], s[4][k][:mk[b]],
+                                            s[5][k][:mk[b]], s[6][k][:mk[b]], cfg)
+        for b in range(B):
+            mu, P = f.state(b)
+            close(mu, ref[b][0])
+            close(P, ref[b][1])
+
+
+def test_predict_and_update_separately(sd):
+    N = 40
+    mean0, diag0, lin, ang, idx, zr, zb = orc.synthetic_stream(N, 20, 6, 2)
+    cfg = orc.EkfConfig()
+    om, oP = mean0.copy(), np.diag(diag0)
+    with sd.EkfSlam(len(mean0)) as f:
+        f.set_state_diag(mean0, diag0)
+        for k in range(20):
+            f.predict(lin[k], ang[k])
+            om, oP = orc.predict_dense(om, oP, lin[k], ang[k], cfg)
+            mu, P = f.state()
+            close(mu, om)
+            close(P, oP)
+            f.update(idx[k], zr[k], zb[k])
+            om, oP = orc.update_dense(om, oP, idx[k], zr[k], zb[k], cfg)
+            mu, P = f.state()
+            close(mu, om)
+            close(P, oP)
+
+
+def test_more_than_sixteen_landmarks_in_one_step(sd):
+    """Lists longer than EKF_MMAX are split into device passes; the order is kept."""
+    N, m = 64, 41
+    mean0, diag0, lin, ang, idx, zr, zb = orc.synthetic_stream(N, 4, m, 5)
+    cfg = orc.EkfConfig()
+    om, oP = mean0.copy(), np.diag(diag0)
+    with sd.EkfSlam(len(mean0)) as f:
+        f.set_state_diag(mean0, diag0)
+        for k in range(4):
+            f.step(lin[k], ang[k], idx[k], zr[k], zb[k])
+            om, oP = orc.ekf_step_dense(om, oP, lin[k], ang[k], idx[k], zr[k], zb[k], cfg)
+        mu, P = f.state()
+    close(mu, om)
+    close(P, oP)
+
+
+@pytest.mark.parametrize("flags", [dict(enable_measurement_model=False), dict(disable_motion_model=True),
+                                   dict(enable_circular_interpolation=False),
+                                   dict(motion_sigma=0.03, meas_sigma=0.2)])
+def test_config_flags(sd, flags):
+    N = 30
+    mean0, diag0, lin, ang, idx, zr, zb = orc.synthetic_stream(N, 25, 5, 7)
+    ang = ang * 30.0            # theta crosses +-pi: wrap (:397) on, no wrap in the linear mode
+    ocfg = orc.EkfConfig(**flags)
+    om, oP = mean0.copy(), np.diag(diag0)
+    with sd.EkfSlam(len(mean0), config=sd.EkfConfig(**flags)) as f:
+        f.set_state_diag(mean0, diag0)
+        for k in range(25):
+            f.step(lin[k], ang[k], idx[k], zr[k], zb[k])
+            om, oP = orc.ekf_step_dense(om, oP, lin[k], ang[k], idx[k], zr[k], zb[k], ocfg)
+        mu, P = f.state()
+    close(mu, om)
+    close(P, oP)
+
+
+def test_augmentation_matches_reference_growth(sd):
+    """add_landmarks == the zero-pad + 1e4 diagonal of :341-360, including cross terms staying zero."""
+    rng = np.random.default_rng(3)
+    n0 = 3 + 2 * 4
+    A = rng.normal(size=(n0, n0))
+    P0 = A @ A.T
+    mu0 = rng.normal(size=n0)
+    xy = rng.normal(size=(3, 2))
+    with sd.EkfSlam(3 + 2 * 10) as f:
+        f.set_state(mu0, P0)
+        f.add_landmarks(xy)
+        mu, P = f.state()
+    tp = {4 + i: [xy[i, 0], xy[i, 1]] for i in range(3)}
+    om, oP = orc.augment(mu0, P0, 7, tp, orc.EkfConfig())
+    assert np.array_equal(mu, om) and np.array_equal(P, oP)
+
+
+def test_upload_download_roundtrip_bitexact(sd):
+    rng = np.random.default_rng(0)
+    n = 3 + 2 * 37
+    P0 = rng.normal(size=(n, n))
+    mu0 = rng.normal(size=n)
+    with sd.EkfSlam(3 + 2 * 50, batch=2) as f:
+        f.set_state(mu0, P0, 1)
+        mu, P = f.state(1)
+        assert np.array_equal(mu, mu0) and np.array_equal(P, P0)
+        assert f.size(0) == 3 and f.size(1) == n
+        assert np.array_equal(f.covariance(0), np.eye(3) * 0.1)      # reference start, :69-70
+
+
+@pytest.mark.parametrize("n", [3, 43, 1003])
+def test_predict_dense_mfma(sd, n):
+    """P <- F P F^T + Q with a general dense F (fp64 MFMA GEMMs) vs NumPy dgemm."""
+    rng = np.random.default_rng(n)
+    A = rng.normal(size=(n, n)) / np.sqrt(n)
+    P0 = A @ A.T + np.eye(n)
+    F = np.eye(n) + rng.normal(size=(n, n)) * 0.1          # asymmetric on purpose
+    Q = np.diag(rng.uniform(0.01, 0.1, n)) + 0.01 * rng.normal(size=(n, n))
+    with sd.EkfSlam(n) as f:
+        f.set_state(np.zeros(n), P0)
+        f.predict_dense(F, Q)
+        P = f.covariance()
+    close(P, F @ P0 @ F.T + Q, 1e-12)
+
+
+def test_proto3_surface(sd):
+    """predict()/update() of src/EKF-SLAM.py:29-84 against vectors from the reference itself."""
+    g = gu.load("proto3")
+    state = np.array([0.0, 0.0, 0.0])
+    cov = np.eye(3) * 0.1
+    for k in range(len(g["dt"])):
+        state, cov = sd.predict(state, cov, tuple(g["control"][k]), g["dt"][k])
+        assert np.allclose(state, g["pred_state"][k], rtol=1e-12, atol=1e-14)
+        close(cov, g["pred_cov"][k])
+        state, cov = sd.update(state, cov, tuple(g["observation"][k]), g["landmark"][k])
+        assert np.allclose(state, g["upd_state"][k], rtol=1e-9, atol=1e-12)
+        close(cov, g["upd_cov"][k])
+
+
+def test_q_zero_propagates_nan_and_sets_flag(sd):
+    """Landmark exactly at the robot: q = 0 -> NaN like NumPy (:466-469), no trap, sticky flag."""
+    mu = np.array([0.0, 0.0, 0.0, 0.0, 0.0])
+    with sd.EkfSlam(5) as f:
+        f.set_state(mu, np.eye(5))
+        f.update([0], [0.5], [0.1])
+        out = f.mean()
+        assert not np.isfinite(out).all()
+        assert f.flags() & 1
+
+
+def test_argument_errors(sd):
+    with sd.EkfSlam(3 + 2 * 5) as f:
+        f.set_state_diag(np.zeros(13), np.ones(13))
+        with pytest.raises(sd.EkfError):
+            f.update([1, 1], [0.5, 0.5], [0.0, 0.0])        # duplicate index
+        with pytest.raises(sd.EkfError):
+            f.update([5], [0.5], [0.0])                      # beyond the state
+        with pytest.raises(sd.EkfError):
+            f.set_state(np.zeros(15), np.eye(15))            # larger than n_max
+    with pytest.raises(sd.EkfError):
+        sd.EkfSlam(12)                                       # n_max must be 3 + 2N
