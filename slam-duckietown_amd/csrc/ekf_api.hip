@@ -10,13 +10,14 @@
 #include "ekf_device.h"
 
 namespace ekf {
-void launch_solve(hipStream_t, const double*, double*, const int*, const StepIn*, SolveOut*, unsigned*,
-                  const DeviceConfig&, int, long, int, int);
-void launch_panels(hipStream_t, int, const double*, double*, const int*, const SolveOut*, double*,
-                   double*, int, long, int, int);
-void launch_pass(hipStream_t, int, double*, const double*, const double*, const int*, const SolveOut*,
+void launch_solve(hipStream_t, const double*, const double*, double*, const int*, const StepIn*, SolveOut*,
+                  unsigned*, const DeviceConfig&, int, long, int);
+void launch_panels(hipStream_t, int, const double*, const double*, double*, const int*, const SolveOut*,
+                   double*, double*, int, long, int, int);
+void launch_pass(hipStream_t, int, bool, double*, const double*, const double*, const int*, const SolveOut*,
                  int, long, int, int, int);
-void launch_predict_rc(hipStream_t, double*, const int*, const SolveOut*, int, long, int, int);
+void launch_predict_rc(hipStream_t, double*, const double*, double*, const int*, const SolveOut*, int, long,
+                       int, int);
 void launch_add_landmarks(hipStream_t, double*, double*, int, int, int, double, const double*);
 void launch_fill_diag(hipStream_t, double*, int, int, const double*);
 int dense_propagate(hipStream_t, double* P, double* tmp, const double* F, const double* Q, int n, int ld);
@@ -33,7 +34,9 @@ struct ekf_handle {
   ekf_config cfg{};
   DeviceConfig dcfg{};
   hipStream_t stream = nullptr;
-  double *dP = nullptr, *dmu = nullptr, *dV = nullptr, *dW = nullptr, *dscratch = nullptr;
+  double *dP = nullptr, *dV = nullptr, *dW = nullptr, *dscratch = nullptr;
+  double* dmu2[2] = {nullptr, nullptr};   // the mean is double-buffered: a step reads [cur], writes [cur^1]
+  int cur = 0;
   int* dn = nullptr;
   unsigned* dflags = nullptr;
   SolveOut* dso = nullptr;
@@ -52,6 +55,7 @@ struct ekf_handle {
   std::vector<hipEvent_t> prof_pool;
   size_t prof_used = 0;
   int opt_rows_per_block = 0;     // 0 = auto
+  int opt_streaming = -1;         // -1 = auto (by working-set size), 0 = resident kernel, 1 = nontemporal kernel
   std::string err;
 };
 
@@ -86,7 +90,7 @@ static void free_all(ekf_handle* h) {
   if (!h) return;
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
-  void* ptrs[] = {h->dP, h->dmu, h->dV, h->dW, h->dscratch, h->dn, h->dflags, h->dso,
+  void* ptrs[] = {h->dP, h->dmu2[0], h->dmu2[1], h->dV, h->dW, h->dscratch, h->dn, h->dflags, h->dso,
                   h->d_ring, h->d_stream, h->dF, h->dQ, h->dTmp};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (h->h_ring) (void)hipHostFree(h->h_ring);
@@ -147,7 +151,8 @@ extern "C" int ekf_create(int device, int n_max, int batch, const ekf_config* cf
   CREATE_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
   const size_t ldz = (size_t)h->ld;
   CREATE_TRY(hipMalloc(&h->dP, sizeof(double) * ldz * ldz * batch));
-  CREATE_TRY(hipMalloc(&h->dmu, sizeof(double) * ldz * batch));
+  CREATE_TRY(hipMalloc(&h->dmu2[0], sizeof(double) * ldz * batch));
+  CREATE_TRY(hipMalloc(&h->dmu2[1], sizeof(double) * ldz * batch));
   CREATE_TRY(hipMalloc(&h->dV, sizeof(double) * ldz * (2 * MMAX + 2) * batch));
   CREATE_TRY(hipMalloc(&h->dW, sizeof(double) * ldz * (2 * MMAX + 2) * batch));
   CREATE_TRY(hipMalloc(&h->dscratch, sizeof(double) * ldz * 2));
@@ -160,7 +165,8 @@ extern "C" int ekf_create(int device, int n_max, int batch, const ekf_config* cf
   CREATE_TRY(hipEventCreate(&h->t0));
   CREATE_TRY(hipEventCreate(&h->t1));
   CREATE_TRY(hipMemsetAsync(h->dP, 0, sizeof(double) * ldz * ldz * batch, h->stream));
-  CREATE_TRY(hipMemsetAsync(h->dmu, 0, sizeof(double) * ldz * batch, h->stream));
+  CREATE_TRY(hipMemsetAsync(h->dmu2[0], 0, sizeof(double) * ldz * batch, h->stream));
+  CREATE_TRY(hipMemsetAsync(h->dmu2[1], 0, sizeof(double) * ldz * batch, h->stream));
   CREATE_TRY(hipMemsetAsync(h->dV, 0, sizeof(double) * ldz * (2 * MMAX + 2) * batch, h->stream));
   CREATE_TRY(hipMemsetAsync(h->dW, 0, sizeof(double) * ldz * (2 * MMAX + 2) * batch, h->stream));
   CREATE_TRY(hipMemsetAsync(h->dflags, 0, sizeof(unsigned) * batch, h->stream));
@@ -205,7 +211,7 @@ extern "C" int ekf_upload_state(ekf_handle* h, int b, const double* mu, const do
   HIP_TRY(h, hipSetDevice(h->device));
   HIP_TRY(h, hipMemcpy2DAsync(h->dP + (size_t)b * h->pstride, sizeof(double) * h->ld, P, sizeof(double) * n,
                               sizeof(double) * n, n, hipMemcpyHostToDevice, h->stream));
-  HIP_TRY(h, hipMemcpyAsync(h->dmu + (size_t)b * h->ld, mu, sizeof(double) * n, hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(h, hipMemcpyAsync(h->dmu2[h->cur] + (size_t)b * h->ld, mu, sizeof(double) * n, hipMemcpyHostToDevice, h->stream));
   if (int rc = set_size(h, b, n)) return rc;
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   return EKF_OK;
@@ -219,7 +225,7 @@ extern "C" int ekf_upload_state_diag(ekf_handle* h, int b, const double* mu, con
   HIP_TRY(h, hipMemcpyAsync(h->dscratch, diagP, sizeof(double) * n, hipMemcpyHostToDevice, h->stream));
   launch_fill_diag(h->stream, h->dP + (size_t)b * h->pstride, h->ld, n, h->dscratch);
   HIP_TRY(h, hipGetLastError());
-  HIP_TRY(h, hipMemcpyAsync(h->dmu + (size_t)b * h->ld, mu, sizeof(double) * n, hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(h, hipMemcpyAsync(h->dmu2[h->cur] + (size_t)b * h->ld, mu, sizeof(double) * n, hipMemcpyHostToDevice, h->stream));
   if (int rc = set_size(h, b, n)) return rc;
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   return EKF_OK;
@@ -233,7 +239,7 @@ extern "C" int ekf_download_state(ekf_handle* h, int b, double* mu, double* P, i
     HIP_TRY(h, hipMemcpy2DAsync(P, sizeof(double) * n, h->dP + (size_t)b * h->pstride, sizeof(double) * h->ld,
                                 sizeof(double) * n, n, hipMemcpyDeviceToHost, h->stream));
   if (mu)
-    HIP_TRY(h, hipMemcpyAsync(mu, h->dmu + (size_t)b * h->ld, sizeof(double) * n, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(mu, h->dmu2[h->cur] + (size_t)b * h->ld, sizeof(double) * n, hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   return EKF_OK;
 }
@@ -261,7 +267,7 @@ extern "C" int ekf_add_landmarks(ekf_handle* h, int b, int first_index, const do
   HIP_TRY(h, hipSetDevice(h->device));
   HIP_TRY(h, hipStreamSynchronize(h->stream));   // xy is staged through a single scratch buffer
   HIP_TRY(h, hipMemcpyAsync(h->dscratch, xy, sizeof(double) * 2 * k, hipMemcpyHostToDevice, h->stream));
-  launch_add_landmarks(h->stream, h->dP + (size_t)b * h->pstride, h->dmu + (size_t)b * h->ld, h->ld, n_old, n_new,
+  launch_add_landmarks(h->stream, h->dP + (size_t)b * h->pstride, h->dmu2[h->cur] + (size_t)b * h->ld, h->ld, n_old, n_new,
                        h->cfg.landmark_init_var, h->dscratch);
   HIP_TRY(h, hipGetLastError());
   if (int rc = set_size(h, b, n_new)) return rc;
@@ -274,11 +280,14 @@ static int cap_for(int m) { return m <= 1 ? 1 : m <= 2 ? 2 : m <= 4 ? 4 : m <= 8
 
 static int auto_rows_per_block(const ekf_handle* h, int n_hi) {
   if (h->opt_rows_per_block > 0) return h->opt_rows_per_block;
-  // aim for >= ~2048 workgroups over the whole batch, 16..128 rows each
-  const long col_blocks = (n_hi + 511) / 512;
-  long rpb = 128;
-  while (rpb > 16 && col_blocks * ((n_hi + rpb - 1) / rpb) * h->batch < 2048) rpb >>= 1;
-  return (int)rpb;
+  (void)n_hi;
+  return 16;      // many small workgroups measured best for both kernels (tools/pass_bench.hip)
+}
+
+// The covariances of the batch stream through HBM when they cannot stay in the 256 MiB Infinity Cache.
+static bool streaming_pass(const ekf_handle* h, int n_hi) {
+  if (h->opt_streaming >= 0) return h->opt_streaming != 0;
+  return (double)h->batch * 8.0 * n_hi * n_hi > 192.0e6;
 }
 
 static int prof_event(ekf_handle* h, hipEvent_t* ev) {
@@ -295,21 +304,24 @@ static int prof_event(ekf_handle* h, hipEvent_t* ev) {
 static int enqueue_pass(ekf_handle* h, const StepIn* d_in, int m_hi) {
   const int n_hi = *std::max_element(h->n.begin(), h->n.end());
   const int mcap = cap_for(m_hi);
-  launch_solve(h->stream, h->dP, h->dmu, h->dn, d_in, h->dso, h->dflags, h->dcfg, h->ld, h->pstride, h->batch, mcap);
+  const double* mu_in = h->dmu2[h->cur];
+  double* mu_out = h->dmu2[h->cur ^ 1];
+  launch_solve(h->stream, h->dP, mu_in, mu_out, h->dn, d_in, h->dso, h->dflags, h->dcfg, h->ld, h->pstride, h->batch);
   if (m_hi == 0) {
-    launch_predict_rc(h->stream, h->dP, h->dn, h->dso, h->ld, h->pstride, h->batch, n_hi);
+    launch_predict_rc(h->stream, h->dP, mu_in, mu_out, h->dn, h->dso, h->ld, h->pstride, h->batch, n_hi);
   } else {
-    launch_panels(h->stream, mcap, h->dP, h->dmu, h->dn, h->dso, h->dV, h->dW, h->ld, h->pstride, h->batch, n_hi);
+    launch_panels(h->stream, mcap, h->dP, mu_in, mu_out, h->dn, h->dso, h->dV, h->dW, h->ld, h->pstride, h->batch, n_hi);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (h->profile) {
       if (int rc = prof_event(h, &e0)) return rc;
       if (int rc = prof_event(h, &e1)) return rc;
       HIP_TRY(h, hipEventRecord(e0, h->stream));
     }
-    launch_pass(h->stream, mcap, h->dP, h->dV, h->dW, h->dn, h->dso, h->ld, h->pstride, h->batch, n_hi,
-                auto_rows_per_block(h, n_hi));
+    launch_pass(h->stream, mcap, streaming_pass(h, n_hi), h->dP, h->dV, h->dW, h->dn, h->dso, h->ld, h->pstride,
+                h->batch, n_hi, auto_rows_per_block(h, n_hi));
     if (h->profile) HIP_TRY(h, hipEventRecord(e1, h->stream));
   }
+  h->cur ^= 1;
   HIP_TRY(h, hipGetLastError());
   return EKF_OK;
 }
@@ -539,6 +551,11 @@ extern "C" int ekf_set_option(ekf_handle* h, const char* name, int value) {
   if (std::strcmp(name, "pass_rows_per_block") == 0) {
     if (value < 0 || value > 4096) return fail(h, EKF_ERR_ARG, "pass_rows_per_block out of range");
     h->opt_rows_per_block = value;
+    return EKF_OK;
+  }
+  if (std::strcmp(name, "pass_streaming") == 0) {
+    if (value < -1 || value > 1) return fail(h, EKF_ERR_ARG, "pass_streaming must be -1 (auto), 0 or 1");
+    h->opt_streaming = value;
     return EKF_OK;
   }
   return fail(h, EKF_ERR_ARG, std::string("unknown option ") + name);

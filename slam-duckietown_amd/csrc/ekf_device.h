@@ -1,14 +1,13 @@
 // Shared host/device records of the EKF-SLAM core (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <cstddef>
 #include "../../include/ekfslam_hip.h"
 
 namespace ekf {
 
 constexpr int MMAX = EKF_MMAX;          // landmarks per update pass
 constexpr int CMAX = 3 + 2 * MMAX;      // compressed sub-state size (35)
-constexpr int TS = 36;                  // row stride of T (>= CMAX)
-constexpr int US = 2 * MMAX;            // row stride of U (32)
 
 constexpr int FLAG_PREDICT = 1;         // StepIn.flags
 constexpr int FLAG_UPDATE = 2;
@@ -23,19 +22,29 @@ struct StepIn {
   double bearing[MMAX];
 };
 
+// What one sequential iteration (one observed landmark j, src/replay_no_ros.py:436-480) hands to
+// the panel kernel, expressed on the compressed index set C.  Pairs are stored adjacent so that a
+// single 16-byte LDS broadcast read fetches both rows of a 2-row quantity.
+struct alignas(16) SolveIter {
+  double h5t[5][2];     // {H[0][k], H[1][k]}: the 2x5 Jacobian on {0,1,2,t_j,t_j+1}    (:466-469)
+  double si[4];         // S_j^{-1} row-major                                             (:473)
+  double y[2];          // innovation                                                     (:455-458)
+  double kc[CMAX][2];   // K_j[C[a],:]                 (0 for a >= c)
+  double hpt[CMAX][2];  // {(H_j P_j)[0,C[a]], (H_j P_j)[1,C[a]]}   (0 for a >= c)
+};
+static_assert(sizeof(SolveIter) % 16 == 0, "SolveIter must stay 16-byte granular");
+
 // Output of the sequential compressed solve for one trajectory; read by the panel and pass kernels.
-struct SolveOut {
+struct alignas(16) SolveOut {
   double g[2];          // G[0,2], G[1,2] of the motion Jacobian (0 when prediction is off)
   double rd[3];         // motion noise added to the pose block (0 when prediction is off)
   double p22h;          // 0.5 * P[2,2] before the step
   int c;                // 3 + 2m
   int m;
-  int C[CMAX + 1];      // gathered state indices, padded with 0
-  double mu_c[CMAX];    // updated mean entries at C
-  double ys[US];        // stacked innovations
-  double T[US][TS];     // V = T P'[C,:]
-  double U[CMAX][US];   // Kst = P'[:,C] U
+  int C[CMAX + 3];      // gathered state indices, padded with 0 (38 ints keep `it` 16-byte aligned)
+  SolveIter it[MMAX];
 };
+static_assert(offsetof(SolveOut, it) % 16 == 0, "SolveOut::it must be 16-byte aligned");
 
 struct DeviceConfig {
   double rd[3];         // diag of R  (src/replay_no_ros.py:421)

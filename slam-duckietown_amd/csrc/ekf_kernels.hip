@@ -2,54 +2,86 @@
 //
 // One reference step (src/replay_no_ros.py:363-482: predict, then one dense (I-KH)P product per
 // observed landmark) is executed as
-//   k_solve    sequential part on the compressed c x c system (c = 3+2m), one wave per trajectory
-//   k_panels   V = T P'[C,:] (2m x n, coalesced row reads) and W = -P'[:,C] U (n x 2m), mean update
+//   k_solve    the sequential part on the compressed c x c system (c = 3+2m), one wave per trajectory
+//   k_panels   thread i replays the m rank-2 down-dates on column i of the row panel P'[C,:] and on
+//              row i of the column panel P'[:,C]:  V = stacked H_j P_j (2m x n, coalesced reads),
+//              W = -stacked K_j (n x 2m); mean update
 //   k_pass     P <- P + Rt + W V   one streaming read-modify-write of P (HBM-bound, 16 n^2 bytes)
 // or, with no observation, k_predict_rc (rows/cols 0,1 of P only, O(n)).
 // The algebra is restated on the CPU in oracle/ekf_oracle.py::ekf_step_structured.
+#include <algorithm>
+
 #include "ekf_device.h"
 
 namespace ekf {
 
 __device__ __forceinline__ double wrap_pi(double a) {
-  // (a + pi) % (2 pi) - pi with NumPy remainder semantics (src/replay_no_ros.py:397, :458)
+  // (a + pi) % (2 pi) - pi with NumPy remainder semantics, result in [-pi, pi)
+  // (src/replay_no_ros.py:397, :458).  fma(-k, 2pi, x) is the exact remainder when k is the right
+  // quotient (the remainder is representable); the two fix-ups cover a quotient that is off by one.
   const double two_pi = 2.0 * M_PI;
-  double r = fmod(a + M_PI, two_pi);
-  if (r != 0.0) {
-    if (r < 0.0) r += two_pi;
-  } else {
-    r = 0.0;
-  }
+  const double x = a + M_PI;
+  const double k = floor(x * (1.0 / two_pi));
+  double r = fma(-k, two_pi, x);
+  if (r < 0.0) r += two_pi;
+  else if (r >= two_pi) r -= two_pi;
   return r - M_PI;
 }
 
+// Innovation and 2x5 Jacobian of one range/bearing observation (src/replay_no_ros.py:443-469).
+// h[r][k] = row r, column k on {x, y, theta, lx, ly}.  q == 0 gives NaN rows like NumPy's 0/0.
+__device__ __forceinline__ void linearize(const double* muc, int a, double z_range, double z_bearing,
+                                          double (&h)[2][5], double& y0, double& y1) {
+  const double dx = muc[a] - muc[0], dy = muc[a + 1] - muc[1];   // :443
+  const double q = dx * dx + dy * dy;                             // :446
+  const double sq = sqrt(q);
+  y0 = z_range - sq;                                              // :455
+  y1 = wrap_pi(z_bearing - (atan2(dy, dx) - muc[2]));             // :453-458
+  const double rq = 1.0 / q;
+  const double hs = sq * rq;                                      // sqrt(q)/q
+  const double nanv = __builtin_nan("");
+  h[0][0] = -hs * dx;
+  h[0][1] = -hs * dy;
+  h[0][2] = (q > 0.0) ? 0.0 : nanv;                               // .0 / q
+  h[0][3] = hs * dx;
+  h[0][4] = hs * dy;
+  h[1][0] = dy * rq;
+  h[1][1] = -dx * rq;
+  h[1][2] = (q > 0.0 && q < __builtin_inf()) ? -1.0 : nanv;       // -q / q
+  h[1][3] = -dy * rq;
+  h[1][4] = dx * rq;
+}
+
 // ---------------------------------------------------------------------------------------------
-// k_solve: one 64-lane wave per trajectory.
+// k_solve: one 64-lane wave per trajectory; lane l < c owns compressed index l.
+// Reads mu_in, writes mu_out[C] (the mean is double-buffered so that no kernel of a step reads
+// an entry another workgroup of the same step writes).
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_solve(const double* __restrict__ P, double* __restrict__ mu,
+__global__ __launch_bounds__(64) void k_solve(const double* __restrict__ P,
+                                              const double* __restrict__ mu_in,
+                                              double* __restrict__ mu_out,
                                               const int* __restrict__ nact,
                                               const StepIn* __restrict__ in,
                                               SolveOut* __restrict__ out,
                                               unsigned* __restrict__ flags, DeviceConfig cfg, int ld,
-                                              long pstride, int mcap) {
+                                              long pstride) {
   const int b = blockIdx.x;
   const int lane = threadIdx.x;
   const StepIn& s = in[b];
   SolveOut& o = out[b];
   const double* Pb = P + (long)b * pstride;
-  double* mub = mu + (long)b * ld;
 
-  __shared__ double Pc[CMAX][CMAX + 1], A[CMAX][CMAX + 1], Bm[CMAX][CMAX + 1];
+  __shared__ double Pc[CMAX][CMAX + 1];
   __shared__ double muc[CMAX];
-  __shared__ double hp[2][CMAX], tj[2][CMAX], ph[CMAX][2], bh[CMAX][2], kc[CMAX][2], uj[CMAX][2];
-  __shared__ int Cs[CMAX + 1];
+  __shared__ double2 hpS[CMAX], kcS[CMAX];
+  __shared__ int Cs[CMAX + 3];
 
   const bool do_pred = (s.flags & FLAG_PREDICT) != 0;
   int m = ((s.flags & FLAG_UPDATE) && cfg.enable_measurement_model) ? s.m : 0;
   if (m > MMAX) m = MMAX;
   const int c = 3 + 2 * m;
 
-  if (lane < CMAX + 1) {
+  if (lane < CMAX + 3) {
     int v = 0;
     if (lane < 3) v = lane;
     else if (lane < c) v = 3 + 2 * s.idx[(lane - 3) >> 1] + ((lane - 3) & 1);
@@ -57,13 +89,19 @@ __global__ __launch_bounds__(64) void k_solve(const double* __restrict__ P, doub
     o.C[lane] = v;
   }
   __syncthreads();
-  for (int e = lane; e < c * c; e += 64) {
-    const int r = e / c, cc = e - r * c;
-    Pc[r][cc] = Pb[(long)Cs[r] * ld + Cs[cc]];
-    A[r][cc] = (r == cc) ? 1.0 : 0.0;
-    Bm[r][cc] = (r == cc) ? 1.0 : 0.0;
+  // element walk e = lane + 64 t over the c x c block without per-element division
+  const int q64 = 64 / c, r64 = 64 - q64 * c;
+  const int r_first = lane / c, c_first = lane - r_first * c;
+  {
+    int r = r_first, cc = c_first;
+    while (r < c) {
+      Pc[r][cc] = Pb[(long)Cs[r] * ld + Cs[cc]];
+      r += q64;
+      cc += r64;
+      if (cc >= c) { cc -= c; ++r; }
+    }
   }
-  if (lane < c) muc[lane] = mub[Cs[lane]];
+  if (lane < c) muc[lane] = mu_in[(long)b * ld + Cs[lane]];
   __syncthreads();
 
   // ---- motion model (src/replay_no_ros.py:368-417), evaluated redundantly by every lane ----
@@ -129,118 +167,129 @@ __global__ __launch_bounds__(64) void k_solve(const double* __restrict__ P, doub
   __syncthreads();
 
   // ---- sequential per-landmark recurrences (:436-480) on the compressed system ----
+  double h[2][5], y0 = 0.0, y1 = 0.0;
+  if (m > 0) linearize(muc, 3, s.range[0], s.bearing[0], h, y0, y1);
   for (int j = 0; j < m; ++j) {
     const int a = 3 + 2 * j;
-    const int sel[5] = {0, 1, 2, a, a + 1};
-    const double dx = muc[a] - muc[0], dy = muc[a + 1] - muc[1];     // :443
-    const double q = dx * dx + dy * dy;                               // :446
-    const double sq = sqrt(q);
-    const double zh1 = atan2(dy, dx) - muc[2];                        // :453
-    const double y0 = s.range[j] - sq;                                // :455
-    const double y1 = wrap_pi(s.bearing[j] - zh1);                    // :458
-    // :466-469, elementwise (array / q) like NumPy so q == 0 propagates NaN/inf the same way
-    const double h5[2][5] = {{(-sq * dx) / q, (-sq * dy) / q, 0.0 / q, (sq * dx) / q, (sq * dy) / q},
-                             {dy / q, -dx / q, -q / q, -dy / q, dx / q}};
+    SolveIter& it = o.it[j];
+    double ph0 = 0.0, ph1 = 0.0;
     if (lane < c) {
+      double hp0 = 0.0, hp1 = 0.0;
 #pragma unroll
-      for (int r = 0; r < 2; ++r) {
-        double s_hp = 0.0, s_ph = 0.0, s_t = 0.0, s_b = 0.0;
+      for (int k = 0; k < 5; ++k) {
+        const int sk = (k < 3) ? k : a + (k - 3);
+        const double pr = Pc[sk][lane];        // row sk of P_j at column C[lane]
+        const double pc = Pc[lane][sk];        // column sk of P_j at row C[lane]
+        hp0 += h[0][k] * pr;                   // (H P)[0, C[lane]]
+        hp1 += h[1][k] * pr;
+        ph0 += pc * h[0][k];                   // (P H^T)[C[lane], 0]
+        ph1 += pc * h[1][k];
+      }
+      hpS[lane] = make_double2(hp0, hp1);
+      *reinterpret_cast<double2*>(it.hpt[lane]) = make_double2(hp0, hp1);
+    } else if (lane < CMAX) {
+      *reinterpret_cast<double2*>(it.hpt[lane]) = make_double2(0.0, 0.0);
+      *reinterpret_cast<double2*>(it.kc[lane]) = make_double2(0.0, 0.0);
+    }
+    __syncthreads();
+    double S00 = cfg.qd[0], S01 = 0.0, S10 = 0.0, S11 = cfg.qd[1];     // :473  S = H P H^T + Q
 #pragma unroll
-        for (int k = 0; k < 5; ++k) {
-          s_hp += h5[r][k] * Pc[sel[k]][lane];      // (H P)[r, C[lane]]
-          s_ph += Pc[lane][sel[k]] * h5[r][k];      // (P H^T)[C[lane], r]
-          s_t += h5[r][k] * A[sel[k]][lane];
-          s_b += Bm[lane][sel[k]] * h5[r][k];
-        }
-        hp[r][lane] = s_hp;
-        ph[lane][r] = s_ph;
-        tj[r][lane] = s_t;
-        bh[lane][r] = s_b;
+    for (int k = 0; k < 5; ++k) {
+      const int sk = (k < 3) ? k : a + (k - 3);
+      const double2 v = hpS[sk];
+      S00 += v.x * h[0][k];
+      S01 += v.x * h[1][k];
+      S10 += v.y * h[0][k];
+      S11 += v.y * h[1][k];
+    }
+    const double rdet = 1.0 / (S00 * S11 - S01 * S10);
+    const double i00 = S11 * rdet, i01 = -S01 * rdet, i10 = -S10 * rdet, i11 = S00 * rdet;
+    if (lane < c) {
+      const double k0 = ph0 * i00 + ph1 * i10;                          // K_j[C[lane], :]
+      const double k1 = ph0 * i01 + ph1 * i11;
+      kcS[lane] = make_double2(k0, k1);
+      *reinterpret_cast<double2*>(it.kc[lane]) = make_double2(k0, k1);
+      muc[lane] += k0 * y0 + k1 * y1;                                   // :476
+    }
+    if (lane == 0) {
+#pragma unroll
+      for (int k = 0; k < 5; ++k) *reinterpret_cast<double2*>(it.h5t[k]) = make_double2(h[0][k], h[1][k]);
+      it.si[0] = i00; it.si[1] = i01; it.si[2] = i10; it.si[3] = i11;
+      it.y[0] = y0; it.y[1] = y1;
+    }
+    __syncthreads();
+    // next landmark's linearisation depends only on the mean: overlaps the covariance down-date
+    double hn[2][5], yn0 = 0.0, yn1 = 0.0;
+    if (j + 1 < m) linearize(muc, a + 2, s.range[j + 1], s.bearing[j + 1], hn, yn0, yn1);
+    {
+      int r = r_first, cc = c_first;                                    // :480 restricted to C
+      while (r < c) {
+        const double2 kr = kcS[r], hc = hpS[cc];
+        Pc[r][cc] -= kr.x * hc.x + kr.y * hc.y;
+        r += q64;
+        cc += r64;
+        if (cc >= c) { cc -= c; ++r; }
       }
     }
     __syncthreads();
-    double S00 = 0.0, S01 = 0.0, S10 = 0.0, S11 = 0.0;                // :473  S = H P H^T + Q
+    if (j + 1 < m) {
 #pragma unroll
-    for (int k = 0; k < 5; ++k) {
-      S00 += hp[0][sel[k]] * h5[0][k];
-      S01 += hp[0][sel[k]] * h5[1][k];
-      S10 += hp[1][sel[k]] * h5[0][k];
-      S11 += hp[1][sel[k]] * h5[1][k];
+      for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int k = 0; k < 5; ++k) h[r][k] = hn[r][k];
+      y0 = yn0;
+      y1 = yn1;
     }
-    S00 += cfg.qd[0];
-    S11 += cfg.qd[1];
-    const double det = S00 * S11 - S01 * S10;
-    const double i00 = S11 / det, i01 = -S01 / det, i10 = -S10 / det, i11 = S00 / det;
-    if (lane < c) {
-      const double k0 = ph[lane][0] * i00 + ph[lane][1] * i10;        // K_j[C[lane], :]
-      const double k1 = ph[lane][0] * i01 + ph[lane][1] * i11;
-      const double u0 = bh[lane][0] * i00 + bh[lane][1] * i10;
-      const double u1 = bh[lane][0] * i01 + bh[lane][1] * i11;
-      kc[lane][0] = k0;
-      kc[lane][1] = k1;
-      uj[lane][0] = u0;
-      uj[lane][1] = u1;
-      muc[lane] += k0 * y0 + k1 * y1;                                 // :476
-      o.U[lane][2 * j] = u0;
-      o.U[lane][2 * j + 1] = u1;
-      o.T[2 * j][lane] = tj[0][lane];
-      o.T[2 * j + 1][lane] = tj[1][lane];
-    }
-    if (lane == 0) {
-      o.ys[2 * j] = y0;
-      o.ys[2 * j + 1] = y1;
-    }
-    __syncthreads();
-    for (int e = lane; e < c * c; e += 64) {                          // :480 restricted to C
-      const int r = e / c, cc = e - r * c;
-      Pc[r][cc] -= kc[r][0] * hp[0][cc] + kc[r][1] * hp[1][cc];
-      A[r][cc] -= kc[r][0] * tj[0][cc] + kc[r][1] * tj[1][cc];
-      Bm[r][cc] -= uj[r][0] * hp[0][cc] + uj[r][1] * hp[1][cc];
-    }
-    __syncthreads();
   }
 
-  // zero the padding the templated consumers (cap = mcap landmarks) will read; each element once
-  const int cc_cap = 3 + 2 * mcap, k_cap = 2 * mcap;
-  for (int e = lane; e < k_cap * cc_cap; e += 64) {
-    const int k = e / cc_cap, a = e - k * cc_cap;
-    if (k >= 2 * m || a >= c) o.T[k][a] = 0.0;
-    if (k >= 2 * m || a >= c) o.U[a][k] = 0.0;
-  }
-  if (lane < k_cap && lane >= 2 * m) o.ys[lane] = 0.0;
   bool bad = false;
   if (lane < c) {
     const double v = muc[lane];
-    o.mu_c[lane] = v;
-    mub[Cs[lane]] = v;
+    mu_out[(long)b * ld + Cs[lane]] = v;
     bad = !(fabs(v) <= 1.79769313486231570815e308);
   }
   if (__any(bad) && lane == 0) atomicOr(&flags[b], EKF_FLAG_NONFINITE);
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_panels: thread j builds column j of V and row j of W.
-//   V[k][j] = sum_a T[k][a] P'[C[a]][j]        k < 2m      (coalesced row reads)
-//   W[j][k] = -sum_a P'[j][C[a]] U[a][k]                    (scattered column reads, ~m+1 lines/row)
-//   rank-2 rows for the motion Jacobian: V[2m] = P[2,:]+p22h*gt, W[:,2m] = gt,
-//                                        V[2m+1] = gt,           W[:,2m+1] = P[:,2]+p22h*gt
-//   mean: mu[j] += Kst[j,:] . ys  for j not in C (k_solve already wrote mu[C]).
+// k_panels: thread i owns column i of the row panel R = P'[C,:] and row i of the column panel
+// L = P'[:,C] (both c values in registers) and replays the m sequential rank-2 down-dates on them
+// with the per-iteration uniforms of k_solve staged in LDS (16-byte broadcast reads):
+//   V[2j..2j+1][i] = H_j P_j[:, i]        = h5_j . R[sel_j]
+//   W[i][2j..2j+1] = -K_j[i, :]           = -(L[sel_j] . h5_j^T) S_j^-1
+//   R -= K_j[C,:] (H_j P_j)[:, i],   L -= K_j[i,:] (H_j P_j)[:, C]
+// plus the two rank-1 pairs of the motion Jacobian (:430) at k = 2*MCAP, 2*MCAP+1:
+//   V[2M] = P[2,:] + p22h*gt, W[:,2M] = gt,   V[2M+1] = gt, W[:,2M+1] = P[:,2] + p22h*gt
+// and the mean: mu_out[i] = mu_in[i] + sum_j K_j[i,:] y_j for i not in C.
 // ---------------------------------------------------------------------------------------------
 template <int MCAP>
-__global__ __launch_bounds__(64) void k_panels(const double* __restrict__ P, double* __restrict__ mu,
+__global__ __launch_bounds__(64) void k_panels(const double* __restrict__ P,
+                                               const double* __restrict__ mu_in,
+                                               double* __restrict__ mu_out,
                                                const int* __restrict__ nact,
                                                const SolveOut* __restrict__ so,
                                                double* __restrict__ V, double* __restrict__ W, int ld,
                                                long pstride) {
-  constexpr int CC = 3 + 2 * MCAP, K2 = 2 * MCAP, KT = K2 + 2;
+  constexpr int CC = 3 + 2 * MCAP, K2 = 2 * MCAP;
+  constexpr int VS = 2 * MMAX + 2;
+  __shared__ SolveIter its[MCAP];
   const int b = blockIdx.y;
   const int n = nact[b];
   if ((int)blockIdx.x * 64 >= n) return;
-  const int j = blockIdx.x * 64 + threadIdx.x;
+  const int tid = threadIdx.x;
+  const int j = blockIdx.x * 64 + tid;
   const bool act = j < n;
   const int jj = act ? j : 0;
   const SolveOut& o = so[b];
   const double* Pb = P + (long)b * pstride;
+  const int m = min(o.m, MCAP), c = o.c;
+
+  {
+    const double2* src = reinterpret_cast<const double2*>(o.it);
+    double2* dst = reinterpret_cast<double2*>(its);
+    const int count = m * (int)(sizeof(SolveIter) / 16);
+    for (int t = tid; t < count; t += 64) dst[t] = src[t];
+  }
   const double g0 = o.g[0], g1 = o.g[1];
   const double gj = (jj == 0) ? g0 : ((jj == 1) ? g1 : 0.0);
 
@@ -250,6 +299,7 @@ __global__ __launch_bounds__(64) void k_panels(const double* __restrict__ P, dou
 #pragma unroll
   for (int a = 0; a < CC; ++a) L[a] = Pb[(long)jj * ld + o.C[a]];
   const double raw_r2 = R[2], raw_c2 = L[2];
+  const double mu_i = mu_in[(long)b * ld + jj];
 
   // P' = G_F P G_F^T + F^T R F  (src/replay_no_ros.py:430) on the two panels
   R[0] += g0 * R[2];
@@ -273,24 +323,54 @@ __global__ __launch_bounds__(64) void k_panels(const double* __restrict__ P, dou
       R[a] += o.rd[a];
       L[a] += o.rd[a];
     }
+  __syncthreads();
 
-  double* Vb = V + (long)b * (2 * MMAX + 2) * ld;
-#pragma unroll
-  for (int k = 0; k < K2; ++k) {
-    double acc = 0.0;
-#pragma unroll
-    for (int a = 0; a < CC; ++a) acc += o.T[k][a] * R[a];
-    if (act) Vb[(long)k * ld + j] = acc;
-  }
+  double* Vb = V + (long)b * VS * ld;
+  double* Wr = W + ((long)b * ld + jj) * VS;
   double dm = 0.0;
-  double* Wr = W + ((long)b * ld + jj) * (2 * MMAX + 2);
 #pragma unroll
-  for (int k = 0; k < K2; ++k) {
-    double acc = 0.0;
+  for (int it = 0; it < MCAP; ++it) {
+    if (it < m) {
+      const SolveIter& I = its[it];
+      const int a0 = 3 + 2 * it;
+      double hp0 = 0.0, hp1 = 0.0, ph0 = 0.0, ph1 = 0.0;
 #pragma unroll
-    for (int a = 0; a < CC; ++a) acc += L[a] * o.U[a][k];
-    dm += acc * o.ys[k];
-    if (act) Wr[k] = -acc;
+      for (int k = 0; k < 5; ++k) {
+        const double2 hk = *reinterpret_cast<const double2*>(I.h5t[k]);
+        const double rv = (k < 3) ? R[k] : R[a0 + (k - 3)];
+        const double lv = (k < 3) ? L[k] : L[a0 + (k - 3)];
+        hp0 += hk.x * rv;
+        hp1 += hk.y * rv;
+        ph0 += lv * hk.x;
+        ph1 += lv * hk.y;
+      }
+      const double2 s01 = *reinterpret_cast<const double2*>(&I.si[0]);
+      const double2 s23 = *reinterpret_cast<const double2*>(&I.si[2]);
+      const double2 yy = *reinterpret_cast<const double2*>(I.y);
+      const double k0 = ph0 * s01.x + ph1 * s23.x;
+      const double k1 = ph0 * s01.y + ph1 * s23.y;
+      dm += k0 * yy.x + k1 * yy.y;
+      if (act) {
+        Vb[(long)(2 * it) * ld + j] = hp0;
+        Vb[(long)(2 * it + 1) * ld + j] = hp1;
+        Wr[2 * it] = -k0;
+        Wr[2 * it + 1] = -k1;
+      }
+      if (it + 1 < m) {
+#pragma unroll
+        for (int a = 0; a < CC; ++a) {
+          const double2 kc = *reinterpret_cast<const double2*>(I.kc[a]);
+          const double2 hc = *reinterpret_cast<const double2*>(I.hpt[a]);
+          R[a] -= kc.x * hp0 + kc.y * hp1;
+          L[a] -= k0 * hc.x + k1 * hc.y;
+        }
+      }
+    } else if (act) {
+      Vb[(long)(2 * it) * ld + j] = 0.0;
+      Vb[(long)(2 * it + 1) * ld + j] = 0.0;
+      Wr[2 * it] = 0.0;
+      Wr[2 * it + 1] = 0.0;
+    }
   }
   if (act) {
     Vb[(long)K2 * ld + j] = raw_r2 + o.p22h * gj;
@@ -298,11 +378,9 @@ __global__ __launch_bounds__(64) void k_panels(const double* __restrict__ P, dou
     Wr[K2] = gj;
     Wr[K2 + 1] = raw_c2 + o.p22h * gj;
     bool inC = false;
-    const int c = o.c;
     for (int a = 0; a < c; ++a) inC |= (o.C[a] == j);
-    if (!inC) mu[(long)b * ld + j] += dm;
+    if (!inC) mu_out[(long)b * ld + j] = mu_i + dm;
   }
-  (void)KT;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -310,83 +388,113 @@ __global__ __launch_bounds__(64) void k_panels(const double* __restrict__ P, dou
 // A wave owns a strip of 128 columns (2 adjacent doubles per lane = one 1 KiB row segment per
 // load/store instruction); its V strip lives in registers for the whole row block, W[i][:] is
 // wave-uniform and comes through the scalar cache.  UNR rows are in flight per wave.
+// NT: nontemporal loads AND stores -- for working sets beyond the 256 MiB Infinity Cache the pair
+// is worth +25 % (5.7-6.0 vs 4.5 TB/s measured); for a resident P plain accesses are faster.
+// The odd last column (n = 3+2N is odd) is done by the wave whose strip holds it, one row per lane.
 // ---------------------------------------------------------------------------------------------
-template <int MCAP, int UNR>
-__global__ __launch_bounds__(256) void k_pass(double* __restrict__ P, const double* __restrict__ V,
-                                              const double* __restrict__ W,
-                                              const int* __restrict__ nact,
-                                              const SolveOut* __restrict__ so, int ld, long pstride,
-                                              int rows_per_block) {
+template <bool NT>
+__device__ __forceinline__ double2 ld2(const double* a) {
+  double2 r;
+  if (NT) {
+    r.x = __builtin_nontemporal_load(a);
+    r.y = __builtin_nontemporal_load(a + 1);
+  } else {
+    r = *reinterpret_cast<const double2*>(a);
+  }
+  return r;
+}
+template <bool NT>
+__device__ __forceinline__ void st2(double* a, double2 v) {
+  if (NT) {
+    __builtin_nontemporal_store(v.x, a);
+    __builtin_nontemporal_store(v.y, a + 1);
+  } else {
+    *reinterpret_cast<double2*>(a) = v;
+  }
+}
+
+template <int MCAP, int UNR, int WAVES, bool NT>
+__global__ __launch_bounds__(WAVES * 64) void k_pass(double* __restrict__ P,
+                                                     const double* __restrict__ V,
+                                                     const double* __restrict__ W,
+                                                     const int* __restrict__ nact,
+                                                     const SolveOut* __restrict__ so, int ld,
+                                                     long pstride, int rows_per_block) {
   constexpr int KT = 2 * MCAP + 2;
   constexpr int WS = 2 * MMAX + 2;
   const int b = blockIdx.z;
   const int n = nact[b];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
-  const int strip = blockIdx.x * 4 + wave;
+  const int strip = blockIdx.x * WAVES + wave;
   const int i0 = blockIdx.y * rows_per_block;
   if (strip * 128 >= n || i0 >= n) return;
   const int i1 = min(n, i0 + rows_per_block);
   const int j0 = strip * 128 + lane * 2;
-  if (j0 >= n) return;
-  const bool two = (j0 + 1) < n;
 
   double* Pb = P + (long)b * pstride;
   const double* Vb = V + (long)b * WS * ld;
   const double* Wb = W + (long)b * ld * WS;
 
-  double2 v[KT];
+  if (j0 + 1 < n) {
+    double2 v[KT];
 #pragma unroll
-  for (int k = 0; k < KT; ++k) v[k] = *reinterpret_cast<const double2*>(Vb + (long)k * ld + j0);
-
-  int i = i0;
-  for (; i + UNR <= i1; i += UNR) {
-    double2 p[UNR];
+    for (int k = 0; k < KT; ++k) v[k] = *reinterpret_cast<const double2*>(Vb + (long)k * ld + j0);
+    int i = i0;
+    for (; i + UNR <= i1; i += UNR) {
+      double2 p[UNR];
 #pragma unroll
-    for (int u = 0; u < UNR; ++u) p[u] = *reinterpret_cast<const double2*>(Pb + (long)(i + u) * ld + j0);
+      for (int u = 0; u < UNR; ++u) p[u] = ld2<NT>(Pb + (long)(i + u) * ld + j0);
 #pragma unroll
-    for (int u = 0; u < UNR; ++u) {
-      const double* w = Wb + (long)(i + u) * WS;
+      for (int u = 0; u < UNR; ++u) {
+        const double* w = Wb + (long)(i + u) * WS;
+#pragma unroll
+        for (int k = 0; k < KT; ++k) {
+          const double wk = w[k];
+          p[u].x += wk * v[k].x;
+          p[u].y += wk * v[k].y;
+        }
+      }
+      if (i < 3) {
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+          const int r = i + u;
+          if (r < 3) {
+            if (j0 == r) p[u].x += so[b].rd[r];
+            if (j0 + 1 == r) p[u].y += so[b].rd[r];
+          }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) st2<NT>(Pb + (long)(i + u) * ld + j0, p[u]);
+    }
+    for (; i < i1; ++i) {
+      double2 p = ld2<NT>(Pb + (long)i * ld + j0);
+      const double* w = Wb + (long)i * WS;
 #pragma unroll
       for (int k = 0; k < KT; ++k) {
         const double wk = w[k];
-        p[u].x += wk * v[k].x;
-        p[u].y += wk * v[k].y;
+        p.x += wk * v[k].x;
+        p.y += wk * v[k].y;
       }
-    }
-    if (i < 3) {
-#pragma unroll
-      for (int u = 0; u < UNR; ++u) {
-        const int r = i + u;
-        if (r < 3) {
-          if (j0 == r) p[u].x += so[b].rd[r];
-          if (j0 + 1 == r) p[u].y += so[b].rd[r];
-        }
+      if (i < 3) {
+        if (j0 == i) p.x += so[b].rd[i];
+        if (j0 + 1 == i) p.y += so[b].rd[i];
       }
-    }
-#pragma unroll
-    for (int u = 0; u < UNR; ++u) {
-      double* dst = Pb + (long)(i + u) * ld + j0;
-      if (two) *reinterpret_cast<double2*>(dst) = p[u];
-      else *dst = p[u].x;
+      st2<NT>(Pb + (long)i * ld + j0, p);
     }
   }
-  for (; i < i1; ++i) {
-    double2 p = *reinterpret_cast<const double2*>(Pb + (long)i * ld + j0);
-    const double* w = Wb + (long)i * WS;
+  // odd last column: one row per lane
+  const int tail = n - 1;
+  if ((n & 1) && tail >= strip * 128 && tail < strip * 128 + 128) {
+    for (int r = i0 + lane; r < i1; r += 64) {
+      double p = Pb[(long)r * ld + tail];
+      const double* w = Wb + (long)r * WS;
 #pragma unroll
-    for (int k = 0; k < KT; ++k) {
-      const double wk = w[k];
-      p.x += wk * v[k].x;
-      p.y += wk * v[k].y;
+      for (int k = 0; k < KT; ++k) p += w[k] * Vb[(long)k * ld + tail];
+      if (r < 3 && r == tail) p += so[b].rd[r];
+      Pb[(long)r * ld + tail] = p;
     }
-    if (i < 3) {
-      if (j0 == i) p.x += so[b].rd[i];
-      if (j0 + 1 == i) p.y += so[b].rd[i];
-    }
-    double* dst = Pb + (long)i * ld + j0;
-    if (two) *reinterpret_cast<double2*>(dst) = p;
-    else *dst = p.x;
   }
 }
 
@@ -395,6 +503,8 @@ __global__ __launch_bounds__(256) void k_pass(double* __restrict__ P, const doub
 // (src/replay_no_ros.py:428-430 with G_F = I outside the 3x3 block).  O(n).
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_predict_rc(double* __restrict__ P,
+                                                    const double* __restrict__ mu_in,
+                                                    double* __restrict__ mu_out,
                                                     const int* __restrict__ nact,
                                                     const SolveOut* __restrict__ so, int ld,
                                                     long pstride) {
@@ -405,6 +515,7 @@ __global__ __launch_bounds__(256) void k_predict_rc(double* __restrict__ P,
   double* Pb = P + (long)b * pstride;
   const double g0 = so[b].g[0], g1 = so[b].g[1];
   if (j >= 3) {
+    mu_out[(long)b * ld + j] = mu_in[(long)b * ld + j];     // k_solve wrote the pose entries
     const double r2 = Pb[2 * (long)ld + j];
     Pb[j] += g0 * r2;
     Pb[(long)ld + j] += g1 * r2;
@@ -456,58 +567,69 @@ __global__ __launch_bounds__(256) void k_fill_diag(double* __restrict__ Pb, int 
 // ---------------------------------------------------------------------------------------------
 // launchers (called from ekf_api.hip)
 // ---------------------------------------------------------------------------------------------
-void launch_solve(hipStream_t st, const double* P, double* mu, const int* nact, const StepIn* in,
-                  SolveOut* out, unsigned* flags, const DeviceConfig& cfg, int ld, long pstride,
-                  int batch, int mcap) {
-  hipLaunchKernelGGL(k_solve, dim3(batch), dim3(64), 0, st, P, mu, nact, in, out, flags, cfg, ld,
-                     pstride, mcap);
+void launch_solve(hipStream_t st, const double* P, const double* mu_in, double* mu_out, const int* nact,
+                  const StepIn* in, SolveOut* out, unsigned* flags, const DeviceConfig& cfg, int ld,
+                  long pstride, int batch) {
+  hipLaunchKernelGGL(k_solve, dim3(batch), dim3(64), 0, st, P, mu_in, mu_out, nact, in, out, flags, cfg,
+                     ld, pstride);
 }
 
 template <int MCAP>
-static void launch_panels_t(hipStream_t st, const double* P, double* mu, const int* nact,
-                            const SolveOut* so, double* V, double* W, int ld, long pstride, int batch,
-                            int n_hi) {
-  hipLaunchKernelGGL(k_panels<MCAP>, dim3((n_hi + 63) / 64, batch), dim3(64), 0, st, P, mu, nact, so,
-                     V, W, ld, pstride);
+static void launch_panels_t(hipStream_t st, const double* P, const double* mu_in, double* mu_out,
+                            const int* nact, const SolveOut* so, double* V, double* W, int ld,
+                            long pstride, int batch, int n_hi) {
+  hipLaunchKernelGGL(k_panels<MCAP>, dim3((n_hi + 63) / 64, batch), dim3(64), 0, st, P, mu_in, mu_out,
+                     nact, so, V, W, ld, pstride);
 }
 
-void launch_panels(hipStream_t st, int mcap, const double* P, double* mu, const int* nact,
-                   const SolveOut* so, double* V, double* W, int ld, long pstride, int batch,
-                   int n_hi) {
+void launch_panels(hipStream_t st, int mcap, const double* P, const double* mu_in, double* mu_out,
+                   const int* nact, const SolveOut* so, double* V, double* W, int ld, long pstride,
+                   int batch, int n_hi) {
   switch (mcap) {
-    case 1: launch_panels_t<1>(st, P, mu, nact, so, V, W, ld, pstride, batch, n_hi); break;
-    case 2: launch_panels_t<2>(st, P, mu, nact, so, V, W, ld, pstride, batch, n_hi); break;
-    case 4: launch_panels_t<4>(st, P, mu, nact, so, V, W, ld, pstride, batch, n_hi); break;
-    case 8: launch_panels_t<8>(st, P, mu, nact, so, V, W, ld, pstride, batch, n_hi); break;
-    default: launch_panels_t<16>(st, P, mu, nact, so, V, W, ld, pstride, batch, n_hi); break;
+    case 1: launch_panels_t<1>(st, P, mu_in, mu_out, nact, so, V, W, ld, pstride, batch, n_hi); break;
+    case 2: launch_panels_t<2>(st, P, mu_in, mu_out, nact, so, V, W, ld, pstride, batch, n_hi); break;
+    case 4: launch_panels_t<4>(st, P, mu_in, mu_out, nact, so, V, W, ld, pstride, batch, n_hi); break;
+    case 8: launch_panels_t<8>(st, P, mu_in, mu_out, nact, so, V, W, ld, pstride, batch, n_hi); break;
+    default: launch_panels_t<16>(st, P, mu_in, mu_out, nact, so, V, W, ld, pstride, batch, n_hi); break;
   }
 }
 
-template <int MCAP, int UNR>
+template <int MCAP, int UNR, int WAVES, bool NT>
 static void launch_pass_t(hipStream_t st, double* P, const double* V, const double* W,
                           const int* nact, const SolveOut* so, int ld, long pstride, int batch,
                           int n_hi, int rows_per_block) {
-  dim3 grid((n_hi + 511) / 512, (n_hi + rows_per_block - 1) / rows_per_block, batch);
-  hipLaunchKernelGGL((k_pass<MCAP, UNR>), grid, dim3(256), 0, st, P, V, W, nact, so, ld, pstride,
-                     rows_per_block);
+  dim3 grid((n_hi + 128 * WAVES - 1) / (128 * WAVES), (n_hi + rows_per_block - 1) / rows_per_block, batch);
+  hipLaunchKernelGGL((k_pass<MCAP, UNR, WAVES, NT>), grid, dim3(WAVES * 64), 0, st, P, V, W, nact, so, ld,
+                     pstride, rows_per_block);
 }
 
-void launch_pass(hipStream_t st, int mcap, double* P, const double* V, const double* W,
+// streaming = the batch's covariances do not fit the Infinity Cache: nontemporal, 4 waves x 8 rows;
+// resident  = plain accesses, 8 waves x 4 rows (measured best on a 128 MB P, tools/pass_bench.hip).
+template <int MCAP>
+static void launch_pass_m(hipStream_t st, bool streaming, double* P, const double* V, const double* W,
+                          const int* nact, const SolveOut* so, int ld, long pstride, int batch, int n_hi,
+                          int rows_per_block) {
+  constexpr int U_S = MCAP >= 16 ? 4 : 8;
+  if (streaming) launch_pass_t<MCAP, U_S, 4, true>(st, P, V, W, nact, so, ld, pstride, batch, n_hi, rows_per_block);
+  else launch_pass_t<MCAP, 4, 8, false>(st, P, V, W, nact, so, ld, pstride, batch, n_hi, rows_per_block);
+}
+
+void launch_pass(hipStream_t st, int mcap, bool streaming, double* P, const double* V, const double* W,
                  const int* nact, const SolveOut* so, int ld, long pstride, int batch, int n_hi,
                  int rows_per_block) {
   switch (mcap) {
-    case 1: launch_pass_t<1, 8>(st, P, V, W, nact, so, ld, pstride, batch, n_hi, rows_per_block); break;
-    case 2: launch_pass_t<2, 8>(st, P, V, W, nact, so, ld, pstride, batch, n_hi, rows_per_block); break;
-    case 4: launch_pass_t<4, 8>(st, P, V, W, nact, so, ld, pstride, batch, n_hi, rows_per_block); break;
-    case 8: launch_pass_t<8, 8>(st, P, V, W, nact, so, ld, pstride, batch, n_hi, rows_per_block); break;
-    default: launch_pass_t<16, 4>(st, P, V, W, nact, so, ld, pstride, batch, n_hi, rows_per_block); break;
+    case 1: launch_pass_m<1>(st, streaming, P, V, W, nact, so, ld, pstride, batch, n_hi, rows_per_block); break;
+    case 2: launch_pass_m<2>(st, streaming, P, V, W, nact, so, ld, pstride, batch, n_hi, rows_per_block); break;
+    case 4: launch_pass_m<4>(st, streaming, P, V, W, nact, so, ld, pstride, batch, n_hi, rows_per_block); break;
+    case 8: launch_pass_m<8>(st, streaming, P, V, W, nact, so, ld, pstride, batch, n_hi, rows_per_block); break;
+    default: launch_pass_m<16>(st, streaming, P, V, W, nact, so, ld, pstride, batch, n_hi, rows_per_block); break;
   }
 }
 
-void launch_predict_rc(hipStream_t st, double* P, const int* nact, const SolveOut* so, int ld,
-                       long pstride, int batch, int n_hi) {
-  hipLaunchKernelGGL(k_predict_rc, dim3((n_hi + 255) / 256, batch), dim3(256), 0, st, P, nact, so, ld,
-                     pstride);
+void launch_predict_rc(hipStream_t st, double* P, const double* mu_in, double* mu_out, const int* nact,
+                       const SolveOut* so, int ld, long pstride, int batch, int n_hi) {
+  hipLaunchKernelGGL(k_predict_rc, dim3((n_hi + 255) / 256, batch), dim3(256), 0, st, P, mu_in, mu_out,
+                     nact, so, ld, pstride);
 }
 
 void launch_add_landmarks(hipStream_t st, double* Pb, double* mub, int ld, int n_old, int n_new,
