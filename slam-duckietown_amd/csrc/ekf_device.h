@@ -43,6 +43,9 @@ struct alignas(16) SolveOut {
   int m;
   int C[CMAX + 3];      // gathered state indices, padded with 0 (38 ints keep `it` 16-byte aligned)
   SolveIter it[MMAX];
+#ifdef EKF_STAMPS
+  unsigned long long stamps[128];   // diagnostic build only (tools/solve_probe.hip)
+#endif
 };
 static_assert(offsetof(SolveOut, it) % 16 == 0, "SolveOut::it must be 16-byte aligned");
 

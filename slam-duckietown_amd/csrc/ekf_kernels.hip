@@ -13,6 +13,20 @@
 
 #include "ekf_device.h"
 
+// Diagnostic stamps (tools/solve_probe.hip builds with -DEKF_STAMPS); compiled out of the product.
+#ifdef EKF_STAMPS
+#define STAMP(o, i)                                                                          \
+  do {                                                                                       \
+    __builtin_amdgcn_sched_barrier(0);                                                       \
+    unsigned long long t_;                                                                   \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");               \
+    __builtin_amdgcn_sched_barrier(0);                                                       \
+    if (threadIdx.x == 0) (o).stamps[i] = t_;                                                \
+  } while (0)
+#else
+#define STAMP(o, i) do { } while (0)
+#endif
+
 namespace ekf {
 
 __device__ __forceinline__ double wrap_pi(double a) {
@@ -33,18 +47,23 @@ __device__ __forceinline__ double wrap_pi(double a) {
 __device__ __forceinline__ void linearize(const double* muc, int a, double z_range, double z_bearing,
                                           double (&h)[2][5], double& y0, double& y1) {
   const double dx = muc[a] - muc[0], dy = muc[a + 1] - muc[1];   // :443
+  const double th = muc[2];
   const double q = dx * dx + dy * dy;                             // :446
-  const double sq = sqrt(q);
+  // 1/sqrt(q) once (hardware estimate + two Newton steps, <= 1 ulp); sqrt(q) = q * rs, 1/q = rs * rs.
+  // q == 0 -> rs = inf -> NaN rows below, like NumPy's 0/0 at :466-469.
+  double rs = __builtin_amdgcn_rsq(q);
+  rs = rs * fma(-0.5 * q * rs, rs, 1.5);
+  rs = rs * fma(-0.5 * q * rs, rs, 1.5);
+  const double sq = q * rs;
+  const double rq = rs * rs;
   y0 = z_range - sq;                                              // :455
-  y1 = wrap_pi(z_bearing - (atan2(dy, dx) - muc[2]));             // :453-458
-  const double rq = 1.0 / q;
-  const double hs = sq * rq;                                      // sqrt(q)/q
+  y1 = wrap_pi(z_bearing - (atan2(dy, dx) - th));                 // :453-458
   const double nanv = __builtin_nan("");
-  h[0][0] = -hs * dx;
-  h[0][1] = -hs * dy;
+  h[0][0] = -rs * dx;                                             // (-sqrt(q) dx) / q
+  h[0][1] = -rs * dy;
   h[0][2] = (q > 0.0) ? 0.0 : nanv;                               // .0 / q
-  h[0][3] = hs * dx;
-  h[0][4] = hs * dy;
+  h[0][3] = rs * dx;
+  h[0][4] = rs * dy;
   h[1][0] = dy * rq;
   h[1][1] = -dx * rq;
   h[1][2] = (q > 0.0 && q < __builtin_inf()) ? -1.0 : nanv;       // -q / q
@@ -53,10 +72,18 @@ __device__ __forceinline__ void linearize(const double* muc, int a, double z_ran
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_solve: one 64-lane wave per trajectory; lane l < c owns compressed index l.
+// k_solve: one 64-lane wave per trajectory; lane l < c owns compressed index l and keeps column l
+// of P[C,C] in registers (written through to LDS for the row/column reads of the other lanes).
+// The kernel is latency-bound (one wave, m sequential iterations): every phase is written as
+// batches of independent operations, and the next landmark's linearisation (atan2, sqrt, 1/q:
+// ~0.2 us) is issued beside the covariance down-date, which does not depend on it.
 // Reads mu_in, writes mu_out[C] (the mean is double-buffered so that no kernel of a step reads
 // an entry another workgroup of the same step writes).
 // ---------------------------------------------------------------------------------------------
+constexpr int PCS = CMAX + 2;   // LDS row stride 37 doubles: column reads by 32 lanes are conflict-free
+constexpr int RCH = 8;          // rows per batch of the down-date
+constexpr int CPAD = (CMAX + RCH - 1) / RCH * RCH;   // 40
+
 __global__ __launch_bounds__(64) void k_solve(const double* __restrict__ P,
                                               const double* __restrict__ mu_in,
                                               double* __restrict__ mu_out,
@@ -71,90 +98,94 @@ __global__ __launch_bounds__(64) void k_solve(const double* __restrict__ P,
   SolveOut& o = out[b];
   const double* Pb = P + (long)b * pstride;
 
-  __shared__ double Pc[CMAX][CMAX + 1];
-  __shared__ double muc[CMAX];
-  __shared__ double2 hpS[CMAX], kcS[CMAX];
-  __shared__ int Cs[CMAX + 3];
+  __shared__ double Pc[CPAD][PCS];
+  __shared__ double muc[CPAD];
+  __shared__ double2 hpS[CPAD], kcS[CPAD];
+  __shared__ int Cs[CPAD];
 
+  STAMP(o, 0);
+  // inputs: the index list is fetched unconditionally so that it travels with flags/m (one round trip)
+  const int my_idx = (lane >= 3 && lane < CMAX) ? s.idx[(lane - 3) >> 1] : 0;
   const bool do_pred = (s.flags & FLAG_PREDICT) != 0;
   int m = ((s.flags & FLAG_UPDATE) && cfg.enable_measurement_model) ? s.m : 0;
   if (m > MMAX) m = MMAX;
   const int c = 3 + 2 * m;
-
-  if (lane < CMAX + 3) {
-    int v = 0;
-    if (lane < 3) v = lane;
-    else if (lane < c) v = 3 + 2 * s.idx[(lane - 3) >> 1] + ((lane - 3) & 1);
-    Cs[lane] = v;
-    o.C[lane] = v;
+  const bool on = lane < c;
+  const int ll = on ? lane : 0;                       // clamped lane for in-bounds LDS reads
+  const int Cl = (lane < 3) ? lane : (on ? 3 + 2 * my_idx + ((lane - 3) & 1) : 0);
+  if (lane < CPAD) {
+    Cs[lane] = Cl;
+    kcS[lane] = make_double2(0.0, 0.0);
+    hpS[lane] = make_double2(0.0, 0.0);
+    if (lane < CMAX + 3) o.C[lane] = Cl;
   }
+  const double mu_l = mu_in[(long)b * ld + Cl];
   __syncthreads();
-  // element walk e = lane + 64 t over the c x c block without per-element division
-  const int q64 = 64 / c, r64 = 64 - q64 * c;
-  const int r_first = lane / c, c_first = lane - r_first * c;
+  STAMP(o, 1);
+  double pcol[CPAD];
   {
-    int r = r_first, cc = c_first;
-    while (r < c) {
-      Pc[r][cc] = Pb[(long)Cs[r] * ld + Cs[cc]];
-      r += q64;
-      cc += r64;
-      if (cc >= c) { cc -= c; ++r; }
+    const double* colp = Pb + Cl;
+#pragma unroll
+    for (int r = 0; r < CPAD; ++r) pcol[r] = (r < 3 || (on && r < c)) ? colp[(long)Cs[r] * ld] : 0.0;
+    if (!on) {
+#pragma unroll
+      for (int r = 0; r < 3; ++r) pcol[r] = 0.0;
     }
   }
-  if (lane < c) muc[lane] = mu_in[(long)b * ld + Cs[lane]];
-  __syncthreads();
-
+  STAMP(o, 2);
   // ---- motion model (src/replay_no_ros.py:368-417), evaluated redundantly by every lane ----
-  const double th = muc[2];
-  double g0 = 0.0, g1 = 0.0, nx = muc[0], ny = muc[1], nth = th;
+  const double th = __shfl(mu_l, 2);
+  double g0 = 0.0, g1 = 0.0, nx = __shfl(mu_l, 0), ny = __shfl(mu_l, 1), nth = th;
   if (do_pred && !cfg.disable_motion_model) {
     const double lin = s.lin, ang = s.ang;
-    if (cfg.enable_circular_interpolation) {
-      if (fabs(ang) <= cfg.arc_threshold) {               // :376 straight, theta not advanced
-        nx += lin * cos(th);
-        ny += lin * sin(th);
-        g0 = -lin * sin(th);
-        g1 = lin * cos(th);
-      } else {                                            // :390 arc
-        const double r = lin / ang;
-        nx += -r * sin(th) + r * sin(th + ang);
-        ny += r * cos(th) - r * cos(th + ang);
-        nth = wrap_pi(th + ang);                          // :397
-        g0 = -r * cos(th) + r * cos(th + ang);            // :401
-        g1 = -r * sin(th) + r * sin(th + ang);            // :402
-      }
-    } else {                                              // :405-417, no wrap
-      nx += lin * cos(th);
-      ny += lin * sin(th);
-      nth = th + ang;
-      g0 = -lin * sin(th);
-      g1 = lin * cos(th);
+    double s0, c0;
+    sincos(th, &s0, &c0);
+    if (cfg.enable_circular_interpolation && fabs(ang) > cfg.arc_threshold) {   // :390 arc
+      double s1, c1;
+      sincos(th + ang, &s1, &c1);
+      const double r = lin / ang;
+      nx += -r * s0 + r * s1;
+      ny += r * c0 - r * c1;
+      nth = wrap_pi(th + ang);                            // :397
+      g0 = -r * c0 + r * c1;                              // :401
+      g1 = -r * s0 + r * s1;                              // :402
+    } else {                                              // :376 straight / :405-417 linear mode
+      nx += lin * c0;
+      ny += lin * s0;
+      if (!cfg.enable_circular_interpolation) nth = th + ang;   // no wrap (:409); :381 keeps theta
+      g0 = -lin * s0;
+      g1 = lin * c0;
     }
   }
   const double rd0 = do_pred ? cfg.rd[0] : 0.0, rd1 = do_pred ? cfg.rd[1] : 0.0,
                rd2 = do_pred ? cfg.rd[2] : 0.0;
-  const double p22 = Pc[2][2];
-  __syncthreads();
-  // P'[C,C] = Gc P[C,C] Gc^T + Rt  (:428-430 restricted to C)
-  if (lane < c) {
-    const double r2 = Pc[2][lane];
-    Pc[0][lane] += g0 * r2;
-    Pc[1][lane] += g1 * r2;
+  STAMP(o, 3);
+  // P'[C,C] = Gc P[C,C] Gc^T + Rt  (:428-430 restricted to C), column `lane` in registers:
+  // row ops on rows 0,1; column ops need column 2 of the row-updated matrix (lane 2's registers).
+  const double p22 = __shfl(pcol[2], 2);
+  pcol[0] += g0 * pcol[2];
+  pcol[1] += g1 * pcol[2];
+  if (lane == 2) {                                   // X[:,2] after the row ops, for the column ops
+#pragma unroll
+    for (int r = 0; r < CPAD; ++r) muc[r] = pcol[r];
   }
   __syncthreads();
-  if (lane < c) {
-    const double c2 = Pc[lane][2];
-    Pc[lane][0] += g0 * c2;
-    Pc[lane][1] += g1 * c2;
+  if (lane < 2) {
+    const double gl = (lane == 0) ? g0 : g1;
+#pragma unroll
+    for (int r = 0; r < CPAD; ++r) pcol[r] = fma(gl, muc[r], pcol[r]);
   }
+  if (lane == 0) pcol[0] += rd0;
+  if (lane == 1) pcol[1] += rd1;
+  if (lane == 2) pcol[2] += rd2;
   __syncthreads();
+  if (on) {
+#pragma unroll
+    for (int r = 0; r < CPAD; ++r) Pc[r][lane] = pcol[r];
+  }
+  double mu_cur = (lane == 0) ? nx : ((lane == 1) ? ny : ((lane == 2) ? nth : mu_l));
+  if (lane < CPAD) muc[lane] = on ? mu_cur : 0.0;
   if (lane == 0) {
-    Pc[0][0] += rd0;
-    Pc[1][1] += rd1;
-    Pc[2][2] += rd2;
-    muc[0] = nx;
-    muc[1] = ny;
-    muc[2] = nth;
     o.g[0] = g0;
     o.g[1] = g1;
     o.rd[0] = rd0;
@@ -166,73 +197,93 @@ __global__ __launch_bounds__(64) void k_solve(const double* __restrict__ P,
   }
   __syncthreads();
 
+  STAMP(o, 4);
   // ---- sequential per-landmark recurrences (:436-480) on the compressed system ----
   double h[2][5], y0 = 0.0, y1 = 0.0;
   if (m > 0) linearize(muc, 3, s.range[0], s.bearing[0], h, y0, y1);
+  STAMP(o, 5);
   for (int j = 0; j < m; ++j) {
     const int a = 3 + 2 * j;
     SolveIter& it = o.it[j];
-    double ph0 = 0.0, ph1 = 0.0;
-    if (lane < c) {
-      double hp0 = 0.0, hp1 = 0.0;
-#pragma unroll
-      for (int k = 0; k < 5; ++k) {
-        const int sk = (k < 3) ? k : a + (k - 3);
-        const double pr = Pc[sk][lane];        // row sk of P_j at column C[lane]
-        const double pc = Pc[lane][sk];        // column sk of P_j at row C[lane]
-        hp0 += h[0][k] * pr;                   // (H P)[0, C[lane]]
-        hp1 += h[1][k] * pr;
-        ph0 += pc * h[0][k];                   // (P H^T)[C[lane], 0]
-        ph1 += pc * h[1][k];
-      }
-      hpS[lane] = make_double2(hp0, hp1);
-      *reinterpret_cast<double2*>(it.hpt[lane]) = make_double2(hp0, hp1);
-    } else if (lane < CMAX) {
-      *reinterpret_cast<double2*>(it.hpt[lane]) = make_double2(0.0, 0.0);
-      *reinterpret_cast<double2*>(it.kc[lane]) = make_double2(0.0, 0.0);
-    }
-    __syncthreads();
-    double S00 = cfg.qd[0], S01 = 0.0, S10 = 0.0, S11 = cfg.qd[1];     // :473  S = H P H^T + Q
+    STAMP(o, 8 + 6 * j);
+    // phase A: rows sel of P_j at column C[lane] (H P) and columns sel at row C[lane] (P H^T).
+    // A lone wave issues one fp64 VALU op per ~8 cycles, so the instruction count is what matters:
+    // S is formed from the five hp pairs the other lanes publish in LDS (20 FMAs), not recomputed.
+    double pr[5], pq[5];
 #pragma unroll
     for (int k = 0; k < 5; ++k) {
       const int sk = (k < 3) ? k : a + (k - 3);
-      const double2 v = hpS[sk];
-      S00 += v.x * h[0][k];
-      S01 += v.x * h[1][k];
-      S10 += v.y * h[0][k];
-      S11 += v.y * h[1][k];
+      pr[k] = Pc[sk][ll];
+      pq[k] = Pc[ll][sk];
+    }
+    double hp0 = h[0][0] * pr[0], hp1 = h[1][0] * pr[0], ph0 = pq[0] * h[0][0], ph1 = pq[0] * h[1][0];
+#pragma unroll
+    for (int k = 1; k < 5; ++k) {
+      hp0 = fma(h[0][k], pr[k], hp0);
+      hp1 = fma(h[1][k], pr[k], hp1);
+      ph0 = fma(pq[k], h[0][k], ph0);
+      ph1 = fma(pq[k], h[1][k], ph1);
+    }
+    if (on) hpS[lane] = make_double2(hp0, hp1);
+    if (lane < CMAX) *reinterpret_cast<double2*>(it.hpt[lane]) = on ? make_double2(hp0, hp1) : make_double2(0.0, 0.0);
+    __syncthreads();
+    STAMP(o, 9 + 6 * j);
+    // phase B: S = H P H^T + Q (:473), every lane redundantly
+    double2 hv[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) hv[k] = hpS[(k < 3) ? k : a + (k - 3)];
+    double S00 = cfg.qd[0], S01 = 0.0, S10 = 0.0, S11 = cfg.qd[1];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+      S00 = fma(hv[k].x, h[0][k], S00);
+      S01 = fma(hv[k].x, h[1][k], S01);
+      S10 = fma(hv[k].y, h[0][k], S10);
+      S11 = fma(hv[k].y, h[1][k], S11);
     }
     const double rdet = 1.0 / (S00 * S11 - S01 * S10);
     const double i00 = S11 * rdet, i01 = -S01 * rdet, i10 = -S10 * rdet, i11 = S00 * rdet;
-    if (lane < c) {
-      const double k0 = ph0 * i00 + ph1 * i10;                          // K_j[C[lane], :]
-      const double k1 = ph0 * i01 + ph1 * i11;
+    const double k0 = ph0 * i00 + ph1 * i10;                            // K_j[C[lane], :]
+    const double k1 = ph0 * i01 + ph1 * i11;
+    if (on) {
       kcS[lane] = make_double2(k0, k1);
-      *reinterpret_cast<double2*>(it.kc[lane]) = make_double2(k0, k1);
-      muc[lane] += k0 * y0 + k1 * y1;                                   // :476
+      mu_cur += k0 * y0 + k1 * y1;                                      // :476
+      muc[lane] = mu_cur;
     }
+    if (lane < CMAX) *reinterpret_cast<double2*>(it.kc[lane]) = on ? make_double2(k0, k1) : make_double2(0.0, 0.0);
     if (lane == 0) {
 #pragma unroll
       for (int k = 0; k < 5; ++k) *reinterpret_cast<double2*>(it.h5t[k]) = make_double2(h[0][k], h[1][k]);
-      it.si[0] = i00; it.si[1] = i01; it.si[2] = i10; it.si[3] = i11;
-      it.y[0] = y0; it.y[1] = y1;
+      *reinterpret_cast<double2*>(&it.si[0]) = make_double2(i00, i01);
+      *reinterpret_cast<double2*>(&it.si[2]) = make_double2(i10, i11);
+      *reinterpret_cast<double2*>(it.y) = make_double2(y0, y1);
     }
     __syncthreads();
-    // next landmark's linearisation depends only on the mean: overlaps the covariance down-date
-    double hn[2][5], yn0 = 0.0, yn1 = 0.0;
-    if (j + 1 < m) linearize(muc, a + 2, s.range[j + 1], s.bearing[j + 1], hn, yn0, yn1);
-    {
-      int r = r_first, cc = c_first;                                    // :480 restricted to C
-      while (r < c) {
-        const double2 kr = kcS[r], hc = hpS[cc];
-        Pc[r][cc] -= kr.x * hc.x + kr.y * hc.y;
-        r += q64;
-        cc += r64;
-        if (cc >= c) { cc -= c; ++r; }
-      }
-    }
-    __syncthreads();
+    STAMP(o, 10 + 6 * j);
+    // phase C: the gains of every row are fetched first, the next landmark's linearisation (needs
+    // only the mean) runs while they land, then the down-date (:480) as batches of independent FMAs
     if (j + 1 < m) {
+      double2 kr[CPAD];
+#pragma unroll
+      for (int r0 = 0; r0 < CPAD; r0 += RCH)
+        if (r0 < c) {
+#pragma unroll
+          for (int u = 0; u < RCH; ++u) kr[r0 + u] = kcS[r0 + u];
+        }
+      double hn[2][5], yn0, yn1;
+      linearize(muc, a + 2, s.range[j + 1], s.bearing[j + 1], hn, yn0, yn1);
+      STAMP(o, 11 + 6 * j);
+#pragma unroll
+      for (int r0 = 0; r0 < CPAD; r0 += RCH)
+        if (r0 < c) {
+#pragma unroll
+          for (int u = 0; u < RCH; ++u) pcol[r0 + u] = fma(-kr[r0 + u].x, hp0, pcol[r0 + u]);
+#pragma unroll
+          for (int u = 0; u < RCH; ++u) pcol[r0 + u] = fma(-kr[r0 + u].y, hp1, pcol[r0 + u]);
+          if (on) {
+#pragma unroll
+            for (int u = 0; u < RCH; ++u) Pc[r0 + u][lane] = pcol[r0 + u];
+          }
+        }
 #pragma unroll
       for (int r = 0; r < 2; ++r)
 #pragma unroll
@@ -240,13 +291,15 @@ __global__ __launch_bounds__(64) void k_solve(const double* __restrict__ P,
       y0 = yn0;
       y1 = yn1;
     }
+    __syncthreads();
+    STAMP(o, 12 + 6 * j);
   }
 
+  STAMP(o, 6);
   bool bad = false;
-  if (lane < c) {
-    const double v = muc[lane];
-    mu_out[(long)b * ld + Cs[lane]] = v;
-    bad = !(fabs(v) <= 1.79769313486231570815e308);
+  if (on) {
+    mu_out[(long)b * ld + Cl] = mu_cur;
+    bad = !(fabs(mu_cur) <= 1.79769313486231570815e308);
   }
   if (__any(bad) && lane == 0) atomicOr(&flags[b], EKF_FLAG_NONFINITE);
 }
@@ -333,20 +386,33 @@ __global__ __launch_bounds__(64) void k_panels(const double* __restrict__ P,
     if (it < m) {
       const SolveIter& I = its[it];
       const int a0 = 3 + 2 * it;
-      double hp0 = 0.0, hp1 = 0.0, ph0 = 0.0, ph1 = 0.0;
+      const bool more = it + 1 < m;
+      // every LDS broadcast read of the iteration is issued up front (one latency exposure)
+      double2 hk[5];
 #pragma unroll
-      for (int k = 0; k < 5; ++k) {
-        const double2 hk = *reinterpret_cast<const double2*>(I.h5t[k]);
-        const double rv = (k < 3) ? R[k] : R[a0 + (k - 3)];
-        const double lv = (k < 3) ? L[k] : L[a0 + (k - 3)];
-        hp0 += hk.x * rv;
-        hp1 += hk.y * rv;
-        ph0 += lv * hk.x;
-        ph1 += lv * hk.y;
-      }
+      for (int k = 0; k < 5; ++k) hk[k] = *reinterpret_cast<const double2*>(I.h5t[k]);
       const double2 s01 = *reinterpret_cast<const double2*>(&I.si[0]);
       const double2 s23 = *reinterpret_cast<const double2*>(&I.si[2]);
       const double2 yy = *reinterpret_cast<const double2*>(I.y);
+      constexpr bool PREFETCH = MCAP <= 8;
+      double2 kcv[PREFETCH ? CC : 1], hcv[PREFETCH ? CC : 1];
+      if (PREFETCH && more) {
+#pragma unroll
+        for (int a = 0; a < CC; ++a) {
+          kcv[a] = *reinterpret_cast<const double2*>(I.kc[a]);
+          hcv[a] = *reinterpret_cast<const double2*>(I.hpt[a]);
+        }
+      }
+      double hp0 = hk[0].x * R[0], hp1 = hk[0].y * R[0], ph0 = L[0] * hk[0].x, ph1 = L[0] * hk[0].y;
+#pragma unroll
+      for (int k = 1; k < 5; ++k) {
+        const double rv = (k < 3) ? R[k] : R[a0 + (k - 3)];
+        const double lv = (k < 3) ? L[k] : L[a0 + (k - 3)];
+        hp0 = fma(hk[k].x, rv, hp0);
+        hp1 = fma(hk[k].y, rv, hp1);
+        ph0 = fma(lv, hk[k].x, ph0);
+        ph1 = fma(lv, hk[k].y, ph1);
+      }
       const double k0 = ph0 * s01.x + ph1 * s23.x;
       const double k1 = ph0 * s01.y + ph1 * s23.y;
       dm += k0 * yy.x + k1 * yy.y;
@@ -356,13 +422,41 @@ __global__ __launch_bounds__(64) void k_panels(const double* __restrict__ P,
         Wr[2 * it] = -k0;
         Wr[2 * it + 1] = -k1;
       }
-      if (it + 1 < m) {
+      if (more) {
+        if (PREFETCH) {
 #pragma unroll
-        for (int a = 0; a < CC; ++a) {
-          const double2 kc = *reinterpret_cast<const double2*>(I.kc[a]);
-          const double2 hc = *reinterpret_cast<const double2*>(I.hpt[a]);
-          R[a] -= kc.x * hp0 + kc.y * hp1;
-          L[a] -= k0 * hc.x + k1 * hc.y;
+          for (int a = 0; a < CC; ++a) {
+            R[a] = fma(-kcv[a].x, hp0, R[a]);
+            L[a] = fma(-k0, hcv[a].x, L[a]);
+          }
+#pragma unroll
+          for (int a = 0; a < CC; ++a) {
+            R[a] = fma(-kcv[a].y, hp1, R[a]);
+            L[a] = fma(-k1, hcv[a].y, L[a]);
+          }
+        } else {
+#pragma unroll
+          for (int c0 = 0; c0 < CC; c0 += 8) {
+            double2 kc[8], hc[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+              if (c0 + u < CC) {
+                kc[u] = *reinterpret_cast<const double2*>(I.kc[c0 + u]);
+                hc[u] = *reinterpret_cast<const double2*>(I.hpt[c0 + u]);
+              }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+              if (c0 + u < CC) {
+                R[c0 + u] = fma(-kc[u].x, hp0, R[c0 + u]);
+                L[c0 + u] = fma(-k0, hc[u].x, L[c0 + u]);
+              }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+              if (c0 + u < CC) {
+                R[c0 + u] = fma(-kc[u].y, hp1, R[c0 + u]);
+                L[c0 + u] = fma(-k1, hc[u].y, L[c0 + u]);
+              }
+          }
         }
       }
     } else if (act) {
