@@ -91,6 +91,10 @@ int ekf_run_stream(ekf_handle *h, int steps, const double *lin, const double *an
  * arbitrary Jacobian. */
 int ekf_predict_dense(ekf_handle *h, int b, const double *F, const double *Q);
 
+/* The covariance is held as P_base + (pending low-rank update of the last few steps); the O(n^2) pass
+ * over P_base is paid once per `flush_every` steps (option, default 4).  ekf_flush applies what is
+ * pending now (asynchronous).  Every call that reads or rewrites the covariance flushes by itself. */
+int ekf_flush(ekf_handle *h);
 int ekf_sync(ekf_handle *h);
 int ekf_status_flags(ekf_handle *h, int b, unsigned *flags);
 
@@ -100,10 +104,11 @@ const char *ekf_last_error(ekf_handle *h);
 /* --- measurement hooks (HIP events on the handle's own stream) --- */
 int ekf_timer_begin(ekf_handle *h);
 int ekf_timer_end(ekf_handle *h, double *elapsed_ms);          /* synchronises */
-/* When enabled every launch of the covariance-pass kernel is bracketed by an event pair. */
+/* When enabled every launch of the covariance pass (flush) kernel is bracketed by an event pair. */
 int ekf_profile_enable(ekf_handle *h, int on);
 int ekf_profile_read(ekf_handle *h, double *pass_ms_total, long long *pass_launches); /* and resets */
-/* Tuning knobs (rows per workgroup of the pass kernel etc.); name/value, unknown names fail. */
+/* Tuning knobs: "flush_every" (steps per covariance pass, 0 = auto), "pass_rows_per_block",
+ * "pass_streaming" (-1 auto / 0 resident / 1 nontemporal); unknown names fail. */
 int ekf_set_option(ekf_handle *h, const char *name, int value);
 
 #ifdef __cplusplus

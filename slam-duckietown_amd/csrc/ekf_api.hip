@@ -10,12 +10,12 @@
 #include "ekf_device.h"
 
 namespace ekf {
-void launch_solve(hipStream_t, const double*, const double*, double*, const int*, const StepIn*, SolveOut*,
-                  unsigned*, const DeviceConfig&, int, long, int);
-void launch_panels(hipStream_t, int, const double*, const double*, double*, const int*, const SolveOut*,
-                   double*, double*, int, long, int, int);
-void launch_pass(hipStream_t, int, bool, double*, const double*, const double*, const int*, const SolveOut*,
-                 int, long, int, int, int);
+void launch_solve(hipStream_t, const double*, const double*, const double*, double*, const double*, double*,
+                  const int*, const StepIn*, SolveOut*, unsigned*, const DeviceConfig&, int, long, int, int);
+void launch_panels(hipStream_t, int, const double*, double*, double*, const double*, double*, const int*,
+                   const SolveOut*, int, long, int, int);
+void launch_flush(hipStream_t, bool, double*, const double*, const double*, const double*, const int*, int,
+                  long, int, int, int, int);
 void launch_predict_rc(hipStream_t, double*, const double*, double*, const int*, const SolveOut*, int, long,
                        int, int);
 void launch_add_landmarks(hipStream_t, double*, double*, int, int, int, double, const double*);
@@ -34,7 +34,8 @@ struct ekf_handle {
   ekf_config cfg{};
   DeviceConfig dcfg{};
   hipStream_t stream = nullptr;
-  double *dP = nullptr, *dV = nullptr, *dW = nullptr, *dscratch = nullptr;
+  double *dP = nullptr, *dV = nullptr, *dW = nullptr, *ddacc = nullptr, *dscratch = nullptr;
+  int pending_k = 0, pending_steps = 0;   // ranks / steps appended to (V, W) since the last flush
   double* dmu2[2] = {nullptr, nullptr};   // the mean is double-buffered: a step reads [cur], writes [cur^1]
   int cur = 0;
   int* dn = nullptr;
@@ -54,7 +55,8 @@ struct ekf_handle {
   bool profile = false;
   std::vector<hipEvent_t> prof_pool;
   size_t prof_used = 0;
-  int opt_rows_per_block = 0;     // 0 = auto
+  int opt_rows_per_block = 0;     // 0 = auto (flush kernel: rows per workgroup, multiple of 16)
+  int opt_flush_every = 0;        // 0 = auto; k = flush the pending low-rank update after k steps
   int opt_streaming = -1;         // -1 = auto (by working-set size), 0 = resident kernel, 1 = nontemporal kernel
   std::string err;
 };
@@ -63,6 +65,8 @@ static int fail(ekf_handle* h, int code, const std::string& msg) {
   if (h) h->err = msg; else g_create_error = msg;
   return code;
 }
+
+static int flush_pending(ekf_handle* h);
 
 #define HIP_TRY(h, expr)                                                                   \
   do {                                                                                     \
@@ -90,7 +94,7 @@ static void free_all(ekf_handle* h) {
   if (!h) return;
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
-  void* ptrs[] = {h->dP, h->dmu2[0], h->dmu2[1], h->dV, h->dW, h->dscratch, h->dn, h->dflags, h->dso,
+  void* ptrs[] = {h->dP, h->dmu2[0], h->dmu2[1], h->dV, h->dW, h->ddacc, h->dscratch, h->dn, h->dflags, h->dso,
                   h->d_ring, h->d_stream, h->dF, h->dQ, h->dTmp};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (h->h_ring) (void)hipHostFree(h->h_ring);
@@ -153,8 +157,9 @@ extern "C" int ekf_create(int device, int n_max, int batch, const ekf_config* cf
   CREATE_TRY(hipMalloc(&h->dP, sizeof(double) * ldz * ldz * batch));
   CREATE_TRY(hipMalloc(&h->dmu2[0], sizeof(double) * ldz * batch));
   CREATE_TRY(hipMalloc(&h->dmu2[1], sizeof(double) * ldz * batch));
-  CREATE_TRY(hipMalloc(&h->dV, sizeof(double) * ldz * (2 * MMAX + 2) * batch));
-  CREATE_TRY(hipMalloc(&h->dW, sizeof(double) * ldz * (2 * MMAX + 2) * batch));
+  CREATE_TRY(hipMalloc(&h->dV, sizeof(double) * ldz * KTOT * batch));
+  CREATE_TRY(hipMalloc(&h->dW, sizeof(double) * ldz * KTOT * batch));
+  CREATE_TRY(hipMalloc(&h->ddacc, sizeof(double) * 4 * batch));
   CREATE_TRY(hipMalloc(&h->dscratch, sizeof(double) * ldz * 2));
   CREATE_TRY(hipMalloc(&h->dn, sizeof(int) * batch));
   CREATE_TRY(hipMalloc(&h->dflags, sizeof(unsigned) * batch));
@@ -167,8 +172,9 @@ extern "C" int ekf_create(int device, int n_max, int batch, const ekf_config* cf
   CREATE_TRY(hipMemsetAsync(h->dP, 0, sizeof(double) * ldz * ldz * batch, h->stream));
   CREATE_TRY(hipMemsetAsync(h->dmu2[0], 0, sizeof(double) * ldz * batch, h->stream));
   CREATE_TRY(hipMemsetAsync(h->dmu2[1], 0, sizeof(double) * ldz * batch, h->stream));
-  CREATE_TRY(hipMemsetAsync(h->dV, 0, sizeof(double) * ldz * (2 * MMAX + 2) * batch, h->stream));
-  CREATE_TRY(hipMemsetAsync(h->dW, 0, sizeof(double) * ldz * (2 * MMAX + 2) * batch, h->stream));
+  CREATE_TRY(hipMemsetAsync(h->dV, 0, sizeof(double) * ldz * KTOT * batch, h->stream));
+  CREATE_TRY(hipMemsetAsync(h->dW, 0, sizeof(double) * ldz * KTOT * batch, h->stream));
+  CREATE_TRY(hipMemsetAsync(h->ddacc, 0, sizeof(double) * 4 * batch, h->stream));
   CREATE_TRY(hipMemsetAsync(h->dflags, 0, sizeof(unsigned) * batch, h->stream));
   CREATE_TRY(hipMemsetAsync(h->dso, 0, sizeof(SolveOut) * batch, h->stream));
   // reference initial state (src/replay_no_ros.py:69-70): mu = 0, P = MOTION_MODEL_VARIANCE * I3
@@ -209,6 +215,7 @@ extern "C" int ekf_upload_state(ekf_handle* h, int b, const double* mu, const do
   if (!mu || !P) return fail(h, EKF_ERR_ARG, "ekf_upload_state: NULL array");
   if (n < 3 || (n & 1) == 0 || n > h->n_max) return fail(h, EKF_ERR_ARG, "ekf_upload_state: n must be 3+2N and <= n_max");
   HIP_TRY(h, hipSetDevice(h->device));
+  if (int rc = flush_pending(h)) return rc;
   HIP_TRY(h, hipMemcpy2DAsync(h->dP + (size_t)b * h->pstride, sizeof(double) * h->ld, P, sizeof(double) * n,
                               sizeof(double) * n, n, hipMemcpyHostToDevice, h->stream));
   HIP_TRY(h, hipMemcpyAsync(h->dmu2[h->cur] + (size_t)b * h->ld, mu, sizeof(double) * n, hipMemcpyHostToDevice, h->stream));
@@ -222,6 +229,7 @@ extern "C" int ekf_upload_state_diag(ekf_handle* h, int b, const double* mu, con
   if (!mu || !diagP) return fail(h, EKF_ERR_ARG, "ekf_upload_state_diag: NULL array");
   if (n < 3 || (n & 1) == 0 || n > h->n_max) return fail(h, EKF_ERR_ARG, "ekf_upload_state_diag: n must be 3+2N and <= n_max");
   HIP_TRY(h, hipSetDevice(h->device));
+  if (int rc = flush_pending(h)) return rc;
   HIP_TRY(h, hipMemcpyAsync(h->dscratch, diagP, sizeof(double) * n, hipMemcpyHostToDevice, h->stream));
   launch_fill_diag(h->stream, h->dP + (size_t)b * h->pstride, h->ld, n, h->dscratch);
   HIP_TRY(h, hipGetLastError());
@@ -235,6 +243,9 @@ extern "C" int ekf_download_state(ekf_handle* h, int b, double* mu, double* P, i
   if (int rc = check_b(h, b, "ekf_download_state")) return rc;
   if (n != h->n[b]) return fail(h, EKF_ERR_ARG, "ekf_download_state: n does not match the state size");
   HIP_TRY(h, hipSetDevice(h->device));
+  if (P) {
+    if (int rc = flush_pending(h)) return rc;      // the covariance is P_base + pending ranks
+  }
   if (P)
     HIP_TRY(h, hipMemcpy2DAsync(P, sizeof(double) * n, h->dP + (size_t)b * h->pstride, sizeof(double) * h->ld,
                                 sizeof(double) * n, n, hipMemcpyDeviceToHost, h->stream));
@@ -265,6 +276,7 @@ extern "C" int ekf_add_landmarks(ekf_handle* h, int b, int first_index, const do
   if (n_new > h->n_max) return fail(h, EKF_ERR_ARG, "ekf_add_landmarks: state would exceed n_max");
   if (2 * k > 2 * h->ld) return fail(h, EKF_ERR_ARG, "ekf_add_landmarks: too many landmarks in one call");
   HIP_TRY(h, hipSetDevice(h->device));
+  if (int rc = flush_pending(h)) return rc;
   HIP_TRY(h, hipStreamSynchronize(h->stream));   // xy is staged through a single scratch buffer
   HIP_TRY(h, hipMemcpyAsync(h->dscratch, xy, sizeof(double) * 2 * k, hipMemcpyHostToDevice, h->stream));
   launch_add_landmarks(h->stream, h->dP + (size_t)b * h->pstride, h->dmu2[h->cur] + (size_t)b * h->ld, h->ld, n_old, n_new,
@@ -278,10 +290,8 @@ extern "C" int ekf_add_landmarks(ekf_handle* h, int b, int first_index, const do
 // ---- step machinery -------------------------------------------------------------------------
 static int cap_for(int m) { return m <= 1 ? 1 : m <= 2 ? 2 : m <= 4 ? 4 : m <= 8 ? 8 : 16; }
 
-static int auto_rows_per_block(const ekf_handle* h, int n_hi) {
-  if (h->opt_rows_per_block > 0) return h->opt_rows_per_block;
-  (void)n_hi;
-  return 16;      // many small workgroups measured best for both kernels (tools/pass_bench.hip)
+static int flush_rows_per_block(const ekf_handle* h) {
+  return h->opt_rows_per_block > 0 ? (h->opt_rows_per_block + 15) / 16 * 16 : 256;
 }
 
 // The covariances of the batch stream through HBM when they cannot stay in the 256 MiB Infinity Cache.
@@ -300,29 +310,56 @@ static int prof_event(ekf_handle* h, hipEvent_t* ev) {
   return EKF_OK;
 }
 
+// Apply the pending low-rank update to P_base:  P_base += W V + diag(dacc)  (one pass over P).
+static int flush_pending(ekf_handle* h) {
+  if (h->pending_k == 0) return EKF_OK;
+  const int n_hi = *std::max_element(h->n.begin(), h->n.end());
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (h->profile) {
+    if (int rc = prof_event(h, &e0)) return rc;
+    if (int rc = prof_event(h, &e1)) return rc;
+    HIP_TRY(h, hipEventRecord(e0, h->stream));
+  }
+  launch_flush(h->stream, streaming_pass(h, n_hi), h->dP, h->dV, h->dW, h->ddacc, h->dn, h->ld, h->pstride,
+               h->batch, n_hi, h->pending_k / 4, flush_rows_per_block(h));
+  if (h->profile) HIP_TRY(h, hipEventRecord(e1, h->stream));
+  HIP_TRY(h, hipGetLastError());
+  HIP_TRY(h, hipMemsetAsync(h->ddacc, 0, sizeof(double) * 4 * h->batch, h->stream));
+  h->pending_k = 0;
+  h->pending_steps = 0;
+  return EKF_OK;
+}
+
 // Enqueue one device pass with inputs already at d_in (StepIn[batch]); m_hi = max m over the batch.
 static int enqueue_pass(ekf_handle* h, const StepIn* d_in, int m_hi) {
   const int n_hi = *std::max_element(h->n.begin(), h->n.end());
   const int mcap = cap_for(m_hi);
+  const int ktp = ranks_for(mcap);
   const double* mu_in = h->dmu2[h->cur];
   double* mu_out = h->dmu2[h->cur ^ 1];
-  launch_solve(h->stream, h->dP, mu_in, mu_out, h->dn, d_in, h->dso, h->dflags, h->dcfg, h->ld, h->pstride, h->batch);
-  if (m_hi == 0) {
+  if (m_hi == 0 && h->pending_k == 0) {
+    // prediction only, nothing pending: rows/cols 0,1 of P_base directly, O(n)
+    launch_solve(h->stream, h->dP, h->dV, h->dW, h->ddacc, mu_in, mu_out, h->dn, d_in, h->dso, h->dflags,
+                 h->dcfg, h->ld, h->pstride, h->batch, 0);
     launch_predict_rc(h->stream, h->dP, mu_in, mu_out, h->dn, h->dso, h->ld, h->pstride, h->batch, n_hi);
-  } else {
-    launch_panels(h->stream, mcap, h->dP, mu_in, mu_out, h->dn, h->dso, h->dV, h->dW, h->ld, h->pstride, h->batch, n_hi);
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (h->profile) {
-      if (int rc = prof_event(h, &e0)) return rc;
-      if (int rc = prof_event(h, &e1)) return rc;
-      HIP_TRY(h, hipEventRecord(e0, h->stream));
-    }
-    launch_pass(h->stream, mcap, streaming_pass(h, n_hi), h->dP, h->dV, h->dW, h->dn, h->dso, h->ld, h->pstride,
-                h->batch, n_hi, auto_rows_per_block(h, n_hi));
-    if (h->profile) HIP_TRY(h, hipEventRecord(e1, h->stream));
+    HIP_TRY(h, hipMemsetAsync(h->ddacc, 0, sizeof(double) * 4 * h->batch, h->stream));  // k_predict_rc applied the noise
+    HIP_TRY(h, hipGetLastError());
+    h->cur ^= 1;
+    return EKF_OK;
   }
-  h->cur ^= 1;
+  if (h->pending_k + ktp > KTOT)
+    if (int rc = flush_pending(h)) return rc;
+  launch_solve(h->stream, h->dP, h->dV, h->dW, h->ddacc, mu_in, mu_out, h->dn, d_in, h->dso, h->dflags, h->dcfg,
+               h->ld, h->pstride, h->batch, h->pending_k);
+  launch_panels(h->stream, mcap, h->dP, h->dV, h->dW, mu_in, mu_out, h->dn, h->dso, h->ld, h->pstride, h->batch,
+                n_hi);
   HIP_TRY(h, hipGetLastError());
+  h->cur ^= 1;
+  h->pending_k += ktp;
+  h->pending_steps += 1;
+  const int every = h->opt_flush_every > 0 ? h->opt_flush_every : 4;
+  if (h->pending_steps >= every || h->pending_k + 4 > KTOT)
+    if (int rc = flush_pending(h)) return rc;
   return EKF_OK;
 }
 
@@ -463,6 +500,7 @@ extern "C" int ekf_predict_dense(ekf_handle* h, int b, const double* F, const do
   const int n = h->n[b];
   const size_t bytes = sizeof(double) * (size_t)h->ld * h->ld;
   HIP_TRY(h, hipSetDevice(h->device));
+  if (int rc = flush_pending(h)) return rc;
   if (!h->dF) {
     HIP_TRY(h, hipMalloc(&h->dF, bytes));
     HIP_TRY(h, hipMalloc(&h->dQ, bytes));
@@ -485,6 +523,12 @@ extern "C" int ekf_predict_dense(ekf_handle* h, int b, const double* F, const do
   HIP_TRY(h, hipGetLastError());
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   return EKF_OK;
+}
+
+extern "C" int ekf_flush(ekf_handle* h) {
+  if (!h) return EKF_ERR_ARG;
+  HIP_TRY(h, hipSetDevice(h->device));
+  return flush_pending(h);
 }
 
 extern "C" int ekf_sync(ekf_handle* h) {
@@ -551,6 +595,11 @@ extern "C" int ekf_set_option(ekf_handle* h, const char* name, int value) {
   if (std::strcmp(name, "pass_rows_per_block") == 0) {
     if (value < 0 || value > 4096) return fail(h, EKF_ERR_ARG, "pass_rows_per_block out of range");
     h->opt_rows_per_block = value;
+    return EKF_OK;
+  }
+  if (std::strcmp(name, "flush_every") == 0) {
+    if (value < 0 || value > 64) return fail(h, EKF_ERR_ARG, "flush_every must be in [0, 64] (0 = auto)");
+    h->opt_flush_every = value;
     return EKF_OK;
   }
   if (std::strcmp(name, "pass_streaming") == 0) {

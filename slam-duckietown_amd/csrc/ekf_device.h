@@ -8,6 +8,11 @@ namespace ekf {
 
 constexpr int MMAX = EKF_MMAX;          // landmarks per update pass
 constexpr int CMAX = 3 + 2 * MMAX;      // compressed sub-state size (35)
+constexpr int KTOT = 80;                // rank slots of the deferred low-rank update  P = P_base + W V
+constexpr int NKT = KTOT / 4;           // the same in MFMA k-tiles (v_mfma_f64_16x16x4)
+
+// ranks one step appends: 2m (landmark updates) + 2 (motion Jacobian), padded to a whole k-tile
+__host__ __device__ constexpr int ranks_for(int mcap) { return (2 * mcap + 2 + 3) / 4 * 4; }
 
 constexpr int FLAG_PREDICT = 1;         // StepIn.flags
 constexpr int FLAG_UPDATE = 2;
@@ -39,9 +44,13 @@ struct alignas(16) SolveOut {
   double g[2];          // G[0,2], G[1,2] of the motion Jacobian (0 when prediction is off)
   double rd[3];         // motion noise added to the pose block (0 when prediction is off)
   double p22h;          // 0.5 * P[2,2] before the step
+  double dacc_old[3];   // pose-block noise already pending before this step
+  double pad0;
   int c;                // 3 + 2m
   int m;
-  int C[CMAX + 3];      // gathered state indices, padded with 0 (38 ints keep `it` 16-byte aligned)
+  int kbase;            // ranks pending before this step (multiple of 4)
+  int pad1;
+  int C[CMAX + 1];      // gathered state indices, padded with 0
   SolveIter it[MMAX];
 #ifdef EKF_STAMPS
   unsigned long long stamps[128];   // diagnostic build only (tools/solve_probe.hip)

@@ -1,13 +1,17 @@
 // Hand-written HIP kernels of the EKF-SLAM step for MI355X (gfx950, wave64).
 //
-// One reference step (src/replay_no_ros.py:363-482: predict, then one dense (I-KH)P product per
-// observed landmark) is executed as
-//   k_solve    the sequential part on the compressed c x c system (c = 3+2m), one wave per trajectory
+// The covariance is kept as   P = P_base + W V + diag(dacc)   with up to KTOT pending ranks:
+// every step appends its own 2m+2 ranks (the m sequential landmark updates of
+// src/replay_no_ros.py:436-480 plus the two rank-1 pairs of G_F P G_F^T, :430) and the O(n^2) pass
+// over P_base ("flush") is paid once per few steps instead of (2+m) dense n x n GEMMs per step:
+//   k_solve    sequential part on the compressed c x c system (c = 3+2m): gathers the CURRENT
+//              P[C,C] (base + pending ranks), one wave runs the recurrences
 //   k_panels   thread i replays the m rank-2 down-dates on column i of the row panel P'[C,:] and on
-//              row i of the column panel P'[:,C]:  V = stacked H_j P_j (2m x n, coalesced reads),
-//              W = -stacked K_j (n x 2m); mean update
-//   k_pass     P <- P + Rt + W V   one streaming read-modify-write of P (HBM-bound, 16 n^2 bytes)
-// or, with no observation, k_predict_rc (rows/cols 0,1 of P only, O(n)).
+//              row i of the column panel P'[:,C] (both of the current P) and appends
+//              V = stacked H_j P_j (coalesced rank-major) and W = -stacked K_j (MFMA-tiled); mean update
+//   k_flush    P_base <- P_base + W V + diag(dacc): one streaming read-modify-write of P_base with
+//              the rank-K product on the fp64 matrix cores (v_mfma_f64_16x16x4_f64)
+// With nothing observed and nothing pending, k_predict_rc touches rows/cols 0,1 of P only (O(n)).
 // The algebra is restated on the CPU in oracle/ekf_oracle.py::ekf_step_structured.
 #include <algorithm>
 
@@ -27,7 +31,23 @@
 #define STAMP(o, i) do { } while (0)
 #endif
 
+// LDS hand-off between lanes of ONE wave (the other waves of the workgroup have exited): LDS
+// operations of a wave execute in issue order, so only the compiler must be kept from reordering.
+#define WAVE_SYNC()                                              \
+  do {                                                           \
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");       \
+    __builtin_amdgcn_wave_barrier();                             \
+  } while (0)
+
 namespace ekf {
+
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
+// W is stored in MFMA A-operand tiles: k-tile (4 ranks) major, then 16-row groups, then [k&3][row&15],
+// so that one 8-byte-per-lane load of 64 consecutive doubles is exactly one 16x4 A fragment.
+__host__ __device__ __forceinline__ long wm_index(int ld16, int k, int i) {
+  return ((long)(k >> 2) * ld16 + (i >> 4)) * 64 + (k & 3) * 16 + (i & 15);
+}
 
 __device__ __forceinline__ double wrap_pi(double a) {
   // (a + pi) % (2 pi) - pi with NumPy remainder semantics, result in [-pi, pi)
@@ -71,37 +91,58 @@ __device__ __forceinline__ void linearize(const double* muc, int a, double z_ran
   h[1][4] = dx * rq;
 }
 
-// ---------------------------------------------------------------------------------------------
-// k_solve: one 64-lane wave per trajectory; lane l < c owns compressed index l and keeps column l
-// of P[C,C] in registers (written through to LDS for the row/column reads of the other lanes).
-// The kernel is latency-bound (one wave, m sequential iterations): every phase is written as
-// batches of independent operations, and the next landmark's linearisation (atan2, sqrt, 1/q:
-// ~0.2 us) is issued beside the covariance down-date, which does not depend on it.
-// Reads mu_in, writes mu_out[C] (the mean is double-buffered so that no kernel of a step reads
-// an entry another workgroup of the same step writes).
-// ---------------------------------------------------------------------------------------------
 constexpr int PCS = CMAX + 2;   // LDS row stride 37 doubles: column reads by 32 lanes are conflict-free
 constexpr int RCH = 8;          // rows per batch of the down-date
 constexpr int CPAD = (CMAX + RCH - 1) / RCH * RCH;   // 40
+constexpr int WCS = KTOT + 2;   // row stride of the staged W[C,:] (82 doubles)
 
-__global__ __launch_bounds__(64) void k_solve(const double* __restrict__ P,
-                                              const double* __restrict__ mu_in,
-                                              double* __restrict__ mu_out,
-                                              const int* __restrict__ nact,
-                                              const StepIn* __restrict__ in,
-                                              SolveOut* __restrict__ out,
-                                              unsigned* __restrict__ flags, DeviceConfig cfg, int ld,
-                                              long pstride) {
+// Stage the pending factors restricted to C into LDS: Wc[a][k] = W[C[a]][k], Vc[k][a] = V[k][C[a]].
+__device__ __forceinline__ void stage_factors(const double* __restrict__ Vb, const double* __restrict__ Wb,
+                                              const int* Cs, int c, int kb, int ld, int tid, int nthreads,
+                                              double (*Wc)[WCS], double (*Vc)[PCS]) {
+  const int ld16 = ld >> 4;
+  for (int a = tid >> 6; a < c; a += nthreads >> 6) {
+    const int row = Cs[a];
+    for (int k = tid & 63; k < kb; k += 64) {
+      Wc[a][k] = Wb[wm_index(ld16, k, row)];
+      Vc[k][a] = Vb[(long)k * ld + row];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_solve: one workgroup per trajectory.  All four waves gather the current P[C,C] (base + pending
+// ranks); then waves 1-3 exit and wave 0 runs the sequential recurrences: lane l < c owns compressed
+// index l and keeps column l of P[C,C] in registers (written through to LDS for the row/column
+// reads of the other lanes).  The chain is latency-bound (a lone wave issues one fp64 VALU op per
+// ~8 cycles): every phase is written as batches of independent operations.
+// Reads mu_in, writes mu_out[C] (the mean is double-buffered so that no kernel of a step reads an
+// entry another workgroup of the same step writes).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_solve(const double* __restrict__ P, const double* __restrict__ V,
+                                               const double* __restrict__ W, double* __restrict__ dacc,
+                                               const double* __restrict__ mu_in,
+                                               double* __restrict__ mu_out,
+                                               const int* __restrict__ nact,
+                                               const StepIn* __restrict__ in,
+                                               SolveOut* __restrict__ out,
+                                               unsigned* __restrict__ flags, DeviceConfig cfg, int ld,
+                                               long pstride, int kbase) {
   const int b = blockIdx.x;
-  const int lane = threadIdx.x;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
   const StepIn& s = in[b];
   SolveOut& o = out[b];
   const double* Pb = P + (long)b * pstride;
+  const double* Vb = V + (long)b * KTOT * ld;
+  const double* Wb = W + (long)b * KTOT * ld;
 
   __shared__ double Pc[CPAD][PCS];
   __shared__ double muc[CPAD];
   __shared__ double2 hpS[CPAD], kcS[CPAD];
   __shared__ int Cs[CPAD];
+  __shared__ double Wc[CMAX][WCS];
+  __shared__ double Vc[KTOT][PCS];
 
   STAMP(o, 0);
   // inputs: the index list is fetched unconditionally so that it travels with flags/m (one round trip)
@@ -113,23 +154,40 @@ __global__ __launch_bounds__(64) void k_solve(const double* __restrict__ P,
   const bool on = lane < c;
   const int ll = on ? lane : 0;                       // clamped lane for in-bounds LDS reads
   const int Cl = (lane < 3) ? lane : (on ? 3 + 2 * my_idx + ((lane - 3) & 1) : 0);
-  if (lane < CPAD) {
-    Cs[lane] = Cl;
-    kcS[lane] = make_double2(0.0, 0.0);
-    hpS[lane] = make_double2(0.0, 0.0);
-    if (lane < CMAX + 3) o.C[lane] = Cl;
+  if (tid < CPAD) {
+    Cs[tid] = Cl;
+    kcS[tid] = make_double2(0.0, 0.0);
+    hpS[tid] = make_double2(0.0, 0.0);
+    if (tid < CMAX + 1) o.C[tid] = Cl;
   }
   const double mu_l = mu_in[(long)b * ld + Cl];
+  const double d0 = dacc[4 * b + 0], d1 = dacc[4 * b + 1], d2 = dacc[4 * b + 2];
   __syncthreads();
+  if (kbase > 0) {
+    stage_factors(Vb, Wb, Cs, c, kbase, ld, tid, 256, Wc, Vc);
+    __syncthreads();
+  }
   STAMP(o, 1);
+  // current P[C,C] = P_base[C,C] + W[C,:] V[:,C] + diag(dacc)
+  for (int e = tid; e < c * c; e += 256) {
+    const int r = e / c, cc = e - r * c;
+    double v = Pb[(long)Cs[r] * ld + Cs[cc]];
+    for (int k = 0; k < kbase; ++k) v = fma(Wc[r][k], Vc[k][cc], v);
+    if (r == cc && r < 3) v += (r == 0) ? d0 : ((r == 1) ? d1 : d2);
+    Pc[r][cc] = v;
+  }
+  __syncthreads();
+  if (tid >= 64) return;                              // waves 1-3 are done; wave 0 carries on alone
+
   double pcol[CPAD];
-  {
-    const double* colp = Pb + Cl;
 #pragma unroll
-    for (int r = 0; r < CPAD; ++r) pcol[r] = (r < 3 || (on && r < c)) ? colp[(long)Cs[r] * ld] : 0.0;
-    if (!on) {
+  for (int r0 = 0; r0 < CPAD; r0 += RCH) {
+    if (r0 < c) {
 #pragma unroll
-      for (int r = 0; r < 3; ++r) pcol[r] = 0.0;
+      for (int r = r0; r < r0 + RCH; ++r) pcol[r] = (on && r < c) ? Pc[r][ll] : 0.0;
+    } else {
+#pragma unroll
+      for (int r = r0; r < r0 + RCH; ++r) pcol[r] = 0.0;
     }
   }
   STAMP(o, 2);
@@ -169,7 +227,7 @@ __global__ __launch_bounds__(64) void k_solve(const double* __restrict__ P,
 #pragma unroll
     for (int r = 0; r < CPAD; ++r) muc[r] = pcol[r];
   }
-  __syncthreads();
+  WAVE_SYNC();
   if (lane < 2) {
     const double gl = (lane == 0) ? g0 : g1;
 #pragma unroll
@@ -178,10 +236,14 @@ __global__ __launch_bounds__(64) void k_solve(const double* __restrict__ P,
   if (lane == 0) pcol[0] += rd0;
   if (lane == 1) pcol[1] += rd1;
   if (lane == 2) pcol[2] += rd2;
-  __syncthreads();
+  WAVE_SYNC();
   if (on) {
 #pragma unroll
-    for (int r = 0; r < CPAD; ++r) Pc[r][lane] = pcol[r];
+    for (int r0 = 0; r0 < CPAD; r0 += RCH)
+      if (r0 < c) {
+#pragma unroll
+        for (int r = r0; r < r0 + RCH; ++r) Pc[r][lane] = pcol[r];
+      }
   }
   double mu_cur = (lane == 0) ? nx : ((lane == 1) ? ny : ((lane == 2) ? nth : mu_l));
   if (lane < CPAD) muc[lane] = on ? mu_cur : 0.0;
@@ -192,10 +254,17 @@ __global__ __launch_bounds__(64) void k_solve(const double* __restrict__ P,
     o.rd[1] = rd1;
     o.rd[2] = rd2;
     o.p22h = 0.5 * p22;
+    o.dacc_old[0] = d0;
+    o.dacc_old[1] = d1;
+    o.dacc_old[2] = d2;
     o.c = c;
     o.m = m;
+    o.kbase = kbase;
+    dacc[4 * b + 0] = d0 + rd0;                      // the pose-block noise joins the pending update
+    dacc[4 * b + 1] = d1 + rd1;
+    dacc[4 * b + 2] = d2 + rd2;
   }
-  __syncthreads();
+  WAVE_SYNC();
 
   STAMP(o, 4);
   // ---- sequential per-landmark recurrences (:436-480) on the compressed system ----
@@ -207,8 +276,8 @@ __global__ __launch_bounds__(64) void k_solve(const double* __restrict__ P,
     SolveIter& it = o.it[j];
     STAMP(o, 8 + 6 * j);
     // phase A: rows sel of P_j at column C[lane] (H P) and columns sel at row C[lane] (P H^T).
-    // A lone wave issues one fp64 VALU op per ~8 cycles, so the instruction count is what matters:
-    // S is formed from the five hp pairs the other lanes publish in LDS (20 FMAs), not recomputed.
+    // The instruction count is what matters for a lone wave: S is formed from the five hp pairs the
+    // other lanes publish in LDS (20 FMAs), not recomputed from the 5x5 block.
     double pr[5], pq[5];
 #pragma unroll
     for (int k = 0; k < 5; ++k) {
@@ -226,7 +295,7 @@ __global__ __launch_bounds__(64) void k_solve(const double* __restrict__ P,
     }
     if (on) hpS[lane] = make_double2(hp0, hp1);
     if (lane < CMAX) *reinterpret_cast<double2*>(it.hpt[lane]) = on ? make_double2(hp0, hp1) : make_double2(0.0, 0.0);
-    __syncthreads();
+    WAVE_SYNC();
     STAMP(o, 9 + 6 * j);
     // phase B: S = H P H^T + Q (:473), every lane redundantly
     double2 hv[5];
@@ -257,7 +326,7 @@ __global__ __launch_bounds__(64) void k_solve(const double* __restrict__ P,
       *reinterpret_cast<double2*>(&it.si[2]) = make_double2(i10, i11);
       *reinterpret_cast<double2*>(it.y) = make_double2(y0, y1);
     }
-    __syncthreads();
+    WAVE_SYNC();
     STAMP(o, 10 + 6 * j);
     // phase C: the gains of every row are fetched first, the next landmark's linearisation (needs
     // only the mean) runs while they land, then the down-date (:480) as batches of independent FMAs
@@ -291,7 +360,7 @@ __global__ __launch_bounds__(64) void k_solve(const double* __restrict__ P,
       y0 = yn0;
       y1 = yn1;
     }
-    __syncthreads();
+    WAVE_SYNC();
     STAMP(o, 12 + 6 * j);
   }
 
@@ -305,89 +374,141 @@ __global__ __launch_bounds__(64) void k_solve(const double* __restrict__ P,
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_panels: thread i owns column i of the row panel R = P'[C,:] and row i of the column panel
-// L = P'[:,C] (both c values in registers) and replays the m sequential rank-2 down-dates on them
-// with the per-iteration uniforms of k_solve staged in LDS (16-byte broadcast reads):
-//   V[2j..2j+1][i] = H_j P_j[:, i]        = h5_j . R[sel_j]
-//   W[i][2j..2j+1] = -K_j[i, :]           = -(L[sel_j] . h5_j^T) S_j^-1
-//   R -= K_j[C,:] (H_j P_j)[:, i],   L -= K_j[i,:] (H_j P_j)[:, C]
-// plus the two rank-1 pairs of the motion Jacobian (:430) at k = 2*MCAP, 2*MCAP+1:
-//   V[2M] = P[2,:] + p22h*gt, W[:,2M] = gt,   V[2M+1] = gt, W[:,2M+1] = P[:,2] + p22h*gt
-// and the mean: mu_out[i] = mu_in[i] + sum_j K_j[i,:] y_j for i not in C.
+// k_panels: one workgroup (4 waves) per 64 state indices i.
+//  phase 1 (all waves, a split a % 4 == wave): current panels
+//      R[a][i] = P[C[a]][i] = P_base[C[a]][i] + sum_k W[C[a]][k] V[k][i]   (coalesced row reads)
+//      L[a][i] = P[i][C[a]] = P_base[i][C[a]] + sum_k W[i][k] V[k][C[a]]   (~m+1 lines per row)
+//  phase 2: wave 0 replays the m rank-2 down-dates on R and appends V[kb+2j..][i] = H_j P_j[:, i];
+//           wave 1 replays them on L and appends W[i][kb+2j..] = -K_j[i,:] and the mean update
+//           mu_out[i] = mu_in[i] + sum_j K_j[i,:] y_j (i not in C); per-iteration uniforms of k_solve
+//           are broadcast from LDS with 16-byte reads issued up front.
+//  The two rank-1 pairs of the motion Jacobian (:430) go to ranks kb+2*MCAP, +1:
+//      V = P[2,:] + p22h*gt, W = gt   and   V = gt, W = P[:,2] + p22h*gt.
 // ---------------------------------------------------------------------------------------------
 template <int MCAP>
-__global__ __launch_bounds__(64) void k_panels(const double* __restrict__ P,
-                                               const double* __restrict__ mu_in,
-                                               double* __restrict__ mu_out,
-                                               const int* __restrict__ nact,
-                                               const SolveOut* __restrict__ so,
-                                               double* __restrict__ V, double* __restrict__ W, int ld,
-                                               long pstride) {
-  constexpr int CC = 3 + 2 * MCAP, K2 = 2 * MCAP;
-  constexpr int VS = 2 * MMAX + 2;
+__global__ __launch_bounds__(256) void k_panels(const double* __restrict__ P, double* __restrict__ V,
+                                                double* __restrict__ W,
+                                                const double* __restrict__ mu_in,
+                                                double* __restrict__ mu_out,
+                                                const int* __restrict__ nact,
+                                                const SolveOut* __restrict__ so, int ld, long pstride) {
+  constexpr int CC = 3 + 2 * MCAP, K2 = 2 * MCAP, KTP = ranks_for(MCAP);
+  constexpr int QA = (CC + 3) / 4;                    // a's per wave in phase 1
   __shared__ SolveIter its[MCAP];
+  __shared__ double Wc[CC][WCS];
+  __shared__ double Vc[KTOT][PCS];
+  __shared__ double Rs[CC][64], Ls[CC][64];
+  __shared__ int Cs[CPAD];
   const int b = blockIdx.y;
   const int n = nact[b];
   if ((int)blockIdx.x * 64 >= n) return;
-  const int tid = threadIdx.x;
-  const int j = blockIdx.x * 64 + tid;
-  const bool act = j < n;
-  const int jj = act ? j : 0;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i = blockIdx.x * 64 + lane;
+  const bool act = i < n;
+  const int ii = act ? i : 0;
   const SolveOut& o = so[b];
   const double* Pb = P + (long)b * pstride;
-  const int m = min(o.m, MCAP), c = o.c;
+  double* Vb = V + (long)b * KTOT * ld;
+  double* Wb = W + (long)b * KTOT * ld;
+  const int ld16 = ld >> 4;
+  const int m = min(o.m, MCAP), c = o.c, kb = o.kbase;
 
   {
     const double2* src = reinterpret_cast<const double2*>(o.it);
     double2* dst = reinterpret_cast<double2*>(its);
     const int count = m * (int)(sizeof(SolveIter) / 16);
-    for (int t = tid; t < count; t += 64) dst[t] = src[t];
+    for (int t = tid; t < count; t += 256) dst[t] = src[t];
   }
-  const double g0 = o.g[0], g1 = o.g[1];
-  const double gj = (jj == 0) ? g0 : ((jj == 1) ? g1 : 0.0);
-
-  double R[CC], L[CC];
+  if (tid < CPAD) Cs[tid] = (tid < CMAX + 1) ? o.C[tid] : 0;
+  __syncthreads();
+  if (kb > 0) {
+    stage_factors(Vb, Wb, Cs, min(c, CC), kb, ld, tid, 256, Wc, Vc);
+    __syncthreads();
+  }
+  // ---- phase 1 ----
+  {
+    double r[QA], l[QA];
 #pragma unroll
-  for (int a = 0; a < CC; ++a) R[a] = Pb[(long)o.C[a] * ld + jj];
+    for (int q = 0; q < QA; ++q) {
+      const int a = wave + 4 * q;
+      const int row = (a < CC) ? Cs[a] : 0;
+      r[q] = Pb[(long)row * ld + ii];
+      l[q] = Pb[(long)ii * ld + row];
+    }
+    for (int k = 0; k < kb; ++k) {
+      const double vk = Vb[(long)k * ld + ii];
+      const double wk = Wb[wm_index(ld16, k, ii)];
 #pragma unroll
-  for (int a = 0; a < CC; ++a) L[a] = Pb[(long)jj * ld + o.C[a]];
-  const double raw_r2 = R[2], raw_c2 = L[2];
-  const double mu_i = mu_in[(long)b * ld + jj];
-
-  // P' = G_F P G_F^T + F^T R F  (src/replay_no_ros.py:430) on the two panels
-  R[0] += g0 * R[2];
-  R[1] += g1 * R[2];
-  if (jj < 2) {
-    const double p22 = Pb[2 * (long)ld + 2];
+      for (int q = 0; q < QA; ++q) {
+        const int a = min(wave + 4 * q, CC - 1);
+        r[q] = fma(Wc[a][k], vk, r[q]);
+        l[q] = fma(wk, Vc[k][a], l[q]);
+      }
+    }
 #pragma unroll
-    for (int a = 0; a < CC; ++a) {
-      double x = Pb[(long)o.C[a] * ld + 2];
-      if (a == 0) x += g0 * p22;
-      if (a == 1) x += g1 * p22;
-      R[a] += gj * x;
-      L[a] += gj * Pb[2 * (long)ld + o.C[a]];
+    for (int q = 0; q < QA; ++q) {
+      const int a = wave + 4 * q;
+      if (a < CC) {
+        double rv = r[q], lv = l[q];
+        if (a < 3 && ii == a) {                        // pending pose-block noise on the diagonal
+          rv += o.dacc_old[a];
+          lv += o.dacc_old[a];
+        }
+        Rs[a][lane] = rv;
+        Ls[a][lane] = lv;
+      }
     }
   }
-  L[0] += g0 * L[2];
-  L[1] += g1 * L[2];
+  __syncthreads();
+  if (wave >= 2) return;
+
+  const double g0 = o.g[0], g1 = o.g[1];
+  const double gj = (ii == 0) ? g0 : ((ii == 1) ? g1 : 0.0);
+  const bool blk0 = blockIdx.x == 0;                   // lanes 0..2 of block 0 hold state indices 0,1,2
+  double X[CC];                                        // R (wave 0) or L (wave 1)
+  if (wave == 0) {
+#pragma unroll
+    for (int a = 0; a < CC; ++a) X[a] = Rs[a][lane];
+  } else {
+#pragma unroll
+    for (int a = 0; a < CC; ++a) X[a] = Ls[a][lane];
+  }
+  const double raw2 = X[2];                            // P[2][i] (wave 0) / P[i][2] (wave 1)
+  // P' = G_F P G_F^T + F^T R F  (src/replay_no_ros.py:430) on the panel
+  if (wave == 0) {
+    X[0] += g0 * X[2];                                 // row ops on rows 0,1
+    X[1] += g1 * X[2];
+    if (blk0 && ii < 2) {                              // column op on column ii: += g_ii * X[:,2]
+      const double p22 = Rs[2][2];
+#pragma unroll
+      for (int a = 0; a < CC; ++a) {
+        double x = Rs[a][2];
+        if (a == 0) x += g0 * p22;
+        if (a == 1) x += g1 * p22;
+        X[a] += gj * x;
+      }
+    }
+  } else {
+    if (blk0 && ii < 2) {                              // row op on row ii: += g_ii * P[2][C[a]]
+#pragma unroll
+      for (int a = 0; a < CC; ++a) X[a] += gj * Ls[a][2];
+    }
+    X[0] += g0 * X[2];                                 // column ops on columns 0,1
+    X[1] += g1 * X[2];
+  }
 #pragma unroll
   for (int a = 0; a < 3; ++a)
-    if (a == jj) {
-      R[a] += o.rd[a];
-      L[a] += o.rd[a];
-    }
-  __syncthreads();
+    if (a == ii) X[a] += o.rd[a];
 
-  double* Vb = V + (long)b * VS * ld;
-  double* Wr = W + ((long)b * ld + jj) * VS;
   double dm = 0.0;
 #pragma unroll
   for (int it = 0; it < MCAP; ++it) {
+    const int kr = kb + 2 * it;
     if (it < m) {
       const SolveIter& I = its[it];
       const int a0 = 3 + 2 * it;
       const bool more = it + 1 < m;
-      // every LDS broadcast read of the iteration is issued up front (one latency exposure)
       double2 hk[5];
 #pragma unroll
       for (int k = 0; k < 5; ++k) hk[k] = *reinterpret_cast<const double2*>(I.h5t[k]);
@@ -395,206 +516,205 @@ __global__ __launch_bounds__(64) void k_panels(const double* __restrict__ P,
       const double2 s23 = *reinterpret_cast<const double2*>(&I.si[2]);
       const double2 yy = *reinterpret_cast<const double2*>(I.y);
       constexpr bool PREFETCH = MCAP <= 8;
-      double2 kcv[PREFETCH ? CC : 1], hcv[PREFETCH ? CC : 1];
+      double2 uv[PREFETCH ? CC : 1];                   // K_j[C[a],:] (wave 0) / (H_j P_j)[:,C[a]] (wave 1)
       if (PREFETCH && more) {
+        if (wave == 0) {
 #pragma unroll
-        for (int a = 0; a < CC; ++a) {
-          kcv[a] = *reinterpret_cast<const double2*>(I.kc[a]);
-          hcv[a] = *reinterpret_cast<const double2*>(I.hpt[a]);
+          for (int a = 0; a < CC; ++a) uv[a] = *reinterpret_cast<const double2*>(I.kc[a]);
+        } else {
+#pragma unroll
+          for (int a = 0; a < CC; ++a) uv[a] = *reinterpret_cast<const double2*>(I.hpt[a]);
         }
       }
-      double hp0 = hk[0].x * R[0], hp1 = hk[0].y * R[0], ph0 = L[0] * hk[0].x, ph1 = L[0] * hk[0].y;
+      double e0 = hk[0].x * X[0], e1 = hk[0].y * X[0];   // h5 . X[sel]: (H P)[:,i] or (P H^T)[i,:]
 #pragma unroll
       for (int k = 1; k < 5; ++k) {
-        const double rv = (k < 3) ? R[k] : R[a0 + (k - 3)];
-        const double lv = (k < 3) ? L[k] : L[a0 + (k - 3)];
-        hp0 = fma(hk[k].x, rv, hp0);
-        hp1 = fma(hk[k].y, rv, hp1);
-        ph0 = fma(lv, hk[k].x, ph0);
-        ph1 = fma(lv, hk[k].y, ph1);
+        const double xv = (k < 3) ? X[k] : X[a0 + (k - 3)];
+        e0 = fma(hk[k].x, xv, e0);
+        e1 = fma(hk[k].y, xv, e1);
       }
-      const double k0 = ph0 * s01.x + ph1 * s23.x;
-      const double k1 = ph0 * s01.y + ph1 * s23.y;
-      dm += k0 * yy.x + k1 * yy.y;
-      if (act) {
-        Vb[(long)(2 * it) * ld + j] = hp0;
-        Vb[(long)(2 * it + 1) * ld + j] = hp1;
-        Wr[2 * it] = -k0;
-        Wr[2 * it + 1] = -k1;
+      double f0, f1;                                   // the pair the down-date multiplies with
+      if (wave == 0) {
+        f0 = e0;
+        f1 = e1;
+        if (act) {
+          Vb[(long)kr * ld + i] = e0;
+          Vb[(long)(kr + 1) * ld + i] = e1;
+        }
+      } else {
+        f0 = e0 * s01.x + e1 * s23.x;                  // K_j[i,:] = (P H^T)[i,:] S^-1
+        f1 = e0 * s01.y + e1 * s23.y;
+        dm += f0 * yy.x + f1 * yy.y;
+        if (act) {
+          Wb[wm_index(ld16, kr, i)] = -f0;
+          Wb[wm_index(ld16, kr + 1, i)] = -f1;
+        }
       }
       if (more) {
         if (PREFETCH) {
+          if (wave == 0) {                             // R[a] -= K_j[C[a],:] . (H P)[:,i]
 #pragma unroll
-          for (int a = 0; a < CC; ++a) {
-            R[a] = fma(-kcv[a].x, hp0, R[a]);
-            L[a] = fma(-k0, hcv[a].x, L[a]);
-          }
+            for (int a = 0; a < CC; ++a) X[a] = fma(-uv[a].x, f0, X[a]);
 #pragma unroll
-          for (int a = 0; a < CC; ++a) {
-            R[a] = fma(-kcv[a].y, hp1, R[a]);
-            L[a] = fma(-k1, hcv[a].y, L[a]);
+            for (int a = 0; a < CC; ++a) X[a] = fma(-uv[a].y, f1, X[a]);
+          } else {                                     // L[a] -= K_j[i,:] . (H P)[:,C[a]]
+#pragma unroll
+            for (int a = 0; a < CC; ++a) X[a] = fma(-f0, uv[a].x, X[a]);
+#pragma unroll
+            for (int a = 0; a < CC; ++a) X[a] = fma(-f1, uv[a].y, X[a]);
           }
         } else {
 #pragma unroll
           for (int c0 = 0; c0 < CC; c0 += 8) {
-            double2 kc[8], hc[8];
+            double2 u[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u)
-              if (c0 + u < CC) {
-                kc[u] = *reinterpret_cast<const double2*>(I.kc[c0 + u]);
-                hc[u] = *reinterpret_cast<const double2*>(I.hpt[c0 + u]);
-              }
+            for (int q = 0; q < 8; ++q)
+              if (c0 + q < CC)
+                u[q] = (wave == 0) ? *reinterpret_cast<const double2*>(I.kc[c0 + q])
+                                   : *reinterpret_cast<const double2*>(I.hpt[c0 + q]);
 #pragma unroll
-            for (int u = 0; u < 8; ++u)
-              if (c0 + u < CC) {
-                R[c0 + u] = fma(-kc[u].x, hp0, R[c0 + u]);
-                L[c0 + u] = fma(-k0, hc[u].x, L[c0 + u]);
-              }
+            for (int q = 0; q < 8; ++q)
+              if (c0 + q < CC) X[c0 + q] = fma(-u[q].x, f0, X[c0 + q]);
 #pragma unroll
-            for (int u = 0; u < 8; ++u)
-              if (c0 + u < CC) {
-                R[c0 + u] = fma(-kc[u].y, hp1, R[c0 + u]);
-                L[c0 + u] = fma(-k1, hc[u].y, L[c0 + u]);
-              }
+            for (int q = 0; q < 8; ++q)
+              if (c0 + q < CC) X[c0 + q] = fma(-u[q].y, f1, X[c0 + q]);
           }
         }
       }
     } else if (act) {
-      Vb[(long)(2 * it) * ld + j] = 0.0;
-      Vb[(long)(2 * it + 1) * ld + j] = 0.0;
-      Wr[2 * it] = 0.0;
-      Wr[2 * it + 1] = 0.0;
+      if (wave == 0) {
+        Vb[(long)kr * ld + i] = 0.0;
+        Vb[(long)(kr + 1) * ld + i] = 0.0;
+      } else {
+        Wb[wm_index(ld16, kr, i)] = 0.0;
+        Wb[wm_index(ld16, kr + 1, i)] = 0.0;
+      }
     }
   }
   if (act) {
-    Vb[(long)K2 * ld + j] = raw_r2 + o.p22h * gj;
-    Vb[(long)(K2 + 1) * ld + j] = gj;
-    Wr[K2] = gj;
-    Wr[K2 + 1] = raw_c2 + o.p22h * gj;
-    bool inC = false;
-    for (int a = 0; a < c; ++a) inC |= (o.C[a] == j);
-    if (!inC) mu_out[(long)b * ld + j] = mu_i + dm;
+    const int kp = kb + K2;
+    if (wave == 0) {
+      Vb[(long)kp * ld + i] = raw2 + o.p22h * gj;
+      Vb[(long)(kp + 1) * ld + i] = gj;
+#pragma unroll
+      for (int k = K2 + 2; k < KTP; ++k) Vb[(long)(kb + k) * ld + i] = 0.0;
+    } else {
+      Wb[wm_index(ld16, kp, i)] = gj;
+      Wb[wm_index(ld16, kp + 1, i)] = raw2 + o.p22h * gj;
+#pragma unroll
+      for (int k = K2 + 2; k < KTP; ++k) Wb[wm_index(ld16, kb + k, i)] = 0.0;
+      bool inC = false;
+      for (int a = 0; a < c; ++a) inC |= (Cs[a] == i);
+      if (!inC) mu_out[(long)b * ld + i] = mu_in[(long)b * ld + i] + dm;
+    }
   }
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_pass: P[i][j] += Rt + sum_{k<KT} W[i][k] V[k][j], in place, one read + one write of P.
-// A wave owns a strip of 128 columns (2 adjacent doubles per lane = one 1 KiB row segment per
-// load/store instruction); its V strip lives in registers for the whole row block, W[i][:] is
-// wave-uniform and comes through the scalar cache.  UNR rows are in flight per wave.
-// NT: nontemporal loads AND stores -- for working sets beyond the 256 MiB Infinity Cache the pair
-// is worth +25 % (5.7-6.0 vs 4.5 TB/s measured); for a resident P plain accesses are faster.
-// The odd last column (n = 3+2N is odd) is done by the wave whose strip holds it, one row per lane.
+// k_flush: P_base[i][j] += sum_{k < 4 nkt} W[i][k] V[k][j] + dacc on the pose diagonal, in place.
+// A wave owns a strip of 64 columns: the V strip lives in registers as MFMA B fragments
+// (nkt x 4 doubles per lane) for the whole row block.  Per 16-row tile it loads the P tiles straight
+// into the fp64 C/D layout (col = lane&15, row = (lane>>4) + 4 reg: each 16 lanes read one 128-B
+// line), the W tile as A fragments (one lane-linear 512-B load per k-tile, wm_index layout), issues
+// 4 x nkt v_mfma_f64_16x16x4_f64 and stores.  The next tile's P and W are prefetched under the MFMAs.
+// NT: nontemporal loads/stores for working sets beyond the 256 MiB Infinity Cache.
+// Algorithmic traffic: 16 n^2 bytes per trajectory per launch, whatever the number of pending steps.
 // ---------------------------------------------------------------------------------------------
 template <bool NT>
-__device__ __forceinline__ double2 ld2(const double* a) {
-  double2 r;
-  if (NT) {
-    r.x = __builtin_nontemporal_load(a);
-    r.y = __builtin_nontemporal_load(a + 1);
-  } else {
-    r = *reinterpret_cast<const double2*>(a);
-  }
-  return r;
-}
+__device__ __forceinline__ double ldn(const double* a) { return NT ? __builtin_nontemporal_load(a) : *a; }
 template <bool NT>
-__device__ __forceinline__ void st2(double* a, double2 v) {
-  if (NT) {
-    __builtin_nontemporal_store(v.x, a);
-    __builtin_nontemporal_store(v.y, a + 1);
-  } else {
-    *reinterpret_cast<double2*>(a) = v;
-  }
+__device__ __forceinline__ void stn(double* a, double v) {
+  if (NT) __builtin_nontemporal_store(v, a);
+  else *a = v;
 }
 
-template <int MCAP, int UNR, int WAVES, bool NT>
-__global__ __launch_bounds__(WAVES * 64) void k_pass(double* __restrict__ P,
-                                                     const double* __restrict__ V,
-                                                     const double* __restrict__ W,
-                                                     const int* __restrict__ nact,
-                                                     const SolveOut* __restrict__ so, int ld,
-                                                     long pstride, int rows_per_block) {
-  constexpr int KT = 2 * MCAP + 2;
-  constexpr int WS = 2 * MMAX + 2;
+template <int NKTM, bool NT>
+__global__ __launch_bounds__(256) void k_flush(double* __restrict__ P, const double* __restrict__ V,
+                                               const double* __restrict__ W,
+                                               const double* __restrict__ dacc,
+                                               const int* __restrict__ nact, int ld, long pstride, int nkt,
+                                               int rows_per_block) {
   const int b = blockIdx.z;
   const int n = nact[b];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
-  const int strip = blockIdx.x * WAVES + wave;
-  const int i0 = blockIdx.y * rows_per_block;
-  if (strip * 128 >= n || i0 >= n) return;
-  const int i1 = min(n, i0 + rows_per_block);
-  const int j0 = strip * 128 + lane * 2;
-
+  const int j0 = (blockIdx.x * 4 + wave) * 64;
+  const int i_begin = blockIdx.y * rows_per_block;
+  if (j0 >= n || i_begin >= n) return;
+  const int i_end = min(n, i_begin + rows_per_block);
+  const int li = lane & 15, lq = lane >> 4;
+  const int ld16 = ld >> 4;
   double* Pb = P + (long)b * pstride;
-  const double* Vb = V + (long)b * WS * ld;
-  const double* Wb = W + (long)b * ld * WS;
+  const double* Vb = V + (long)b * KTOT * ld;
+  const double* Wb = W + (long)b * KTOT * ld;
+  int nct = (n - j0 + 15) >> 4;                        // column tiles of this strip that start below n
+  if (nct > 4) nct = 4;
 
-  if (j0 + 1 < n) {
-    double2 v[KT];
+  double vf[NKTM][4];
 #pragma unroll
-    for (int k = 0; k < KT; ++k) v[k] = *reinterpret_cast<const double2*>(Vb + (long)k * ld + j0);
-    int i = i0;
-    for (; i + UNR <= i1; i += UNR) {
-      double2 p[UNR];
+  for (int t = 0; t < NKTM; ++t)
 #pragma unroll
-      for (int u = 0; u < UNR; ++u) p[u] = ld2<NT>(Pb + (long)(i + u) * ld + j0);
+    for (int ct = 0; ct < 4; ++ct)
+      vf[t][ct] = (t < nkt && ct < nct) ? Vb[(long)(4 * t + lq) * ld + j0 + ct * 16 + li] : 0.0;
+
+  double wf[NKTM], wn[NKTM];
+  double4_t pf[4], pn[4];
+  auto load_tile = [&](int i0, double (&w)[NKTM], double4_t (&p)[4]) {
+    const double* wsrc = Wb + (long)(i0 >> 4) * 64 + lane;
 #pragma unroll
-      for (int u = 0; u < UNR; ++u) {
-        const double* w = Wb + (long)(i + u) * WS;
+    for (int t = 0; t < NKTM; ++t) w[t] = (t < nkt) ? wsrc[(long)t * ld16 * 64] : 0.0;
 #pragma unroll
-        for (int k = 0; k < KT; ++k) {
-          const double wk = w[k];
-          p[u].x += wk * v[k].x;
-          p[u].y += wk * v[k].y;
+    for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        p[ct][r] = (ct < nct) ? ldn<NT>(Pb + (long)(i0 + lq + 4 * r) * ld + j0 + ct * 16 + li) : 0.0;
+  };
+  auto mma_store = [&](int i0, const double (&w)[NKTM], double4_t (&p)[4]) {
+#pragma unroll
+    for (int t = 0; t < NKTM; ++t)
+      if (t < nkt) {
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) p[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(w[t], vf[t][ct], p[ct], 0, 0, 0);
+      }
+    if (i0 == 0 && j0 == 0) {                          // pose-block noise accumulated since the last flush
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = lq + 4 * r;
+        if (row < 3 && li == row) p[0][r] += dacc[4 * b + row];
+      }
+    }
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+      if (ct < nct) {
+        const int col = j0 + ct * 16 + li;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = i0 + lq + 4 * r;
+          if (row < n && col < n) stn<NT>(Pb + (long)row * ld + col, p[ct][r]);
         }
       }
-      if (i < 3) {
-#pragma unroll
-        for (int u = 0; u < UNR; ++u) {
-          const int r = i + u;
-          if (r < 3) {
-            if (j0 == r) p[u].x += so[b].rd[r];
-            if (j0 + 1 == r) p[u].y += so[b].rd[r];
-          }
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < UNR; ++u) st2<NT>(Pb + (long)(i + u) * ld + j0, p[u]);
-    }
-    for (; i < i1; ++i) {
-      double2 p = ld2<NT>(Pb + (long)i * ld + j0);
-      const double* w = Wb + (long)i * WS;
-#pragma unroll
-      for (int k = 0; k < KT; ++k) {
-        const double wk = w[k];
-        p.x += wk * v[k].x;
-        p.y += wk * v[k].y;
-      }
-      if (i < 3) {
-        if (j0 == i) p.x += so[b].rd[i];
-        if (j0 + 1 == i) p.y += so[b].rd[i];
-      }
-      st2<NT>(Pb + (long)i * ld + j0, p);
-    }
-  }
-  // odd last column: one row per lane
-  const int tail = n - 1;
-  if ((n & 1) && tail >= strip * 128 && tail < strip * 128 + 128) {
-    for (int r = i0 + lane; r < i1; r += 64) {
-      double p = Pb[(long)r * ld + tail];
-      const double* w = Wb + (long)r * WS;
-#pragma unroll
-      for (int k = 0; k < KT; ++k) p += w[k] * Vb[(long)k * ld + tail];
-      if (r < 3 && r == tail) p += so[b].rd[r];
-      Pb[(long)r * ld + tail] = p;
-    }
+  };
+
+  int i0 = i_begin;
+  load_tile(i0, wf, pf);
+  while (true) {
+    const int i1 = i0 + 16;
+    const bool more1 = i1 < i_end;
+    if (more1) load_tile(i1, wn, pn);
+    mma_store(i0, wf, pf);
+    if (!more1) break;
+    const int i2 = i1 + 16;
+    const bool more2 = i2 < i_end;
+    if (more2) load_tile(i2, wf, pf);
+    mma_store(i1, wn, pn);
+    if (!more2) break;
+    i0 = i2;
   }
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_predict_rc: prediction with no observation touches only rows/cols 0,1 and the pose diagonal
-// (src/replay_no_ros.py:428-430 with G_F = I outside the 3x3 block).  O(n).
+// k_predict_rc: prediction with no observation and nothing pending touches only rows/cols 0,1 and
+// the pose diagonal (src/replay_no_ros.py:428-430 with G_F = I outside the 3x3 block).  O(n).
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_predict_rc(double* __restrict__ P,
                                                     const double* __restrict__ mu_in,
@@ -661,63 +781,55 @@ __global__ __launch_bounds__(256) void k_fill_diag(double* __restrict__ Pb, int 
 // ---------------------------------------------------------------------------------------------
 // launchers (called from ekf_api.hip)
 // ---------------------------------------------------------------------------------------------
-void launch_solve(hipStream_t st, const double* P, const double* mu_in, double* mu_out, const int* nact,
-                  const StepIn* in, SolveOut* out, unsigned* flags, const DeviceConfig& cfg, int ld,
-                  long pstride, int batch) {
-  hipLaunchKernelGGL(k_solve, dim3(batch), dim3(64), 0, st, P, mu_in, mu_out, nact, in, out, flags, cfg,
-                     ld, pstride);
+void launch_solve(hipStream_t st, const double* P, const double* V, const double* W, double* dacc,
+                  const double* mu_in, double* mu_out, const int* nact, const StepIn* in, SolveOut* out,
+                  unsigned* flags, const DeviceConfig& cfg, int ld, long pstride, int batch, int kbase) {
+  hipLaunchKernelGGL(k_solve, dim3(batch), dim3(256), 0, st, P, V, W, dacc, mu_in, mu_out, nact, in, out,
+                     flags, cfg, ld, pstride, kbase);
 }
 
 template <int MCAP>
-static void launch_panels_t(hipStream_t st, const double* P, const double* mu_in, double* mu_out,
-                            const int* nact, const SolveOut* so, double* V, double* W, int ld,
-                            long pstride, int batch, int n_hi) {
-  hipLaunchKernelGGL(k_panels<MCAP>, dim3((n_hi + 63) / 64, batch), dim3(64), 0, st, P, mu_in, mu_out,
-                     nact, so, V, W, ld, pstride);
+static void launch_panels_t(hipStream_t st, const double* P, double* V, double* W, const double* mu_in,
+                            double* mu_out, const int* nact, const SolveOut* so, int ld, long pstride,
+                            int batch, int n_hi) {
+  hipLaunchKernelGGL(k_panels<MCAP>, dim3((n_hi + 63) / 64, batch), dim3(256), 0, st, P, V, W, mu_in,
+                     mu_out, nact, so, ld, pstride);
 }
 
-void launch_panels(hipStream_t st, int mcap, const double* P, const double* mu_in, double* mu_out,
-                   const int* nact, const SolveOut* so, double* V, double* W, int ld, long pstride,
-                   int batch, int n_hi) {
+void launch_panels(hipStream_t st, int mcap, const double* P, double* V, double* W, const double* mu_in,
+                   double* mu_out, const int* nact, const SolveOut* so, int ld, long pstride, int batch,
+                   int n_hi) {
   switch (mcap) {
-    case 1: launch_panels_t<1>(st, P, mu_in, mu_out, nact, so, V, W, ld, pstride, batch, n_hi); break;
-    case 2: launch_panels_t<2>(st, P, mu_in, mu_out, nact, so, V, W, ld, pstride, batch, n_hi); break;
-    case 4: launch_panels_t<4>(st, P, mu_in, mu_out, nact, so, V, W, ld, pstride, batch, n_hi); break;
-    case 8: launch_panels_t<8>(st, P, mu_in, mu_out, nact, so, V, W, ld, pstride, batch, n_hi); break;
-    default: launch_panels_t<16>(st, P, mu_in, mu_out, nact, so, V, W, ld, pstride, batch, n_hi); break;
+    case 1: launch_panels_t<1>(st, P, V, W, mu_in, mu_out, nact, so, ld, pstride, batch, n_hi); break;
+    case 2: launch_panels_t<2>(st, P, V, W, mu_in, mu_out, nact, so, ld, pstride, batch, n_hi); break;
+    case 4: launch_panels_t<4>(st, P, V, W, mu_in, mu_out, nact, so, ld, pstride, batch, n_hi); break;
+    case 8: launch_panels_t<8>(st, P, V, W, mu_in, mu_out, nact, so, ld, pstride, batch, n_hi); break;
+    default: launch_panels_t<16>(st, P, V, W, mu_in, mu_out, nact, so, ld, pstride, batch, n_hi); break;
   }
 }
 
-template <int MCAP, int UNR, int WAVES, bool NT>
-static void launch_pass_t(hipStream_t st, double* P, const double* V, const double* W,
-                          const int* nact, const SolveOut* so, int ld, long pstride, int batch,
-                          int n_hi, int rows_per_block) {
-  dim3 grid((n_hi + 128 * WAVES - 1) / (128 * WAVES), (n_hi + rows_per_block - 1) / rows_per_block, batch);
-  hipLaunchKernelGGL((k_pass<MCAP, UNR, WAVES, NT>), grid, dim3(WAVES * 64), 0, st, P, V, W, nact, so, ld,
-                     pstride, rows_per_block);
+template <int NKTM, bool NT>
+static void launch_flush_t(hipStream_t st, double* P, const double* V, const double* W, const double* dacc,
+                           const int* nact, int ld, long pstride, int batch, int n_hi, int nkt,
+                           int rows_per_block) {
+  dim3 grid((n_hi + 255) / 256, (n_hi + rows_per_block - 1) / rows_per_block, batch);
+  hipLaunchKernelGGL((k_flush<NKTM, NT>), grid, dim3(256), 0, st, P, V, W, dacc, nact, ld, pstride, nkt,
+                     rows_per_block);
 }
 
-// streaming = the batch's covariances do not fit the Infinity Cache: nontemporal, 4 waves x 8 rows;
-// resident  = plain accesses, 8 waves x 4 rows (measured best on a 128 MB P, tools/pass_bench.hip).
-template <int MCAP>
-static void launch_pass_m(hipStream_t st, bool streaming, double* P, const double* V, const double* W,
-                          const int* nact, const SolveOut* so, int ld, long pstride, int batch, int n_hi,
-                          int rows_per_block) {
-  constexpr int U_S = MCAP >= 16 ? 4 : 8;
-  if (streaming) launch_pass_t<MCAP, U_S, 4, true>(st, P, V, W, nact, so, ld, pstride, batch, n_hi, rows_per_block);
-  else launch_pass_t<MCAP, 4, 8, false>(st, P, V, W, nact, so, ld, pstride, batch, n_hi, rows_per_block);
-}
-
-void launch_pass(hipStream_t st, int mcap, bool streaming, double* P, const double* V, const double* W,
-                 const int* nact, const SolveOut* so, int ld, long pstride, int batch, int n_hi,
-                 int rows_per_block) {
-  switch (mcap) {
-    case 1: launch_pass_m<1>(st, streaming, P, V, W, nact, so, ld, pstride, batch, n_hi, rows_per_block); break;
-    case 2: launch_pass_m<2>(st, streaming, P, V, W, nact, so, ld, pstride, batch, n_hi, rows_per_block); break;
-    case 4: launch_pass_m<4>(st, streaming, P, V, W, nact, so, ld, pstride, batch, n_hi, rows_per_block); break;
-    case 8: launch_pass_m<8>(st, streaming, P, V, W, nact, so, ld, pstride, batch, n_hi, rows_per_block); break;
-    default: launch_pass_m<16>(st, streaming, P, V, W, nact, so, ld, pstride, batch, n_hi, rows_per_block); break;
-  }
+void launch_flush(hipStream_t st, bool streaming, double* P, const double* V, const double* W,
+                  const double* dacc, const int* nact, int ld, long pstride, int batch, int n_hi, int nkt,
+                  int rows_per_block) {
+#define EKF_FLUSH(N)                                                                                      \
+  do {                                                                                                    \
+    if (streaming) launch_flush_t<N, true>(st, P, V, W, dacc, nact, ld, pstride, batch, n_hi, nkt, rows_per_block); \
+    else launch_flush_t<N, false>(st, P, V, W, dacc, nact, ld, pstride, batch, n_hi, nkt, rows_per_block);          \
+  } while (0)
+  if (nkt <= 5) EKF_FLUSH(5);
+  else if (nkt <= 10) EKF_FLUSH(10);
+  else if (nkt <= 15) EKF_FLUSH(15);
+  else EKF_FLUSH(20);
+#undef EKF_FLUSH
 }
 
 void launch_predict_rc(hipStream_t st, double* P, const double* mu_in, double* mu_out, const int* nact,

@@ -101,6 +101,7 @@ ABI = {
     "ekf_stream_run": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "ekf_run_stream": (C.c_int, [C.c_void_p, C.c_int, _dp, _dp, _ip, _dp, _dp, _ip, C.c_int]),
     "ekf_predict_dense": (C.c_int, [C.c_void_p, C.c_int, _dp, _dp]),
+    "ekf_flush": (C.c_int, [C.c_void_p]),
     "ekf_sync": (C.c_int, [C.c_void_p]),
     "ekf_status_flags": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_uint)]),
     "ekf_last_error": (C.c_char_p, [C.c_void_p]),
@@ -264,6 +265,10 @@ class EkfSlam:
         f = C.c_uint()
         self._check(self._lib.ekf_status_flags(self._h, b, C.byref(f)))
         return f.value
+
+    def flush(self):
+        """Apply the pending low-rank covariance update to P now (asynchronous)."""
+        self._check(self._lib.ekf_flush(self._h))
 
     def sync(self):
         self._check(self._lib.ekf_sync(self._h))

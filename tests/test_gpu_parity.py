@@ -337,3 +337,51 @@ def test_argument_errors(sd):
             f.set_state(np.zeros(15), np.eye(15))            # larger than n_max
     with pytest.raises(sd.EkfError):
         sd.EkfSlam(12)                                       # n_max must be 3 + 2N
+
+
+@pytest.mark.parametrize("every", [1, 2, 3, 4, 9])
+def test_deferred_covariance_pass(sd, every):
+    """The covariance lives as P_base + pending low-rank factors; whatever the flush cadence, mean and
+    covariance equal the dense reference path.  Steps mix 0..20 observations (0 = prediction only on
+    top of pending ranks, > 16 = two device passes) so that rank slots fill unevenly."""
+    N, steps = 70, 26
+    mean0, diag0, lin, ang, idx, zr, zb = orc.synthetic_stream(N, steps, 20, 11)
+    ms = [8, 3, 0, 20, 1, 8, 8, 0, 0, 5, 16, 2, 8, 8, 8, 8, 0, 4, 17, 8, 1, 1, 8, 6, 0, 8]
+    cfg = orc.EkfConfig()
+    om, oP = mean0.copy(), np.diag(diag0)
+    with sd.EkfSlam(len(mean0)) as f:
+        f.set_option("flush_every", every)
+        f.set_state_diag(mean0, diag0)
+        for k in range(steps):
+            mk = ms[k]
+            f.step(lin[k], ang[k], idx[k][:mk], zr[k][:mk], zb[k][:mk])
+            om, oP = orc.ekf_step_dense(om, oP, lin[k], ang[k], idx[k][:mk], zr[k][:mk], zb[k][:mk], cfg)
+            close(f.mean(), om)                      # the mean never waits for a flush
+            if k in (6, 13, 25):
+                close(f.covariance(), oP)            # reading the covariance flushes
+        mu, P = f.state()
+    close(mu, om)
+    close(P, oP)
+
+
+def test_deferred_pass_batched_n500(sd):
+    """N=500, 3 trajectories, default cadence (4 steps per covariance pass), 10 steps (odd tail)."""
+    N, steps, B = 500, 10, 3
+    cfg = orc.EkfConfig()
+    streams = [orc.synthetic_stream(N, steps, 8, 20 + t) for t in range(B)]
+    ref = []
+    for s in streams:
+        om, oP = s[0].copy(), np.diag(s[1])
+        for k in range(steps):
+            om, oP = orc.ekf_step_structured(om, oP, s[2][k], s[3][k], s[4][k], s[5][k], s[6][k], cfg)
+        ref.append((om, oP))
+    with sd.EkfSlam(3 + 2 * N, batch=B) as f:
+        for b, s in enumerate(streams):
+            f.set_state_diag(s[0], s[1], b)
+        f.run_stream(np.stack([s[2] for s in streams], 1), np.stack([s[3] for s in streams], 1),
+                     np.stack([s[4] for s in streams], 1), np.stack([s[5] for s in streams], 1),
+                     np.stack([s[6] for s in streams], 1))
+        for b in range(B):
+            mu, P = f.state(b)
+            close(mu, ref[b][0])
+            close(P, ref[b][1])
