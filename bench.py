@@ -46,12 +46,15 @@ def make_streams(sd_syn, traj_ids, n_landmarks, steps, m):
     return streams, lin, ang, idx, zr, zb
 
 
-def time_filter(sd, sd_syn, device, traj_ids, n_landmarks, m, steps, warmup, barrier, profile_leg=True):
+def time_filter(sd, sd_syn, device, traj_ids, n_landmarks, m, steps, warmup, barrier, profile_leg=True, options=()):
     """Returns (seconds for `steps` steps on this rank, pass_ms_total, pass_launches, device_ms)."""
     n = 3 + 2 * n_landmarks
     total = warmup + steps + (steps if profile_leg else 0)
     streams, lin, ang, idx, zr, zb = make_streams(sd_syn, traj_ids, n_landmarks, total, m)
     f = sd.EkfSlam(n, batch=len(traj_ids), device=device)
+    for opt in options:
+        name, value = opt.split("=")
+        f.set_option(name, int(value))
     for b, s in enumerate(streams):
         f.set_state_diag(s[0], s[1], b)
     f.stream_upload(lin, ang, idx, zr, zb)
@@ -116,6 +119,8 @@ def main():
     ap.add_argument("--trajectories", type=int, default=32, help="trajectories per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-single", action="store_true")
+    ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE",
+                    help="ekf_set_option knob, e.g. flush_every=3 (default: library defaults)")
     args = ap.parse_args()
 
     import slam_duckietown_amd.sharding as shard
@@ -133,7 +138,7 @@ def main():
     n = 3 + 2 * args.landmarks
     traj_ids = shard.shard_trajectories(B * world, world, rank)
     dt, pass_ms, launches, dev_ms = time_filter(sd, sd_syn, local_rank, traj_ids, args.landmarks, args.obs,
-                                                args.steps, args.warmup, barrier)
+                                                args.steps, args.warmup, barrier, options=args.option)
     dt = grp.max_over_ranks(dt)
     total_units = grp.sum_over_ranks(len(traj_ids) * args.steps)
 
@@ -170,7 +175,7 @@ def main():
     if world == 1 and rank == 0:
         if not args.no_single:
             dt1, p1, l1, _ = time_filter(sd, sd_syn, local_rank, [0], args.landmarks, args.obs, args.steps,
-                                         args.warmup, lambda: None)
+                                         args.warmup, lambda: None, options=args.option)
             a1 = 16.0 * n * n / ((p1 / max(l1, 1)) * 1e-3) / 1e9 if p1 > 0 else 0.0
             out["single_trajectory"] = {"workload": f"N={args.landmarks}, m={args.obs}, 1 trajectory (BASELINE config 3)",
                                         "value": args.steps / dt1, "unit": "steps/s",

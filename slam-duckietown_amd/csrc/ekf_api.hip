@@ -290,8 +290,11 @@ extern "C" int ekf_add_landmarks(ekf_handle* h, int b, int first_index, const do
 // ---- step machinery -------------------------------------------------------------------------
 static int cap_for(int m) { return m <= 1 ? 1 : m <= 2 ? 2 : m <= 4 ? 4 : m <= 8 ? 8 : 16; }
 
-static int flush_rows_per_block(const ekf_handle* h) {
-  return h->opt_rows_per_block > 0 ? (h->opt_rows_per_block + 15) / 16 * 16 : 256;
+// Rows per workgroup of k_flush: every wave re-reads its V strip (K x 1 KiB, from L2) per row block, so
+// the block must be long where many ranks are pending, and short enough to give every CU several waves.
+static int flush_rows_per_block(const ekf_handle* h, bool streaming) {
+  if (h->opt_rows_per_block > 0) return (h->opt_rows_per_block + 15) / 16 * 16;
+  return streaming ? 256 : 128;
 }
 
 // The covariances of the batch stream through HBM when they cannot stay in the 256 MiB Infinity Cache.
@@ -321,7 +324,7 @@ static int flush_pending(ekf_handle* h) {
     HIP_TRY(h, hipEventRecord(e0, h->stream));
   }
   launch_flush(h->stream, streaming_pass(h, n_hi), h->dP, h->dV, h->dW, h->ddacc, h->dn, h->ld, h->pstride,
-               h->batch, n_hi, h->pending_k / 4, flush_rows_per_block(h));
+               h->batch, n_hi, h->pending_k / 4, flush_rows_per_block(h, streaming_pass(h, n_hi)));
   if (h->profile) HIP_TRY(h, hipEventRecord(e1, h->stream));
   HIP_TRY(h, hipGetLastError());
   HIP_TRY(h, hipMemsetAsync(h->ddacc, 0, sizeof(double) * 4 * h->batch, h->stream));
@@ -357,7 +360,7 @@ static int enqueue_pass(ekf_handle* h, const StepIn* d_in, int m_hi) {
   h->cur ^= 1;
   h->pending_k += ktp;
   h->pending_steps += 1;
-  const int every = h->opt_flush_every > 0 ? h->opt_flush_every : 4;
+  const int every = h->opt_flush_every > 0 ? h->opt_flush_every : 3;
   if (h->pending_steps >= every || h->pending_k + 4 > KTOT)
     if (int rc = flush_pending(h)) return rc;
   return EKF_OK;

@@ -8,7 +8,7 @@
 //              P[C,C] (base + pending ranks), one wave runs the recurrences
 //   k_panels   thread i replays the m rank-2 down-dates on column i of the row panel P'[C,:] and on
 //              row i of the column panel P'[:,C] (both of the current P) and appends
-//              V = stacked H_j P_j (coalesced rank-major) and W = -stacked K_j (MFMA-tiled); mean update
+//              V = stacked H_j P_j (rank-major, coalesced) and W = -stacked K_j (MFMA-tiled); mean update
 //   k_flush    P_base <- P_base + W V + diag(dacc): one streaming read-modify-write of P_base with
 //              the rank-K product on the fp64 matrix cores (v_mfma_f64_16x16x4_f64)
 // With nothing observed and nothing pending, k_predict_rc touches rows/cols 0,1 of P only (O(n)).
@@ -611,29 +611,55 @@ __global__ __launch_bounds__(256) void k_panels(const double* __restrict__ P, do
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_flush: P_base[i][j] += sum_{k < 4 nkt} W[i][k] V[k][j] + dacc on the pose diagonal, in place.
-// A wave owns a strip of 64 columns: the V strip lives in registers as MFMA B fragments
-// (nkt x 4 doubles per lane) for the whole row block.  Per 16-row tile it loads the P tiles straight
-// into the fp64 C/D layout (col = lane&15, row = (lane>>4) + 4 reg: each 16 lanes read one 128-B
-// line), the W tile as A fragments (one lane-linear 512-B load per k-tile, wm_index layout), issues
-// 4 x nkt v_mfma_f64_16x16x4_f64 and stores.  The next tile's P and W are prefetched under the MFMAs.
+// k_flush: P_base[i][j] += sum_{k < 4 nkt} W[i][k] V[k][j] + dacc on the pose diagonal, in place:
+// one read + one write of P_base (16 n^2 bytes per trajectory) for ALL pending steps, with the
+// rank-K product on the fp64 matrix cores.
+// A wave owns a strip of 64 columns; the V strip lives in registers as MFMA B fragments (nkt x 4
+// doubles per lane) for the whole row block.  Per 16-row tile:
+//   global -> registers   8 x global_load_dwordx4: every instruction is two full 512-B row segments
+//                         (the tile after this one is prefetched while this one computes)
+//   registers -> LDS      row-major image, wave-private (no workgroup barrier anywhere)
+//   LDS -> accumulators   16 x ds_read_b64 in the fp64 C/D layout (col = lane&15, row = lane>>4 + 4 reg);
+//                         the row stride of 80 doubles puts the two rows of a 32-lane group on
+//                         disjoint bank halves
+//   W tile                A fragments, one lane-linear 512-B load per k-tile (wm_index layout), L2-resident
+//   4 x nkt v_mfma_f64_16x16x4_f64, then the same path back (LDS transpose, 1 KiB stores).
+// Going through LDS keeps every HBM access 16 B per lane; loading the C/D layout straight from global
+// memory (8 B per lane, 128-B segments) ran at 0.6x the streaming rate.
 // NT: nontemporal loads/stores for working sets beyond the 256 MiB Infinity Cache.
-// Algorithmic traffic: 16 n^2 bytes per trajectory per launch, whatever the number of pending steps.
+// Bound: HBM up to ~48 pending ranks, fp64 MFMA beyond (2 K flop per 16 B; v_mfma_f64_16x16x4 sustains
+// 47 TFLOP/s on this part, profiles/mfma_probe.txt).
 // ---------------------------------------------------------------------------------------------
 template <bool NT>
-__device__ __forceinline__ double ldn(const double* a) { return NT ? __builtin_nontemporal_load(a) : *a; }
+__device__ __forceinline__ double2 ld2(const double* a) {
+  double2 r;
+  if (NT) {
+    r.x = __builtin_nontemporal_load(a);
+    r.y = __builtin_nontemporal_load(a + 1);
+  } else {
+    r = *reinterpret_cast<const double2*>(a);
+  }
+  return r;
+}
 template <bool NT>
-__device__ __forceinline__ void stn(double* a, double v) {
-  if (NT) __builtin_nontemporal_store(v, a);
-  else *a = v;
+__device__ __forceinline__ void st2(double* a, double2 v) {
+  if (NT) {
+    __builtin_nontemporal_store(v.x, a);
+    __builtin_nontemporal_store(v.y, a + 1);
+  } else {
+    *reinterpret_cast<double2*>(a) = v;
+  }
 }
 
+constexpr int FTS = 80;                 // LDS row stride of a wave's 16 x 64 tile image (doubles)
+
 template <int NKTM, bool NT>
-__global__ __launch_bounds__(256) void k_flush(double* __restrict__ P, const double* __restrict__ V,
-                                               const double* __restrict__ W,
-                                               const double* __restrict__ dacc,
-                                               const int* __restrict__ nact, int ld, long pstride, int nkt,
-                                               int rows_per_block) {
+__global__ __launch_bounds__(256, 2) void k_flush(double* __restrict__ P, const double* __restrict__ V,
+                                                  const double* __restrict__ W,
+                                                  const double* __restrict__ dacc,
+                                                  const int* __restrict__ nact, int ld, long pstride,
+                                                  int nkt, int rows_per_block) {
+  __shared__ double tiles[4][16 * FTS];
   const int b = blockIdx.z;
   const int n = nact[b];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -642,13 +668,17 @@ __global__ __launch_bounds__(256) void k_flush(double* __restrict__ P, const dou
   const int i_begin = blockIdx.y * rows_per_block;
   if (j0 >= n || i_begin >= n) return;
   const int i_end = min(n, i_begin + rows_per_block);
-  const int li = lane & 15, lq = lane >> 4;
+  const int li = lane & 15, lq = lane >> 4;            // C/D layout coordinates
+  const int rr = lane >> 5, rc = (lane & 31) * 2;      // row-major image: 2 rows per instruction
   const int ld16 = ld >> 4;
   double* Pb = P + (long)b * pstride;
   const double* Vb = V + (long)b * KTOT * ld;
   const double* Wb = W + (long)b * KTOT * ld;
+  double* T = tiles[wave];
   int nct = (n - j0 + 15) >> 4;                        // column tiles of this strip that start below n
   if (nct > 4) nct = 4;
+  const bool colok = (j0 + rc + 1) < ld;               // the 16-byte access stays inside the row
+  const bool col0 = (j0 + rc) < n, col1 = (j0 + rc + 1) < n;
 
   double vf[NKTM][4];
 #pragma unroll
@@ -657,58 +687,62 @@ __global__ __launch_bounds__(256) void k_flush(double* __restrict__ P, const dou
     for (int ct = 0; ct < 4; ++ct)
       vf[t][ct] = (t < nkt && ct < nct) ? Vb[(long)(4 * t + lq) * ld + j0 + ct * 16 + li] : 0.0;
 
-  double wf[NKTM], wn[NKTM];
-  double4_t pf[4], pn[4];
-  auto load_tile = [&](int i0, double (&w)[NKTM], double4_t (&p)[4]) {
-    const double* wsrc = Wb + (long)(i0 >> 4) * 64 + lane;
+  double2 g[8];                                        // row-major registers of the tile in flight
+  auto gload = [&](int i0) {
 #pragma unroll
-    for (int t = 0; t < NKTM; ++t) w[t] = (t < nkt) ? wsrc[(long)t * ld16 * 64] : 0.0;
+    for (int q = 0; q < 8; ++q) {
+      const int row = i0 + 2 * q + rr;
+      g[q] = (row < n && colok) ? ld2<NT>(Pb + (long)row * ld + j0 + rc) : make_double2(0.0, 0.0);
+    }
+  };
+  gload(i_begin);
+  for (int i0 = i_begin; i0 < i_end; i0 += 16) {
+    double wf[NKTM];
+    {
+      const double* wsrc = Wb + (long)(i0 >> 4) * 64 + lane;
+#pragma unroll
+      for (int t = 0; t < NKTM; ++t) wf[t] = (t < nkt) ? wsrc[(long)t * ld16 * 64] : 0.0;
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) *reinterpret_cast<double2*>(&T[(2 * q + rr) * FTS + rc]) = g[q];
+    WAVE_SYNC();
+    if (i0 + 16 < i_end) gload(i0 + 16);               // prefetch under the MFMAs
+    double4_t acc[4];
 #pragma unroll
     for (int ct = 0; ct < 4; ++ct)
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
-        p[ct][r] = (ct < nct) ? ldn<NT>(Pb + (long)(i0 + lq + 4 * r) * ld + j0 + ct * 16 + li) : 0.0;
-  };
-  auto mma_store = [&](int i0, const double (&w)[NKTM], double4_t (&p)[4]) {
+      for (int r = 0; r < 4; ++r) acc[ct][r] = T[(lq + 4 * r) * FTS + ct * 16 + li];
+    WAVE_SYNC();
 #pragma unroll
     for (int t = 0; t < NKTM; ++t)
       if (t < nkt) {
 #pragma unroll
-        for (int ct = 0; ct < 4; ++ct) p[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(w[t], vf[t][ct], p[ct], 0, 0, 0);
+        for (int ct = 0; ct < 4; ++ct)
+          acc[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(wf[t], vf[t][ct], acc[ct], 0, 0, 0);
       }
     if (i0 == 0 && j0 == 0) {                          // pose-block noise accumulated since the last flush
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int row = lq + 4 * r;
-        if (row < 3 && li == row) p[0][r] += dacc[4 * b + row];
+        if (row < 3 && li == row) acc[0][r] += dacc[4 * b + row];
       }
     }
 #pragma unroll
     for (int ct = 0; ct < 4; ++ct)
-      if (ct < nct) {
-        const int col = j0 + ct * 16 + li;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = i0 + lq + 4 * r;
-          if (row < n && col < n) stn<NT>(Pb + (long)row * ld + col, p[ct][r]);
-        }
+      for (int r = 0; r < 4; ++r) T[(lq + 4 * r) * FTS + ct * 16 + li] = acc[ct][r];
+    WAVE_SYNC();
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int row = i0 + 2 * q + rr;
+      const double2 o = *reinterpret_cast<const double2*>(&T[(2 * q + rr) * FTS + rc]);
+      if (row < n) {
+        double* dst = Pb + (long)row * ld + j0 + rc;
+        if (col1) st2<NT>(dst, o);
+        else if (col0) *dst = o.x;
       }
-  };
-
-  int i0 = i_begin;
-  load_tile(i0, wf, pf);
-  while (true) {
-    const int i1 = i0 + 16;
-    const bool more1 = i1 < i_end;
-    if (more1) load_tile(i1, wn, pn);
-    mma_store(i0, wf, pf);
-    if (!more1) break;
-    const int i2 = i1 + 16;
-    const bool more2 = i2 < i_end;
-    if (more2) load_tile(i2, wf, pf);
-    mma_store(i1, wn, pn);
-    if (!more2) break;
-    i0 = i2;
+    }
+    WAVE_SYNC();
   }
 }
 
@@ -817,6 +851,7 @@ static void launch_flush_t(hipStream_t st, double* P, const double* V, const dou
                      rows_per_block);
 }
 
+// streaming = the batch's covariances do not fit the Infinity Cache: nontemporal accesses
 void launch_flush(hipStream_t st, bool streaming, double* P, const double* V, const double* W,
                   const double* dacc, const int* nact, int ld, long pstride, int batch, int n_hi, int nkt,
                   int rows_per_block) {
