@@ -145,9 +145,13 @@ def main():
     out = None
     if rank == 0:
         value = total_units / dt
-        alg_bytes = B * 16.0 * n * n                     # per pass launch: every trajectory's P read + written
+        # The covariance pass (k_flush) reads and writes every trajectory's P exactly once per launch,
+        # whatever the number of steps it folds in: 16 n^2 bytes per trajectory per launch.
+        alg_bytes = B * 16.0 * n * n
         avg_s = (pass_ms / max(launches, 1)) * 1e-3
         achieved = alg_bytes / avg_s / 1e9 if avg_s > 0 else 0.0
+        steps_per_launch = args.steps / max(launches, 1)
+        ranks = steps_per_launch * (2 * args.obs + 2)
         out = {
             "metric": "EKF update steps/sec", "value": value, "unit": "steps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -156,10 +160,18 @@ def main():
             "config": {"workload": f"N={args.landmarks} landmarks (n={n}), m={args.obs} obs/step, "
                                    f"{B} trajectories/GPU x {world} GPU(s), fused predict+update step",
                        "landmarks": args.landmarks, "state_dim": n, "obs_per_step": args.obs,
-                       "trajectories_per_gpu": B, "parallelism": f"trajectory-sharded x{world}, no collective"},
+                       "trajectories_per_gpu": B, "parallelism": f"trajectory-sharded x{world}, no collective",
+                       "options": args.option},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "ekf::k_pass",
-                         "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_s * 1e3, "launches": launches},
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "ekf::k_flush",
+                         "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_s * 1e3, "launches": launches,
+                         "steps_per_launch": steps_per_launch,
+                         "step_equivalent_GBs": achieved * steps_per_launch,
+                         "fp64_mfma_TFLOPs": 2.0 * ranks * B * n * n / avg_s / 1e12 if avg_s > 0 else 0.0,
+                         "note": "one launch applies the pending rank-K update of steps_per_launch steps: "
+                                 "SURVEY 8(d)'s 16 n^2 bytes per step are paid once per launch; achieved/frac "
+                                 "count the bytes this launch must move (one read + one write of P), "
+                                 "step_equivalent_GBs multiplies by the steps folded in"},
             "device_ms_per_step": dev_ms / args.steps,
         }
         traffic_file = os.path.join(ROOT, "profiles", "pass_traffic.json")
@@ -179,7 +191,7 @@ def main():
             a1 = 16.0 * n * n / ((p1 / max(l1, 1)) * 1e-3) / 1e9 if p1 > 0 else 0.0
             out["single_trajectory"] = {"workload": f"N={args.landmarks}, m={args.obs}, 1 trajectory (BASELINE config 3)",
                                         "value": args.steps / dt1, "unit": "steps/s",
-                                        "pass_avg_launch_ms": p1 / max(l1, 1),
+                                        "pass_avg_launch_ms": p1 / max(l1, 1), "pass_launches": l1,
                                         "pass_achieved_GBs": a1, "pass_frac_of_hbm_peak": a1 / HBM_PEAK_GBS}
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.landmarks, args.obs)
