@@ -14,8 +14,8 @@ void launch_solve(hipStream_t, const double*, const double*, const double*, doub
                   const int*, const StepIn*, SolveOut*, unsigned*, const DeviceConfig&, int, long, int, int);
 void launch_panels(hipStream_t, int, const double*, double*, double*, const double*, double*, const int*,
                    const SolveOut*, int, long, int, int);
-void launch_flush(hipStream_t, bool, double*, const double*, const double*, const double*, const int*, int,
-                  long, int, int, int, int);
+void launch_flush(hipStream_t, bool, double*, const double*, const double*, const double*, const int*,
+                  const SolveOut*, int, long, int, int, int, int);
 void launch_predict_rc(hipStream_t, double*, const double*, double*, const int*, const SolveOut*, int, long,
                        int, int);
 void launch_add_landmarks(hipStream_t, double*, double*, int, int, int, double, const double*);
@@ -49,8 +49,12 @@ struct ekf_handle {
   size_t stream_cap = 0;
   int stream_steps = 0;
   std::vector<int> stream_mhi;
+  std::vector<int> stream_neff;   // per (step, trajectory) active bound of the uploaded stream
   double *dF = nullptr, *dQ = nullptr, *dTmp = nullptr;   // dense path, allocated on first use
   std::vector<int> n;
+  std::vector<int> neff_enq;      // active bound of the last ENQUEUED step (what dso[b].neff holds)
+  std::vector<int> neff;          // active bound per trajectory (<= n): indices beyond were never correlated
+  int opt_active_bound = 1;       // 0 = always treat the whole state as active
   hipEvent_t t0 = nullptr, t1 = nullptr;
   bool profile = false;
   std::vector<hipEvent_t> prof_pool;
@@ -141,6 +145,8 @@ extern "C" int ekf_create(int device, int n_max, int batch, const ekf_config* cf
   h->dcfg.enable_circular_interpolation = h->cfg.enable_circular_interpolation;
   h->dcfg.disable_motion_model = h->cfg.disable_motion_model;
   h->n.assign(batch, 3);
+  h->neff.assign(batch, 3);
+  h->neff_enq.assign(batch, 3);
 
 #define CREATE_TRY(expr)                                                                  \
   do {                                                                                    \
@@ -220,6 +226,7 @@ extern "C" int ekf_upload_state(ekf_handle* h, int b, const double* mu, const do
                               sizeof(double) * n, n, hipMemcpyHostToDevice, h->stream));
   HIP_TRY(h, hipMemcpyAsync(h->dmu2[h->cur] + (size_t)b * h->ld, mu, sizeof(double) * n, hipMemcpyHostToDevice, h->stream));
   if (int rc = set_size(h, b, n)) return rc;
+  h->neff[b] = n;                                      // arbitrary dense covariance: everything is active
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   return EKF_OK;
 }
@@ -233,6 +240,7 @@ extern "C" int ekf_upload_state_diag(ekf_handle* h, int b, const double* mu, con
   HIP_TRY(h, hipMemcpyAsync(h->dscratch, diagP, sizeof(double) * n, hipMemcpyHostToDevice, h->stream));
   launch_fill_diag(h->stream, h->dP + (size_t)b * h->pstride, h->ld, n, h->dscratch);
   HIP_TRY(h, hipGetLastError());
+  h->neff[b] = 3;                                      // diagonal covariance: nothing is correlated yet
   HIP_TRY(h, hipMemcpyAsync(h->dmu2[h->cur] + (size_t)b * h->ld, mu, sizeof(double) * n, hipMemcpyHostToDevice, h->stream));
   if (int rc = set_size(h, b, n)) return rc;
   HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -323,8 +331,10 @@ static int flush_pending(ekf_handle* h) {
     if (int rc = prof_event(h, &e1)) return rc;
     HIP_TRY(h, hipEventRecord(e0, h->stream));
   }
-  launch_flush(h->stream, streaming_pass(h, n_hi), h->dP, h->dV, h->dW, h->ddacc, h->dn, h->ld, h->pstride,
-               h->batch, n_hi, h->pending_k / 4, flush_rows_per_block(h, streaming_pass(h, n_hi)));
+  int e_hi = 3;                                        // grid covers the largest active bound of the batch
+  for (int b = 0; b < h->batch; ++b) e_hi = std::max(e_hi, std::min(h->n[b], h->neff_enq[b]));
+  launch_flush(h->stream, streaming_pass(h, n_hi), h->dP, h->dV, h->dW, h->ddacc, h->dn, h->dso, h->ld, h->pstride,
+               h->batch, e_hi, h->pending_k / 4, flush_rows_per_block(h, streaming_pass(h, n_hi)));
   if (h->profile) HIP_TRY(h, hipEventRecord(e1, h->stream));
   HIP_TRY(h, hipGetLastError());
   HIP_TRY(h, hipMemsetAsync(h->ddacc, 0, sizeof(double) * 4 * h->batch, h->stream));
@@ -385,6 +395,12 @@ static int fill_step(ekf_handle* h, StepIn& s, int b, double lin, double ang, in
     s.bearing[i] = bearing[lo + i];
   }
   for (int i = cnt; i < MMAX; ++i) { s.idx[i] = 0; s.range[i] = 0.0; s.bearing[i] = 0.0; }
+  // active bound (monotone): an observed landmark and everything below it may be correlated from now on
+  int bound = h->neff[b];
+  for (int i = 0; i < cnt; ++i) bound = std::max(bound, 3 + 2 * (s.idx[i] + 1));
+  h->neff[b] = std::min(bound, h->n[b]);
+  s.neff = h->opt_active_bound ? h->neff[b] : h->n[b];
+  s.pad = 0;
   return EKF_OK;
 }
 
@@ -420,6 +436,7 @@ static int do_step(ekf_handle* h, int base_flags, const double* lin, const doubl
         return rc;
       m_pass_hi = std::max(m_pass_hi, hs[b].m);
     }
+    for (int b = 0; b < h->batch; ++b) h->neff_enq[b] = hs[b].neff;
     HIP_TRY(h, hipMemcpyAsync(ds, hs, sizeof(StepIn) * h->batch, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipEventRecord(h->ring_ev[slot], h->stream));
     h->ring_used[slot] = true;
@@ -451,6 +468,7 @@ extern "C" int ekf_stream_upload(ekf_handle* h, int steps, const double* lin, co
   const size_t count = (size_t)steps * h->batch;
   std::vector<StepIn> host(count);
   h->stream_mhi.assign(steps, 0);
+  h->stream_neff.assign(count, 3);
   h->stream_steps = 0;
   for (int k = 0; k < steps; ++k)
     for (int b = 0; b < h->batch; ++b) {
@@ -463,6 +481,7 @@ extern "C" int ekf_stream_upload(ekf_handle* h, int steps, const double* lin, co
                              bearing ? bearing + e * stride : nullptr, mb, 0))
         return rc;
       h->stream_mhi[k] = std::max(h->stream_mhi[k], mb);
+      h->stream_neff[e] = host[e].neff;
     }
   HIP_TRY(h, hipSetDevice(h->device));
   if (h->stream_cap < count) {
@@ -484,8 +503,10 @@ extern "C" int ekf_stream_run(ekf_handle* h, int first, int count) {
   if (first < 0 || count < 0 || first + count > h->stream_steps)
     return fail(h, EKF_ERR_STATE, "ekf_stream_run: range outside the uploaded stream");
   HIP_TRY(h, hipSetDevice(h->device));
-  for (int k = first; k < first + count; ++k)
+  for (int k = first; k < first + count; ++k) {
+    for (int b = 0; b < h->batch; ++b) h->neff_enq[b] = h->stream_neff[(size_t)k * h->batch + b];
     if (int rc = enqueue_pass(h, h->d_stream + (size_t)k * h->batch, h->stream_mhi[k])) return rc;
+  }
   return EKF_OK;
 }
 
@@ -520,6 +541,7 @@ extern "C" int ekf_predict_dense(ekf_handle* h, int b, const double* F, const do
     if (int rc = prof_event(h, &e1)) return rc;
     HIP_TRY(h, hipEventRecord(e0, h->stream));
   }
+  h->neff[b] = n;                                      // a general F correlates everything
   if (dense_propagate(h->stream, h->dP + (size_t)b * h->pstride, h->dTmp, h->dF, h->dQ, n, h->ld) != 0)
     return fail(h, EKF_ERR_HIP, "ekf_predict_dense: launch failed");
   if (h->profile) HIP_TRY(h, hipEventRecord(e1, h->stream));
@@ -598,6 +620,12 @@ extern "C" int ekf_set_option(ekf_handle* h, const char* name, int value) {
   if (std::strcmp(name, "pass_rows_per_block") == 0) {
     if (value < 0 || value > 4096) return fail(h, EKF_ERR_ARG, "pass_rows_per_block out of range");
     h->opt_rows_per_block = value;
+    return EKF_OK;
+  }
+  if (std::strcmp(name, "active_bound") == 0) {
+    if (value != 0 && value != 1) return fail(h, EKF_ERR_ARG, "active_bound must be 0 or 1");
+    if (int rc = flush_pending(h)) return rc;
+    h->opt_active_bound = value;
     return EKF_OK;
   }
   if (std::strcmp(name, "flush_every") == 0) {

@@ -17,11 +17,13 @@ __host__ __device__ constexpr int ranks_for(int mcap) { return (2 * mcap + 2 + 3
 constexpr int FLAG_PREDICT = 1;         // StepIn.flags
 constexpr int FLAG_UPDATE = 2;
 
-// One step's inputs for one trajectory (host -> device, 344 B).
+// One step's inputs for one trajectory (host -> device, 352 B).
 struct StepIn {
   double lin, ang;
   int m;
   int flags;
+  int neff;             // active bound: state indices >= neff have never been correlated with anything
+  int pad;
   int idx[MMAX];
   double range[MMAX];
   double bearing[MMAX];
@@ -49,7 +51,7 @@ struct alignas(16) SolveOut {
   int c;                // 3 + 2m
   int m;
   int kbase;            // ranks pending before this step (multiple of 4)
-  int pad1;
+  int neff;             // active bound of this step (rows/cols >= neff of P are untouched diagonal)
   int C[CMAX + 1];      // gathered state indices, padded with 0
   SolveIter it[MMAX];
 #ifdef EKF_STAMPS

@@ -260,6 +260,7 @@ __global__ __launch_bounds__(256) void k_solve(const double* __restrict__ P, con
     o.c = c;
     o.m = m;
     o.kbase = kbase;
+    o.neff = s.neff;
     dacc[4 * b + 0] = d0 + rd0;                      // the pose-block noise joins the pending update
     dacc[4 * b + 1] = d1 + rd1;
     dacc[4 * b + 2] = d2 + rd2;
@@ -414,6 +415,20 @@ __global__ __launch_bounds__(256) void k_panels(const double* __restrict__ P, do
   const int ld16 = ld >> 4;
   const int m = min(o.m, MCAP), c = o.c, kb = o.kbase;
 
+  if ((int)blockIdx.x * 64 >= o.neff) {
+    // every state index of this workgroup lies beyond the active bound: its rows and columns of P are
+    // exactly zero off the diagonal, so this step's V columns / W rows are zero and the mean is unchanged
+    if (act && wave == 0) {
+#pragma unroll
+      for (int k = 0; k < KTP; ++k) Vb[(long)(kb + k) * ld + i] = 0.0;
+    }
+    if (act && wave == 1) {
+#pragma unroll
+      for (int k = 0; k < KTP; ++k) Wb[wm_index(ld16, kb + k, i)] = 0.0;
+      mu_out[(long)b * ld + i] = mu_in[(long)b * ld + i];
+    }
+    return;
+  }
   {
     const double2* src = reinterpret_cast<const double2*>(o.it);
     double2* dst = reinterpret_cast<double2*>(its);
@@ -657,11 +672,12 @@ template <int NKTM, bool NT>
 __global__ __launch_bounds__(256, 2) void k_flush(double* __restrict__ P, const double* __restrict__ V,
                                                   const double* __restrict__ W,
                                                   const double* __restrict__ dacc,
-                                                  const int* __restrict__ nact, int ld, long pstride,
+                                                  const int* __restrict__ nact,
+                                                  const SolveOut* __restrict__ so, int ld, long pstride,
                                                   int nkt, int rows_per_block) {
   __shared__ double tiles[4][16 * FTS];
   const int b = blockIdx.z;
-  const int n = nact[b];
+  const int n = min(nact[b], so[b].neff);              // rows/cols beyond the active bound are untouched
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   const int j0 = (blockIdx.x * 4 + wave) * 64;
@@ -764,6 +780,7 @@ __global__ __launch_bounds__(256) void k_predict_rc(double* __restrict__ P,
   const double g0 = so[b].g[0], g1 = so[b].g[1];
   if (j >= 3) {
     mu_out[(long)b * ld + j] = mu_in[(long)b * ld + j];     // k_solve wrote the pose entries
+    if (j >= so[b].neff) return;                            // P[2][j] = P[j][2] = 0 beyond the active bound
     const double r2 = Pb[2 * (long)ld + j];
     Pb[j] += g0 * r2;
     Pb[(long)ld + j] += g1 * r2;
@@ -844,21 +861,21 @@ void launch_panels(hipStream_t st, int mcap, const double* P, double* V, double*
 
 template <int NKTM, bool NT>
 static void launch_flush_t(hipStream_t st, double* P, const double* V, const double* W, const double* dacc,
-                           const int* nact, int ld, long pstride, int batch, int n_hi, int nkt,
-                           int rows_per_block) {
+                           const int* nact, const SolveOut* so, int ld, long pstride, int batch, int n_hi,
+                           int nkt, int rows_per_block) {
   dim3 grid((n_hi + 255) / 256, (n_hi + rows_per_block - 1) / rows_per_block, batch);
-  hipLaunchKernelGGL((k_flush<NKTM, NT>), grid, dim3(256), 0, st, P, V, W, dacc, nact, ld, pstride, nkt,
+  hipLaunchKernelGGL((k_flush<NKTM, NT>), grid, dim3(256), 0, st, P, V, W, dacc, nact, so, ld, pstride, nkt,
                      rows_per_block);
 }
 
 // streaming = the batch's covariances do not fit the Infinity Cache: nontemporal accesses
 void launch_flush(hipStream_t st, bool streaming, double* P, const double* V, const double* W,
-                  const double* dacc, const int* nact, int ld, long pstride, int batch, int n_hi, int nkt,
-                  int rows_per_block) {
+                  const double* dacc, const int* nact, const SolveOut* so, int ld, long pstride, int batch,
+                  int n_hi, int nkt, int rows_per_block) {
 #define EKF_FLUSH(N)                                                                                      \
   do {                                                                                                    \
-    if (streaming) launch_flush_t<N, true>(st, P, V, W, dacc, nact, ld, pstride, batch, n_hi, nkt, rows_per_block); \
-    else launch_flush_t<N, false>(st, P, V, W, dacc, nact, ld, pstride, batch, n_hi, nkt, rows_per_block);          \
+    if (streaming) launch_flush_t<N, true>(st, P, V, W, dacc, nact, so, ld, pstride, batch, n_hi, nkt, rows_per_block); \
+    else launch_flush_t<N, false>(st, P, V, W, dacc, nact, so, ld, pstride, batch, n_hi, nkt, rows_per_block);          \
   } while (0)
   if (nkt <= 5) EKF_FLUSH(5);
   else if (nkt <= 10) EKF_FLUSH(10);

@@ -385,3 +385,28 @@ def test_deferred_pass_batched_n500(sd):
             mu, P = f.state(b)
             close(mu, ref[b][0])
             close(P, ref[b][1])
+
+
+def test_active_bound_is_exact(sd):
+    """State indices beyond the highest landmark observed so far have exactly zero cross-covariance
+    (block-diagonal start, BASELINE config 5): skipping them must change nothing, bit for bit."""
+    N, steps = 300, 14
+    mean0, diag0, lin, ang, idx, zr, zb = orc.synthetic_stream(N, steps, 8, 4)
+    idx = (idx * 7 + 3) % 120          # observations wander inside the first 120 landmarks only
+    for k in range(steps):             # (keep each step's indices distinct)
+        assert len(set(idx[k])) == 8
+    out = []
+    for bound in (1, 0):
+        with sd.EkfSlam(len(mean0)) as f:
+            f.set_option("active_bound", bound)
+            f.set_state_diag(mean0, diag0)
+            f.run_stream(lin, ang, idx, zr, zb)
+            out.append(f.state())
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+    cfg = orc.EkfConfig()
+    om, oP = mean0.copy(), np.diag(diag0)
+    for k in range(steps):
+        om, oP = orc.ekf_step_dense(om, oP, lin[k], ang[k], idx[k], zr[k], zb[k], cfg)
+    close(out[0][0], om)
+    close(out[0][1], oP)
+    assert np.array_equal(out[0][1][243:, :243], np.zeros((len(mean0) - 243, 243)))   # never touched
