@@ -139,6 +139,12 @@ def main():
     import slam_duckietown_amd.synthetic as sd_syn
     sd.load_library()
 
+    # one rank per GPU (LOCAL_RANK = device index on the driver's 8-GPU node); the modulo only matters
+    # when more ranks than devices are launched to rehearse the multi-rank path on a smaller box
+    n_dev = sd.device_count()
+    if n_dev < 1:
+        raise SystemExit("no MI355X visible: the HIP path has no CPU fallback")
+    local_rank = local_rank % n_dev
     B = args.trajectories
     n = 3 + 2 * args.landmarks
     traj_ids = shard.shard_trajectories(B * world, world, rank)

@@ -46,6 +46,9 @@ typedef struct ekf_config {
 
 int ekf_config_default(ekf_config *cfg);
 
+/* Number of HIP devices visible to the process (0, and EKF_OK, when there is none). */
+int ekf_device_count(int *count);
+
 /* Create a filter bank of `batch` independent trajectories on HIP device `device`, each with room
  * for n_max = 3 + 2*N_max states.  All trajectories start as the reference does
  * (src/replay_no_ros.py:69-70): n = 3, mu = 0, P = motion_sigma * I3.  Fails (EKF_ERR_HIP) when no

@@ -92,6 +92,14 @@ extern "C" int ekf_config_default(ekf_config* cfg) {
   return EKF_OK;
 }
 
+extern "C" int ekf_device_count(int* count) {
+  if (!count) return EKF_ERR_ARG;
+  int c = 0;
+  if (hipGetDeviceCount(&c) != hipSuccess) c = 0;
+  *count = c;
+  return EKF_OK;
+}
+
 extern "C" const char* ekf_last_error(ekf_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
 
 static void free_all(ekf_handle* h) {

@@ -86,6 +86,7 @@ _ip = C.POINTER(C.c_int)
 # name -> (restype, argtypes): every symbol include/ekfslam_hip.h declares
 ABI = {
     "ekf_config_default": (C.c_int, [C.POINTER(_CConfig)]),
+    "ekf_device_count": (C.c_int, [_ip]),
     "ekf_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(_CConfig), C.POINTER(C.c_void_p)]),
     "ekf_destroy": (C.c_int, [C.c_void_p]),
     "ekf_upload_state": (C.c_int, [C.c_void_p, C.c_int, _dp, _dp, C.c_int]),
@@ -132,6 +133,13 @@ def load_library():
         fn.argtypes = args
     _lib = lib
     return lib
+
+
+def device_count() -> int:
+    """Number of HIP devices visible to this process (0 without a GPU)."""
+    n = C.c_int(0)
+    load_library().ekf_device_count(C.byref(n))
+    return n.value
 
 
 def _f64(a, shape=None):

@@ -8,6 +8,7 @@ __path__.insert(0, _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.absp
                                  "slam-duckietown_amd"))
 
 from .ekf_bindings import (  # noqa: E402,F401
-    EKF_pose_estimation, EkfConfig, EkfError, EkfSlam, build_library, library_path, load_library, predict, update,
+    EKF_pose_estimation, EkfConfig, EkfError, EkfSlam, build_library, device_count, library_path, load_library,
+    predict, update,
 )
 from .frontend import associate, delta_phi, displacement  # noqa: E402,F401
