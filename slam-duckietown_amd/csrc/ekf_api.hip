@@ -342,7 +342,7 @@ static int flush_pending(ekf_handle* h) {
   int e_hi = 3;                                        // grid covers the largest active bound of the batch
   for (int b = 0; b < h->batch; ++b) e_hi = std::max(e_hi, std::min(h->n[b], h->neff_enq[b]));
   launch_flush(h->stream, streaming_pass(h, n_hi), h->dP, h->dV, h->dW, h->ddacc, h->dn, h->dso, h->ld, h->pstride,
-               h->batch, e_hi, h->pending_k / 4, flush_rows_per_block(h, streaming_pass(h, n_hi)));
+               h->batch, e_hi, (h->pending_k + 3) / 4, flush_rows_per_block(h, streaming_pass(h, n_hi)));
   if (h->profile) HIP_TRY(h, hipEventRecord(e1, h->stream));
   HIP_TRY(h, hipGetLastError());
   HIP_TRY(h, hipMemsetAsync(h->ddacc, 0, sizeof(double) * 4 * h->batch, h->stream));
@@ -379,7 +379,7 @@ static int enqueue_pass(ekf_handle* h, const StepIn* d_in, int m_hi) {
   h->pending_k += ktp;
   h->pending_steps += 1;
   const int every = h->opt_flush_every > 0 ? h->opt_flush_every : 3;
-  if (h->pending_steps >= every || h->pending_k + 4 > KTOT)
+  if (h->pending_steps >= every || h->pending_k + 2 > KTOT)
     if (int rc = flush_pending(h)) return rc;
   return EKF_OK;
 }

@@ -11,8 +11,9 @@ constexpr int CMAX = 3 + 2 * MMAX;      // compressed sub-state size (35)
 constexpr int KTOT = 80;                // rank slots of the deferred low-rank update  P = P_base + W V
 constexpr int NKT = KTOT / 4;           // the same in MFMA k-tiles (v_mfma_f64_16x16x4)
 
-// ranks one step appends: 2m (landmark updates) + 2 (motion Jacobian), padded to a whole k-tile
-__host__ __device__ constexpr int ranks_for(int mcap) { return (2 * mcap + 2 + 3) / 4 * 4; }
+// ranks one step appends: 2m (landmark updates) + 2 (motion Jacobian); steps are packed back to back and
+// only the total is padded to a whole k-tile (the step that is last so far zero-fills the pad ranks)
+__host__ __device__ constexpr int ranks_for(int mcap) { return 2 * mcap + 2; }
 
 constexpr int FLAG_PREDICT = 1;         // StepIn.flags
 constexpr int FLAG_UPDATE = 2;

@@ -419,12 +419,10 @@ __global__ __launch_bounds__(256) void k_panels(const double* __restrict__ P, do
     // every state index of this workgroup lies beyond the active bound: its rows and columns of P are
     // exactly zero off the diagonal, so this step's V columns / W rows are zero and the mean is unchanged
     if (act && wave == 0) {
-#pragma unroll
-      for (int k = 0; k < KTP; ++k) Vb[(long)(kb + k) * ld + i] = 0.0;
+      for (int k = kb; k < ((kb + KTP + 3) & ~3); ++k) Vb[(long)k * ld + i] = 0.0;
     }
     if (act && wave == 1) {
-#pragma unroll
-      for (int k = 0; k < KTP; ++k) Wb[wm_index(ld16, kb + k, i)] = 0.0;
+      for (int k = kb; k < ((kb + KTP + 3) & ~3); ++k) Wb[wm_index(ld16, k, i)] = 0.0;
       mu_out[(long)b * ld + i] = mu_in[(long)b * ld + i];
     }
     return;
@@ -611,13 +609,11 @@ __global__ __launch_bounds__(256) void k_panels(const double* __restrict__ P, do
     if (wave == 0) {
       Vb[(long)kp * ld + i] = raw2 + o.p22h * gj;
       Vb[(long)(kp + 1) * ld + i] = gj;
-#pragma unroll
-      for (int k = K2 + 2; k < KTP; ++k) Vb[(long)(kb + k) * ld + i] = 0.0;
+      for (int k = kb + KTP; k < ((kb + KTP + 3) & ~3); ++k) Vb[(long)k * ld + i] = 0.0;   // k-tile pad
     } else {
       Wb[wm_index(ld16, kp, i)] = gj;
       Wb[wm_index(ld16, kp + 1, i)] = raw2 + o.p22h * gj;
-#pragma unroll
-      for (int k = K2 + 2; k < KTP; ++k) Wb[wm_index(ld16, kb + k, i)] = 0.0;
+      for (int k = kb + KTP; k < ((kb + KTP + 3) & ~3); ++k) Wb[wm_index(ld16, k, i)] = 0.0;
       bool inC = false;
       for (int a = 0; a < c; ++a) inC |= (Cs[a] == i);
       if (!inC) mu_out[(long)b * ld + i] = mu_in[(long)b * ld + i] + dm;
@@ -878,8 +874,9 @@ void launch_flush(hipStream_t st, bool streaming, double* P, const double* V, co
     else launch_flush_t<N, false>(st, P, V, W, dacc, nact, so, ld, pstride, batch, n_hi, nkt, rows_per_block);          \
   } while (0)
   if (nkt <= 5) EKF_FLUSH(5);
-  else if (nkt <= 10) EKF_FLUSH(10);
-  else if (nkt <= 15) EKF_FLUSH(15);
+  else if (nkt <= 9) EKF_FLUSH(9);
+  else if (nkt <= 14) EKF_FLUSH(14);
+  else if (nkt <= 18) EKF_FLUSH(18);
   else EKF_FLUSH(20);
 #undef EKF_FLUSH
 }
