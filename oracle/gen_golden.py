@@ -9,7 +9,10 @@ lifted with ``ast`` -- FunctionDef nodes plus the upper-case module constants --
 and executed unmodified against NumPy:
 
   src/replay_no_ros.py : EKF_pose_estimation (:269-482), delta_phi (:250-266),
-                         displacement (:484-497), flags (:15-36)
+                         displacement (:484-497), flags (:15-36), and the offline
+                         loop replay (:66-248) with its I/O boundary replaced
+                         (frames looked up in a table instead of cv2 + dt_apriltags,
+                         plot_path recording its arguments instead of drawing)
   src/EKF-SLAM.py      : predict (:29-56), update (:59-84), noise globals (:12-13)
 
 Fixtures hold inputs and the reference's outputs only (data, no source text).
@@ -47,7 +50,7 @@ def lift(path: str, func_names, const_pred):
 
 def load_reference(ref_root: str):
     slam = lift(os.path.join(ref_root, "src", "replay_no_ros.py"),
-                {"EKF_pose_estimation", "delta_phi", "displacement"}, str.isupper)
+                {"EKF_pose_estimation", "delta_phi", "displacement", "replay"}, str.isupper)
     proto = lift(os.path.join(ref_root, "src", "EKF-SLAM.py"),
                  {"predict", "update"}, lambda s: s in ("motion_noise", "observation_noise"))
     return slam, proto
@@ -200,6 +203,89 @@ def run_proto(proto, seed, steps):
 TWO_PI = 2 * np.pi
 
 
+def make_events_csv(seed: int, duration: float, n_tags: int):
+    """A synthetic log in the writer's format (scripts/decode_bag_file.py:337-347): wheel ticks at ~30 Hz,
+    'image' frames at ~8 Hz, Vicon ground truth, one landmarks line, one camera_intrinsis line.
+    Returns (csv text, {frame name: [(tag_id, pose_t(3), pose_err), ...]})."""
+    rng = np.random.default_rng(seed)
+    lm = np.stack([rng.uniform(-1.0, 1.2, n_tags), rng.uniform(-0.9, 1.1, n_tags)], axis=1)
+    tag_ids = rng.permutation(np.arange(10, 10 + 4 * n_tags))[:n_tags]
+    t0 = 1700000000.25
+    events = [(t0 - 1.0, "camera_intrinsis", repr([(0.1, -0.2, 0.0, 0.0, 0.0), (320.5, 0.0, 331.25, 0.0, 318.75, 247.5, 0.0, 0.0, 1.0),
+                                                   (1.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 1.0), (320.5, 0.0, 331.25, 0.0)]))]
+    events.append((t0 + 0.01, "landmarks", repr([(float(x), float(y)) for x, y in lm])))
+    pose = np.zeros(3)
+    lt, rt = 3, 0              # the right wheel starts at tick 0: exercises the `== False` re-latch (:114)
+    frames = {}
+    t = t0
+    k = 0
+    while t < t0 + duration:
+        t += 1.0 / 30.0 + rng.uniform(0, 2e-3)
+        v = 0.12 + 0.05 * np.sin(0.7 * (t - t0))
+        w = 0.5 * np.sin(0.31 * (t - t0)) + (0.0 if (t - t0) % 9 > 2 else 0.003)
+        dt = 1.0 / 30.0
+        pose = pose + np.array([v * dt * np.cos(pose[2]), v * dt * np.sin(pose[2]), w * dt])
+        dl = (v - w * 0.05) * dt / 0.0318 * 135 / TWO_PI
+        dr = (v + w * 0.05) * dt / 0.0318 * 135 / TWO_PI
+        lt += int(round(dl + rng.normal(0, 0.2)))
+        rt += int(round(dr + rng.normal(0, 0.2)))
+        events.append((t, "left_wheel", lt))
+        events.append((t + 1e-4, "right_wheel", rt))
+        if k % 4 == 0:
+            name = "frame%06i.png" % (k // 4)
+            tags = []
+            for j in rng.permutation(n_tags):
+                d = lm[j] - pose[0:2]
+                xr = np.cos(pose[2]) * d[0] + np.sin(pose[2]) * d[1]
+                yr = -np.sin(pose[2]) * d[0] + np.cos(pose[2]) * d[1]
+                if xr > 0.05 and abs(np.arctan2(yr, xr)) < 0.9 and rng.random() < 0.8:
+                    tags.append((int(tag_ids[j]), [float(-yr + rng.normal(0, 0.01)), 0.04, float(xr + rng.normal(0, 0.01))],
+                                 float(rng.uniform(1e-4, 1e-2))))
+            frames[name] = tags
+            events.append((t + 2e-4, "image", name))
+        if k % 3 == 0:
+            events.append((t + 3e-4, "ground_truth", "%r,%r" % (float(pose[0]), float(pose[1]))))
+        k += 1
+    events.sort(key=lambda e: e[0])
+    text = "".join(str(e[0]) + "," + e[1] + "," + (e[2] if isinstance(e[2], str) else repr(e[2])) + "\n" for e in events)
+    return text, frames
+
+
+def run_reference_replay(slam, text, frames, tmpdir):
+    """Execute the reference's own replay() (src/replay_no_ros.py:66-248) on the synthetic log.  Its I/O
+    boundary is replaced: frames are looked up in `frames` instead of cv2.imread + dt_apriltags
+    (:587-597), and plot_path (:499-580) records what it is handed instead of drawing."""
+    os.makedirs(tmpdir, exist_ok=True)
+    with open(os.path.join(tmpdir, "events.csv"), "w") as fh:
+        fh.write(text)
+    rec = dict(mean=[], cov=[], path=[], ntags=[], gt=[])
+
+    def fake_detect(img, camera_params):
+        rec.setdefault("camera_params", list(camera_params))
+        return [SimpleNamespace(tag_id=i, pose_R=np.eye(3), pose_t=np.array(t, dtype=float).reshape(3, 1), pose_err=e,
+                                center=np.zeros(2), corners=np.zeros((4, 2))) for i, t, e in frames[os.path.basename(img)]]
+
+    def fake_plot(vertices, gt, landmarks, mean, cov, measured, tag_index):
+        rec["mean"].append(np.array(mean)); rec["cov"].append(np.array(cov)); rec["path"].append(tuple(vertices[-1]))
+        rec["ntags"].append(len(tag_index)); rec["gt"].append(len(gt)); rec["landmarks"] = landmarks
+        rec["tag_index"] = dict(tag_index)
+
+    saved = {k: slam.get(k) for k in ("load_grayscale", "detect_tags", "plot_path", "plt", "visualize_bounding_boxes",
+                                      "ENABLE_CAMERA_VISUALIZATION", "os", "image_list", "print")}
+    slam.update(load_grayscale=lambda path: path, detect_tags=fake_detect, plot_path=fake_plot,
+                plt=SimpleNamespace(pause=lambda *_a: None), visualize_bounding_boxes=lambda *_a: None,
+                ENABLE_CAMERA_VISUALIZATION=False, os=os, image_list=[], print=lambda *_a: None)
+    try:
+        slam["replay"](tmpdir)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                slam.pop(k, None)
+            else:
+                slam[k] = v
+    return rec
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
@@ -237,6 +323,30 @@ def main():
     save("stream_n50_m8", **run_stream(slam, 50, 30, 8, keep_every=5))
     rows = np.array([0, 1, 2, 3, 4, 17, 18, 101, 500, 501, 777, 1001, 1002])
     save("stream_n500_m8", **run_stream(slam, 500, 6, 8, keep_every=3, rows_only=rows))
+
+    # 2b. the offline replay loop itself (windowing, tick latching, odometry) on a synthetic events.csv
+    import tempfile
+    text, frames = make_events_csv(5, 40.0, 9)
+    with tempfile.TemporaryDirectory() as tmp:
+        rec = run_reference_replay(slam, text, frames, tmp)
+    nmax = max(len(m) for m in rec["mean"])
+    W = len(rec["mean"])
+    M = np.zeros((W, nmax)); Pm = np.zeros((W, nmax, nmax)); sizes = np.zeros(W, dtype=np.int64)
+    for k in range(W):
+        n = len(rec["mean"][k]); sizes[k] = n
+        M[k, :n] = rec["mean"][k]; Pm[k, :n, :n] = rec["cov"][k]
+    names = sorted(frames)
+    det_frame, det_id, det_t, det_err = [], [], [], []
+    for fi, name in enumerate(names):
+        for tid, t, e in frames[name]:
+            det_frame.append(fi); det_id.append(tid); det_t.append(t); det_err.append(e)
+    save("replay_events", events_csv=np.array(text), frame_names=np.array(names), det_frame=np.array(det_frame),
+         det_tag_id=np.array(det_id), det_pose_t=np.array(det_t, dtype=float).reshape(-1, 3), det_err=np.array(det_err),
+         out_mean=M, out_cov=Pm, out_size=sizes, out_path=np.array(rec["path"], dtype=float),
+         out_ntags=np.array(rec["ntags"]), out_gt_count=np.array(rec["gt"]),
+         out_tag_index=np.array(sorted(rec["tag_index"].items(), key=lambda kv: kv[1]), dtype=np.int64).reshape(-1, 2),
+         out_camera_params=np.array(rec["camera_params"], dtype=float),
+         out_landmarks=np.array(rec["landmarks"], dtype=float))
 
     # 3. 3-state predict/update prototype
     save("proto3", **run_proto(proto, 7, 60))
