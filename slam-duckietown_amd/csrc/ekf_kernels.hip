@@ -143,6 +143,7 @@ __global__ __launch_bounds__(256) void k_solve(const double* __restrict__ P, con
   __shared__ int Cs[CPAD];
   __shared__ double Wc[CMAX][WCS];
   __shared__ double Vc[KTOT][PCS];
+  __shared__ double2 hS[6];                            // next linearisation: {h[0][k], h[1][k]} k<5, {y0, y1}
 
   STAMP(o, 0);
   // inputs: the index list is fetched unconditionally so that it travels with flags/m (one round trip)
@@ -177,7 +178,26 @@ __global__ __launch_bounds__(256) void k_solve(const double* __restrict__ P, con
     Pc[r][cc] = v;
   }
   __syncthreads();
-  if (tid >= 64) return;                              // waves 1-3 are done; wave 0 carries on alone
+  if (tid >= 64) {
+    // Helper waves.  Wave 1 linearises landmark j+1 (atan2, rsqrt: ~1200 cycles of a lone wave) while
+    // wave 0 down-dates the covariance block for landmark j; waves 2-3 only keep the barrier count.
+    const int hw = tid >> 6;
+    __syncthreads();                                  // S0: predicted mean published
+    for (int j = 0; j < m; ++j) {
+      __syncthreads();                                // b1(j): mean after landmark j is in muc
+      if (hw == 1 && j + 1 < m) {
+        double hn[2][5], yn0, yn1;
+        linearize(muc, 3 + 2 * (j + 1), s.range[j + 1], s.bearing[j + 1], hn, yn0, yn1);
+        if (lane == 0) {
+#pragma unroll
+          for (int k = 0; k < 5; ++k) hS[k] = make_double2(hn[0][k], hn[1][k]);
+          hS[5] = make_double2(yn0, yn1);
+        }
+      }
+      __syncthreads();                                // b2(j): hS ready, covariance block down-dated
+    }
+    return;
+  }
 
   double pcol[CPAD];
 #pragma unroll
@@ -265,7 +285,7 @@ __global__ __launch_bounds__(256) void k_solve(const double* __restrict__ P, con
     dacc[4 * b + 1] = d1 + rd1;
     dacc[4 * b + 2] = d2 + rd2;
   }
-  WAVE_SYNC();
+  __syncthreads();                                    // S0 (helper waves wait here too)
 
   STAMP(o, 4);
   // ---- sequential per-landmark recurrences (:436-480) on the compressed system ----
@@ -327,10 +347,9 @@ __global__ __launch_bounds__(256) void k_solve(const double* __restrict__ P, con
       *reinterpret_cast<double2*>(&it.si[2]) = make_double2(i10, i11);
       *reinterpret_cast<double2*>(it.y) = make_double2(y0, y1);
     }
-    WAVE_SYNC();
+    __syncthreads();                                  // b1(j): wave 1 starts the next linearisation
     STAMP(o, 10 + 6 * j);
-    // phase C: the gains of every row are fetched first, the next landmark's linearisation (needs
-    // only the mean) runs while they land, then the down-date (:480) as batches of independent FMAs
+    // phase C: down-date (:480) as batches of independent FMAs while wave 1 linearises landmark j+1
     if (j + 1 < m) {
       double2 kr[CPAD];
 #pragma unroll
@@ -339,8 +358,6 @@ __global__ __launch_bounds__(256) void k_solve(const double* __restrict__ P, con
 #pragma unroll
           for (int u = 0; u < RCH; ++u) kr[r0 + u] = kcS[r0 + u];
         }
-      double hn[2][5], yn0, yn1;
-      linearize(muc, a + 2, s.range[j + 1], s.bearing[j + 1], hn, yn0, yn1);
       STAMP(o, 11 + 6 * j);
 #pragma unroll
       for (int r0 = 0; r0 < CPAD; r0 += RCH)
@@ -354,14 +371,19 @@ __global__ __launch_bounds__(256) void k_solve(const double* __restrict__ P, con
             for (int u = 0; u < RCH; ++u) Pc[r0 + u][lane] = pcol[r0 + u];
           }
         }
-#pragma unroll
-      for (int r = 0; r < 2; ++r)
-#pragma unroll
-        for (int k = 0; k < 5; ++k) h[r][k] = hn[r][k];
-      y0 = yn0;
-      y1 = yn1;
     }
-    WAVE_SYNC();
+    __syncthreads();                                  // b2(j)
+    if (j + 1 < m) {
+#pragma unroll
+      for (int k = 0; k < 5; ++k) {
+        const double2 t = hS[k];
+        h[0][k] = t.x;
+        h[1][k] = t.y;
+      }
+      const double2 t = hS[5];
+      y0 = t.x;
+      y1 = t.y;
+    }
     STAMP(o, 12 + 6 * j);
   }
 
@@ -435,11 +457,7 @@ __global__ __launch_bounds__(256) void k_panels(const double* __restrict__ P, do
   }
   if (tid < CPAD) Cs[tid] = (tid < CMAX + 1) ? o.C[tid] : 0;
   __syncthreads();
-  if (kb > 0) {
-    stage_factors(Vb, Wb, Cs, min(c, CC), kb, ld, tid, 256, Wc, Vc);
-    __syncthreads();
-  }
-  // ---- phase 1 ----
+  // ---- phase 1 ----  (the base-panel loads are issued first: their latency overlaps the staging)
   {
     double r[QA], l[QA];
 #pragma unroll
@@ -449,14 +467,28 @@ __global__ __launch_bounds__(256) void k_panels(const double* __restrict__ P, do
       r[q] = Pb[(long)row * ld + ii];
       l[q] = Pb[(long)ii * ld + row];
     }
-    for (int k = 0; k < kb; ++k) {
-      const double vk = Vb[(long)k * ld + ii];
-      const double wk = Wb[wm_index(ld16, k, ii)];
+    if (kb > 0) {
+      stage_factors(Vb, Wb, Cs, min(c, CC), kb, ld, tid, 256, Wc, Vc);
+      __syncthreads();
+    }
+    for (int k0 = 0; k0 < kb; k0 += 8) {               // pending ranks, 8 at a time (loads batched)
+      double vk[8], wk[8];
 #pragma unroll
-      for (int q = 0; q < QA; ++q) {
-        const int a = min(wave + 4 * q, CC - 1);
-        r[q] = fma(Wc[a][k], vk, r[q]);
-        l[q] = fma(wk, Vc[k][a], l[q]);
+      for (int u = 0; u < 8; ++u) {
+        const int k = min(k0 + u, kb - 1);
+        vk[u] = Vb[(long)k * ld + ii];
+        wk[u] = Wb[wm_index(ld16, k, ii)];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int k = min(k0 + u, kb - 1);
+        const double vv = (k0 + u < kb) ? vk[u] : 0.0, ww = (k0 + u < kb) ? wk[u] : 0.0;
+#pragma unroll
+        for (int q = 0; q < QA; ++q) {
+          const int a = min(wave + 4 * q, CC - 1);
+          r[q] = fma(Wc[a][k], vv, r[q]);
+          l[q] = fma(ww, Vc[k][a], l[q]);
+        }
       }
     }
 #pragma unroll
