@@ -61,6 +61,9 @@ int ekf_upload_state(ekf_handle *h, int b, const double *mu, const double *P, in
 int ekf_upload_state_diag(ekf_handle *h, int b, const double *mu, const double *diagP, int n);
 int ekf_download_state(ekf_handle *h, int b, double *mu, double *P, int n);
 int ekf_download_mean(ekf_handle *h, int b, double *mu, int n);
+/* rows [r0, r0+rows) x cols [c0, c0+cols) of the covariance into out (row-major rows x cols), e.g. the 3x3
+ * pose block for consistency statistics without shipping n^2 doubles.  Flushes the pending update. */
+int ekf_download_block(ekf_handle *h, int b, int r0, int c0, int rows, int cols, double *out);
 int ekf_state_size(ekf_handle *h, int b, int *n);
 
 /* State augmentation, src/replay_no_ros.py:341-360: append k landmarks (indices must continue the

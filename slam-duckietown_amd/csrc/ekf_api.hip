@@ -271,6 +271,19 @@ extern "C" int ekf_download_state(ekf_handle* h, int b, double* mu, double* P, i
   return EKF_OK;
 }
 
+extern "C" int ekf_download_block(ekf_handle* h, int b, int r0, int c0, int rows, int cols, double* out) {
+  if (int rc = check_b(h, b, "ekf_download_block")) return rc;
+  const int n = h->n[b];
+  if (!out || rows <= 0 || cols <= 0 || r0 < 0 || c0 < 0 || r0 + rows > n || c0 + cols > n)
+    return fail(h, EKF_ERR_ARG, "ekf_download_block: block outside the state");
+  HIP_TRY(h, hipSetDevice(h->device));
+  if (int rc = flush_pending(h)) return rc;
+  HIP_TRY(h, hipMemcpy2DAsync(out, sizeof(double) * cols, h->dP + (size_t)b * h->pstride + (size_t)r0 * h->ld + c0,
+                              sizeof(double) * h->ld, sizeof(double) * cols, rows, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return EKF_OK;
+}
+
 extern "C" int ekf_download_mean(ekf_handle* h, int b, double* mu, int n) {
   return ekf_download_state(h, b, mu, nullptr, n);
 }

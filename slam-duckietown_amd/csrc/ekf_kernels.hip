@@ -708,8 +708,20 @@ __global__ __launch_bounds__(256, 2) void k_flush(double* __restrict__ P, const 
   const int n = min(nact[b], so[b].neff);              // rows/cols beyond the active bound are untouched
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
-  const int j0 = (blockIdx.x * 4 + wave) * 64;
-  const int i_begin = blockIdx.y * rows_per_block;
+  // XCD-aware tile order (speed only): workgroups are dealt round-robin over the 8 XCDs by linear id, so
+  // consecutive ids are remapped to walk the column strips of one row block inside one XCD: the W rows
+  // of that block (and the V strips) are then fetched into one L2 instead of eight.
+  int bx = blockIdx.x, by = blockIdx.y;
+  {
+    const int gx = gridDim.x, total = gx * gridDim.y;
+    const int lin = by * gx + bx;
+    const int q = total >> 3, r = total & 7, xcd = lin & 7, slot = lin >> 3;
+    const int remapped = ((xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+    bx = remapped % gx;
+    by = remapped / gx;
+  }
+  const int j0 = (bx * 4 + wave) * 64;
+  const int i_begin = by * rows_per_block;
   if (j0 >= n || i_begin >= n) return;
   const int i_end = min(n, i_begin + rows_per_block);
   const int li = lane & 15, lq = lane >> 4;            // C/D layout coordinates

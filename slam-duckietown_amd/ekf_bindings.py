@@ -93,6 +93,7 @@ ABI = {
     "ekf_upload_state_diag": (C.c_int, [C.c_void_p, C.c_int, _dp, _dp, C.c_int]),
     "ekf_download_state": (C.c_int, [C.c_void_p, C.c_int, _dp, _dp, C.c_int]),
     "ekf_download_mean": (C.c_int, [C.c_void_p, C.c_int, _dp, C.c_int]),
+    "ekf_download_block": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _dp]),
     "ekf_state_size": (C.c_int, [C.c_void_p, C.c_int, _ip]),
     "ekf_add_landmarks": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _dp, C.c_int]),
     "ekf_predict": (C.c_int, [C.c_void_p, _dp, _dp]),
@@ -255,6 +256,12 @@ class EkfSlam:
         n = self.size(b)
         out = np.empty((n, n))
         self._check(self._lib.ekf_download_state(self._h, b, None, _p(out), n))
+        return out
+
+    def covariance_block(self, r0: int, c0: int, rows: int, cols: int, b: int = 0) -> np.ndarray:
+        """P[r0:r0+rows, c0:c0+cols] only (e.g. the 3x3 pose block) -- O(rows*cols) over PCIe."""
+        out = np.empty((rows, cols))
+        self._check(self._lib.ekf_download_block(self._h, b, r0, c0, rows, cols, _p(out)))
         return out
 
     def state(self, b: int = 0):

@@ -19,6 +19,19 @@ def _advance(pose, lin, ang):
     return np.array([x + (-r * np.sin(th) + r * np.sin(th + ang)), y + (r * np.cos(th) - r * np.cos(th + ang)), th2])
 
 
+def true_poses(steps: int) -> np.ndarray:
+    """The robot's true pose after each step of synthetic_stream (identical for every trajectory id)."""
+    lin = np.full(steps, 0.004)
+    ang = np.full(steps, 0.02)
+    ang[9::10] = 0.005
+    pose = np.zeros(3)
+    out = np.zeros((steps, 3))
+    for k in range(steps):
+        pose = _advance(pose, lin[k], ang[k])
+        out[k] = pose
+    return out
+
+
 def synthetic_stream(n_landmarks: int, steps: int, m: int = 8, trajectory_id: int = 0):
     """-> mean0 (n,), diagP0 (n,), lin[steps], ang[steps], idx[steps,m] int32, range[steps,m], bearing[steps,m]."""
     rng = np.random.default_rng(1234 + trajectory_id)
