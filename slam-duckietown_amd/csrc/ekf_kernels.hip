@@ -752,13 +752,12 @@ __global__ __launch_bounds__(256, 2) void k_flush(double* __restrict__ P, const 
     }
   };
   gload(i_begin);
+  constexpr int WH = (NKTM + 1) / 2;                   // W fragments are fetched in two halves (registers)
   for (int i0 = i_begin; i0 < i_end; i0 += 16) {
-    double wf[NKTM];
-    {
-      const double* wsrc = Wb + (long)(i0 >> 4) * 64 + lane;
+    const double* wsrc = Wb + (long)(i0 >> 4) * 64 + lane;
+    double wf[WH];
 #pragma unroll
-      for (int t = 0; t < NKTM; ++t) wf[t] = (t < nkt) ? wsrc[(long)t * ld16 * 64] : 0.0;
-    }
+    for (int t = 0; t < WH; ++t) wf[t] = (t < nkt) ? wsrc[(long)t * ld16 * 64] : 0.0;
 #pragma unroll
     for (int q = 0; q < 8; ++q) *reinterpret_cast<double2*>(&T[(2 * q + rr) * FTS + rc]) = g[q];
     WAVE_SYNC();
@@ -770,11 +769,21 @@ __global__ __launch_bounds__(256, 2) void k_flush(double* __restrict__ P, const 
       for (int r = 0; r < 4; ++r) acc[ct][r] = T[(lq + 4 * r) * FTS + ct * 16 + li];
     WAVE_SYNC();
 #pragma unroll
-    for (int t = 0; t < NKTM; ++t)
+    for (int t = 0; t < WH; ++t)
       if (t < nkt) {
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct)
           acc[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(wf[t], vf[t][ct], acc[ct], 0, 0, 0);
+      }
+    // second half: the loads reuse the registers as soon as the first half's MFMAs have issued
+#pragma unroll
+    for (int t = WH; t < NKTM; ++t) wf[t - WH] = (t < nkt) ? wsrc[(long)t * ld16 * 64] : 0.0;
+#pragma unroll
+    for (int t = WH; t < NKTM; ++t)
+      if (t < nkt) {
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct)
+          acc[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(wf[t - WH], vf[t][ct], acc[ct], 0, 0, 0);
       }
     if (i0 == 0 && j0 == 0) {                          // pose-block noise accumulated since the last flush
 #pragma unroll
