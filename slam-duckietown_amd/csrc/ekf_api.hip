@@ -391,7 +391,7 @@ static int enqueue_pass(ekf_handle* h, const StepIn* d_in, int m_hi) {
   h->cur ^= 1;
   h->pending_k += ktp;
   h->pending_steps += 1;
-  const int every = h->opt_flush_every > 0 ? h->opt_flush_every : 3;
+  const int every = h->opt_flush_every > 0 ? h->opt_flush_every : 4;
   if (h->pending_steps >= every || h->pending_k + 2 > KTOT)
     if (int rc = flush_pending(h)) return rc;
   return EKF_OK;
