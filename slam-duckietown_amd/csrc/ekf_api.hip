@@ -10,8 +10,8 @@
 #include "ekf_device.h"
 
 namespace ekf {
-void launch_solve(hipStream_t, const double*, const double*, const double*, double*, const double*, double*,
-                  const int*, const StepIn*, SolveOut*, unsigned*, const DeviceConfig&, int, long, int, int);
+void launch_solve(hipStream_t, const double*, const double*, const double*, const double*, double*, const double*,
+                  double*, const int*, const StepIn*, SolveOut*, unsigned*, const DeviceConfig&, int, long, int, int);
 void launch_panels(hipStream_t, int, const double*, double*, double*, const double*, double*, const int*,
                    const SolveOut*, int, long, int, int);
 void launch_flush(hipStream_t, bool, double*, const double*, const double*, const double*, const int*,
@@ -34,7 +34,9 @@ struct ekf_handle {
   ekf_config cfg{};
   DeviceConfig dcfg{};
   hipStream_t stream = nullptr;
-  double *dP = nullptr, *dV = nullptr, *dW = nullptr, *ddacc = nullptr, *dscratch = nullptr;
+  double *dP = nullptr, *dV = nullptr, *dW = nullptr, *dscratch = nullptr;
+  double* ddacc2[2] = {nullptr, nullptr};  // pending pose-block noise, double-buffered like the mean
+  int dcur = 0;
   int pending_k = 0, pending_steps = 0;   // ranks / steps appended to (V, W) since the last flush
   double* dmu2[2] = {nullptr, nullptr};   // the mean is double-buffered: a step reads [cur], writes [cur^1]
   int cur = 0;
@@ -106,7 +108,7 @@ static void free_all(ekf_handle* h) {
   if (!h) return;
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
-  void* ptrs[] = {h->dP, h->dmu2[0], h->dmu2[1], h->dV, h->dW, h->ddacc, h->dscratch, h->dn, h->dflags, h->dso,
+  void* ptrs[] = {h->dP, h->dmu2[0], h->dmu2[1], h->dV, h->dW, h->ddacc2[0], h->ddacc2[1], h->dscratch, h->dn, h->dflags, h->dso,
                   h->d_ring, h->d_stream, h->dF, h->dQ, h->dTmp};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (h->h_ring) (void)hipHostFree(h->h_ring);
@@ -173,7 +175,8 @@ extern "C" int ekf_create(int device, int n_max, int batch, const ekf_config* cf
   CREATE_TRY(hipMalloc(&h->dmu2[1], sizeof(double) * ldz * batch));
   CREATE_TRY(hipMalloc(&h->dV, sizeof(double) * ldz * KTOT * batch));
   CREATE_TRY(hipMalloc(&h->dW, sizeof(double) * ldz * KTOT * batch));
-  CREATE_TRY(hipMalloc(&h->ddacc, sizeof(double) * 4 * batch));
+  CREATE_TRY(hipMalloc(&h->ddacc2[0], sizeof(double) * 4 * batch));
+  CREATE_TRY(hipMalloc(&h->ddacc2[1], sizeof(double) * 4 * batch));
   CREATE_TRY(hipMalloc(&h->dscratch, sizeof(double) * ldz * 2));
   CREATE_TRY(hipMalloc(&h->dn, sizeof(int) * batch));
   CREATE_TRY(hipMalloc(&h->dflags, sizeof(unsigned) * batch));
@@ -188,7 +191,8 @@ extern "C" int ekf_create(int device, int n_max, int batch, const ekf_config* cf
   CREATE_TRY(hipMemsetAsync(h->dmu2[1], 0, sizeof(double) * ldz * batch, h->stream));
   CREATE_TRY(hipMemsetAsync(h->dV, 0, sizeof(double) * ldz * KTOT * batch, h->stream));
   CREATE_TRY(hipMemsetAsync(h->dW, 0, sizeof(double) * ldz * KTOT * batch, h->stream));
-  CREATE_TRY(hipMemsetAsync(h->ddacc, 0, sizeof(double) * 4 * batch, h->stream));
+  CREATE_TRY(hipMemsetAsync(h->ddacc2[0], 0, sizeof(double) * 4 * batch, h->stream));
+  CREATE_TRY(hipMemsetAsync(h->ddacc2[1], 0, sizeof(double) * 4 * batch, h->stream));
   CREATE_TRY(hipMemsetAsync(h->dflags, 0, sizeof(unsigned) * batch, h->stream));
   CREATE_TRY(hipMemsetAsync(h->dso, 0, sizeof(SolveOut) * batch, h->stream));
   // reference initial state (src/replay_no_ros.py:69-70): mu = 0, P = MOTION_MODEL_VARIANCE * I3
@@ -354,11 +358,12 @@ static int flush_pending(ekf_handle* h) {
   }
   int e_hi = 3;                                        // grid covers the largest active bound of the batch
   for (int b = 0; b < h->batch; ++b) e_hi = std::max(e_hi, std::min(h->n[b], h->neff_enq[b]));
-  launch_flush(h->stream, streaming_pass(h, n_hi), h->dP, h->dV, h->dW, h->ddacc, h->dn, h->dso, h->ld, h->pstride,
+  launch_flush(h->stream, streaming_pass(h, n_hi), h->dP, h->dV, h->dW, h->ddacc2[h->dcur], h->dn, h->dso, h->ld, h->pstride,
                h->batch, e_hi, (h->pending_k + 3) / 4, flush_rows_per_block(h, streaming_pass(h, n_hi)));
   if (h->profile) HIP_TRY(h, hipEventRecord(e1, h->stream));
   HIP_TRY(h, hipGetLastError());
-  HIP_TRY(h, hipMemsetAsync(h->ddacc, 0, sizeof(double) * 4 * h->batch, h->stream));
+  HIP_TRY(h, hipMemsetAsync(h->ddacc2[0], 0, sizeof(double) * 4 * h->batch, h->stream));
+  HIP_TRY(h, hipMemsetAsync(h->ddacc2[1], 0, sizeof(double) * 4 * h->batch, h->stream));
   h->pending_k = 0;
   h->pending_steps = 0;
   return EKF_OK;
@@ -371,23 +376,30 @@ static int enqueue_pass(ekf_handle* h, const StepIn* d_in, int m_hi) {
   const int ktp = ranks_for(mcap);
   const double* mu_in = h->dmu2[h->cur];
   double* mu_out = h->dmu2[h->cur ^ 1];
+  const double* dacc_in = h->ddacc2[h->dcur];
+  double* dacc_out = h->ddacc2[h->dcur ^ 1];
   if (m_hi == 0 && h->pending_k == 0) {
     // prediction only, nothing pending: rows/cols 0,1 of P_base directly, O(n)
-    launch_solve(h->stream, h->dP, h->dV, h->dW, h->ddacc, mu_in, mu_out, h->dn, d_in, h->dso, h->dflags,
+    launch_solve(h->stream, h->dP, h->dV, h->dW, dacc_in, dacc_out, mu_in, mu_out, h->dn, d_in, h->dso, h->dflags,
                  h->dcfg, h->ld, h->pstride, h->batch, 0);
     launch_predict_rc(h->stream, h->dP, mu_in, mu_out, h->dn, h->dso, h->ld, h->pstride, h->batch, n_hi);
-    HIP_TRY(h, hipMemsetAsync(h->ddacc, 0, sizeof(double) * 4 * h->batch, h->stream));  // k_predict_rc applied the noise
+    // k_predict_rc applied the noise itself
+    HIP_TRY(h, hipMemsetAsync(h->ddacc2[0], 0, sizeof(double) * 4 * h->batch, h->stream));
+    HIP_TRY(h, hipMemsetAsync(h->ddacc2[1], 0, sizeof(double) * 4 * h->batch, h->stream));
     HIP_TRY(h, hipGetLastError());
     h->cur ^= 1;
     return EKF_OK;
   }
   if (h->pending_k + ktp > KTOT)
     if (int rc = flush_pending(h)) return rc;
-  launch_solve(h->stream, h->dP, h->dV, h->dW, h->ddacc, mu_in, mu_out, h->dn, d_in, h->dso, h->dflags, h->dcfg,
-               h->ld, h->pstride, h->batch, h->pending_k);
+  dacc_in = h->ddacc2[h->dcur];
+  dacc_out = h->ddacc2[h->dcur ^ 1];
+  launch_solve(h->stream, h->dP, h->dV, h->dW, dacc_in, dacc_out, mu_in, mu_out, h->dn, d_in, h->dso, h->dflags,
+               h->dcfg, h->ld, h->pstride, h->batch, h->pending_k);
   launch_panels(h->stream, mcap, h->dP, h->dV, h->dW, mu_in, mu_out, h->dn, h->dso, h->ld, h->pstride, h->batch,
                 n_hi);
   HIP_TRY(h, hipGetLastError());
+  h->dcur ^= 1;
   h->cur ^= 1;
   h->pending_k += ktp;
   h->pending_steps += 1;

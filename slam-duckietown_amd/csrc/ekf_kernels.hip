@@ -111,39 +111,50 @@ __device__ __forceinline__ void stage_factors(const double* __restrict__ Vb, con
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_solve: one workgroup per trajectory.  All four waves gather the current P[C,C] (base + pending
-// ranks); then waves 1-3 exit and wave 0 runs the sequential recurrences: lane l < c owns compressed
-// index l and keeps column l of P[C,C] in registers (written through to LDS for the row/column
-// reads of the other lanes).  The chain is latency-bound (a lone wave issues one fp64 VALU op per
-// ~8 cycles): every phase is written as batches of independent operations.
-// Reads mu_in, writes mu_out[C] (the mean is double-buffered so that no kernel of a step reads an
-// entry another workgroup of the same step writes).
+// solve_body: the sequential part of one step for one trajectory, executed by a 256-thread workgroup.
+// All four waves gather the current P[C,C] (base + pending ranks); then wave 0 runs the recurrences:
+// lane l < c owns compressed index l and keeps column l of P[C,C] in registers (written through to
+// LDS for the row/column reads of the other lanes); wave 1 linearises the next landmark beside the
+// down-date; waves 2-3 only keep the barrier count.  The chain is latency-bound (a lone wave issues
+// one fp64 VALU op per ~8 cycles): every phase is written as batches of independent operations.
+// Reads mu_in / dacc_in, and -- only where `writer` -- writes mu_out[C], dacc_out, the flags and the
+// global SolveOut header (the mean and the pending noise are double-buffered so that no workgroup
+// of a step reads an entry another workgroup of the same step writes).  `its` receives the
+// per-landmark records.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_solve(const double* __restrict__ P, const double* __restrict__ V,
-                                               const double* __restrict__ W, double* __restrict__ dacc,
-                                               const double* __restrict__ mu_in,
-                                               double* __restrict__ mu_out,
-                                               const int* __restrict__ nact,
-                                               const StepIn* __restrict__ in,
-                                               SolveOut* __restrict__ out,
-                                               unsigned* __restrict__ flags, DeviceConfig cfg, int ld,
-                                               long pstride, int kbase) {
-  const int b = blockIdx.x;
+struct SolveHdr {
+  double g[2], rd[3], p22h, dacc_old[3];
+  int c, m, kbase, neff;
+};
+
+struct SolveLds {
+  double Pc[CPAD][PCS];
+  double muc[CPAD];
+  double2 hpS[CPAD], kcS[CPAD];
+  int Cs[CPAD];
+  double Wc[CMAX][WCS];
+  double Vc[KTOT][PCS];
+  double2 hS[6];                                       // next linearisation: {h[0][k], h[1][k]} k<5, {y0, y1}
+  double xs[CPAD];                                     // column 2 of the row-updated block (prediction)
+  SolveHdr hdr;
+};
+
+__device__ __forceinline__ void solve_body(SolveLds& L, const double* __restrict__ Pb,
+                                           const double* __restrict__ Vb, const double* __restrict__ Wb,
+                                           const double* __restrict__ dacc_in, double* __restrict__ dacc_out,
+                                           const double* __restrict__ mu_in_b, double* __restrict__ mu_out_b,
+                                           const StepIn& s, SolveOut& o, SolveIter* its, unsigned* flag_b,
+                                           const DeviceConfig& cfg, int ld, int kbase, bool writer) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const StepIn& s = in[b];
-  SolveOut& o = out[b];
-  const double* Pb = P + (long)b * pstride;
-  const double* Vb = V + (long)b * KTOT * ld;
-  const double* Wb = W + (long)b * KTOT * ld;
-
-  __shared__ double Pc[CPAD][PCS];
-  __shared__ double muc[CPAD];
-  __shared__ double2 hpS[CPAD], kcS[CPAD];
-  __shared__ int Cs[CPAD];
-  __shared__ double Wc[CMAX][WCS];
-  __shared__ double Vc[KTOT][PCS];
-  __shared__ double2 hS[6];                            // next linearisation: {h[0][k], h[1][k]} k<5, {y0, y1}
+  auto& Pc = L.Pc;
+  auto& muc = L.muc;
+  auto& hpS = L.hpS;
+  auto& kcS = L.kcS;
+  auto& Cs = L.Cs;
+  auto& Wc = L.Wc;
+  auto& Vc = L.Vc;
+  auto& hS = L.hS;
 
   STAMP(o, 0);
   // inputs: the index list is fetched unconditionally so that it travels with flags/m (one round trip)
@@ -159,59 +170,28 @@ __global__ __launch_bounds__(256) void k_solve(const double* __restrict__ P, con
     Cs[tid] = Cl;
     kcS[tid] = make_double2(0.0, 0.0);
     hpS[tid] = make_double2(0.0, 0.0);
-    if (tid < CMAX + 1) o.C[tid] = Cl;
+    if (writer && tid < CMAX + 1) o.C[tid] = Cl;
   }
-  const double mu_l = mu_in[(long)b * ld + Cl];
-  const double d0 = dacc[4 * b + 0], d1 = dacc[4 * b + 1], d2 = dacc[4 * b + 2];
+  const double mu_l = mu_in_b[Cl];
+  const double d0 = dacc_in[0], d1 = dacc_in[1], d2 = dacc_in[2];
   __syncthreads();
   if (kbase > 0) {
     stage_factors(Vb, Wb, Cs, c, kbase, ld, tid, 256, Wc, Vc);
     __syncthreads();
   }
   STAMP(o, 1);
-  // current P[C,C] = P_base[C,C] + W[C,:] V[:,C] + diag(dacc)
-  for (int e = tid; e < c * c; e += 256) {
-    const int r = e / c, cc = e - r * c;
-    double v = Pb[(long)Cs[r] * ld + Cs[cc]];
-    for (int k = 0; k < kbase; ++k) v = fma(Wc[r][k], Vc[k][cc], v);
-    if (r == cc && r < 3) v += (r == 0) ? d0 : ((r == 1) ? d1 : d2);
-    Pc[r][cc] = v;
+  // current P[C,C] = P_base[C,C] + W[C,:] V[:,C] + diag(dacc): the base loads are issued first ...
+  // (thread = (wave w, lane): column C[lane] of rows w, w+4, ...: no integer division on the path)
+  constexpr int GQ = (CMAX + 3) / 4;                   // 9 rows per wave at most
+  const int gw = tid >> 6;
+  double gv[GQ];
+#pragma unroll
+  for (int q = 0; q < GQ; ++q) {
+    const int r = gw + 4 * q;
+    gv[q] = (on && r < c) ? Pb[(long)Cs[r] * ld + Cl] : 0.0;
   }
-  __syncthreads();
-  if (tid >= 64) {
-    // Helper waves.  Wave 1 linearises landmark j+1 (atan2, rsqrt: ~1200 cycles of a lone wave) while
-    // wave 0 down-dates the covariance block for landmark j; waves 2-3 only keep the barrier count.
-    const int hw = tid >> 6;
-    __syncthreads();                                  // S0: predicted mean published
-    for (int j = 0; j < m; ++j) {
-      __syncthreads();                                // b1(j): mean after landmark j is in muc
-      if (hw == 1 && j + 1 < m) {
-        double hn[2][5], yn0, yn1;
-        linearize(muc, 3 + 2 * (j + 1), s.range[j + 1], s.bearing[j + 1], hn, yn0, yn1);
-        if (lane == 0) {
-#pragma unroll
-          for (int k = 0; k < 5; ++k) hS[k] = make_double2(hn[0][k], hn[1][k]);
-          hS[5] = make_double2(yn0, yn1);
-        }
-      }
-      __syncthreads();                                // b2(j): hS ready, covariance block down-dated
-    }
-    return;
-  }
-
-  double pcol[CPAD];
-#pragma unroll
-  for (int r0 = 0; r0 < CPAD; r0 += RCH) {
-    if (r0 < c) {
-#pragma unroll
-      for (int r = r0; r < r0 + RCH; ++r) pcol[r] = (on && r < c) ? Pc[r][ll] : 0.0;
-    } else {
-#pragma unroll
-      for (int r = r0; r < r0 + RCH; ++r) pcol[r] = 0.0;
-    }
-  }
-  STAMP(o, 2);
-  // ---- motion model (src/replay_no_ros.py:368-417), evaluated redundantly by every lane ----
+  // ---- ... and the motion model (src/replay_no_ros.py:368-417) runs under their latency, redundantly in
+  // every lane of every wave (wave 1 needs the predicted pose for the first linearisation) ----
   const double th = __shfl(mu_l, 2);
   double g0 = 0.0, g1 = 0.0, nx = __shfl(mu_l, 0), ny = __shfl(mu_l, 1), nth = th;
   if (do_pred && !cfg.disable_motion_model) {
@@ -235,6 +215,63 @@ __global__ __launch_bounds__(256) void k_solve(const double* __restrict__ P, con
       g1 = lin * c0;
     }
   }
+  const double mu_pred = (lane == 0) ? nx : ((lane == 1) ? ny : ((lane == 2) ? nth : mu_l));
+#pragma unroll
+  for (int q = 0; q < GQ; ++q) {
+    const int r = gw + 4 * q;
+    if (on && r < c) {
+      double v = gv[q];
+      for (int k = 0; k < kbase; ++k) v = fma(Wc[r][k], Vc[k][lane], v);
+      if (r == lane && r < 3) v += (r == 0) ? d0 : ((r == 1) ? d1 : d2);
+      Pc[r][lane] = v;
+    }
+  }
+  __syncthreads();
+  if (tid >= 64) {
+    // Helper waves.  Wave 1 publishes the predicted mean and linearises landmark 0 while wave 0 forms the
+    // predicted covariance block; later it linearises landmark j+1 (atan2, rsqrt: ~1200 cycles of a lone
+    // wave) while wave 0 down-dates for landmark j.  Waves 2-3 only keep the barrier count.
+    const int hw = tid >> 6;
+    if (hw == 1) {
+      if (lane < CPAD) muc[lane] = on ? mu_pred : 0.0;
+      WAVE_SYNC();
+      if (m > 0) {
+        double hn[2][5], yn0, yn1;
+        linearize(muc, 3, s.range[0], s.bearing[0], hn, yn0, yn1);
+        if (lane == 0) {
+#pragma unroll
+          for (int k = 0; k < 5; ++k) hS[k] = make_double2(hn[0][k], hn[1][k]);
+          hS[5] = make_double2(yn0, yn1);
+        }
+      }
+    }
+    __syncthreads();                                  // S0: predicted mean, covariance block and hS published
+    for (int j = 0; j < m; ++j) {
+      __syncthreads();                                // b1(j): mean after landmark j is in muc
+      if (hw == 1 && j + 1 < m) {
+        double hn[2][5], yn0, yn1;
+        linearize(muc, 3 + 2 * (j + 1), s.range[j + 1], s.bearing[j + 1], hn, yn0, yn1);
+        if (lane == 0) {
+#pragma unroll
+          for (int k = 0; k < 5; ++k) hS[k] = make_double2(hn[0][k], hn[1][k]);
+          hS[5] = make_double2(yn0, yn1);
+        }
+      }
+      __syncthreads();                                // b2(j): hS ready, covariance block down-dated
+    }
+  } else {
+  double pcol[CPAD];
+#pragma unroll
+  for (int r0 = 0; r0 < CPAD; r0 += RCH) {
+    if (r0 < c) {
+#pragma unroll
+      for (int r = r0; r < r0 + RCH; ++r) pcol[r] = (on && r < c) ? Pc[r][ll] : 0.0;
+    } else {
+#pragma unroll
+      for (int r = r0; r < r0 + RCH; ++r) pcol[r] = 0.0;
+    }
+  }
+  STAMP(o, 2);
   const double rd0 = do_pred ? cfg.rd[0] : 0.0, rd1 = do_pred ? cfg.rd[1] : 0.0,
                rd2 = do_pred ? cfg.rd[2] : 0.0;
   STAMP(o, 3);
@@ -245,13 +282,21 @@ __global__ __launch_bounds__(256) void k_solve(const double* __restrict__ P, con
   pcol[1] += g1 * pcol[2];
   if (lane == 2) {                                   // X[:,2] after the row ops, for the column ops
 #pragma unroll
-    for (int r = 0; r < CPAD; ++r) muc[r] = pcol[r];
+    for (int r0 = 0; r0 < CPAD; r0 += RCH)
+      if (r0 < c) {
+#pragma unroll
+        for (int r = r0; r < r0 + RCH; ++r) L.xs[r] = pcol[r];
+      }
   }
   WAVE_SYNC();
   if (lane < 2) {
     const double gl = (lane == 0) ? g0 : g1;
 #pragma unroll
-    for (int r = 0; r < CPAD; ++r) pcol[r] = fma(gl, muc[r], pcol[r]);
+    for (int r0 = 0; r0 < CPAD; r0 += RCH)
+      if (r0 < c) {
+#pragma unroll
+        for (int r = r0; r < r0 + RCH; ++r) pcol[r] = fma(gl, L.xs[r], pcol[r]);
+      }
   }
   if (lane == 0) pcol[0] += rd0;
   if (lane == 1) pcol[1] += rd1;
@@ -265,36 +310,62 @@ __global__ __launch_bounds__(256) void k_solve(const double* __restrict__ P, con
         for (int r = r0; r < r0 + RCH; ++r) Pc[r][lane] = pcol[r];
       }
   }
-  double mu_cur = (lane == 0) ? nx : ((lane == 1) ? ny : ((lane == 2) ? nth : mu_l));
-  if (lane < CPAD) muc[lane] = on ? mu_cur : 0.0;
+  double mu_cur = mu_pred;                             // (wave 1 published it in muc)
   if (lane == 0) {
-    o.g[0] = g0;
-    o.g[1] = g1;
-    o.rd[0] = rd0;
-    o.rd[1] = rd1;
-    o.rd[2] = rd2;
-    o.p22h = 0.5 * p22;
-    o.dacc_old[0] = d0;
-    o.dacc_old[1] = d1;
-    o.dacc_old[2] = d2;
-    o.c = c;
-    o.m = m;
-    o.kbase = kbase;
-    o.neff = s.neff;
-    dacc[4 * b + 0] = d0 + rd0;                      // the pose-block noise joins the pending update
-    dacc[4 * b + 1] = d1 + rd1;
-    dacc[4 * b + 2] = d2 + rd2;
+    SolveHdr hd;
+    hd.g[0] = g0;
+    hd.g[1] = g1;
+    hd.rd[0] = rd0;
+    hd.rd[1] = rd1;
+    hd.rd[2] = rd2;
+    hd.p22h = 0.5 * p22;
+    hd.dacc_old[0] = d0;
+    hd.dacc_old[1] = d1;
+    hd.dacc_old[2] = d2;
+    hd.c = c;
+    hd.m = m;
+    hd.kbase = kbase;
+    hd.neff = s.neff;
+    L.hdr = hd;
+    if (writer) {
+      o.g[0] = g0;
+      o.g[1] = g1;
+      o.rd[0] = rd0;
+      o.rd[1] = rd1;
+      o.rd[2] = rd2;
+      o.p22h = hd.p22h;
+      o.dacc_old[0] = d0;
+      o.dacc_old[1] = d1;
+      o.dacc_old[2] = d2;
+      o.c = c;
+      o.m = m;
+      o.kbase = kbase;
+      o.neff = s.neff;
+      dacc_out[0] = d0 + rd0;                        // the pose-block noise joins the pending update
+      dacc_out[1] = d1 + rd1;
+      dacc_out[2] = d2 + rd2;
+    }
   }
   __syncthreads();                                    // S0 (helper waves wait here too)
 
   STAMP(o, 4);
   // ---- sequential per-landmark recurrences (:436-480) on the compressed system ----
   double h[2][5], y0 = 0.0, y1 = 0.0;
-  if (m > 0) linearize(muc, 3, s.range[0], s.bearing[0], h, y0, y1);
+  if (m > 0) {                                         // landmark 0 was linearised by wave 1
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+      const double2 t = hS[k];
+      h[0][k] = t.x;
+      h[1][k] = t.y;
+    }
+    const double2 t = hS[5];
+    y0 = t.x;
+    y1 = t.y;
+  }
   STAMP(o, 5);
   for (int j = 0; j < m; ++j) {
     const int a = 3 + 2 * j;
-    SolveIter& it = o.it[j];
+    SolveIter& it = its[j];
     STAMP(o, 8 + 6 * j);
     // phase A: rows sel of P_j at column C[lane] (H P) and columns sel at row C[lane] (P H^T).
     // The instruction count is what matters for a lone wave: S is formed from the five hp pairs the
@@ -389,11 +460,30 @@ __global__ __launch_bounds__(256) void k_solve(const double* __restrict__ P, con
 
   STAMP(o, 6);
   bool bad = false;
-  if (on) {
-    mu_out[(long)b * ld + Cl] = mu_cur;
+  if (on && writer) {
+    mu_out_b[Cl] = mu_cur;
     bad = !(fabs(mu_cur) <= 1.79769313486231570815e308);
   }
-  if (__any(bad) && lane == 0) atomicOr(&flags[b], EKF_FLAG_NONFINITE);
+  if (__any(bad) && lane == 0) atomicOr(flag_b, EKF_FLAG_NONFINITE);
+  }   // wave 0
+}
+
+__global__ __launch_bounds__(256) void k_solve(const double* __restrict__ P, const double* __restrict__ V,
+                                               const double* __restrict__ W,
+                                               const double* __restrict__ dacc_in,
+                                               double* __restrict__ dacc_out,
+                                               const double* __restrict__ mu_in,
+                                               double* __restrict__ mu_out,
+                                               const int* __restrict__ nact,
+                                               const StepIn* __restrict__ in,
+                                               SolveOut* __restrict__ out,
+                                               unsigned* __restrict__ flags, DeviceConfig cfg, int ld,
+                                               long pstride, int kbase) {
+  __shared__ SolveLds L;
+  const int b = blockIdx.x;
+  solve_body(L, P + (long)b * pstride, V + (long)b * KTOT * ld, W + (long)b * KTOT * ld, dacc_in + 4 * b,
+             dacc_out + 4 * b, mu_in + (long)b * ld, mu_out + (long)b * ld, in[b], out[b], out[b].it,
+             flags + b, cfg, ld, kbase, true);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -408,55 +498,38 @@ __global__ __launch_bounds__(256) void k_solve(const double* __restrict__ P, con
 //  The two rank-1 pairs of the motion Jacobian (:430) go to ranks kb+2*MCAP, +1:
 //      V = P[2,:] + p22h*gt, W = gt   and   V = gt, W = P[:,2] + p22h*gt.
 // ---------------------------------------------------------------------------------------------
+// Zero V columns / W rows of this step and carry the mean over: workgroups whose 64 state indices all lie
+// beyond the active bound (their rows and columns of P are exactly zero off the diagonal).
+template <int KTP>
+__device__ __forceinline__ void panels_beyond_bound(double* Vb, double* Wb, const double* mu_in_b, double* mu_out_b,
+                                                    int ld, int kb, int i, bool act, int wave) {
+  const int ld16 = ld >> 4;
+  if (act && wave == 0) {
+    for (int k = kb; k < ((kb + KTP + 3) & ~3); ++k) Vb[(long)k * ld + i] = 0.0;
+  }
+  if (act && wave == 1) {
+    for (int k = kb; k < ((kb + KTP + 3) & ~3); ++k) Wb[wm_index(ld16, k, i)] = 0.0;
+    mu_out_b[i] = mu_in_b[i];
+  }
+}
+
+// panels_body: phases 1 and 2 for the 64 state indices of this workgroup.  `its`, `Cs`, `Wc`, `Vc` are in
+// LDS (its/Cs always valid; Wc/Vc are staged here unless the fused kernel's solve already did).
 template <int MCAP>
-__global__ __launch_bounds__(256) void k_panels(const double* __restrict__ P, double* __restrict__ V,
-                                                double* __restrict__ W,
-                                                const double* __restrict__ mu_in,
-                                                double* __restrict__ mu_out,
-                                                const int* __restrict__ nact,
-                                                const SolveOut* __restrict__ so, int ld, long pstride) {
+__device__ __forceinline__ void panels_body(const double* __restrict__ Pb, double* __restrict__ Vb,
+                                            double* __restrict__ Wb, const double* __restrict__ mu_in_b,
+                                            double* __restrict__ mu_out_b, int n, int ld, const SolveIter* its,
+                                            const int* Cs, const SolveHdr& o, double (*Wc)[WCS], double (*Vc)[PCS],
+                                            double (*Rs)[64], double (*Ls)[64], bool factors_staged) {
   constexpr int CC = 3 + 2 * MCAP, K2 = 2 * MCAP, KTP = ranks_for(MCAP);
   constexpr int QA = (CC + 3) / 4;                    // a's per wave in phase 1
-  __shared__ SolveIter its[MCAP];
-  __shared__ double Wc[CC][WCS];
-  __shared__ double Vc[KTOT][PCS];
-  __shared__ double Rs[CC][64], Ls[CC][64];
-  __shared__ int Cs[CPAD];
-  const int b = blockIdx.y;
-  const int n = nact[b];
-  if ((int)blockIdx.x * 64 >= n) return;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int i = blockIdx.x * 64 + lane;
   const bool act = i < n;
   const int ii = act ? i : 0;
-  const SolveOut& o = so[b];
-  const double* Pb = P + (long)b * pstride;
-  double* Vb = V + (long)b * KTOT * ld;
-  double* Wb = W + (long)b * KTOT * ld;
   const int ld16 = ld >> 4;
   const int m = min(o.m, MCAP), c = o.c, kb = o.kbase;
-
-  if ((int)blockIdx.x * 64 >= o.neff) {
-    // every state index of this workgroup lies beyond the active bound: its rows and columns of P are
-    // exactly zero off the diagonal, so this step's V columns / W rows are zero and the mean is unchanged
-    if (act && wave == 0) {
-      for (int k = kb; k < ((kb + KTP + 3) & ~3); ++k) Vb[(long)k * ld + i] = 0.0;
-    }
-    if (act && wave == 1) {
-      for (int k = kb; k < ((kb + KTP + 3) & ~3); ++k) Wb[wm_index(ld16, k, i)] = 0.0;
-      mu_out[(long)b * ld + i] = mu_in[(long)b * ld + i];
-    }
-    return;
-  }
-  {
-    const double2* src = reinterpret_cast<const double2*>(o.it);
-    double2* dst = reinterpret_cast<double2*>(its);
-    const int count = m * (int)(sizeof(SolveIter) / 16);
-    for (int t = tid; t < count; t += 256) dst[t] = src[t];
-  }
-  if (tid < CPAD) Cs[tid] = (tid < CMAX + 1) ? o.C[tid] : 0;
-  __syncthreads();
   // ---- phase 1 ----  (the base-panel loads are issued first: their latency overlaps the staging)
   {
     double r[QA], l[QA];
@@ -467,7 +540,7 @@ __global__ __launch_bounds__(256) void k_panels(const double* __restrict__ P, do
       r[q] = Pb[(long)row * ld + ii];
       l[q] = Pb[(long)ii * ld + row];
     }
-    if (kb > 0) {
+    if (kb > 0 && !factors_staged) {
       stage_factors(Vb, Wb, Cs, min(c, CC), kb, ld, tid, 256, Wc, Vc);
       __syncthreads();
     }
@@ -648,9 +721,58 @@ __global__ __launch_bounds__(256) void k_panels(const double* __restrict__ P, do
       for (int k = kb + KTP; k < ((kb + KTP + 3) & ~3); ++k) Wb[wm_index(ld16, k, i)] = 0.0;
       bool inC = false;
       for (int a = 0; a < c; ++a) inC |= (Cs[a] == i);
-      if (!inC) mu_out[(long)b * ld + i] = mu_in[(long)b * ld + i] + dm;
+      if (!inC) mu_out_b[i] = mu_in_b[i] + dm;
     }
   }
+}
+
+template <int MCAP>
+__global__ __launch_bounds__(256) void k_panels(const double* __restrict__ P, double* __restrict__ V,
+                                                double* __restrict__ W,
+                                                const double* __restrict__ mu_in,
+                                                double* __restrict__ mu_out,
+                                                const int* __restrict__ nact,
+                                                const SolveOut* __restrict__ so, int ld, long pstride) {
+  constexpr int CC = 3 + 2 * MCAP, KTP = ranks_for(MCAP);
+  __shared__ SolveIter its[MCAP];
+  __shared__ double Wc[CC][WCS];
+  __shared__ double Vc[KTOT][PCS];
+  __shared__ double Rs[CC][64], Ls[CC][64];
+  __shared__ int Cs[CPAD];
+  __shared__ SolveHdr hdr;
+  const int b = blockIdx.y;
+  const int n = nact[b];
+  if ((int)blockIdx.x * 64 >= n) return;
+  const int tid = threadIdx.x;
+  const SolveOut& o = so[b];
+  const double* Pb = P + (long)b * pstride;
+  double* Vb = V + (long)b * KTOT * ld;
+  double* Wb = W + (long)b * KTOT * ld;
+  if ((int)blockIdx.x * 64 >= o.neff) {
+    const int i = blockIdx.x * 64 + (tid & 63);
+    panels_beyond_bound<KTP>(Vb, Wb, mu_in + (long)b * ld, mu_out + (long)b * ld, ld, o.kbase, i, i < n, tid >> 6);
+    return;
+  }
+  {
+    const int m = min(o.m, MCAP);
+    const double2* src = reinterpret_cast<const double2*>(o.it);
+    double2* dst = reinterpret_cast<double2*>(its);
+    const int count = m * (int)(sizeof(SolveIter) / 16);
+    for (int t = tid; t < count; t += 256) dst[t] = src[t];
+  }
+  if (tid < CPAD) Cs[tid] = (tid < CMAX + 1) ? o.C[tid] : 0;
+  if (tid == 0) {
+    SolveHdr h;
+    h.g[0] = o.g[0]; h.g[1] = o.g[1];
+    h.rd[0] = o.rd[0]; h.rd[1] = o.rd[1]; h.rd[2] = o.rd[2];
+    h.p22h = o.p22h;
+    h.dacc_old[0] = o.dacc_old[0]; h.dacc_old[1] = o.dacc_old[1]; h.dacc_old[2] = o.dacc_old[2];
+    h.c = o.c; h.m = o.m; h.kbase = o.kbase; h.neff = o.neff;
+    hdr = h;
+  }
+  __syncthreads();
+  panels_body<MCAP>(Pb, Vb, Wb, mu_in + (long)b * ld, mu_out + (long)b * ld, n, ld, its, Cs, hdr, Wc, Vc, Rs, Ls,
+                    false);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -881,11 +1003,12 @@ __global__ __launch_bounds__(256) void k_fill_diag(double* __restrict__ Pb, int 
 // ---------------------------------------------------------------------------------------------
 // launchers (called from ekf_api.hip)
 // ---------------------------------------------------------------------------------------------
-void launch_solve(hipStream_t st, const double* P, const double* V, const double* W, double* dacc,
-                  const double* mu_in, double* mu_out, const int* nact, const StepIn* in, SolveOut* out,
-                  unsigned* flags, const DeviceConfig& cfg, int ld, long pstride, int batch, int kbase) {
-  hipLaunchKernelGGL(k_solve, dim3(batch), dim3(256), 0, st, P, V, W, dacc, mu_in, mu_out, nact, in, out,
-                     flags, cfg, ld, pstride, kbase);
+void launch_solve(hipStream_t st, const double* P, const double* V, const double* W, const double* dacc_in,
+                  double* dacc_out, const double* mu_in, double* mu_out, const int* nact, const StepIn* in,
+                  SolveOut* out, unsigned* flags, const DeviceConfig& cfg, int ld, long pstride, int batch,
+                  int kbase) {
+  hipLaunchKernelGGL(k_solve, dim3(batch), dim3(256), 0, st, P, V, W, dacc_in, dacc_out, mu_in, mu_out, nact, in,
+                     out, flags, cfg, ld, pstride, kbase);
 }
 
 template <int MCAP>

@@ -8,22 +8,23 @@ using namespace ekf;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1;} } while (0)
 int main(int argc, char** argv) {
   const int N = 2000, n = 3 + 2 * N, ld = (n + 15) / 16 * 16, m = argc > 1 ? atoi(argv[1]) : 8;
-  double *P, *mu0, *mu1; int* dn; StepIn* din; SolveOut* dso; unsigned* dfl;
+  double *P, *mu0, *mu1, *V, *W, *dacc; int* dn; StepIn* din; SolveOut* dso; unsigned* dfl;
   CK(hipMalloc(&P, sizeof(double) * ld * ld)); CK(hipMalloc(&mu0, sizeof(double) * ld)); CK(hipMalloc(&mu1, sizeof(double) * ld));
+  CK(hipMalloc(&V, sizeof(double) * KTOT * ld)); CK(hipMalloc(&W, sizeof(double) * KTOT * ld)); CK(hipMalloc(&dacc, 64)); CK(hipMemset(dacc, 0, 64));
   CK(hipMalloc(&dn, 4)); CK(hipMalloc(&din, sizeof(StepIn))); CK(hipMalloc(&dso, sizeof(SolveOut))); CK(hipMalloc(&dfl, 4));
   std::vector<double> hP((size_t)ld * ld, 0.0), hmu(ld, 0.0);
   for (int i = 0; i < n; ++i) { hP[(size_t)i * ld + i] = i < 3 ? 0.1 : 1e4; if (i >= 3) hmu[i] = 0.3 + 0.001 * i * ((i & 1) ? 1 : -1); }
   CK(hipMemcpy(P, hP.data(), sizeof(double) * ld * ld, hipMemcpyHostToDevice));
   CK(hipMemcpy(mu0, hmu.data(), sizeof(double) * ld, hipMemcpyHostToDevice));
   CK(hipMemcpy(dn, &n, 4, hipMemcpyHostToDevice)); CK(hipMemset(dfl, 0, 4));
-  StepIn s{}; s.lin = 0.004; s.ang = 0.02; s.m = m; s.flags = 3;
+  StepIn s{}; s.lin = 0.004; s.ang = 0.02; s.m = m; s.flags = 3; s.neff = n;
   for (int i = 0; i < m; ++i) { s.idx[i] = 7 * i + 3; s.range[i] = 0.8; s.bearing[i] = 0.1 * i; }
   CK(hipMemcpy(din, &s, sizeof(s), hipMemcpyHostToDevice));
   DeviceConfig cfg{}; cfg.rd[0] = cfg.rd[1] = 0.01; cfg.rd[2] = 0.0025; cfg.qd[0] = cfg.qd[1] = 0.49; cfg.arc_threshold = 1e-2;
   cfg.enable_measurement_model = 1; cfg.enable_circular_interpolation = 1; cfg.disable_motion_model = 0;
   SolveOut ho;
   for (int rep = 0; rep < 3; ++rep) {
-    launch_solve(0, P, mu0, mu1, dn, din, dso, dfl, cfg, ld, (long)ld * ld, 1);
+    launch_solve(0, P, V, W, dacc, dacc + 4, mu0, mu1, dn, din, dso, dfl, cfg, ld, (long)ld * ld, 1, 0);
     CK(hipDeviceSynchronize());
   }
   CK(hipMemcpy(&ho, dso, sizeof(ho), hipMemcpyDeviceToHost));
