@@ -34,6 +34,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+MFMA_F64_SPEC_TF = 78.6        # public datasheet figure (the local guide lists no fp64 matrix peak)
+MFMA_F64_MEASURED_TF = 47.3    # sustained v_mfma_f64_16x16x4 on this part: profiles/mfma_probe.txt
 
 
 def make_streams(sd_syn, traj_ids, n_landmarks, steps, m):
@@ -178,11 +180,16 @@ def main():
                          "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_s * 1e3, "launches": launches,
                          "steps_per_launch": steps_per_launch,
                          "step_equivalent_GBs": achieved * steps_per_launch,
-                         "fp64_mfma_TFLOPs": 2.0 * ranks * B * n * n / avg_s / 1e12 if avg_s > 0 else 0.0,
+                         "mfma": {"achieved": 2.0 * ranks * B * n * n / avg_s / 1e12 if avg_s > 0 else 0.0,
+                                  "unit": "TFLOP/s fp64", "peak_spec": MFMA_F64_SPEC_TF,
+                                  "peak_measured": MFMA_F64_MEASURED_TF,
+                                  "frac_of_spec": (2.0 * ranks * B * n * n / avg_s / 1e12 / MFMA_F64_SPEC_TF) if avg_s > 0 else 0.0,
+                                  "frac_of_measured": (2.0 * ranks * B * n * n / avg_s / 1e12 / MFMA_F64_MEASURED_TF) if avg_s > 0 else 0.0},
                          "note": "one launch applies the pending rank-K update of steps_per_launch steps: "
                                  "SURVEY 8(d)'s 16 n^2 bytes per step are paid once per launch; achieved/frac "
                                  "count the bytes this launch must move (one read + one write of P), "
-                                 "step_equivalent_GBs multiplies by the steps folded in"},
+                                 "step_equivalent_GBs multiplies by the steps folded in; at 4 steps (72 ranks) "
+                                 "per launch the kernel sits on the ridge (2K flop per 16 B), see `mfma`"},
             "device_ms_per_step": dev_ms / args.steps,
         }
         traffic_file = os.path.join(ROOT, "profiles", "pass_traffic.json")
