@@ -410,3 +410,22 @@ def test_active_bound_is_exact(sd):
     close(out[0][0], om)
     close(out[0][1], oP)
     assert np.array_equal(out[0][1][243:, :243], np.zeros((len(mean0) - 243, 243)))   # never touched
+
+
+def test_long_run_stays_on_the_reference(sd):
+    """1600 steps at N=40 (every landmark revisited ~300 times) with the default deferred pass: no slow
+    drift away from the dense reference path, no growth of the antisymmetric part of P."""
+    N, steps, m = 40, 1600, 8
+    mean0, diag0, lin, ang, idx, zr, zb = orc.synthetic_stream(N, steps, m, 6)
+    cfg = orc.EkfConfig()
+    om, oP = mean0.copy(), np.diag(diag0)
+    for k in range(steps):
+        om, oP = orc.ekf_step_dense(om, oP, lin[k], ang[k], idx[k], zr[k], zb[k], cfg)
+    with sd.EkfSlam(len(mean0)) as f:
+        f.set_state_diag(mean0, diag0)
+        f.run_stream(lin, ang, idx, zr, zb)
+        mu, P = f.state()
+        assert f.flags() == 0
+    close(mu, om)
+    close(P, oP)
+    assert np.abs(P - P.T).max() <= 1e-11 * np.abs(P).max()
