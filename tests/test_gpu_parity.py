@@ -429,3 +429,31 @@ def test_long_run_stays_on_the_reference(sd):
     close(mu, om)
     close(P, oP)
     assert np.abs(P - P.T).max() <= 1e-11 * np.abs(P).max()
+
+
+def test_max_size_n8000_three_steps(sd):
+    """BASELINE config 5 size (n = 16003, P = 2.05 GB): three steps against the O(n^2) oracle, checked on
+    the rows/columns the steps touch plus row/column sums (size-independent checksums of the rest)."""
+    N, steps, m = 8000, 3, 8
+    mean0, diag0, lin, ang, idx, zr, zb = orc.synthetic_stream(N, steps, m, 2)
+    idx = (idx * 997 + 13) % N                       # scatter the observations over the whole state
+    cfg = orc.EkfConfig()
+    om, oP = mean0.copy(), np.diag(diag0)
+    for k in range(steps):
+        om, oP = orc.ekf_step_structured(om, oP, lin[k], ang[k], idx[k], zr[k], zb[k], cfg)
+    n = len(mean0)
+    with sd.EkfSlam(n) as f:
+        f.set_option("active_bound", 0)              # exercise the full-size pass
+        f.set_state_diag(mean0, diag0)
+        f.run_stream(lin, ang, idx, zr, zb)
+        mu = f.mean()
+        rows = sorted({0, 1, 2, n - 1} | {3 + 2 * int(j) for j in idx.ravel()})
+        for r in rows[:12]:
+            close(f.covariance_block(r, 0, 1, n)[0], oP[r])
+            close(f.covariance_block(0, r, n, 1)[:, 0], oP[:, r])
+        P = f.covariance()
+    close(mu, om)
+    close(P.sum(axis=1), oP.sum(axis=1))
+    close(P.sum(axis=0), oP.sum(axis=0))
+    close(np.diag(P), np.diag(oP))
+    del P, oP
