@@ -86,6 +86,27 @@ def time_filter(sd, sd_syn, device, traj_ids, n_landmarks, m, steps, warmup, bar
     return dt, pass_ms, launches, dev_ms
 
 
+def dense_propagate_leg(sd, device, n_landmarks, reps=3):
+    """ekf_predict_dense (general F, two fp64 MFMA GEMMs of n^3 MACs each): SURVEY 8(d) config 3's MFMA-busy
+    evidence.  Device time from HIP events around the GEMM pair (uploads of F, Q excluded)."""
+    n = 3 + 2 * n_landmarks
+    rng = np.random.default_rng(0)
+    F = np.eye(n) + 0.01 * rng.standard_normal((n, n))
+    Q = np.eye(n) * 0.01
+    f = sd.EkfSlam(n, batch=1, device=device)
+    f.set_state_diag(np.zeros(n), np.ones(n))
+    f.predict_dense(F, Q)                      # warm-up (allocates the work buffers)
+    f.profile_enable(True)
+    for _ in range(reps):
+        f.predict_dense(F, Q)
+    ms, cnt = f.profile_read()
+    f.close()
+    per = ms / max(cnt, 1)
+    tf = 4.0 * n ** 3 / (per * 1e-3) / 1e12 if per > 0 else 0.0
+    return {"workload": f"P <- F P F^T + Q, dense F, n={n}", "ms": per, "TFLOPs_fp64": tf,
+            "frac_of_spec": tf / MFMA_F64_SPEC_TF, "frac_of_measured_mfma_rate": tf / MFMA_F64_MEASURED_TF}
+
+
 def cpu_baseline(n_landmarks, m, budget_s=25.0):
     """Reference-shaped dense NumPy step (oracle/ekf_oracle.py::ekf_step_dense) on the host cores."""
     from oracle import ekf_oracle as orc          # checker / baseline only
@@ -211,6 +232,11 @@ def main():
                                         "value": args.steps / dt1, "unit": "steps/s",
                                         "pass_avg_launch_ms": p1 / max(l1, 1), "pass_launches": l1,
                                         "pass_achieved_GBs": a1, "pass_frac_of_hbm_peak": a1 / HBM_PEAK_GBS}
+            dtm, _, _, _ = time_filter(sd, sd_syn, local_rank, traj_ids, args.landmarks, 1, args.steps, args.warmup,
+                                       lambda: None, profile_leg=False, options=args.option)
+            out["obs_1_per_step"] = {"workload": f"N={args.landmarks}, m=1 obs/step, {B} trajectories",
+                                     "value": len(traj_ids) * args.steps / dtm, "unit": "steps/s"}
+            out["dense_propagate"] = dense_propagate_leg(sd, local_rank, args.landmarks)
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.landmarks, args.obs)
     if rank == 0:

@@ -98,7 +98,8 @@ int ekf_run_stream(ekf_handle *h, int steps, const double *lin, const double *an
 int ekf_predict_dense(ekf_handle *h, int b, const double *F, const double *Q);
 
 /* The covariance is held as P_base + (pending low-rank update of the last few steps); the O(n^2) pass
- * over P_base is paid once per `flush_every` steps (option, default 4).  ekf_flush applies what is
+ * over P_base is paid once per `flush_every` steps (option; default 0 = as many steps as fit 72 pending
+ * ranks: 4 steps at 8 observations per step, 18 at one).  ekf_flush applies what is
  * pending now (asynchronous).  Every call that reads or rewrites the covariance flushes by itself. */
 int ekf_flush(ekf_handle *h);
 int ekf_sync(ekf_handle *h);

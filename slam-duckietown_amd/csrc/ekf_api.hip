@@ -403,8 +403,11 @@ static int enqueue_pass(ekf_handle* h, const StepIn* d_in, int m_hi) {
   h->cur ^= 1;
   h->pending_k += ktp;
   h->pending_steps += 1;
-  const int every = h->opt_flush_every > 0 ? h->opt_flush_every : 4;
-  if (h->pending_steps >= every || h->pending_k + 2 > KTOT)
+  // cadence of the covariance pass: a fixed number of steps if asked for, otherwise as many steps as fit
+  // 72 pending ranks (18 MFMA k-tiles: the largest k_flush instantiation that keeps 2 waves/SIMD without
+  // spilling) -- 4 steps at m = 8, 7 at m = 4, 18 at m = 1
+  const bool due = h->opt_flush_every > 0 ? h->pending_steps >= h->opt_flush_every : h->pending_k + ktp > 72;
+  if (due || h->pending_k + 2 > KTOT)
     if (int rc = flush_pending(h)) return rc;
   return EKF_OK;
 }
