@@ -29,6 +29,9 @@ extern "C" {
 
 /* sticky per-trajectory flags, ekf_status_flags() */
 #define EKF_FLAG_NONFINITE 1u /* a non-finite mean entry was produced (q = 0 at :466-469, singular S at :473) */
+#define EKF_FLAG_ASSOC 2u     /* device-side association dropped a detection: tag id outside [0, 1024), state full,
+                                 or more than EKF_MMAX distinct tags in one window */
+#define EKF_DMAX 64           /* detections per window for ekf_step_detections */
 
 typedef struct ekf_handle ekf_handle;
 
@@ -81,6 +84,19 @@ int ekf_update(ekf_handle *h, const int *idx, const double *range, const double 
  * association/augmentation, src/replay_no_ros.py:363-482).  Asynchronous on the handle's stream. */
 int ekf_step(ekf_handle *h, const double *lin, const double *ang, const int *idx,
              const double *range, const double *bearing, const int *m, int stride);
+
+/* Device-side front end (association, 1.5 m gate, per-tag averaging, augmentation: src/replay_no_ros.py:280-360)
+ * followed by the fused step: one window of raw AprilTag detections per trajectory, frames concatenated in
+ * order -- count[b] detections at tag_id / pose_t (x, y, z of tag.pose_t) / pose_err [b*stride + i].  The tag-id
+ * -> landmark-index table lives on the device (ekf_download_tag_index); ekf_download_tags returns what the
+ * reference returns as tags_positions for the last window.  ekf_set_association sets gate and IGNORE_TAGS. */
+int ekf_set_association(ekf_handle *h, double gate_range, const int *ignore_tags, int n_ignore);
+int ekf_step_detections(ekf_handle *h, const double *lin, const double *ang, const int *count, const int *tag_id,
+                        const double *pose_t, const double *pose_err, int stride);
+int ekf_download_tags(ekf_handle *h, int b, int *m, int *idx, int *tag_id, double *xw, double *yw, double *err,
+                      double *range, double *bearing);     /* arrays of EKF_MMAX entries */
+int ekf_download_tag_index(ekf_handle *h, int b, int *tag_of_index, int capacity, int *n_landmarks);
+int ekf_upload_tag_index(ekf_handle *h, int b, const int *tag_of_index, int n_landmarks);
 
 /* Streams of pre-uploaded inputs ([step][batch] and [step][batch][stride] arrays, stride <= EKF_MMAX).
  * ekf_stream_upload copies and validates `steps` steps of inputs into HBM (blocking);

@@ -19,6 +19,8 @@ void launch_flush(hipStream_t, bool, double*, const double*, const double*, cons
 void launch_predict_rc(hipStream_t, double*, const double*, double*, const int*, const SolveOut*, int, long,
                        int, int);
 void launch_add_landmarks(hipStream_t, double*, double*, int, int, int, double, const double*);
+void launch_associate(hipStream_t, const DetIn*, int*, int*, int*, double*, double*, double*, double*, StepIn*,
+                      AssocOut*, unsigned*, const AssocConfig&, int, long, int, int, int);
 void launch_fill_diag(hipStream_t, double*, int, int, const double*);
 int dense_propagate(hipStream_t, double* P, double* tmp, const double* F, const double* Q, int n, int ld);
 }  // namespace ekf
@@ -53,6 +55,13 @@ struct ekf_handle {
   std::vector<int> stream_mhi;
   std::vector<int> stream_neff;   // per (step, trajectory) active bound of the uploaded stream
   double *dF = nullptr, *dQ = nullptr, *dTmp = nullptr;   // dense path, allocated on first use
+  // device-side association (allocated on first use)
+  int *dtagmap = nullptr, *dneff = nullptr;
+  DetIn *d_det = nullptr, *h_det = nullptr;
+  StepIn* d_assoc_step = nullptr;
+  AssocOut* d_assoc_out = nullptr;
+  AssocConfig acfg{};
+  bool sizes_dirty = false;       // the device grew the state: h->n / h->neff must be read back before use
   std::vector<int> n;
   std::vector<int> neff_enq;      // active bound of the last ENQUEUED step (what dso[b].neff holds)
   std::vector<int> neff;          // active bound per trajectory (<= n): indices beyond were never correlated
@@ -109,9 +118,11 @@ static void free_all(ekf_handle* h) {
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   void* ptrs[] = {h->dP, h->dmu2[0], h->dmu2[1], h->dV, h->dW, h->ddacc2[0], h->ddacc2[1], h->dscratch, h->dn, h->dflags, h->dso,
-                  h->d_ring, h->d_stream, h->dF, h->dQ, h->dTmp};
+                  h->d_ring, h->d_stream, h->dF, h->dQ, h->dTmp, h->dtagmap, h->dneff, h->d_det, h->d_assoc_step,
+                  h->d_assoc_out};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (h->h_ring) (void)hipHostFree(h->h_ring);
+  if (h->h_det) (void)hipHostFree(h->h_det);
   for (auto& e : h->ring_ev) if (e) (void)hipEventDestroy(e);
   for (auto& e : h->prof_pool) (void)hipEventDestroy(e);
   if (h->t0) (void)hipEventDestroy(h->t0);
@@ -154,6 +165,10 @@ extern "C" int ekf_create(int device, int n_max, int batch, const ekf_config* cf
   h->dcfg.enable_measurement_model = h->cfg.enable_measurement_model;
   h->dcfg.enable_circular_interpolation = h->cfg.enable_circular_interpolation;
   h->dcfg.disable_motion_model = h->cfg.disable_motion_model;
+  h->acfg.gate2 = 1.5 * 1.5;                      // src/replay_no_ros.py:289
+  h->acfg.init_var = h->cfg.landmark_init_var;
+  h->acfg.n_ignore = 0;
+  h->acfg.active_bound = 1;
   h->n.assign(batch, 3);
   h->neff.assign(batch, 3);
   h->neff_enq.assign(batch, 3);
@@ -216,8 +231,21 @@ extern "C" int ekf_destroy(ekf_handle* h) {
   return EKF_OK;
 }
 
+// After a device-side association the state may have grown on the device: read the sizes back.
+static int refresh_sizes(ekf_handle* h) {
+  if (!h->sizes_dirty) return EKF_OK;
+  HIP_TRY(h, hipSetDevice(h->device));
+  HIP_TRY(h, hipMemcpyAsync(h->n.data(), h->dn, sizeof(int) * h->batch, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipMemcpyAsync(h->neff.data(), h->dneff, sizeof(int) * h->batch, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  h->neff_enq = h->neff;
+  h->sizes_dirty = false;
+  return EKF_OK;
+}
+
 static int check_b(ekf_handle* h, int b, const char* fn) {
   if (!h) return EKF_ERR_ARG;
+  if (int rc = refresh_sizes(h)) return rc;
   if (b < 0 || b >= h->batch) return fail(h, EKF_ERR_ARG, std::string(fn) + ": trajectory index out of range");
   return EKF_OK;
 }
@@ -349,7 +377,7 @@ static int prof_event(ekf_handle* h, hipEvent_t* ev) {
 // Apply the pending low-rank update to P_base:  P_base += W V + diag(dacc)  (one pass over P).
 static int flush_pending(ekf_handle* h) {
   if (h->pending_k == 0) return EKF_OK;
-  const int n_hi = *std::max_element(h->n.begin(), h->n.end());
+  const int n_hi = h->sizes_dirty ? h->n_max : *std::max_element(h->n.begin(), h->n.end());
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (h->profile) {
     if (int rc = prof_event(h, &e0)) return rc;
@@ -358,6 +386,7 @@ static int flush_pending(ekf_handle* h) {
   }
   int e_hi = 3;                                        // grid covers the largest active bound of the batch
   for (int b = 0; b < h->batch; ++b) e_hi = std::max(e_hi, std::min(h->n[b], h->neff_enq[b]));
+  if (h->sizes_dirty) e_hi = h->n_max;
   launch_flush(h->stream, streaming_pass(h, n_hi), h->dP, h->dV, h->dW, h->ddacc2[h->dcur], h->dn, h->dso, h->ld, h->pstride,
                h->batch, e_hi, (h->pending_k + 3) / 4, flush_rows_per_block(h, streaming_pass(h, n_hi)));
   if (h->profile) HIP_TRY(h, hipEventRecord(e1, h->stream));
@@ -371,7 +400,7 @@ static int flush_pending(ekf_handle* h) {
 
 // Enqueue one device pass with inputs already at d_in (StepIn[batch]); m_hi = max m over the batch.
 static int enqueue_pass(ekf_handle* h, const StepIn* d_in, int m_hi) {
-  const int n_hi = *std::max_element(h->n.begin(), h->n.end());
+  const int n_hi = h->sizes_dirty ? h->n_max : *std::max_element(h->n.begin(), h->n.end());
   const int mcap = cap_for(m_hi);
   const int ktp = ranks_for(mcap);
   const double* mu_in = h->dmu2[h->cur];
@@ -443,6 +472,7 @@ static int fill_step(ekf_handle* h, StepIn& s, int b, double lin, double ang, in
 static int do_step(ekf_handle* h, int base_flags, const double* lin, const double* ang, const int* idx,
                    const double* range, const double* bearing, const int* m, int stride) {
   if (!h) return EKF_ERR_ARG;
+  if (int rc = refresh_sizes(h)) return rc;
   const bool upd = (base_flags & FLAG_UPDATE) != 0, pred = (base_flags & FLAG_PREDICT) != 0;
   if (pred && (!lin || !ang)) return fail(h, EKF_ERR_ARG, "NULL lin/ang");
   if (upd && (!m || stride < 0)) return fail(h, EKF_ERR_ARG, "NULL m / bad stride");
@@ -481,6 +511,139 @@ static int do_step(ekf_handle* h, int base_flags, const double* lin, const doubl
   return EKF_OK;
 }
 
+// ---- device-side association ------------------------------------------------------------------
+static int assoc_init(ekf_handle* h) {
+  if (h->dtagmap) return EKF_OK;
+  HIP_TRY(h, hipSetDevice(h->device));
+  HIP_TRY(h, hipMalloc(&h->dtagmap, sizeof(int) * TAGMAX * h->batch));
+  HIP_TRY(h, hipMemsetAsync(h->dtagmap, 0xFF, sizeof(int) * TAGMAX * h->batch, h->stream));   // -1
+  HIP_TRY(h, hipMalloc(&h->dneff, sizeof(int) * h->batch));
+  HIP_TRY(h, hipMalloc(&h->d_det, sizeof(DetIn) * h->batch * RING));
+  HIP_TRY(h, hipHostMalloc(&h->h_det, sizeof(DetIn) * h->batch * RING, hipHostMallocDefault));
+  HIP_TRY(h, hipMalloc(&h->d_assoc_step, sizeof(StepIn) * h->batch));
+  HIP_TRY(h, hipMalloc(&h->d_assoc_out, sizeof(AssocOut) * h->batch));
+  HIP_TRY(h, hipMemsetAsync(h->d_assoc_out, 0, sizeof(AssocOut) * h->batch, h->stream));
+  return EKF_OK;
+}
+
+extern "C" int ekf_set_association(ekf_handle* h, double gate_range, const int* ignore_tags, int n_ignore) {
+  if (!h) return EKF_ERR_ARG;
+  if (n_ignore < 0 || n_ignore > IGNMAX || (n_ignore > 0 && !ignore_tags))
+    return fail(h, EKF_ERR_ARG, "ekf_set_association: at most 16 ignored tags");
+  h->acfg.gate2 = gate_range * gate_range;
+  h->acfg.n_ignore = n_ignore;
+  for (int i = 0; i < n_ignore; ++i) h->acfg.ignore[i] = ignore_tags[i];
+  return EKF_OK;
+}
+
+extern "C" int ekf_step_detections(ekf_handle* h, const double* lin, const double* ang, const int* count,
+                                   const int* tag_id, const double* pose_t, const double* pose_err, int stride) {
+  if (!h) return EKF_ERR_ARG;
+  if (!lin || !ang || !count || stride < 0) return fail(h, EKF_ERR_ARG, "ekf_step_detections: NULL array");
+  if (int rc = assoc_init(h)) return rc;
+  HIP_TRY(h, hipSetDevice(h->device));
+  // an upper bound of the landmarks observed this window (distinct tag ids) selects the kernel instantiation
+  int m_hi = 0;
+  const int slot = h->ring_pos;
+  h->ring_pos = (h->ring_pos + 1) % RING;
+  if (h->ring_used[slot]) HIP_TRY(h, hipEventSynchronize(h->ring_ev[slot]));
+  DetIn* hs = h->h_det + (size_t)slot * h->batch;
+  DetIn* ds = h->d_det + (size_t)slot * h->batch;
+  for (int b = 0; b < h->batch; ++b) {
+    const int c = count[b];
+    if (c < 0 || c > stride || c > DMAX) return fail(h, EKF_ERR_ARG, "ekf_step_detections: count must be <= min(stride, EKF_DMAX)");
+    if (c > 0 && (!tag_id || !pose_t || !pose_err)) return fail(h, EKF_ERR_ARG, "ekf_step_detections: NULL detection arrays");
+    DetIn& d = hs[b];
+    d.lin = lin[b];
+    d.ang = ang[b];
+    d.count = c;
+    d.pad = 0;
+    int distinct = 0;
+    for (int i = 0; i < c; ++i) {
+      const long e = (long)b * stride + i;
+      d.tag_id[i] = tag_id[e];
+      d.pose_err[i] = pose_err[e];
+      d.pose_t[i][0] = pose_t[3 * e];
+      d.pose_t[i][1] = pose_t[3 * e + 1];
+      d.pose_t[i][2] = pose_t[3 * e + 2];
+      bool seen = false;
+      for (int k = 0; k < i; ++k) seen |= (d.tag_id[k] == d.tag_id[i]);
+      distinct += seen ? 0 : 1;
+    }
+    m_hi = std::max(m_hi, std::min(distinct, MMAX));
+  }
+  if (!h->cfg.enable_measurement_model) m_hi = 0;
+  // the host's view of the active bound must be on the device before the first device-side window
+  if (!h->sizes_dirty)
+    HIP_TRY(h, hipMemcpyAsync(h->dneff, h->neff.data(), sizeof(int) * h->batch, hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(h, hipMemcpyAsync(ds, hs, sizeof(DetIn) * h->batch, hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(h, hipEventRecord(h->ring_ev[slot], h->stream));
+  h->ring_used[slot] = true;
+  const int mcap = cap_for(m_hi);
+  if (h->pending_k + ranks_for(mcap) > KTOT)
+    if (int rc = flush_pending(h)) return rc;
+  h->acfg.active_bound = h->opt_active_bound;
+  launch_associate(h->stream, ds, h->dtagmap, h->dn, h->dneff, h->dmu2[h->cur], h->dP, h->dV, h->dW, h->d_assoc_step,
+                   h->d_assoc_out, h->dflags, h->acfg, h->ld, h->pstride, h->n_max, h->pending_k, h->batch);
+  HIP_TRY(h, hipGetLastError());
+  h->sizes_dirty = true;
+  // m_hi == 0 only when no trajectory has a detection (or the measurement model is off): then, with nothing
+  // pending, the O(n) prediction-only kernel applies; any detection selects the generic path, which is also
+  // right when the gate leaves nothing (its ranks are zero)
+  return enqueue_pass(h, h->d_assoc_step, m_hi);
+}
+
+extern "C" int ekf_download_tags(ekf_handle* h, int b, int* m, int* idx, int* tag_id, double* xw, double* yw,
+                                 double* err, double* range, double* bearing) {
+  if (int rc = check_b(h, b, "ekf_download_tags")) return rc;
+  if (!h->d_assoc_out) return fail(h, EKF_ERR_STATE, "ekf_download_tags: no device-side association has run");
+  AssocOut a;
+  HIP_TRY(h, hipMemcpyAsync(&a, h->d_assoc_out + b, sizeof(a), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  if (m) *m = a.m;
+  for (int i = 0; i < MMAX; ++i) {
+    if (idx) idx[i] = a.idx[i];
+    if (tag_id) tag_id[i] = a.tag_id[i];
+    if (xw) xw[i] = a.xw[i];
+    if (yw) yw[i] = a.yw[i];
+    if (err) err[i] = a.err[i];
+    if (range) range[i] = a.range[i];
+    if (bearing) bearing[i] = a.bearing[i];
+  }
+  return EKF_OK;
+}
+
+extern "C" int ekf_download_tag_index(ekf_handle* h, int b, int* tag_of_index, int capacity, int* n_landmarks) {
+  if (int rc = check_b(h, b, "ekf_download_tag_index")) return rc;
+  if (!n_landmarks) return fail(h, EKF_ERR_ARG, "ekf_download_tag_index: NULL");
+  if (int rc = assoc_init(h)) return rc;
+  std::vector<int> tm(TAGMAX);
+  HIP_TRY(h, hipMemcpyAsync(tm.data(), h->dtagmap + (size_t)b * TAGMAX, sizeof(int) * TAGMAX, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  int count = 0;
+  for (int id = 0; id < TAGMAX; ++id)
+    if (tm[id] >= 0) {
+      count = std::max(count, tm[id] + 1);
+      if (tag_of_index && tm[id] < capacity) tag_of_index[tm[id]] = id;
+    }
+  *n_landmarks = count;
+  return EKF_OK;
+}
+
+extern "C" int ekf_upload_tag_index(ekf_handle* h, int b, const int* tag_of_index, int n_landmarks) {
+  if (int rc = check_b(h, b, "ekf_upload_tag_index")) return rc;
+  if (n_landmarks < 0 || (n_landmarks > 0 && !tag_of_index)) return fail(h, EKF_ERR_ARG, "ekf_upload_tag_index: bad arguments");
+  if (int rc = assoc_init(h)) return rc;
+  std::vector<int> tm(TAGMAX, -1);
+  for (int i = 0; i < n_landmarks; ++i) {
+    if (tag_of_index[i] < 0 || tag_of_index[i] >= TAGMAX) return fail(h, EKF_ERR_ARG, "ekf_upload_tag_index: tag id outside [0, 1024)");
+    tm[tag_of_index[i]] = i;
+  }
+  HIP_TRY(h, hipMemcpyAsync(h->dtagmap + (size_t)b * TAGMAX, tm.data(), sizeof(int) * TAGMAX, hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return EKF_OK;
+}
+
 extern "C" int ekf_predict(ekf_handle* h, const double* lin, const double* ang) {
   return do_step(h, FLAG_PREDICT, lin, ang, nullptr, nullptr, nullptr, nullptr, 0);
 }
@@ -498,6 +661,7 @@ extern "C" int ekf_step(ekf_handle* h, const double* lin, const double* ang, con
 extern "C" int ekf_stream_upload(ekf_handle* h, int steps, const double* lin, const double* ang, const int* idx,
                                  const double* range, const double* bearing, const int* m, int stride) {
   if (!h) return EKF_ERR_ARG;
+  if (int rc = refresh_sizes(h)) return rc;
   if (steps <= 0) return fail(h, EKF_ERR_ARG, "ekf_stream_upload: steps must be > 0");
   if (!lin || !ang || !m || stride < 0) return fail(h, EKF_ERR_ARG, "ekf_stream_upload: NULL array");
   if (stride > MMAX) return fail(h, EKF_ERR_ARG, "ekf_stream_upload: stride must be <= EKF_MMAX");

@@ -61,6 +61,36 @@ struct alignas(16) SolveOut {
 };
 static_assert(offsetof(SolveOut, it) % 16 == 0, "SolveOut::it must be 16-byte aligned");
 
+// Device-side association: one window of raw AprilTag detections per trajectory.
+constexpr int DMAX = 64;                // detections per window
+constexpr int TAGMAX = 1024;            // tag ids [0, TAGMAX) (tag36h11 has 587)
+constexpr int IGNMAX = 16;
+
+struct DetIn {                          // host -> device
+  double lin, ang;
+  int count;
+  int pad;
+  int tag_id[DMAX];
+  double pose_err[DMAX];
+  double pose_t[DMAX][3];
+};
+
+struct AssocOut {                       // what the reference returns as tags_positions (:331-337), update order
+  int m;
+  int n_after;
+  int idx[MMAX];
+  int tag_id[MMAX];
+  double xw[MMAX], yw[MMAX], err[MMAX], range[MMAX], bearing[MMAX];
+};
+
+struct AssocConfig {
+  double gate2;                         // 1.5^2 (:289)
+  double init_var;                      // 1e4   (:356-357)
+  int n_ignore;
+  int active_bound;
+  int ignore[IGNMAX];                   // IGNORE_TAGS (:36, :286)
+};
+
 struct DeviceConfig {
   double rd[3];         // diag of R  (src/replay_no_ros.py:421)
   double qd[2];         // diag of Q  (:438)

@@ -977,6 +977,146 @@ __global__ __launch_bounds__(256) void k_predict_rc(double* __restrict__ P,
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// k_associate: association, gate, averaging and augmentation of one window on the device
+// (src/replay_no_ros.py:280-360), one workgroup per trajectory.  Lane 0 walks the detections in
+// order (the order defines landmark indices, :294-295, and the update order, :436); the per-tag
+// arithmetic and the zeroing of new rows/columns are spread over the lanes.  Writes the StepIn the
+// solve kernel consumes, the tags_positions record, the new state size and the active bound.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_associate(const DetIn* __restrict__ det, int* __restrict__ tagmap,
+                                                  int* __restrict__ nact, int* __restrict__ neff_dev,
+                                                  double* __restrict__ mu, double* __restrict__ P,
+                                                  double* __restrict__ V, double* __restrict__ W,
+                                                  StepIn* __restrict__ step_out,
+                                                  AssocOut* __restrict__ assoc_out,
+                                                  unsigned* __restrict__ flags, AssocConfig cfg, int ld,
+                                                  long pstride, int n_max, int pending_k) {
+#pragma clang fp contract(off)
+  const int b = blockIdx.x, lane = threadIdx.x;
+  const DetIn& d = det[b];
+  int* tm = tagmap + (long)b * TAGMAX;
+  double* mub = mu + (long)b * ld;
+  double* Pb = P + (long)b * pstride;
+  double* Vb = V + (long)b * KTOT * ld;
+  double* Wb = W + (long)b * KTOT * ld;
+  __shared__ int s_m, s_nl_old, s_nl;
+  __shared__ int s_idx[MMAX], s_tag[MMAX], s_cnt[MMAX];
+  __shared__ double s_t[MMAX][3], s_err[MMAX];
+  if (lane == 0) {
+    const int n_old = nact[b];
+    int nl = (n_old - 3) / 2, m = 0;
+    unsigned bad = 0;
+    const int count = min(d.count, DMAX);
+    for (int q = 0; q < count; ++q) {
+      const int id = d.tag_id[q];
+      if (id < 0 || id >= TAGMAX) { bad |= EKF_FLAG_ASSOC; continue; }
+      bool ign = false;
+      for (int u = 0; u < cfg.n_ignore; ++u) ign |= (cfg.ignore[u] == id);       // :286
+      if (ign) continue;
+      const double tx = d.pose_t[q][0], tz = d.pose_t[q][2];
+      if (tz * tz + tx * tx > cfg.gate2) continue;                                // :289
+      int lm = tm[id];
+      if (lm < 0) {                                                               // :294-295
+        if (3 + 2 * (nl + 1) > n_max) { bad |= EKF_FLAG_ASSOC; continue; }
+        lm = nl++;
+        tm[id] = lm;
+      }
+      int slot = -1;
+      for (int u = 0; u < m; ++u)
+        if (s_idx[u] == lm) slot = u;
+      if (slot < 0) {
+        if (m >= MMAX) { bad |= EKF_FLAG_ASSOC; continue; }
+        slot = m++;
+        s_idx[slot] = lm;
+        s_tag[slot] = id;
+        s_cnt[slot] = 0;
+        s_t[slot][0] = s_t[slot][1] = s_t[slot][2] = 0.0;
+        s_err[slot] = 0.0;
+      }
+      s_t[slot][0] += d.pose_t[q][0];                                             // np.mean(..., axis=0): :315
+      s_t[slot][1] += d.pose_t[q][1];
+      s_t[slot][2] += tz;
+      s_err[slot] += d.pose_err[q];                                               // :317
+      s_cnt[slot] += 1;
+    }
+    s_m = m;
+    s_nl_old = (n_old - 3) / 2;
+    s_nl = nl;
+    if (bad) atomicOr(&flags[b], bad);
+  }
+  __syncthreads();
+  const int m = s_m, nl_old = s_nl_old, nl = s_nl;
+  const int n_old = 3 + 2 * nl_old, n_new = 3 + 2 * nl;
+  StepIn& so = step_out[b];
+  AssocOut& ao = assoc_out[b];
+  const double px = mub[0], py = mub[1], pth = mub[2];         // pose BEFORE the prediction (:331-332)
+  if (lane < MMAX) {
+    if (lane < m) {
+      const double k = (double)s_cnt[lane];
+      const double t0 = s_t[lane][0] / k, t2 = s_t[lane][2] / k;
+      const double xr = t2, yr = -t0;                                             // :321
+      const double rng = sqrt(xr * xr + yr * yr);                                 // :329
+      const double brg = atan2(yr, xr);                                           // :330
+      const double xw = px + rng * cos(brg + pth), yw = py + rng * sin(brg + pth);
+      const int lm = s_idx[lane];
+      so.idx[lane] = lm;
+      so.range[lane] = rng;
+      so.bearing[lane] = brg;
+      ao.idx[lane] = lm;
+      ao.tag_id[lane] = s_tag[lane];
+      ao.xw[lane] = xw;
+      ao.yw[lane] = yw;
+      ao.err[lane] = s_err[lane] / k;
+      ao.range[lane] = rng;
+      ao.bearing[lane] = brg;
+      if (lm >= nl_old) {                                                         // :359-360
+        mub[3 + 2 * lm] = xw;
+        mub[4 + 2 * lm] = yw;
+      }
+    } else {
+      so.idx[lane] = 0;
+      so.range[lane] = 0.0;
+      so.bearing[lane] = 0.0;
+    }
+  }
+  // augmentation (:341-360): zero the new rows/columns, set the new diagonal; pending ranks see zeros
+  const int dn = n_new - n_old;
+  const int ld16 = ld >> 4;
+  for (long e = lane; e < (long)n_new * dn; e += 64) {
+    const int r = (int)(e / dn), q = n_old + (int)(e - (long)r * dn);
+    Pb[(long)r * ld + q] = (r == q) ? cfg.init_var : 0.0;
+    if (r < n_old) Pb[(long)q * ld + r] = 0.0;
+  }
+  for (int e = lane; e < pending_k * dn; e += 64) {
+    const int k = e / dn, q = n_old + (e - k * dn);
+    Vb[(long)k * ld + q] = 0.0;
+    Wb[wm_index(ld16, k, q)] = 0.0;
+  }
+  if (lane == 0) {
+    int bound = neff_dev[b];
+    for (int u = 0; u < m; ++u) bound = max(bound, 3 + 2 * (s_idx[u] + 1));
+    bound = min(bound, n_new);
+    neff_dev[b] = bound;
+    nact[b] = n_new;
+    so.lin = d.lin;
+    so.ang = d.ang;
+    so.m = m;
+    so.flags = FLAG_PREDICT | FLAG_UPDATE;
+    so.neff = cfg.active_bound ? bound : n_new;
+    so.pad = 0;
+    ao.m = m;
+    ao.n_after = n_new;
+  }
+}
+
+void launch_associate(hipStream_t st, const DetIn* det, int* tagmap, int* nact, int* neff_dev, double* mu, double* P,
+                      double* V, double* W, StepIn* step_out, AssocOut* assoc_out, unsigned* flags,
+                      const AssocConfig& cfg, int ld, long pstride, int n_max, int pending_k, int batch) {
+  hipLaunchKernelGGL(k_associate, dim3(batch), dim3(64), 0, st, det, tagmap, nact, neff_dev, mu, P, V, W, step_out,
+                     assoc_out, flags, cfg, ld, pstride, n_max, pending_k);
+}
+
 // Augmentation (src/replay_no_ros.py:341-360): zero rows/cols [n_old, n_new), set the new diagonal.
 __global__ __launch_bounds__(256) void k_add_landmarks(double* __restrict__ Pb, double* __restrict__ mub,
                                                        int ld, int n_old, int n_new, double var,

@@ -99,6 +99,11 @@ ABI = {
     "ekf_predict": (C.c_int, [C.c_void_p, _dp, _dp]),
     "ekf_update": (C.c_int, [C.c_void_p, _ip, _dp, _dp, _ip, C.c_int]),
     "ekf_step": (C.c_int, [C.c_void_p, _dp, _dp, _ip, _dp, _dp, _ip, C.c_int]),
+    "ekf_set_association": (C.c_int, [C.c_void_p, C.c_double, _ip, C.c_int]),
+    "ekf_step_detections": (C.c_int, [C.c_void_p, _dp, _dp, _ip, _ip, _dp, _dp, C.c_int]),
+    "ekf_download_tags": (C.c_int, [C.c_void_p, C.c_int, _ip, _ip, _ip, _dp, _dp, _dp, _dp, _dp]),
+    "ekf_download_tag_index": (C.c_int, [C.c_void_p, C.c_int, _ip, C.c_int, _ip]),
+    "ekf_upload_tag_index": (C.c_int, [C.c_void_p, C.c_int, _ip, C.c_int]),
     "ekf_stream_upload": (C.c_int, [C.c_void_p, C.c_int, _dp, _dp, _ip, _dp, _dp, _ip, C.c_int]),
     "ekf_stream_run": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "ekf_run_stream": (C.c_int, [C.c_void_p, C.c_int, _dp, _dp, _ip, _dp, _dp, _ip, C.c_int]),
@@ -304,6 +309,59 @@ class EkfSlam:
         lin, ang = self._per_traj(lin, "lin"), self._per_traj(ang, "ang")
         I, R, B, m, stride = self._obs(idx, ranges, bearings)
         self._check(self._lib.ekf_step(self._h, _p(lin), _p(ang), _p(I, _ip), _p(R), _p(B), _p(m, _ip), stride))
+
+    # -- device-side front end (association, gate, averaging, augmentation on the GPU) -----------------
+    def set_association(self, gate_range: float = 1.5, ignore_tags: Sequence[int] = ()):
+        ig = _i32(list(ignore_tags)) if len(ignore_tags) else None
+        self._check(self._lib.ekf_set_association(self._h, float(gate_range), _p(ig, _ip) if ig is not None else None,
+                                                  len(ignore_tags)))
+
+    def step_detections(self, lin, ang, detections):
+        """One window of raw detections per trajectory: the reference's ``[(timestamp, [tag, ...])]`` list
+        (src/replay_no_ros.py:280-284), or a list of such lists for a batch.  Association, the 1.5 m gate,
+        per-tag averaging, augmentation, prediction and update all run on the GPU."""
+        lin, ang = self._per_traj(lin, "lin"), self._per_traj(ang, "ang")
+        if self.batch == 1 and (len(detections) == 0 or isinstance(detections[0], tuple)):
+            detections = [detections]
+        if len(detections) != self.batch:
+            raise ValueError("detections: one window per trajectory expected")
+        flat = [[tag for _stamp, tags in win for tag in tags] for win in detections]
+        count = np.array([len(w) for w in flat], dtype=np.int32)
+        stride = max(1, int(count.max()))
+        ids = np.zeros((self.batch, stride), dtype=np.int32)
+        pt = np.zeros((self.batch, stride, 3))
+        pe = np.zeros((self.batch, stride))
+        for b, w in enumerate(flat):
+            for i, tag in enumerate(w):
+                ids[b, i] = tag.tag_id
+                pt[b, i] = np.asarray(tag.pose_t, dtype=np.float64).ravel()[:3]
+                pe[b, i] = tag.pose_err
+        self._check(self._lib.ekf_step_detections(self._h, _p(lin), _p(ang), _p(count, _ip), _p(ids, _ip), _p(pt), _p(pe),
+                                                  stride))
+
+    def tags_positions(self, b: int = 0) -> dict:
+        """What EKF_pose_estimation returns as its third value for the last window (:331-337), update order."""
+        m = C.c_int()
+        idx, tid = np.zeros(EKF_MMAX, dtype=np.int32), np.zeros(EKF_MMAX, dtype=np.int32)
+        arrs = [np.zeros(EKF_MMAX) for _ in range(5)]
+        self._check(self._lib.ekf_download_tags(self._h, b, C.byref(m), _p(idx, _ip), _p(tid, _ip), *[_p(a) for a in arrs]))
+        xw, yw, err, rng, brg = arrs
+        return {int(idx[i]): [xw[i], yw[i], err[i], int(tid[i]), rng[i], brg[i]] for i in range(m.value)}
+
+    def tag_index(self, b: int = 0) -> dict:
+        """The device's TAG_INDEX: {tag_id: landmark index} (:294-295)."""
+        cap = max(1, (self.n_max - 3) // 2)
+        tags = np.full(cap, -1, dtype=np.int32)
+        cnt = C.c_int()
+        self._check(self._lib.ekf_download_tag_index(self._h, b, _p(tags, _ip), cap, C.byref(cnt)))
+        return {int(tags[i]): i for i in range(cnt.value)}
+
+    def set_tag_index(self, tag_index: dict, b: int = 0):
+        order = [t for t, _ in sorted(tag_index.items(), key=lambda kv: kv[1])]
+        if sorted(tag_index.values()) != list(range(len(order))):
+            raise ValueError("TAG_INDEX values must be 0..len-1")
+        arr = _i32(order) if order else None
+        self._check(self._lib.ekf_upload_tag_index(self._h, b, _p(arr, _ip) if arr is not None else None, len(order)))
 
     def stream_upload(self, lin, ang, idx, ranges, bearings, m=None) -> int:
         """Copy a whole input stream into HBM (blocking).  Returns the number of steps.

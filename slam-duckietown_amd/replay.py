@@ -50,11 +50,16 @@ class ReplayResult:
 class GpuBackend:
     """Runs association on the host and augmentation + predict + update on the MI355X."""
 
-    def __init__(self, config=None, capacity: int = 203, device: int = 0):
+    def __init__(self, config=None, capacity: int = 203, device: int = 0, device_association: bool = False):
+        """device_association=True: association / gate / averaging / augmentation run on the GPU too
+        (`EkfSlam.step_detections`); the capacity must then cover the whole map (no regrowth)."""
         from .ekf_bindings import EkfConfig, EkfSlam
         self.config = config or EkfConfig()
+        self.device_association = device_association
         self._make = lambda cap: EkfSlam(cap | 1, 1, device, self.config)
         self.filt = self._make(capacity)
+        if device_association:
+            self.filt.set_association(self.config.gate_range, self.config.ignore_tags)
 
     def set_state(self, mean, cov):
         n = len(mean)
@@ -76,6 +81,14 @@ class GpuBackend:
         return self.filt.state()
 
     def step(self, ang, lin, detections, tag_index) -> dict:
+        if self.device_association:
+            if tag_index and not self.filt.tag_index():           # a pre-filled TAG_INDEX (god mode) goes to the device
+                self.filt.set_tag_index(tag_index)
+            self.filt.step_detections(lin, ang, detections)
+            tags = self.filt.tags_positions()
+            tag_index.clear()
+            tag_index.update(self.filt.tag_index())
+            return tags
         pose = self.pose()                                        # world guesses use the pre-step pose (:331-332)
         tags = associate(detections, tag_index, pose, self.config.gate_range, self.config.ignore_tags)
         n_old = self.filt.size()

@@ -457,3 +457,55 @@ def test_max_size_n8000_three_steps(sd):
     close(P.sum(axis=0), oP.sum(axis=0))
     close(np.diag(P), np.diag(oP))
     del P, oP
+
+
+@pytest.mark.parametrize("case", gu.REPLAY_CASES)
+def test_device_side_association_golden(sd, case):
+    """association, gate, averaging and augmentation on the GPU (`step_detections`)
+    against the reference's own outputs: state size, update order, TAG_INDEX, mean and covariance."""
+    g = gu.load(case)
+    cfg = sd.EkfConfig(enable_measurement_model=bool(g["flag_measurement"]),
+                       enable_circular_interpolation=bool(g["flag_circular"]),
+                       disable_motion_model=bool(g["flag_no_motion"]))
+    with sd.EkfSlam(3 + 2 * 12, config=cfg) as f:
+        for k in range(len(g["lin"])):
+            det = gu.detections_for_step(g, k)
+            f.step_detections(g["lin"][k], g["ang"][k], det)
+            n = int(g["out_size"][k])
+            assert f.size() == n
+            if k % 4 == 0 or k == len(g["lin"]) - 1:
+                tp = f.tags_positions()
+                assert list(tp.keys()) == [i for i in g["out_obs_order"][k] if i >= 0]
+                mu, P = f.state()
+                close(mu, g["out_mean"][k, :n])
+                close(P, g["out_cov"][k, :n, :n])
+        assert sorted(f.tag_index().items(), key=lambda kv: kv[1]) == [tuple(r) for r in g["out_tag_index"]]
+        assert f.flags() == 0
+
+
+def test_device_association_matches_host_association(sd):
+    """tags_positions from the device equal the host front end's (ulp-level differences only)."""
+    g = gu.load("replay_default")
+    ti = {}
+    with sd.EkfSlam(3 + 2 * 12) as f:
+        for k in range(20):
+            det = gu.detections_for_step(g, k)
+            pose = f.mean()[:3]
+            host = sd.associate(det, ti, pose)
+            f.step_detections(g["lin"][k], g["ang"][k], det)
+            dev = f.tags_positions()
+            assert list(dev.keys()) == list(host.keys())
+            for key in host:
+                assert dev[key][3] == host[key][3]
+                assert np.allclose([dev[key][i] for i in (0, 1, 2, 4, 5)], [host[key][i] for i in (0, 1, 2, 4, 5)],
+                                   rtol=1e-13, atol=1e-15)
+        assert f.tag_index() == ti
+
+
+def test_device_association_overflow_flag(sd):
+    from types import SimpleNamespace as NS
+    mk = lambda i, x, z: NS(tag_id=i, pose_R=np.eye(3), pose_t=np.array([[x], [0.0], [z]]), pose_err=0.0)
+    with sd.EkfSlam(3 + 2 * 2) as f:                    # room for two landmarks only
+        f.step_detections(0.01, 0.0, [(0.0, [mk(5, 0.1, 0.5), mk(6, -0.1, 0.6), mk(7, 0.0, 0.7)])])
+        assert f.size() == 7 and f.tag_index() == {5: 0, 6: 1}
+        assert f.flags() & 2                              # EKF_FLAG_ASSOC: the third tag did not fit

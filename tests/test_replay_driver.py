@@ -120,3 +120,17 @@ def test_replay_loop_matches_reference_gpu():
     detect, seen = fixture_detector(g)
     res = rp.replay(str(g["events_csv"]).splitlines(), detector=detect)        # GpuBackend
     check_against_reference_loop(res, g, seen, 1e-9)
+
+
+@pytest.mark.gpu
+def test_replay_loop_with_device_association_gpu():
+    """The same log with the whole front end on the GPU (GpuBackend(device_association=True))."""
+    import slam_duckietown_amd.replay as rp
+    g = gu.load("replay_events")
+    detect, seen = fixture_detector(g)
+    be = rp.GpuBackend(capacity=3 + 2 * 16, device_association=True)
+    try:
+        res = rp.replay(str(g["events_csv"]).splitlines(), backend=be, detector=detect)
+    finally:
+        be.close()
+    check_against_reference_loop(res, g, seen, 1e-9)
