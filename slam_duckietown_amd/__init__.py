@@ -13,4 +13,5 @@ from .ekf_bindings import (  # noqa: E402,F401
 )
 from .frontend import associate, delta_phi, displacement  # noqa: E402,F401
 from .replay import GpuBackend, ReplayResult  # noqa: E402,F401
+from .node_adapter import EkfNodeAdapter  # noqa: E402,F401
 from .replay import replay as replay_events  # noqa: E402,F401  (the submodule keeps the name `replay`)
