@@ -19,6 +19,7 @@ void launch_flush(hipStream_t, bool, double*, const double*, const double*, cons
 void launch_predict_rc(hipStream_t, double*, const double*, double*, const int*, const SolveOut*, int, long,
                        int, int);
 void launch_add_landmarks(hipStream_t, double*, double*, int, int, int, double, const double*);
+void launch_mirror(hipStream_t, double*, const int*, int, long, int, int);
 void launch_associate(hipStream_t, const DetIn*, int*, int*, int*, double*, double*, double*, double*, StepIn*,
                       AssocOut*, unsigned*, const AssocConfig&, int, long, int, int, int);
 void launch_fill_diag(hipStream_t, double*, int, int, const double*);
@@ -82,6 +83,7 @@ static int fail(ekf_handle* h, int code, const std::string& msg) {
 }
 
 static int flush_pending(ekf_handle* h);
+static int materialize(ekf_handle* h, int b);
 
 #define HIP_TRY(h, expr)                                                                   \
   do {                                                                                     \
@@ -287,12 +289,23 @@ extern "C" int ekf_upload_state_diag(ekf_handle* h, int b, const double* mu, con
   return EKF_OK;
 }
 
+// The step kernels keep only the upper triangle of P_base current.  Before the host (or the dense product)
+// looks at trajectory b: apply the pending ranks, then mirror the upper triangle into the lower one.
+static int materialize(ekf_handle* h, int b) {
+  if (int rc = flush_pending(h)) return rc;
+  if (h->sizes_dirty)
+    if (int rc = refresh_sizes(h)) return rc;
+  launch_mirror(h->stream, h->dP + (size_t)b * h->pstride, h->dn + b, h->ld, h->pstride, 1, h->n[b]);
+  HIP_TRY(h, hipGetLastError());
+  return EKF_OK;
+}
+
 extern "C" int ekf_download_state(ekf_handle* h, int b, double* mu, double* P, int n) {
   if (int rc = check_b(h, b, "ekf_download_state")) return rc;
   if (n != h->n[b]) return fail(h, EKF_ERR_ARG, "ekf_download_state: n does not match the state size");
   HIP_TRY(h, hipSetDevice(h->device));
   if (P) {
-    if (int rc = flush_pending(h)) return rc;      // the covariance is P_base + pending ranks
+    if (int rc = materialize(h, b)) return rc;     // the covariance is P_base + pending ranks, upper triangle
   }
   if (P)
     HIP_TRY(h, hipMemcpy2DAsync(P, sizeof(double) * n, h->dP + (size_t)b * h->pstride, sizeof(double) * h->ld,
@@ -309,7 +322,7 @@ extern "C" int ekf_download_block(ekf_handle* h, int b, int r0, int c0, int rows
   if (!out || rows <= 0 || cols <= 0 || r0 < 0 || c0 < 0 || r0 + rows > n || c0 + cols > n)
     return fail(h, EKF_ERR_ARG, "ekf_download_block: block outside the state");
   HIP_TRY(h, hipSetDevice(h->device));
-  if (int rc = flush_pending(h)) return rc;
+  if (int rc = materialize(h, b)) return rc;
   HIP_TRY(h, hipMemcpy2DAsync(out, sizeof(double) * cols, h->dP + (size_t)b * h->pstride + (size_t)r0 * h->ld + c0,
                               sizeof(double) * h->ld, sizeof(double) * cols, rows, hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -724,7 +737,7 @@ extern "C" int ekf_predict_dense(ekf_handle* h, int b, const double* F, const do
   const int n = h->n[b];
   const size_t bytes = sizeof(double) * (size_t)h->ld * h->ld;
   HIP_TRY(h, hipSetDevice(h->device));
-  if (int rc = flush_pending(h)) return rc;
+  if (int rc = materialize(h, b)) return rc;           // the product needs the full matrix
   if (!h->dF) {
     HIP_TRY(h, hipMalloc(&h->dF, bytes));
     HIP_TRY(h, hipMalloc(&h->dQ, bytes));

@@ -38,7 +38,6 @@ struct alignas(16) SolveIter {
   double si[4];         // S_j^{-1} row-major                                             (:473)
   double y[2];          // innovation                                                     (:455-458)
   double kc[CMAX][2];   // K_j[C[a],:]                 (0 for a >= c)
-  double hpt[CMAX][2];  // {(H_j P_j)[0,C[a]], (H_j P_j)[1,C[a]]}   (0 for a >= c)
 };
 static_assert(sizeof(SolveIter) % 16 == 0, "SolveIter must stay 16-byte granular");
 

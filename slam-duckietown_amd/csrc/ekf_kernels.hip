@@ -94,7 +94,7 @@ __device__ __forceinline__ void linearize(const double* muc, int a, double z_ran
 constexpr int PCS = CMAX + 2;   // LDS row stride 37 doubles: column reads by 32 lanes are conflict-free
 constexpr int RCH = 8;          // rows per batch of the down-date
 constexpr int CPAD = (CMAX + RCH - 1) / RCH * RCH;   // 40
-constexpr int WCS = KTOT + 2;   // row stride of the staged W[C,:] (82 doubles)
+constexpr int WCS = KTOT + 1;   // row stride of the staged W[C,:] (81 doubles: per-lane rows are conflict-free)
 
 // Stage the pending factors restricted to C into LDS: Wc[a][k] = W[C[a]][k], Vc[k][a] = V[k][C[a]].
 __device__ __forceinline__ void stage_factors(const double* __restrict__ Vb, const double* __restrict__ Wb,
@@ -188,7 +188,8 @@ __device__ __forceinline__ void solve_body(SolveLds& L, const double* __restrict
 #pragma unroll
   for (int q = 0; q < GQ; ++q) {
     const int r = gw + 4 * q;
-    gv[q] = (on && r < c) ? Pb[(long)Cs[r] * ld + Cl] : 0.0;
+    const int Cr = (r < c) ? Cs[r] : 0;
+    gv[q] = (on && r < c) ? Pb[(long)min(Cr, Cl) * ld + max(Cr, Cl)] : 0.0;   // the upper triangle is authoritative
   }
   // ---- ... and the motion model (src/replay_no_ros.py:368-417) runs under their latency, redundantly in
   // every lane of every wave (wave 1 needs the predicted pose for the first linearisation) ----
@@ -221,7 +222,10 @@ __device__ __forceinline__ void solve_body(SolveLds& L, const double* __restrict
     const int r = gw + 4 * q;
     if (on && r < c) {
       double v = gv[q];
-      for (int k = 0; k < kbase; ++k) v = fma(Wc[r][k], Vc[k][lane], v);
+      const bool up = Cs[r] <= Cl;                      // entry (C[r], C[lane]) or its mirror (C[lane], C[r])
+      const double* wrow = Wc[up ? r : lane];
+      const int vcol = up ? lane : r;
+      for (int k = 0; k < kbase; ++k) v = fma(wrow[k], Vc[k][vcol], v);
       if (r == lane && r < 3) v += (r == 0) ? d0 : ((r == 1) ? d1 : d2);
       Pc[r][lane] = v;
     }
@@ -367,26 +371,20 @@ __device__ __forceinline__ void solve_body(SolveLds& L, const double* __restrict
     const int a = 3 + 2 * j;
     SolveIter& it = its[j];
     STAMP(o, 8 + 6 * j);
-    // phase A: rows sel of P_j at column C[lane] (H P) and columns sel at row C[lane] (P H^T).
+    // phase A: rows sel of P_j at column C[lane] give (H P)[:, C[lane]]; P is symmetric (only its upper
+    // triangle is stored), so P H^T is the transpose and the gain needs no second product.
     // The instruction count is what matters for a lone wave: S is formed from the five hp pairs the
     // other lanes publish in LDS (20 FMAs), not recomputed from the 5x5 block.
-    double pr[5], pq[5];
+    double pr[5];
 #pragma unroll
-    for (int k = 0; k < 5; ++k) {
-      const int sk = (k < 3) ? k : a + (k - 3);
-      pr[k] = Pc[sk][ll];
-      pq[k] = Pc[ll][sk];
-    }
-    double hp0 = h[0][0] * pr[0], hp1 = h[1][0] * pr[0], ph0 = pq[0] * h[0][0], ph1 = pq[0] * h[1][0];
+    for (int k = 0; k < 5; ++k) pr[k] = Pc[(k < 3) ? k : a + (k - 3)][ll];
+    double hp0 = h[0][0] * pr[0], hp1 = h[1][0] * pr[0];
 #pragma unroll
     for (int k = 1; k < 5; ++k) {
       hp0 = fma(h[0][k], pr[k], hp0);
       hp1 = fma(h[1][k], pr[k], hp1);
-      ph0 = fma(pq[k], h[0][k], ph0);
-      ph1 = fma(pq[k], h[1][k], ph1);
     }
     if (on) hpS[lane] = make_double2(hp0, hp1);
-    if (lane < CMAX) *reinterpret_cast<double2*>(it.hpt[lane]) = on ? make_double2(hp0, hp1) : make_double2(0.0, 0.0);
     WAVE_SYNC();
     STAMP(o, 9 + 6 * j);
     // phase B: S = H P H^T + Q (:473), every lane redundantly
@@ -403,8 +401,8 @@ __device__ __forceinline__ void solve_body(SolveLds& L, const double* __restrict
     }
     const double rdet = 1.0 / (S00 * S11 - S01 * S10);
     const double i00 = S11 * rdet, i01 = -S01 * rdet, i10 = -S10 * rdet, i11 = S00 * rdet;
-    const double k0 = ph0 * i00 + ph1 * i10;                            // K_j[C[lane], :]
-    const double k1 = ph0 * i01 + ph1 * i11;
+    const double k0 = hp0 * i00 + hp1 * i10;                            // K_j[C[lane], :] = (H P)[:, C[lane]]^T S^-1
+    const double k1 = hp0 * i01 + hp1 * i11;
     if (on) {
       kcS[lane] = make_double2(k0, k1);
       mu_cur += k0 * y0 + k1 * y1;                                      // :476
@@ -514,13 +512,13 @@ __device__ __forceinline__ void panels_beyond_bound(double* Vb, double* Wb, cons
 }
 
 // panels_body: phases 1 and 2 for the 64 state indices of this workgroup.  `its`, `Cs`, `Wc`, `Vc` are in
-// LDS (its/Cs always valid; Wc/Vc are staged here unless the fused kernel's solve already did).
+// LDS (its/Cs always valid; Wc/Vc are staged here unless the caller already did).
 template <int MCAP>
 __device__ __forceinline__ void panels_body(const double* __restrict__ Pb, double* __restrict__ Vb,
                                             double* __restrict__ Wb, const double* __restrict__ mu_in_b,
                                             double* __restrict__ mu_out_b, int n, int ld, const SolveIter* its,
                                             const int* Cs, const SolveHdr& o, double (*Wc)[WCS], double (*Vc)[PCS],
-                                            double (*Rs)[64], double (*Ls)[64], bool factors_staged) {
+                                            double (*Rs)[64], bool factors_staged) {
   constexpr int CC = 3 + 2 * MCAP, K2 = 2 * MCAP, KTP = ranks_for(MCAP);
   constexpr int QA = (CC + 3) / 4;                    // a's per wave in phase 1
   const int tid = threadIdx.x, lane = tid & 63;
@@ -532,14 +530,18 @@ __device__ __forceinline__ void panels_body(const double* __restrict__ Pb, doubl
   const int m = min(o.m, MCAP), c = o.c, kb = o.kbase;
   // ---- phase 1 ----  (the base-panel loads are issued first: their latency overlaps the staging)
   {
-    double r[QA], l[QA];
+    double r[QA];
+    bool up[QA];                                       // entry (C[a], i) is stored; otherwise its mirror (i, C[a])
+    bool mirrored = false;
 #pragma unroll
     for (int q = 0; q < QA; ++q) {
       const int a = wave + 4 * q;
       const int row = (a < CC) ? Cs[a] : 0;
-      r[q] = Pb[(long)row * ld + ii];
-      l[q] = Pb[(long)ii * ld + row];
+      up[q] = row <= ii;
+      mirrored |= !up[q];
+      r[q] = Pb[(long)min(row, ii) * ld + max(row, ii)];
     }
+    const bool need_w = __any(mirrored);               // W[i,:] is only read where some C[a] lies beyond i
     if (kb > 0 && !factors_staged) {
       stage_factors(Vb, Wb, Cs, min(c, CC), kb, ld, tid, 256, Wc, Vc);
       __syncthreads();
@@ -550,17 +552,26 @@ __device__ __forceinline__ void panels_body(const double* __restrict__ Pb, doubl
       for (int u = 0; u < 8; ++u) {
         const int k = min(k0 + u, kb - 1);
         vk[u] = Vb[(long)k * ld + ii];
-        wk[u] = Wb[wm_index(ld16, k, ii)];
+        wk[u] = need_w ? Wb[wm_index(ld16, k, ii)] : 0.0;
       }
+      if (!need_w) {
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int k = min(k0 + u, kb - 1);
-        const double vv = (k0 + u < kb) ? vk[u] : 0.0, ww = (k0 + u < kb) ? wk[u] : 0.0;
+        for (int u = 0; u < 8; ++u) {
+          const int k = min(k0 + u, kb - 1);
+          const double vv = (k0 + u < kb) ? vk[u] : 0.0;
 #pragma unroll
-        for (int q = 0; q < QA; ++q) {
-          const int a = min(wave + 4 * q, CC - 1);
-          r[q] = fma(Wc[a][k], vv, r[q]);
-          l[q] = fma(ww, Vc[k][a], l[q]);
+          for (int q = 0; q < QA; ++q) r[q] = fma(Wc[min(wave + 4 * q, CC - 1)][k], vv, r[q]);
+        }
+      } else {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int k = min(k0 + u, kb - 1);
+          const double vv = (k0 + u < kb) ? vk[u] : 0.0, ww = (k0 + u < kb) ? wk[u] : 0.0;
+#pragma unroll
+          for (int q = 0; q < QA; ++q) {
+            const int a = min(wave + 4 * q, CC - 1);
+            r[q] = fma(up[q] ? Wc[a][k] : ww, up[q] ? vv : Vc[k][a], r[q]);
+          }
         }
       }
     }
@@ -568,52 +579,35 @@ __device__ __forceinline__ void panels_body(const double* __restrict__ Pb, doubl
     for (int q = 0; q < QA; ++q) {
       const int a = wave + 4 * q;
       if (a < CC) {
-        double rv = r[q], lv = l[q];
-        if (a < 3 && ii == a) {                        // pending pose-block noise on the diagonal
-          rv += o.dacc_old[a];
-          lv += o.dacc_old[a];
-        }
+        double rv = r[q];
+        if (a < 3 && ii == a) rv += o.dacc_old[a];     // pending pose-block noise on the diagonal
         Rs[a][lane] = rv;
-        Ls[a][lane] = lv;
       }
     }
   }
   __syncthreads();
-  if (wave >= 2) return;
+  if (wave >= 1) return;
 
+  // ---- phase 2: thread i replays the step on x[a] = P(C[a], i) ----
   const double g0 = o.g[0], g1 = o.g[1];
   const double gj = (ii == 0) ? g0 : ((ii == 1) ? g1 : 0.0);
   const bool blk0 = blockIdx.x == 0;                   // lanes 0..2 of block 0 hold state indices 0,1,2
-  double X[CC];                                        // R (wave 0) or L (wave 1)
-  if (wave == 0) {
+  double X[CC];
 #pragma unroll
-    for (int a = 0; a < CC; ++a) X[a] = Rs[a][lane];
-  } else {
-#pragma unroll
-    for (int a = 0; a < CC; ++a) X[a] = Ls[a][lane];
-  }
-  const double raw2 = X[2];                            // P[2][i] (wave 0) / P[i][2] (wave 1)
+  for (int a = 0; a < CC; ++a) X[a] = Rs[a][lane];
+  const double raw2 = X[2];                            // P(2, i)
   // P' = G_F P G_F^T + F^T R F  (src/replay_no_ros.py:430) on the panel
-  if (wave == 0) {
-    X[0] += g0 * X[2];                                 // row ops on rows 0,1
-    X[1] += g1 * X[2];
-    if (blk0 && ii < 2) {                              // column op on column ii: += g_ii * X[:,2]
-      const double p22 = Rs[2][2];
+  X[0] += g0 * X[2];                                   // row ops on rows 0,1
+  X[1] += g1 * X[2];
+  if (blk0 && ii < 2) {                                // column op on column ii: += g_ii * X[:,2]
+    const double p22 = Rs[2][2];
 #pragma unroll
-      for (int a = 0; a < CC; ++a) {
-        double x = Rs[a][2];
-        if (a == 0) x += g0 * p22;
-        if (a == 1) x += g1 * p22;
-        X[a] += gj * x;
-      }
+    for (int a = 0; a < CC; ++a) {
+      double x = Rs[a][2];
+      if (a == 0) x += g0 * p22;
+      if (a == 1) x += g1 * p22;
+      X[a] += gj * x;
     }
-  } else {
-    if (blk0 && ii < 2) {                              // row op on row ii: += g_ii * P[2][C[a]]
-#pragma unroll
-      for (int a = 0; a < CC; ++a) X[a] += gj * Ls[a][2];
-    }
-    X[0] += g0 * X[2];                                 // column ops on columns 0,1
-    X[1] += g1 * X[2];
   }
 #pragma unroll
   for (int a = 0; a < 3; ++a)
@@ -634,95 +628,70 @@ __device__ __forceinline__ void panels_body(const double* __restrict__ Pb, doubl
       const double2 s23 = *reinterpret_cast<const double2*>(&I.si[2]);
       const double2 yy = *reinterpret_cast<const double2*>(I.y);
       constexpr bool PREFETCH = MCAP <= 8;
-      double2 uv[PREFETCH ? CC : 1];                   // K_j[C[a],:] (wave 0) / (H_j P_j)[:,C[a]] (wave 1)
+      double2 uv[PREFETCH ? CC : 1];                   // K_j[C[a],:]
       if (PREFETCH && more) {
-        if (wave == 0) {
 #pragma unroll
-          for (int a = 0; a < CC; ++a) uv[a] = *reinterpret_cast<const double2*>(I.kc[a]);
-        } else {
-#pragma unroll
-          for (int a = 0; a < CC; ++a) uv[a] = *reinterpret_cast<const double2*>(I.hpt[a]);
-        }
+        for (int a = 0; a < CC; ++a) uv[a] = *reinterpret_cast<const double2*>(I.kc[a]);
       }
-      double e0 = hk[0].x * X[0], e1 = hk[0].y * X[0];   // h5 . X[sel]: (H P)[:,i] or (P H^T)[i,:]
+      double e0 = hk[0].x * X[0], e1 = hk[0].y * X[0];   // (H_j P_j)[:, i] = h5 . x[sel]
 #pragma unroll
       for (int k = 1; k < 5; ++k) {
         const double xv = (k < 3) ? X[k] : X[a0 + (k - 3)];
         e0 = fma(hk[k].x, xv, e0);
         e1 = fma(hk[k].y, xv, e1);
       }
-      double f0, f1;                                   // the pair the down-date multiplies with
-      if (wave == 0) {
-        f0 = e0;
-        f1 = e1;
-        if (act) {
-          Vb[(long)kr * ld + i] = e0;
-          Vb[(long)(kr + 1) * ld + i] = e1;
-        }
-      } else {
-        f0 = e0 * s01.x + e1 * s23.x;                  // K_j[i,:] = (P H^T)[i,:] S^-1
-        f1 = e0 * s01.y + e1 * s23.y;
-        dm += f0 * yy.x + f1 * yy.y;
-        if (act) {
-          Wb[wm_index(ld16, kr, i)] = -f0;
-          Wb[wm_index(ld16, kr + 1, i)] = -f1;
-        }
+      const double f0 = e0 * s01.x + e1 * s23.x;       // K_j[i,:] = (H_j P_j)[:, i]^T S^-1  (P symmetric)
+      const double f1 = e0 * s01.y + e1 * s23.y;
+      dm += f0 * yy.x + f1 * yy.y;
+      if (act) {
+        Vb[(long)kr * ld + i] = e0;
+        Vb[(long)(kr + 1) * ld + i] = e1;
+        Wb[wm_index(ld16, kr, i)] = -f0;
+        Wb[wm_index(ld16, kr + 1, i)] = -f1;
       }
-      if (more) {
+      if (more) {                                      // x[a] -= K_j[C[a],:] . (H_j P_j)[:, i]
         if (PREFETCH) {
-          if (wave == 0) {                             // R[a] -= K_j[C[a],:] . (H P)[:,i]
 #pragma unroll
-            for (int a = 0; a < CC; ++a) X[a] = fma(-uv[a].x, f0, X[a]);
+          for (int a = 0; a < CC; ++a) X[a] = fma(-uv[a].x, e0, X[a]);
 #pragma unroll
-            for (int a = 0; a < CC; ++a) X[a] = fma(-uv[a].y, f1, X[a]);
-          } else {                                     // L[a] -= K_j[i,:] . (H P)[:,C[a]]
-#pragma unroll
-            for (int a = 0; a < CC; ++a) X[a] = fma(-f0, uv[a].x, X[a]);
-#pragma unroll
-            for (int a = 0; a < CC; ++a) X[a] = fma(-f1, uv[a].y, X[a]);
-          }
+          for (int a = 0; a < CC; ++a) X[a] = fma(-uv[a].y, e1, X[a]);
         } else {
 #pragma unroll
           for (int c0 = 0; c0 < CC; c0 += 8) {
             double2 u[8];
 #pragma unroll
             for (int q = 0; q < 8; ++q)
-              if (c0 + q < CC)
-                u[q] = (wave == 0) ? *reinterpret_cast<const double2*>(I.kc[c0 + q])
-                                   : *reinterpret_cast<const double2*>(I.hpt[c0 + q]);
+              if (c0 + q < CC) u[q] = *reinterpret_cast<const double2*>(I.kc[c0 + q]);
 #pragma unroll
             for (int q = 0; q < 8; ++q)
-              if (c0 + q < CC) X[c0 + q] = fma(-u[q].x, f0, X[c0 + q]);
+              if (c0 + q < CC) X[c0 + q] = fma(-u[q].x, e0, X[c0 + q]);
 #pragma unroll
             for (int q = 0; q < 8; ++q)
-              if (c0 + q < CC) X[c0 + q] = fma(-u[q].y, f1, X[c0 + q]);
+              if (c0 + q < CC) X[c0 + q] = fma(-u[q].y, e1, X[c0 + q]);
           }
         }
       }
     } else if (act) {
-      if (wave == 0) {
-        Vb[(long)kr * ld + i] = 0.0;
-        Vb[(long)(kr + 1) * ld + i] = 0.0;
-      } else {
-        Wb[wm_index(ld16, kr, i)] = 0.0;
-        Wb[wm_index(ld16, kr + 1, i)] = 0.0;
-      }
+      Vb[(long)kr * ld + i] = 0.0;
+      Vb[(long)(kr + 1) * ld + i] = 0.0;
+      Wb[wm_index(ld16, kr, i)] = 0.0;
+      Wb[wm_index(ld16, kr + 1, i)] = 0.0;
     }
   }
   if (act) {
     const int kp = kb + K2;
-    if (wave == 0) {
-      Vb[(long)kp * ld + i] = raw2 + o.p22h * gj;
-      Vb[(long)(kp + 1) * ld + i] = gj;
-      for (int k = kb + KTP; k < ((kb + KTP + 3) & ~3); ++k) Vb[(long)k * ld + i] = 0.0;   // k-tile pad
-    } else {
-      Wb[wm_index(ld16, kp, i)] = gj;
-      Wb[wm_index(ld16, kp + 1, i)] = raw2 + o.p22h * gj;
-      for (int k = kb + KTP; k < ((kb + KTP + 3) & ~3); ++k) Wb[wm_index(ld16, k, i)] = 0.0;
-      bool inC = false;
-      for (int a = 0; a < c; ++a) inC |= (Cs[a] == i);
-      if (!inC) mu_out_b[i] = mu_in_b[i] + dm;
+    const double q2 = raw2 + o.p22h * gj;
+    Vb[(long)kp * ld + i] = q2;
+    Vb[(long)(kp + 1) * ld + i] = gj;
+    Wb[wm_index(ld16, kp, i)] = gj;
+    Wb[wm_index(ld16, kp + 1, i)] = q2;
+    for (int k = kb + KTP; k < ((kb + KTP + 3) & ~3); ++k) {   // k-tile pad
+      Vb[(long)k * ld + i] = 0.0;
+      Wb[wm_index(ld16, k, i)] = 0.0;
     }
+    bool inC = false;
+    for (int a = 0; a < c; ++a) inC |= (Cs[a] == i);
+    if (!inC) mu_out_b[i] = mu_in_b[i] + dm;
   }
 }
 
@@ -737,7 +706,7 @@ __global__ __launch_bounds__(256) void k_panels(const double* __restrict__ P, do
   __shared__ SolveIter its[MCAP];
   __shared__ double Wc[CC][WCS];
   __shared__ double Vc[KTOT][PCS];
-  __shared__ double Rs[CC][64], Ls[CC][64];
+  __shared__ double Rs[CC][64];
   __shared__ int Cs[CPAD];
   __shared__ SolveHdr hdr;
   const int b = blockIdx.y;
@@ -771,8 +740,7 @@ __global__ __launch_bounds__(256) void k_panels(const double* __restrict__ P, do
     hdr = h;
   }
   __syncthreads();
-  panels_body<MCAP>(Pb, Vb, Wb, mu_in + (long)b * ld, mu_out + (long)b * ld, n, ld, its, Cs, hdr, Wc, Vc, Rs, Ls,
-                    false);
+  panels_body<MCAP>(Pb, Vb, Wb, mu_in + (long)b * ld, mu_out + (long)b * ld, n, ld, its, Cs, hdr, Wc, Vc, Rs, false);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -824,28 +792,35 @@ __global__ __launch_bounds__(256, 2) void k_flush(double* __restrict__ P, const 
                                                   const double* __restrict__ dacc,
                                                   const int* __restrict__ nact,
                                                   const SolveOut* __restrict__ so, int ld, long pstride,
-                                                  int nkt, int rows_per_block) {
+                                                  int nkt, int rows_per_block, int gx) {
   __shared__ double tiles[4][16 * FTS];
   const int b = blockIdx.z;
   const int n = min(nact[b], so[b].neff);              // rows/cols beyond the active bound are untouched
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
-  // XCD-aware tile order (speed only): workgroups are dealt round-robin over the 8 XCDs by linear id, so
-  // consecutive ids are remapped to walk the column strips of one row block inside one XCD: the W rows
-  // of that block (and the V strips) are then fetched into one L2 instead of eight.
-  int bx = blockIdx.x, by = blockIdx.y;
+  // Only workgroups that touch the upper triangle are launched: blockIdx.x enumerates, row block by row
+  // block, the column groups bx >= by * rows_per_block / 256.  XCD-aware order (speed only): workgroups are
+  // dealt round-robin over the 8 XCDs by linear id, so consecutive ids are remapped to give every XCD one
+  // contiguous, equally long piece of that enumeration: the W rows of a row block (and the V strips) are
+  // fetched into one L2 instead of eight, and the triangle is split evenly.
+  int bx, by = 0;
   {
-    const int gx = gridDim.x, total = gx * gridDim.y;
-    const int lin = by * gx + bx;
+    const int total = gridDim.x;
+    const int lin = blockIdx.x;
     const int q = total >> 3, r = total & 7, xcd = lin & 7, slot = lin >> 3;
-    const int remapped = ((xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
-    bx = remapped % gx;
-    by = remapped / gx;
+    int rem = ((xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+    for (;; ++by) {
+      const int cnt = gx - (by * rows_per_block) / 256;
+      if (rem < cnt || cnt <= 0) break;
+      rem -= cnt;
+    }
+    bx = (by * rows_per_block) / 256 + rem;
   }
   const int j0 = (bx * 4 + wave) * 64;
   const int i_begin = by * rows_per_block;
-  if (j0 >= n || i_begin >= n) return;
-  const int i_end = min(n, i_begin + rows_per_block);
+  const int i_lim = min(n, j0 + 64);                   // only the upper triangle is stored: tiles strictly below
+  if (j0 >= n || i_begin >= i_lim) return;             // the diagonal are skipped (a diagonal tile computes a few
+  const int i_end = min(i_lim, i_begin + rows_per_block);   // lower entries nobody reads)
   const int li = lane & 15, lq = lane >> 4;            // C/D layout coordinates
   const int rr = lane >> 5, rc = (lane & 31) * 2;      // row-major image: 2 rows per instruction
   const int ld16 = ld >> 4;
@@ -951,17 +926,14 @@ __global__ __launch_bounds__(256) void k_predict_rc(double* __restrict__ P,
   const double g0 = so[b].g[0], g1 = so[b].g[1];
   if (j >= 3) {
     mu_out[(long)b * ld + j] = mu_in[(long)b * ld + j];     // k_solve wrote the pose entries
-    if (j >= so[b].neff) return;                            // P[2][j] = P[j][2] = 0 beyond the active bound
-    const double r2 = Pb[2 * (long)ld + j];
-    Pb[j] += g0 * r2;
+    if (j >= so[b].neff) return;                            // P(2, j) = 0 beyond the active bound
+    const double r2 = Pb[2 * (long)ld + j];                 // rows 0,1 of the upper triangle carry the mirrored
+    Pb[j] += g0 * r2;                                       // column op too
     Pb[(long)ld + j] += g1 * r2;
-    const double c2 = Pb[(long)j * ld + 2];
-    Pb[(long)j * ld + 0] += g0 * c2;
-    Pb[(long)j * ld + 1] += g1 * c2;
   } else if (j == 0) {
     double X[3][3], Y[3][3];
     for (int r = 0; r < 3; ++r)
-      for (int c = 0; c < 3; ++c) X[r][c] = Pb[(long)r * ld + c];
+      for (int c = 0; c < 3; ++c) X[r][c] = Pb[(long)min(r, c) * ld + max(r, c)];
     for (int c = 0; c < 3; ++c) {
       X[0][c] += g0 * X[2][c];
       X[1][c] += g1 * X[2][c];
@@ -973,7 +945,31 @@ __global__ __launch_bounds__(256) void k_predict_rc(double* __restrict__ P,
       Y[r][r] += so[b].rd[r];
     }
     for (int r = 0; r < 3; ++r)
-      for (int c = 0; c < 3; ++c) Pb[(long)r * ld + c] = Y[r][c];
+      for (int c = r; c < 3; ++c) Pb[(long)r * ld + c] = Y[r][c];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_mirror: lower triangle <- transpose of the upper one (before a download or a dense product; the
+// step kernels never read below the diagonal).  64 x 64 tiles through LDS, both sides coalesced.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_mirror(double* __restrict__ P, const int* __restrict__ nact, int ld,
+                                                long pstride) {
+  __shared__ double T[64][65];
+  const int b = blockIdx.z;
+  const int n = nact[b];
+  const int ti = blockIdx.y, tj = blockIdx.x;           // destination tile (rows ti, cols tj), tj <= ti
+  if (tj > ti || ti * 64 >= n) return;
+  double* Pb = P + (long)b * pstride;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int r = ty; r < 64; r += 4) {                    // source tile (rows tj, cols ti)
+    const int row = tj * 64 + r, col = ti * 64 + tx;
+    T[r][tx] = (row < n && col < n) ? Pb[(long)row * ld + col] : 0.0;
+  }
+  __syncthreads();
+  for (int r = ty; r < 64; r += 4) {
+    const int row = ti * 64 + r, col = tj * 64 + tx;
+    if (row < n && col < n && col < row) Pb[(long)row * ld + col] = T[tx][r];
   }
 }
 
@@ -1175,9 +1171,11 @@ template <int NKTM, bool NT>
 static void launch_flush_t(hipStream_t st, double* P, const double* V, const double* W, const double* dacc,
                            const int* nact, const SolveOut* so, int ld, long pstride, int batch, int n_hi,
                            int nkt, int rows_per_block) {
-  dim3 grid((n_hi + 255) / 256, (n_hi + rows_per_block - 1) / rows_per_block, batch);
-  hipLaunchKernelGGL((k_flush<NKTM, NT>), grid, dim3(256), 0, st, P, V, W, dacc, nact, so, ld, pstride, nkt,
-                     rows_per_block);
+  const int gx = (n_hi + 255) / 256, gy = (n_hi + rows_per_block - 1) / rows_per_block;
+  int total = 0;                                       // workgroups that reach the upper triangle
+  for (int by = 0; by < gy; ++by) total += std::max(0, gx - (by * rows_per_block) / 256);
+  hipLaunchKernelGGL((k_flush<NKTM, NT>), dim3(total, 1, batch), dim3(256), 0, st, P, V, W, dacc, nact, so, ld,
+                     pstride, nkt, rows_per_block, gx);
 }
 
 // streaming = the batch's covariances do not fit the Infinity Cache: nontemporal accesses
@@ -1201,6 +1199,11 @@ void launch_predict_rc(hipStream_t st, double* P, const double* mu_in, double* m
                        const SolveOut* so, int ld, long pstride, int batch, int n_hi) {
   hipLaunchKernelGGL(k_predict_rc, dim3((n_hi + 255) / 256, batch), dim3(256), 0, st, P, mu_in, mu_out,
                      nact, so, ld, pstride);
+}
+
+void launch_mirror(hipStream_t st, double* P, const int* nact, int ld, long pstride, int batch, int n_hi) {
+  const int t = (n_hi + 63) / 64;
+  hipLaunchKernelGGL(k_mirror, dim3(t, t, batch), dim3(256), 0, st, P, nact, ld, pstride);
 }
 
 void launch_add_landmarks(hipStream_t st, double* Pb, double* mub, int ld, int n_old, int n_new,

@@ -276,7 +276,8 @@ def test_augmentation_matches_reference_growth(sd):
 def test_upload_download_roundtrip_bitexact(sd):
     rng = np.random.default_rng(0)
     n = 3 + 2 * 37
-    P0 = rng.normal(size=(n, n))
+    A = rng.normal(size=(n, n))
+    P0 = A + A.T
     mu0 = rng.normal(size=n)
     with sd.EkfSlam(3 + 2 * 50, batch=2) as f:
         f.set_state(mu0, P0, 1)
@@ -284,6 +285,10 @@ def test_upload_download_roundtrip_bitexact(sd):
         assert np.array_equal(mu, mu0) and np.array_equal(P, P0)
         assert f.size(0) == 3 and f.size(1) == n
         assert np.array_equal(f.covariance(0), np.eye(3) * 0.1)      # reference start, :69-70
+        # a covariance is symmetric: the upper triangle of what the host hands over is authoritative
+        f.set_state(mu0, A, 1)
+        assert np.array_equal(f.covariance(1), np.triu(A) + np.triu(A, 1).T)
+        assert np.array_equal(f.covariance_block(5, 2, 4, 3, 1), (np.triu(A) + np.triu(A, 1).T)[5:9, 2:5])
 
 
 @pytest.mark.parametrize("n", [3, 43, 1003])
@@ -293,7 +298,8 @@ def test_predict_dense_mfma(sd, n):
     A = rng.normal(size=(n, n)) / np.sqrt(n)
     P0 = A @ A.T + np.eye(n)
     F = np.eye(n) + rng.normal(size=(n, n)) * 0.1          # asymmetric on purpose
-    Q = np.diag(rng.uniform(0.01, 0.1, n)) + 0.01 * rng.normal(size=(n, n))
+    Nq = 0.01 * rng.normal(size=(n, n))
+    Q = np.diag(rng.uniform(0.01, 0.1, n)) + Nq + Nq.T          # a covariance: symmetric
     with sd.EkfSlam(n) as f:
         f.set_state(np.zeros(n), P0)
         f.predict_dense(F, Q)
