@@ -179,9 +179,10 @@ def main():
     out = None
     if rank == 0:
         value = total_units / dt
-        # The covariance pass (k_flush) reads and writes every trajectory's P exactly once per launch,
-        # whatever the number of steps it folds in: 16 n^2 bytes per trajectory per launch.
-        alg_bytes = B * 16.0 * n * n
+        # The covariance pass (k_flush) reads and writes the stored (upper) triangle of every trajectory's P
+        # exactly once per launch, whatever the number of steps it folds in: 2 * 8 * n(n+1)/2 bytes each.
+        tri = n * (n + 1) / 2.0
+        alg_bytes = B * 16.0 * tri
         avg_s = (pass_ms / max(launches, 1)) * 1e-3
         achieved = alg_bytes / avg_s / 1e9 if avg_s > 0 else 0.0
         steps_per_launch = args.steps / max(launches, 1)
@@ -200,17 +201,19 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "ekf::k_flush",
                          "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_s * 1e3, "launches": launches,
                          "steps_per_launch": steps_per_launch,
-                         "step_equivalent_GBs": achieved * steps_per_launch,
-                         "mfma": {"achieved": 2.0 * ranks * B * n * n / avg_s / 1e12 if avg_s > 0 else 0.0,
+                         "step_equivalent_GBs": (B * 16.0 * n * n * steps_per_launch / avg_s / 1e9) if avg_s > 0 else 0.0,
+                         "mfma": {"achieved": 2.0 * ranks * B * tri / avg_s / 1e12 if avg_s > 0 else 0.0,
                                   "unit": "TFLOP/s fp64", "peak_spec": MFMA_F64_SPEC_TF,
                                   "peak_measured": MFMA_F64_MEASURED_TF,
-                                  "frac_of_spec": (2.0 * ranks * B * n * n / avg_s / 1e12 / MFMA_F64_SPEC_TF) if avg_s > 0 else 0.0,
-                                  "frac_of_measured": (2.0 * ranks * B * n * n / avg_s / 1e12 / MFMA_F64_MEASURED_TF) if avg_s > 0 else 0.0},
-                         "note": "one launch applies the pending rank-K update of steps_per_launch steps: "
-                                 "SURVEY 8(d)'s 16 n^2 bytes per step are paid once per launch; achieved/frac "
-                                 "count the bytes this launch must move (one read + one write of P), "
-                                 "step_equivalent_GBs multiplies by the steps folded in; at 4 steps (72 ranks) "
-                                 "per launch the kernel sits on the ridge (2K flop per 16 B), see `mfma`"},
+                                  "frac_of_spec": (2.0 * ranks * B * tri / avg_s / 1e12 / MFMA_F64_SPEC_TF) if avg_s > 0 else 0.0,
+                                  "frac_of_measured": (2.0 * ranks * B * tri / avg_s / 1e12 / MFMA_F64_MEASURED_TF) if avg_s > 0 else 0.0},
+                         "note": "one launch applies the pending rank-K update of steps_per_launch steps to the "
+                                 "stored upper triangle of P (P is symmetric; the lower triangle is never read): "
+                                 "SURVEY 8(d)'s 16 n^2 bytes per step become 8 n(n+1) bytes per LAUNCH; achieved/frac "
+                                 "count the bytes this launch must move (one read + one write of the triangle), "
+                                 "step_equivalent_GBs = SURVEY's 16 n^2 per step x steps folded in / launch time; "
+                                 "at 4 steps (72 ranks) per launch the kernel sits on the ridge (2K flop per 16 B), "
+                                 "see `mfma`"},
             "device_ms_per_step": dev_ms / args.steps,
         }
         traffic_file = os.path.join(ROOT, "profiles", "pass_traffic.json")
@@ -227,7 +230,7 @@ def main():
         if not args.no_single:
             dt1, p1, l1, _ = time_filter(sd, sd_syn, local_rank, [0], args.landmarks, args.obs, args.steps,
                                          args.warmup, lambda: None, options=args.option)
-            a1 = 16.0 * n * n / ((p1 / max(l1, 1)) * 1e-3) / 1e9 if p1 > 0 else 0.0
+            a1 = 16.0 * tri / ((p1 / max(l1, 1)) * 1e-3) / 1e9 if p1 > 0 else 0.0
             out["single_trajectory"] = {"workload": f"N={args.landmarks}, m={args.obs}, 1 trajectory (BASELINE config 3)",
                                         "value": args.steps / dt1, "unit": "steps/s",
                                         "pass_avg_launch_ms": p1 / max(l1, 1), "pass_launches": l1,

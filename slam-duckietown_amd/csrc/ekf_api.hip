@@ -11,9 +11,9 @@
 
 namespace ekf {
 void launch_solve(hipStream_t, const double*, const double*, const double*, const double*, double*, const double*,
-                  double*, const int*, const StepIn*, SolveOut*, unsigned*, const DeviceConfig&, int, long, int, int);
+                  double*, const int*, const StepIn*, SolveOut*, unsigned*, double*, const DeviceConfig&, int, long, int, int);
 void launch_panels(hipStream_t, int, const double*, double*, double*, const double*, double*, const int*,
-                   const SolveOut*, int, long, int, int);
+                   const SolveOut*, const double*, int, long, int, int);
 void launch_flush(hipStream_t, bool, double*, const double*, const double*, const double*, const int*,
                   const SolveOut*, int, long, int, int, int, int);
 void launch_predict_rc(hipStream_t, double*, const double*, double*, const int*, const SolveOut*, int, long,
@@ -46,6 +46,7 @@ struct ekf_handle {
   int* dn = nullptr;
   unsigned* dflags = nullptr;
   SolveOut* dso = nullptr;
+  double* dfac = nullptr;         // pending factors restricted to the gathered indices (k_solve -> k_panels)
   StepIn *d_ring = nullptr, *h_ring = nullptr;
   hipEvent_t ring_ev[RING]{};
   bool ring_used[RING]{};
@@ -119,7 +120,7 @@ static void free_all(ekf_handle* h) {
   if (!h) return;
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
-  void* ptrs[] = {h->dP, h->dmu2[0], h->dmu2[1], h->dV, h->dW, h->ddacc2[0], h->ddacc2[1], h->dscratch, h->dn, h->dflags, h->dso,
+  void* ptrs[] = {h->dP, h->dmu2[0], h->dmu2[1], h->dV, h->dW, h->ddacc2[0], h->ddacc2[1], h->dscratch, h->dn, h->dflags, h->dso, h->dfac,
                   h->d_ring, h->d_stream, h->dF, h->dQ, h->dTmp, h->dtagmap, h->dneff, h->d_det, h->d_assoc_step,
                   h->d_assoc_out};
   for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -198,6 +199,7 @@ extern "C" int ekf_create(int device, int n_max, int batch, const ekf_config* cf
   CREATE_TRY(hipMalloc(&h->dn, sizeof(int) * batch));
   CREATE_TRY(hipMalloc(&h->dflags, sizeof(unsigned) * batch));
   CREATE_TRY(hipMalloc(&h->dso, sizeof(SolveOut) * batch));
+  CREATE_TRY(hipMalloc(&h->dfac, sizeof(double) * FACS * batch));
   CREATE_TRY(hipMalloc(&h->d_ring, sizeof(StepIn) * batch * RING));
   CREATE_TRY(hipHostMalloc(&h->h_ring, sizeof(StepIn) * batch * RING, hipHostMallocDefault));
   for (auto& ev : h->ring_ev) CREATE_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
@@ -212,6 +214,7 @@ extern "C" int ekf_create(int device, int n_max, int batch, const ekf_config* cf
   CREATE_TRY(hipMemsetAsync(h->ddacc2[1], 0, sizeof(double) * 4 * batch, h->stream));
   CREATE_TRY(hipMemsetAsync(h->dflags, 0, sizeof(unsigned) * batch, h->stream));
   CREATE_TRY(hipMemsetAsync(h->dso, 0, sizeof(SolveOut) * batch, h->stream));
+  CREATE_TRY(hipMemsetAsync(h->dfac, 0, sizeof(double) * FACS * batch, h->stream));
   // reference initial state (src/replay_no_ros.py:69-70): mu = 0, P = MOTION_MODEL_VARIANCE * I3
   {
     std::vector<double> p3(3 * 3, 0.0);
@@ -423,7 +426,7 @@ static int enqueue_pass(ekf_handle* h, const StepIn* d_in, int m_hi) {
   if (m_hi == 0 && h->pending_k == 0) {
     // prediction only, nothing pending: rows/cols 0,1 of P_base directly, O(n)
     launch_solve(h->stream, h->dP, h->dV, h->dW, dacc_in, dacc_out, mu_in, mu_out, h->dn, d_in, h->dso, h->dflags,
-                 h->dcfg, h->ld, h->pstride, h->batch, 0);
+                 h->dfac, h->dcfg, h->ld, h->pstride, h->batch, 0);
     launch_predict_rc(h->stream, h->dP, mu_in, mu_out, h->dn, h->dso, h->ld, h->pstride, h->batch, n_hi);
     // k_predict_rc applied the noise itself
     HIP_TRY(h, hipMemsetAsync(h->ddacc2[0], 0, sizeof(double) * 4 * h->batch, h->stream));
@@ -437,9 +440,9 @@ static int enqueue_pass(ekf_handle* h, const StepIn* d_in, int m_hi) {
   dacc_in = h->ddacc2[h->dcur];
   dacc_out = h->ddacc2[h->dcur ^ 1];
   launch_solve(h->stream, h->dP, h->dV, h->dW, dacc_in, dacc_out, mu_in, mu_out, h->dn, d_in, h->dso, h->dflags,
-               h->dcfg, h->ld, h->pstride, h->batch, h->pending_k);
-  launch_panels(h->stream, mcap, h->dP, h->dV, h->dW, mu_in, mu_out, h->dn, h->dso, h->ld, h->pstride, h->batch,
-                n_hi);
+               h->dfac, h->dcfg, h->ld, h->pstride, h->batch, h->pending_k);
+  launch_panels(h->stream, mcap, h->dP, h->dV, h->dW, mu_in, mu_out, h->dn, h->dso, h->dfac, h->ld, h->pstride,
+                h->batch, n_hi);
   HIP_TRY(h, hipGetLastError());
   h->dcur ^= 1;
   h->cur ^= 1;

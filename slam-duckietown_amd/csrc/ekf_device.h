@@ -41,13 +41,19 @@ struct alignas(16) SolveIter {
 };
 static_assert(sizeof(SolveIter) % 16 == 0, "SolveIter must stay 16-byte granular");
 
+// The pending factors restricted to C, written by the solve kernel for the panel kernel's scalar loads:
+// per trajectory  facW[a][k] = W[C[a]][k]  then  facV[a][k] = V[k][C[a]],  both [CMAX][KTOT], zero-filled
+// up to the next multiple of 8 ranks.
+constexpr int FACS = 2 * CMAX * KTOT;
+
 // Output of the sequential compressed solve for one trajectory; read by the panel and pass kernels.
 struct alignas(16) SolveOut {
   double g[2];          // G[0,2], G[1,2] of the motion Jacobian (0 when prediction is off)
   double rd[3];         // motion noise added to the pose block (0 when prediction is off)
   double p22h;          // 0.5 * P[2,2] before the step
   double dacc_old[3];   // pose-block noise already pending before this step
-  double pad0;
+  int cmax;             // largest gathered state index (panel waves starting beyond it never read W)
+  int pad0;
   int c;                // 3 + 2m
   int m;
   int kbase;            // ranks pending before this step (multiple of 4)

@@ -96,16 +96,28 @@ constexpr int RCH = 8;          // rows per batch of the down-date
 constexpr int CPAD = (CMAX + RCH - 1) / RCH * RCH;   // 40
 constexpr int WCS = KTOT + 1;   // row stride of the staged W[C,:] (81 doubles: per-lane rows are conflict-free)
 
-// Stage the pending factors restricted to C into LDS: Wc[a][k] = W[C[a]][k], Vc[k][a] = V[k][C[a]].
+// Stage the pending factors restricted to C into LDS: Wc[a][k] = W[C[a]][k], Vc[k][a] = V[k][C[a]]; with
+// `fac` they are also written out compactly (facW[a][k], facV[a][k], zero-filled to a multiple of 8 ranks) for
+// the panel kernel, whose waves read them through the scalar cache.
 __device__ __forceinline__ void stage_factors(const double* __restrict__ Vb, const double* __restrict__ Wb,
                                               const int* Cs, int c, int kb, int ld, int tid, int nthreads,
-                                              double (*Wc)[WCS], double (*Vc)[PCS]) {
+                                              double (*Wc)[WCS], double (*Vc)[PCS], double* __restrict__ fac) {
   const int ld16 = ld >> 4;
+  const int k8 = (kb + 7) & ~7;
   for (int a = tid >> 6; a < c; a += nthreads >> 6) {
     const int row = Cs[a];
-    for (int k = tid & 63; k < kb; k += 64) {
-      Wc[a][k] = Wb[wm_index(ld16, k, row)];
-      Vc[k][a] = Vb[(long)k * ld + row];
+    for (int k = tid & 63; k < k8; k += 64) {
+      const bool in = k < kb;
+      const double wv = in ? Wb[wm_index(ld16, k, row)] : 0.0;
+      const double vv = in ? Vb[(long)k * ld + row] : 0.0;
+      if (in) {
+        Wc[a][k] = wv;
+        Vc[k][a] = vv;
+      }
+      if (fac) {
+        fac[a * KTOT + k] = wv;
+        fac[CMAX * KTOT + a * KTOT + k] = vv;
+      }
     }
   }
 }
@@ -144,7 +156,8 @@ __device__ __forceinline__ void solve_body(SolveLds& L, const double* __restrict
                                            const double* __restrict__ dacc_in, double* __restrict__ dacc_out,
                                            const double* __restrict__ mu_in_b, double* __restrict__ mu_out_b,
                                            const StepIn& s, SolveOut& o, SolveIter* its, unsigned* flag_b,
-                                           const DeviceConfig& cfg, int ld, int kbase, bool writer) {
+                                           double* __restrict__ fac_b, const DeviceConfig& cfg, int ld, int kbase,
+                                           bool writer) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   auto& Pc = L.Pc;
@@ -174,9 +187,12 @@ __device__ __forceinline__ void solve_body(SolveLds& L, const double* __restrict
   }
   const double mu_l = mu_in_b[Cl];
   const double d0 = dacc_in[0], d1 = dacc_in[1], d2 = dacc_in[2];
+  int cmax = Cl;                                       // largest gathered index (wave-wide maximum)
+#pragma unroll
+  for (int sh = 32; sh > 0; sh >>= 1) cmax = max(cmax, __shfl_xor(cmax, sh));
   __syncthreads();
   if (kbase > 0) {
-    stage_factors(Vb, Wb, Cs, c, kbase, ld, tid, 256, Wc, Vc);
+    stage_factors(Vb, Wb, Cs, c, kbase, ld, tid, 256, Wc, Vc, writer ? fac_b : nullptr);
     __syncthreads();
   }
   STAMP(o, 1);
@@ -332,6 +348,7 @@ __device__ __forceinline__ void solve_body(SolveLds& L, const double* __restrict
     hd.neff = s.neff;
     L.hdr = hd;
     if (writer) {
+      o.cmax = cmax;
       o.g[0] = g0;
       o.g[1] = g1;
       o.rd[0] = rd0;
@@ -475,164 +492,251 @@ __global__ __launch_bounds__(256) void k_solve(const double* __restrict__ P, con
                                                const int* __restrict__ nact,
                                                const StepIn* __restrict__ in,
                                                SolveOut* __restrict__ out,
-                                               unsigned* __restrict__ flags, DeviceConfig cfg, int ld,
-                                               long pstride, int kbase) {
+                                               unsigned* __restrict__ flags, double* __restrict__ fac,
+                                               DeviceConfig cfg, int ld, long pstride, int kbase) {
   __shared__ SolveLds L;
   const int b = blockIdx.x;
   solve_body(L, P + (long)b * pstride, V + (long)b * KTOT * ld, W + (long)b * KTOT * ld, dacc_in + 4 * b,
              dacc_out + 4 * b, mu_in + (long)b * ld, mu_out + (long)b * ld, in[b], out[b], out[b].it,
-             flags + b, cfg, ld, kbase, true);
+             flags + b, fac + (long)b * FACS, cfg, ld, kbase, true);
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_panels: one workgroup (4 waves) per 64 state indices i.
-//  phase 1 (all waves, a split a % 4 == wave): current panels
-//      R[a][i] = P[C[a]][i] = P_base[C[a]][i] + sum_k W[C[a]][k] V[k][i]   (coalesced row reads)
-//      L[a][i] = P[i][C[a]] = P_base[i][C[a]] + sum_k W[i][k] V[k][C[a]]   (~m+1 lines per row)
-//  phase 2: wave 0 replays the m rank-2 down-dates on R and appends V[kb+2j..][i] = H_j P_j[:, i];
-//           wave 1 replays them on L and appends W[i][kb+2j..] = -K_j[i,:] and the mean update
-//           mu_out[i] = mu_in[i] + sum_j K_j[i,:] y_j (i not in C); per-iteration uniforms of k_solve
-//           are broadcast from LDS with 16-byte reads issued up front.
-//  The two rank-1 pairs of the motion Jacobian (:430) go to ranks kb+2*MCAP, +1:
-//      V = P[2,:] + p22h*gt, W = gt   and   V = gt, W = P[:,2] + p22h*gt.
+// k_panels: thread i replays the step on x[a] = P(C[a], i), the column of the current covariance at its
+// own state index restricted to the gathered rows C (P is symmetric, only the upper triangle of P_base
+// is stored):
+//   gather     x[a] = P_base(min(C[a],i), max(C[a],i)) + pending ranks:  sum_k W[C[a]][k] V[k][i]  where the
+//              entry is stored as (C[a], i), else  sum_k W[i][k] V[k][C[a]]   (its mirror);  V[:,i] and W[i,:]
+//              are coalesced vector loads (8 ranks at a time, the next 8 in flight under the FMAs)
+//   predict    P' = G_F P G_F^T + F^T R F on the panel (src/replay_no_ros.py:430)
+//   m updates  u = (H_j P_j)[:, i] = h5 . x[sel];  K_j[i,:] = u^T S_j^-1;  x -= K_j[C,:] u   (:473-480)
+//              appended ranks  V[kb+2j..][i] = u,  W[i][kb+2j..] = -K_j[i,:];  mean += K_j[i,:] y_j  (:476)
+//   the two rank-1 pairs of the motion Jacobian go to ranks kb+2*MCAP, +1:
+//              V = q, W = gt   and   V = gt, W = q   with q = P(2,:) + p22h*gt
+// A workgroup is NW independent waves of 64 state indices.  What they share (the per-landmark records of
+// k_solve and its compact copy of the factors at C) is staged into LDS once, with one round of loads, and
+// then read as 16-byte broadcasts; after the single barrier the waves never synchronise again.
 // ---------------------------------------------------------------------------------------------
-// Zero V columns / W rows of this step and carry the mean over: workgroups whose 64 state indices all lie
-// beyond the active bound (their rows and columns of P are exactly zero off the diagonal).
-template <int KTP>
-__device__ __forceinline__ void panels_beyond_bound(double* Vb, double* Wb, const double* mu_in_b, double* mu_out_b,
-                                                    int ld, int kb, int i, bool act, int wave) {
-  const int ld16 = ld >> 4;
-  if (act && wave == 0) {
-    for (int k = kb; k < ((kb + KTP + 3) & ~3); ++k) Vb[(long)k * ld + i] = 0.0;
-  }
-  if (act && wave == 1) {
-    for (int k = kb; k < ((kb + KTP + 3) & ~3); ++k) Wb[wm_index(ld16, k, i)] = 0.0;
-    mu_out_b[i] = mu_in_b[i];
-  }
-}
-
-// panels_body: phases 1 and 2 for the 64 state indices of this workgroup.  `its`, `Cs`, `Wc`, `Vc` are in
-// LDS (its/Cs always valid; Wc/Vc are staged here unless the caller already did).
-template <int MCAP>
-__device__ __forceinline__ void panels_body(const double* __restrict__ Pb, double* __restrict__ Vb,
-                                            double* __restrict__ Wb, const double* __restrict__ mu_in_b,
-                                            double* __restrict__ mu_out_b, int n, int ld, const SolveIter* its,
-                                            const int* Cs, const SolveHdr& o, double (*Wc)[WCS], double (*Vc)[PCS],
-                                            double (*Rs)[64], bool factors_staged) {
-  constexpr int CC = 3 + 2 * MCAP, K2 = 2 * MCAP, KTP = ranks_for(MCAP);
-  constexpr int QA = (CC + 3) / 4;                    // a's per wave in phase 1
+template <int MCAP, int NW, bool KSPLIT>
+__global__ __launch_bounds__(64 * NW) void k_panels(const double* __restrict__ P, double* __restrict__ V,
+                                                    double* __restrict__ W, const double* __restrict__ mu_in,
+                                                    double* __restrict__ mu_out, const int* __restrict__ nact,
+                                                    const SolveOut* __restrict__ so,
+                                                    const double* __restrict__ fac, int ld, long pstride) {
+  constexpr int CC = 3 + 2 * MCAP, K2 = 2 * MCAP, KTP = ranks_for(MCAP), NT = 64 * NW;
+  __shared__ __attribute__((aligned(16))) double sF[2][CC][KTOT];   // [0]: W[C[a]][k], [1]: V[k][C[a]]
+  __shared__ SolveIter sIt[MCAP];
+  __shared__ int sC[CC + 1];
+  __shared__ double sPart[KSPLIT ? NW - 1 : 1][KSPLIT ? CC : 1][64];   // KSPLIT: partial gathers of waves 1..
+  const int b = blockIdx.y;
+  const int n = nact[b];
+  const int w0 = blockIdx.x * (KSPLIT ? 64 : NT);
+  if (w0 >= n) return;
+  const SolveOut& o = so[b];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int i = blockIdx.x * 64 + lane;
-  const bool act = i < n;
-  const int ii = act ? i : 0;
   const int ld16 = ld >> 4;
-  const int m = min(o.m, MCAP), c = o.c, kb = o.kbase;
-  // ---- phase 1 ----  (the base-panel loads are issued first: their latency overlaps the staging)
-  {
-    double r[QA];
-    bool up[QA];                                       // entry (C[a], i) is stored; otherwise its mirror (i, C[a])
-    bool mirrored = false;
+  const double* Pb = P + (long)b * pstride;
+  double* Vb = V + (long)b * KTOT * ld;
+  double* Wb = W + (long)b * KTOT * ld;
+  const double* mu_in_b = mu_in + (long)b * ld;
+  double* mu_out_b = mu_out + (long)b * ld;
+  const int kb = o.kbase, neff = o.neff;
+  const int m = min(o.m, MCAP), c = o.c;
+  const int i0 = KSPLIT ? w0 : w0 + wave * 64;
+  const int i = i0 + lane;
+  const bool act = i < n;
+  const int ii = act ? i : n - 1;                      // idle lanes shadow the last state index (no stores)
+  const int kw = KSPLIT ? wave : 0;                    // KSPLIT: this wave takes every NW-th group of 8 ranks
+  constexpr int KSTEP = KSPLIT ? 8 * NW : 8;
+
+  if (w0 < neff) {                                     // (uniform) some wave of this workgroup replays the step
+    if (kb > 0) {
+      const double2* src0 = reinterpret_cast<const double2*>(fac + (long)b * FACS);
+      const double2* src1 = src0 + CMAX * KTOT / 2;
+      double2* dst0 = reinterpret_cast<double2*>(&sF[0][0][0]);
+      double2* dst1 = reinterpret_cast<double2*>(&sF[1][0][0]);
+      constexpr int CNT = CC * KTOT / 2, Q = (CNT + NT - 1) / NT;
+      double2 t0[Q], t1[Q];
 #pragma unroll
-    for (int q = 0; q < QA; ++q) {
-      const int a = wave + 4 * q;
-      const int row = (a < CC) ? Cs[a] : 0;
-      up[q] = row <= ii;
-      mirrored |= !up[q];
-      r[q] = Pb[(long)min(row, ii) * ld + max(row, ii)];
+      for (int q = 0; q < Q; ++q) {
+        const int t = min(tid + q * NT, CNT - 1);
+        t0[q] = src0[t];
+        t1[q] = src1[t];
+      }
+#pragma unroll
+      for (int q = 0; q < Q; ++q) {
+        const int t = tid + q * NT;
+        if (t < CNT) {
+          dst0[t] = t0[q];
+          dst1[t] = t1[q];
+        }
+      }
     }
-    const bool need_w = __any(mirrored);               // W[i,:] is only read where some C[a] lies beyond i
-    if (kb > 0 && !factors_staged) {
-      stage_factors(Vb, Wb, Cs, min(c, CC), kb, ld, tid, 256, Wc, Vc);
-      __syncthreads();
+    {
+      const double2* src = reinterpret_cast<const double2*>(o.it);
+      double2* dst = reinterpret_cast<double2*>(sIt);
+      constexpr int PER = (int)(sizeof(SolveIter) / 16), CNT = MCAP * PER, Q = (CNT + NT - 1) / NT;
+      const int count = m * PER;
+      double2 t0[Q];
+#pragma unroll
+      for (int q = 0; q < Q; ++q) t0[q] = src[min(tid + q * NT, CNT - 1)];
+#pragma unroll
+      for (int q = 0; q < Q; ++q)
+        if (tid + q * NT < count) dst[tid + q * NT] = t0[q];
     }
-    for (int k0 = 0; k0 < kb; k0 += 8) {               // pending ranks, 8 at a time (loads batched)
-      double vk[8], wk[8];
+    if (tid < CC + 1) sC[tid] = o.C[tid];
+  }
+  // the base entries of the gather do not depend on the staged data: issue them before the barrier
+  double X[CC];
+  if (i0 < neff && i0 < n && kw == 0) {
+#pragma unroll
+    for (int a = 0; a < CC; ++a) {
+      const int row = o.C[a];
+      X[a] = Pb[(long)min(row, ii) * ld + max(row, ii)];
+    }
+  } else {
+#pragma unroll
+    for (int a = 0; a < CC; ++a) X[a] = 0.0;
+  }
+  __syncthreads();
+  if (i0 >= n) return;
+  if (i0 >= neff) {
+    // beyond the active bound the rows and columns of P are exactly zero off the diagonal: this step's
+    // ranks are zero there and the mean is carried over
+    if (act && kw == 0) {
+      for (int k = kb; k < ((kb + KTP + 3) & ~3); ++k) {
+        Vb[(long)k * ld + i] = 0.0;
+        Wb[wm_index(ld16, k, i)] = 0.0;
+      }
+      mu_out_b[i] = mu_in_b[i];
+    }
+    return;
+  }
+
+  // ---- pending ranks of the gather ----
+  const bool need_w = o.cmax > i0;                     // some gathered index lies beyond this wave's first one
+  double v[8], w[8];
+  const double* vlane = Vb + ii;
+  const double* wlane = Wb + (long)(ii >> 4) * 64 + (ii & 15);   // wm_index = rank part + lane part
+  auto load_vw = [&](int k0, double (&vv)[8], double (&ww)[8]) {   // ranks up to KTOT exist: no clamping
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const double x = vlane[(long)(k0 + u) * ld];
+      vv[u] = (k0 + u < kb) ? x : 0.0;
+    }
+    if (need_w) {
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
-        const int k = min(k0 + u, kb - 1);
-        vk[u] = Vb[(long)k * ld + ii];
-        wk[u] = need_w ? Wb[wm_index(ld16, k, ii)] : 0.0;
+        const double x = wlane[((long)((k0 + u) >> 2) * ld16) * 64 + ((k0 + u) & 3) * 16];
+        ww[u] = (k0 + u < kb) ? x : 0.0;
       }
-      if (!need_w) {
+    } else {
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int k = min(k0 + u, kb - 1);
-          const double vv = (k0 + u < kb) ? vk[u] : 0.0;
+      for (int u = 0; u < 8; ++u) ww[u] = 0.0;
+    }
+  };
+  if (8 * kw < kb) load_vw(8 * kw, v, w);
+  for (int k0 = 8 * kw; k0 < kb; k0 += KSTEP) {
+    double vn[8], wn[8];
+    if (k0 + KSTEP < kb) load_vw(k0 + KSTEP, vn, wn);
 #pragma unroll
-          for (int q = 0; q < QA; ++q) r[q] = fma(Wc[min(wave + 4 * q, CC - 1)][k], vv, r[q]);
-        }
-      } else {
+    for (int a = 0; a < CC; ++a) {
+      if (a < c) {
+        const int row = sC[a];
+        const double2* wa = reinterpret_cast<const double2*>(&sF[0][a][k0]);
+        const double2* va = reinterpret_cast<const double2*>(&sF[1][a][k0]);
+        if (row <= i0) {                               // stored as (C[a], i) for the whole wave
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int k = min(k0 + u, kb - 1);
-          const double vv = (k0 + u < kb) ? vk[u] : 0.0, ww = (k0 + u < kb) ? wk[u] : 0.0;
+          for (int u = 0; u < 4; ++u) {
+            const double2 f = wa[u];
+            X[a] = fma(f.x, v[2 * u], X[a]);
+            X[a] = fma(f.y, v[2 * u + 1], X[a]);
+          }
+        } else if (row > i0 + 63) {                    // mirrored for the whole wave
 #pragma unroll
-          for (int q = 0; q < QA; ++q) {
-            const int a = min(wave + 4 * q, CC - 1);
-            r[q] = fma(up[q] ? Wc[a][k] : ww, up[q] ? vv : Vc[k][a], r[q]);
+          for (int u = 0; u < 4; ++u) {
+            const double2 f = va[u];
+            X[a] = fma(w[2 * u], f.x, X[a]);
+            X[a] = fma(w[2 * u + 1], f.y, X[a]);
+          }
+        } else {
+          const bool up = row <= ii;
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const double2 fw2 = wa[u], fv2 = va[u];
+            X[a] = fma(up ? fw2.x : w[2 * u], up ? v[2 * u] : fv2.x, X[a]);
+            X[a] = fma(up ? fw2.y : w[2 * u + 1], up ? v[2 * u + 1] : fv2.y, X[a]);
           }
         }
       }
     }
+    if (k0 + KSTEP < kb) {
 #pragma unroll
-    for (int q = 0; q < QA; ++q) {
-      const int a = wave + 4 * q;
-      if (a < CC) {
-        double rv = r[q];
-        if (a < 3 && ii == a) rv += o.dacc_old[a];     // pending pose-block noise on the diagonal
-        Rs[a][lane] = rv;
+      for (int u = 0; u < 8; ++u) {
+        v[u] = vn[u];
+        w[u] = wn[u];
       }
     }
   }
-  __syncthreads();
-  if (wave >= 1) return;
-
-  // ---- phase 2: thread i replays the step on x[a] = P(C[a], i) ----
-  const double g0 = o.g[0], g1 = o.g[1];
-  const double gj = (ii == 0) ? g0 : ((ii == 1) ? g1 : 0.0);
-  const bool blk0 = blockIdx.x == 0;                   // lanes 0..2 of block 0 hold state indices 0,1,2
-  double X[CC];
+  if (KSPLIT) {                                        // waves 1.. hand their partial sums to wave 0 and leave
+    if (kw > 0) {
 #pragma unroll
-  for (int a = 0; a < CC; ++a) X[a] = Rs[a][lane];
-  const double raw2 = X[2];                            // P(2, i)
-  // P' = G_F P G_F^T + F^T R F  (src/replay_no_ros.py:430) on the panel
-  X[0] += g0 * X[2];                                   // row ops on rows 0,1
-  X[1] += g1 * X[2];
-  if (blk0 && ii < 2) {                                // column op on column ii: += g_ii * X[:,2]
-    const double p22 = Rs[2][2];
+      for (int a = 0; a < CC; ++a) sPart[kw - 1][a][lane] = X[a];
+    }
+    __syncthreads();
+    if (kw > 0) return;
 #pragma unroll
     for (int a = 0; a < CC; ++a) {
-      double x = Rs[a][2];
-      if (a == 0) x += g0 * p22;
-      if (a == 1) x += g1 * p22;
-      X[a] += gj * x;
+      double t = X[a];
+#pragma unroll
+      for (int q = 0; q < NW - 1; ++q) t += sPart[q][a][lane];
+      X[a] = t;
     }
+  }
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+    if (ii == a) X[a] += o.dacc_old[a];                // pending pose-block noise on the diagonal
+
+  // ---- predict:  P' = G_F P G_F^T + F^T R F  (src/replay_no_ros.py:430) on the panel ----
+  const double g0 = o.g[0], g1 = o.g[1];
+  const double gj = (ii == 0) ? g0 : ((ii == 1) ? g1 : 0.0);
+  const double raw2 = X[2];                            // P(2, i)
+  if (i0 == 0) {                                       // lanes 0,1 hold columns 0,1: column op += g_i * X[:,2]
+    const double p22 = __shfl(X[2], 2);
+    double col2[CC];
+#pragma unroll
+    for (int a = 0; a < CC; ++a) col2[a] = __shfl(X[a], 2);
+    col2[0] += g0 * p22;
+    col2[1] += g1 * p22;
+    X[0] += g0 * X[2];                                 // row ops on rows 0,1
+    X[1] += g1 * X[2];
+    if (ii < 2) {
+#pragma unroll
+      for (int a = 0; a < CC; ++a) X[a] += gj * col2[a];
+    }
+  } else {
+    X[0] += g0 * X[2];
+    X[1] += g1 * X[2];
   }
 #pragma unroll
   for (int a = 0; a < 3; ++a)
     if (a == ii) X[a] += o.rd[a];
 
+  // ---- sequential landmark updates ----
   double dm = 0.0;
 #pragma unroll
   for (int it = 0; it < MCAP; ++it) {
     const int kr = kb + 2 * it;
     if (it < m) {
-      const SolveIter& I = its[it];
+      const SolveIter& I = sIt[it];
       const int a0 = 3 + 2 * it;
-      const bool more = it + 1 < m;
       double2 hk[5];
 #pragma unroll
       for (int k = 0; k < 5; ++k) hk[k] = *reinterpret_cast<const double2*>(I.h5t[k]);
       const double2 s01 = *reinterpret_cast<const double2*>(&I.si[0]);
       const double2 s23 = *reinterpret_cast<const double2*>(&I.si[2]);
       const double2 yy = *reinterpret_cast<const double2*>(I.y);
-      constexpr bool PREFETCH = MCAP <= 8;
-      double2 uv[PREFETCH ? CC : 1];                   // K_j[C[a],:]
-      if (PREFETCH && more) {
-#pragma unroll
-        for (int a = 0; a < CC; ++a) uv[a] = *reinterpret_cast<const double2*>(I.kc[a]);
-      }
       double e0 = hk[0].x * X[0], e1 = hk[0].y * X[0];   // (H_j P_j)[:, i] = h5 . x[sel]
 #pragma unroll
       for (int k = 1; k < 5; ++k) {
@@ -649,26 +753,12 @@ __device__ __forceinline__ void panels_body(const double* __restrict__ Pb, doubl
         Wb[wm_index(ld16, kr, i)] = -f0;
         Wb[wm_index(ld16, kr + 1, i)] = -f1;
       }
-      if (more) {                                      // x[a] -= K_j[C[a],:] . (H_j P_j)[:, i]
-        if (PREFETCH) {
+      if (it + 1 < m) {                                // x[a] -= K_j[C[a],:] . (H_j P_j)[:, i]
 #pragma unroll
-          for (int a = 0; a < CC; ++a) X[a] = fma(-uv[a].x, e0, X[a]);
-#pragma unroll
-          for (int a = 0; a < CC; ++a) X[a] = fma(-uv[a].y, e1, X[a]);
-        } else {
-#pragma unroll
-          for (int c0 = 0; c0 < CC; c0 += 8) {
-            double2 u[8];
-#pragma unroll
-            for (int q = 0; q < 8; ++q)
-              if (c0 + q < CC) u[q] = *reinterpret_cast<const double2*>(I.kc[c0 + q]);
-#pragma unroll
-            for (int q = 0; q < 8; ++q)
-              if (c0 + q < CC) X[c0 + q] = fma(-u[q].x, e0, X[c0 + q]);
-#pragma unroll
-            for (int q = 0; q < 8; ++q)
-              if (c0 + q < CC) X[c0 + q] = fma(-u[q].y, e1, X[c0 + q]);
-          }
+        for (int a = 0; a < CC; ++a) {
+          const double2 kc = *reinterpret_cast<const double2*>(I.kc[a]);
+          X[a] = fma(-kc.x, e0, X[a]);
+          X[a] = fma(-kc.y, e1, X[a]);
         }
       }
     } else if (act) {
@@ -690,57 +780,9 @@ __device__ __forceinline__ void panels_body(const double* __restrict__ Pb, doubl
       Wb[wm_index(ld16, k, i)] = 0.0;
     }
     bool inC = false;
-    for (int a = 0; a < c; ++a) inC |= (Cs[a] == i);
-    if (!inC) mu_out_b[i] = mu_in_b[i] + dm;
+    for (int a = 0; a < c; ++a) inC |= (sC[a] == i);
+    if (!inC) mu_out_b[i] = mu_in_b[i] + dm;           // k_solve wrote the entries in C
   }
-}
-
-template <int MCAP>
-__global__ __launch_bounds__(256) void k_panels(const double* __restrict__ P, double* __restrict__ V,
-                                                double* __restrict__ W,
-                                                const double* __restrict__ mu_in,
-                                                double* __restrict__ mu_out,
-                                                const int* __restrict__ nact,
-                                                const SolveOut* __restrict__ so, int ld, long pstride) {
-  constexpr int CC = 3 + 2 * MCAP, KTP = ranks_for(MCAP);
-  __shared__ SolveIter its[MCAP];
-  __shared__ double Wc[CC][WCS];
-  __shared__ double Vc[KTOT][PCS];
-  __shared__ double Rs[CC][64];
-  __shared__ int Cs[CPAD];
-  __shared__ SolveHdr hdr;
-  const int b = blockIdx.y;
-  const int n = nact[b];
-  if ((int)blockIdx.x * 64 >= n) return;
-  const int tid = threadIdx.x;
-  const SolveOut& o = so[b];
-  const double* Pb = P + (long)b * pstride;
-  double* Vb = V + (long)b * KTOT * ld;
-  double* Wb = W + (long)b * KTOT * ld;
-  if ((int)blockIdx.x * 64 >= o.neff) {
-    const int i = blockIdx.x * 64 + (tid & 63);
-    panels_beyond_bound<KTP>(Vb, Wb, mu_in + (long)b * ld, mu_out + (long)b * ld, ld, o.kbase, i, i < n, tid >> 6);
-    return;
-  }
-  {
-    const int m = min(o.m, MCAP);
-    const double2* src = reinterpret_cast<const double2*>(o.it);
-    double2* dst = reinterpret_cast<double2*>(its);
-    const int count = m * (int)(sizeof(SolveIter) / 16);
-    for (int t = tid; t < count; t += 256) dst[t] = src[t];
-  }
-  if (tid < CPAD) Cs[tid] = (tid < CMAX + 1) ? o.C[tid] : 0;
-  if (tid == 0) {
-    SolveHdr h;
-    h.g[0] = o.g[0]; h.g[1] = o.g[1];
-    h.rd[0] = o.rd[0]; h.rd[1] = o.rd[1]; h.rd[2] = o.rd[2];
-    h.p22h = o.p22h;
-    h.dacc_old[0] = o.dacc_old[0]; h.dacc_old[1] = o.dacc_old[1]; h.dacc_old[2] = o.dacc_old[2];
-    h.c = o.c; h.m = o.m; h.kbase = o.kbase; h.neff = o.neff;
-    hdr = h;
-  }
-  __syncthreads();
-  panels_body<MCAP>(Pb, Vb, Wb, mu_in + (long)b * ld, mu_out + (long)b * ld, n, ld, its, Cs, hdr, Wc, Vc, Rs, false);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1141,29 +1183,35 @@ __global__ __launch_bounds__(256) void k_fill_diag(double* __restrict__ Pb, int 
 // ---------------------------------------------------------------------------------------------
 void launch_solve(hipStream_t st, const double* P, const double* V, const double* W, const double* dacc_in,
                   double* dacc_out, const double* mu_in, double* mu_out, const int* nact, const StepIn* in,
-                  SolveOut* out, unsigned* flags, const DeviceConfig& cfg, int ld, long pstride, int batch,
-                  int kbase) {
+                  SolveOut* out, unsigned* flags, double* fac, const DeviceConfig& cfg, int ld, long pstride,
+                  int batch, int kbase) {
   hipLaunchKernelGGL(k_solve, dim3(batch), dim3(256), 0, st, P, V, W, dacc_in, dacc_out, mu_in, mu_out, nact, in,
-                     out, flags, cfg, ld, pstride, kbase);
+                     out, flags, fac, cfg, ld, pstride, kbase);
 }
 
 template <int MCAP>
 static void launch_panels_t(hipStream_t st, const double* P, double* V, double* W, const double* mu_in,
-                            double* mu_out, const int* nact, const SolveOut* so, int ld, long pstride,
-                            int batch, int n_hi) {
-  hipLaunchKernelGGL(k_panels<MCAP>, dim3((n_hi + 63) / 64, batch), dim3(256), 0, st, P, V, W, mu_in,
-                     mu_out, nact, so, ld, pstride);
+                            double* mu_out, const int* nact, const SolveOut* so, const double* fac, int ld,
+                            long pstride, int batch, int n_hi) {
+  // throughput form: a workgroup is four independent waves of 64 state indices sharing one staging
+  const long waves = (long)((n_hi + 63) / 64) * batch;
+  if (waves <= 512)                                     // latency-bound: four waves split the pending ranks of 64 indices
+    hipLaunchKernelGGL((k_panels<MCAP, 4, true>), dim3((n_hi + 63) / 64, batch), dim3(256), 0, st, P, V, W, mu_in,
+                       mu_out, nact, so, fac, ld, pstride);
+  else
+    hipLaunchKernelGGL((k_panels<MCAP, 4, false>), dim3((n_hi + 255) / 256, batch), dim3(256), 0, st, P, V, W, mu_in,
+                       mu_out, nact, so, fac, ld, pstride);
 }
 
 void launch_panels(hipStream_t st, int mcap, const double* P, double* V, double* W, const double* mu_in,
-                   double* mu_out, const int* nact, const SolveOut* so, int ld, long pstride, int batch,
-                   int n_hi) {
+                   double* mu_out, const int* nact, const SolveOut* so, const double* fac, int ld, long pstride,
+                   int batch, int n_hi) {
   switch (mcap) {
-    case 1: launch_panels_t<1>(st, P, V, W, mu_in, mu_out, nact, so, ld, pstride, batch, n_hi); break;
-    case 2: launch_panels_t<2>(st, P, V, W, mu_in, mu_out, nact, so, ld, pstride, batch, n_hi); break;
-    case 4: launch_panels_t<4>(st, P, V, W, mu_in, mu_out, nact, so, ld, pstride, batch, n_hi); break;
-    case 8: launch_panels_t<8>(st, P, V, W, mu_in, mu_out, nact, so, ld, pstride, batch, n_hi); break;
-    default: launch_panels_t<16>(st, P, V, W, mu_in, mu_out, nact, so, ld, pstride, batch, n_hi); break;
+    case 1: launch_panels_t<1>(st, P, V, W, mu_in, mu_out, nact, so, fac, ld, pstride, batch, n_hi); break;
+    case 2: launch_panels_t<2>(st, P, V, W, mu_in, mu_out, nact, so, fac, ld, pstride, batch, n_hi); break;
+    case 4: launch_panels_t<4>(st, P, V, W, mu_in, mu_out, nact, so, fac, ld, pstride, batch, n_hi); break;
+    case 8: launch_panels_t<8>(st, P, V, W, mu_in, mu_out, nact, so, fac, ld, pstride, batch, n_hi); break;
+    default: launch_panels_t<16>(st, P, V, W, mu_in, mu_out, nact, so, fac, ld, pstride, batch, n_hi); break;
   }
 }
 
