@@ -12,7 +12,7 @@
 namespace ekf {
 void launch_solve(hipStream_t, const double*, const double*, const double*, const double*, double*, const double*,
                   double*, const int*, const StepIn*, SolveOut*, unsigned*, double*, const DeviceConfig&, int, long, int, int);
-void launch_panels(hipStream_t, int, const double*, double*, double*, const double*, double*, const int*,
+void launch_panels(hipStream_t, int, double*, double*, double*, const double*, double*, const int*,
                    const SolveOut*, const double*, int, long, int, int);
 void launch_flush(hipStream_t, bool, double*, const double*, const double*, const double*, const int*,
                   const SolveOut*, int, long, int, int, int, int);
@@ -72,6 +72,8 @@ struct ekf_handle {
   bool profile = false;
   std::vector<hipEvent_t> prof_pool;
   size_t prof_used = 0;
+  int opt_rank_limit = 64;        // automatic cadence: flush when the next step would exceed this many ranks
+                                  // (16 MFMA k-tiles: the largest k_flush instantiation without register spills)
   int opt_rows_per_block = 0;     // 0 = auto (flush kernel: rows per workgroup, multiple of 16)
   int opt_flush_every = 0;        // 0 = auto; k = flush the pending low-rank update after k steps
   int opt_streaming = -1;         // -1 = auto (by working-set size), 0 = resident kernel, 1 = nontemporal kernel
@@ -449,9 +451,8 @@ static int enqueue_pass(ekf_handle* h, const StepIn* d_in, int m_hi) {
   h->pending_k += ktp;
   h->pending_steps += 1;
   // cadence of the covariance pass: a fixed number of steps if asked for, otherwise as many steps as fit
-  // 72 pending ranks (18 MFMA k-tiles: the largest k_flush instantiation that keeps 2 waves/SIMD without
-  // spilling) -- 4 steps at m = 8, 7 at m = 4, 18 at m = 1
-  const bool due = h->opt_flush_every > 0 ? h->pending_steps >= h->opt_flush_every : h->pending_k + ktp > 72;
+  // `rank_limit` pending ranks (default 64) -- 4 steps at m = 8, 8 at m = 4, 32 at m = 1
+  const bool due = h->opt_flush_every > 0 ? h->pending_steps >= h->opt_flush_every : h->pending_k + ktp > h->opt_rank_limit;
   if (due || h->pending_k + 2 > KTOT)
     if (int rc = flush_pending(h)) return rc;
   return EKF_OK;
@@ -833,6 +834,11 @@ extern "C" int ekf_profile_read(ekf_handle* h, double* pass_ms_total, long long*
 
 extern "C" int ekf_set_option(ekf_handle* h, const char* name, int value) {
   if (!h || !name) return EKF_ERR_ARG;
+  if (std::strcmp(name, "rank_limit") == 0) {
+    if (value < 2 || value > KTOT) return fail(h, EKF_ERR_ARG, "rank_limit out of range");
+    h->opt_rank_limit = value;
+    return EKF_OK;
+  }
   if (std::strcmp(name, "pass_rows_per_block") == 0) {
     if (value < 0 || value > 4096) return fail(h, EKF_ERR_ARG, "pass_rows_per_block out of range");
     h->opt_rows_per_block = value;

@@ -11,9 +11,10 @@ constexpr int CMAX = 3 + 2 * MMAX;      // compressed sub-state size (35)
 constexpr int KTOT = 80;                // rank slots of the deferred low-rank update  P = P_base + W V
 constexpr int NKT = KTOT / 4;           // the same in MFMA k-tiles (v_mfma_f64_16x16x4)
 
-// ranks one step appends: 2m (landmark updates) + 2 (motion Jacobian); steps are packed back to back and
-// only the total is padded to a whole k-tile (the step that is last so far zero-fills the pad ranks)
-__host__ __device__ constexpr int ranks_for(int mcap) { return 2 * mcap + 2; }
+// ranks one step appends: 2 per observed landmark (the prediction only changes rows 0,1 of the stored
+// triangle and is applied to P_base directly); steps are packed back to back and only the total is padded
+// to a whole k-tile (the step that is last so far zero-fills the pad ranks)
+__host__ __device__ constexpr int ranks_for(int mcap) { return 2 * mcap; }
 
 constexpr int FLAG_PREDICT = 1;         // StepIn.flags
 constexpr int FLAG_UPDATE = 2;
@@ -59,6 +60,7 @@ struct alignas(16) SolveOut {
   int kbase;            // ranks pending before this step (multiple of 4)
   int neff;             // active bound of this step (rows/cols >= neff of P are untouched diagonal)
   int C[CMAX + 1];      // gathered state indices, padded with 0
+  double prow[2][CMAX + 1];   // P(0, C[a]) and P(1, C[a]) before the step (what state indices 0,1 gather)
   SolveIter it[MMAX];
 #ifdef EKF_STAMPS
   unsigned long long stamps[128];   // diagnostic build only (tools/solve_probe.hip)

@@ -298,6 +298,10 @@ __device__ __forceinline__ void solve_body(SolveLds& L, const double* __restrict
   // P'[C,C] = Gc P[C,C] Gc^T + Rt  (:428-430 restricted to C), column `lane` in registers:
   // row ops on rows 0,1; column ops need column 2 of the row-updated matrix (lane 2's registers).
   const double p22 = __shfl(pcol[2], 2);
+  if (writer && lane < CMAX + 1) {                     // rows 0,1 of the gathered block before the step: the panel
+    o.prow[0][lane] = on ? pcol[0] : 0.0;              // kernel's state indices 0,1 start from these (their own
+    o.prow[1][lane] = on ? pcol[1] : 0.0;              // gather would race with the row update of other columns)
+  }
   pcol[0] += g0 * pcol[2];
   pcol[1] += g1 * pcol[2];
   if (lane == 2) {                                   // X[:,2] after the row ops, for the column ops
@@ -508,22 +512,21 @@ __global__ __launch_bounds__(256) void k_solve(const double* __restrict__ P, con
 //   gather     x[a] = P_base(min(C[a],i), max(C[a],i)) + pending ranks:  sum_k W[C[a]][k] V[k][i]  where the
 //              entry is stored as (C[a], i), else  sum_k W[i][k] V[k][C[a]]   (its mirror);  V[:,i] and W[i,:]
 //              are coalesced vector loads (8 ranks at a time, the next 8 in flight under the FMAs)
-//   predict    P' = G_F P G_F^T + F^T R F on the panel (src/replay_no_ros.py:430)
+//   predict    P' = G_F P G_F^T + F^T R F on the panel (src/replay_no_ros.py:430); of the stored triangle it
+//              changes rows 0,1 only, and thread i adds its two entries to P_base in place
 //   m updates  u = (H_j P_j)[:, i] = h5 . x[sel];  K_j[i,:] = u^T S_j^-1;  x -= K_j[C,:] u   (:473-480)
 //              appended ranks  V[kb+2j..][i] = u,  W[i][kb+2j..] = -K_j[i,:];  mean += K_j[i,:] y_j  (:476)
-//   the two rank-1 pairs of the motion Jacobian go to ranks kb+2*MCAP, +1:
-//              V = q, W = gt   and   V = gt, W = q   with q = P(2,:) + p22h*gt
 // A workgroup is NW independent waves of 64 state indices.  What they share (the per-landmark records of
 // k_solve and its compact copy of the factors at C) is staged into LDS once, with one round of loads, and
 // then read as 16-byte broadcasts; after the single barrier the waves never synchronise again.
 // ---------------------------------------------------------------------------------------------
 template <int MCAP, int NW, bool KSPLIT>
-__global__ __launch_bounds__(64 * NW) void k_panels(const double* __restrict__ P, double* __restrict__ V,
+__global__ __launch_bounds__(64 * NW) void k_panels(double* __restrict__ P, double* __restrict__ V,
                                                     double* __restrict__ W, const double* __restrict__ mu_in,
                                                     double* __restrict__ mu_out, const int* __restrict__ nact,
                                                     const SolveOut* __restrict__ so,
                                                     const double* __restrict__ fac, int ld, long pstride) {
-  constexpr int CC = 3 + 2 * MCAP, K2 = 2 * MCAP, KTP = ranks_for(MCAP), NT = 64 * NW;
+  constexpr int CC = 3 + 2 * MCAP, KTP = ranks_for(MCAP), NT = 64 * NW;
   __shared__ __attribute__((aligned(16))) double sF[2][CC][KTOT];   // [0]: W[C[a]][k], [1]: V[k][C[a]]
   __shared__ SolveIter sIt[MCAP];
   __shared__ int sC[CC + 1];
@@ -536,7 +539,7 @@ __global__ __launch_bounds__(64 * NW) void k_panels(const double* __restrict__ P
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int ld16 = ld >> 4;
-  const double* Pb = P + (long)b * pstride;
+  double* Pb = P + (long)b * pstride;
   double* Vb = V + (long)b * KTOT * ld;
   double* Wb = W + (long)b * KTOT * ld;
   const double* mu_in_b = mu_in + (long)b * ld;
@@ -699,25 +702,40 @@ __global__ __launch_bounds__(64 * NW) void k_panels(const double* __restrict__ P
     if (ii == a) X[a] += o.dacc_old[a];                // pending pose-block noise on the diagonal
 
   // ---- predict:  P' = G_F P G_F^T + F^T R F  (src/replay_no_ros.py:430) on the panel ----
+  // Of the stored triangle it changes rows 0 and 1 only: thread i adds its two entries to P_base directly
+  // (the pending ranks are unaffected), so the prediction costs no rank of the covariance pass.
   const double g0 = o.g[0], g1 = o.g[1];
   const double gj = (ii == 0) ? g0 : ((ii == 1) ? g1 : 0.0);
-  const double raw2 = X[2];                            // P(2, i)
-  if (i0 == 0) {                                       // lanes 0,1 hold columns 0,1: column op += g_i * X[:,2]
+  double d0, d1;                                       // P'(0,i) - P(0,i),  P'(1,i) - P(1,i)
+  if (i0 == 0) {
+    if (lane < 2) {                                    // rows 0,1 of P_base are being rewritten by the other columns:
+#pragma unroll
+      for (int a = 0; a < CC; ++a) X[a] = o.prow[lane][a];   // state indices 0,1 take k_solve's gather
+    }
     const double p22 = __shfl(X[2], 2);
-    double col2[CC];
+    double col2[CC];                                   // X[:,2] after the row ops, for the column ops of lanes 0,1
 #pragma unroll
     for (int a = 0; a < CC; ++a) col2[a] = __shfl(X[a], 2);
     col2[0] += g0 * p22;
     col2[1] += g1 * p22;
-    X[0] += g0 * X[2];                                 // row ops on rows 0,1
-    X[1] += g1 * X[2];
+    d0 = g0 * X[2];                                    // row ops on rows 0,1
+    d1 = g1 * X[2];
     if (ii < 2) {
+      d0 += gj * col2[0];
+      d1 += gj * col2[1];
 #pragma unroll
-      for (int a = 0; a < CC; ++a) X[a] += gj * col2[a];
+      for (int a = 2; a < CC; ++a) X[a] += gj * col2[a];
     }
   } else {
-    X[0] += g0 * X[2];
-    X[1] += g1 * X[2];
+    d0 = g0 * X[2];
+    d1 = g1 * X[2];
+  }
+  X[0] += d0;
+  X[1] += d1;
+  if (act) {
+    double* p0 = Pb + i;                               // entry (0, i)
+    *p0 += d0;
+    if (i >= 1) p0[ld] += d1;                          // entry (1, i); (1, 0) lies below the diagonal
   }
 #pragma unroll
   for (int a = 0; a < 3; ++a)
@@ -769,12 +787,6 @@ __global__ __launch_bounds__(64 * NW) void k_panels(const double* __restrict__ P
     }
   }
   if (act) {
-    const int kp = kb + K2;
-    const double q2 = raw2 + o.p22h * gj;
-    Vb[(long)kp * ld + i] = q2;
-    Vb[(long)(kp + 1) * ld + i] = gj;
-    Wb[wm_index(ld16, kp, i)] = gj;
-    Wb[wm_index(ld16, kp + 1, i)] = q2;
     for (int k = kb + KTP; k < ((kb + KTP + 3) & ~3); ++k) {   // k-tile pad
       Vb[(long)k * ld + i] = 0.0;
       Wb[wm_index(ld16, k, i)] = 0.0;
@@ -1190,7 +1202,7 @@ void launch_solve(hipStream_t st, const double* P, const double* V, const double
 }
 
 template <int MCAP>
-static void launch_panels_t(hipStream_t st, const double* P, double* V, double* W, const double* mu_in,
+static void launch_panels_t(hipStream_t st, double* P, double* V, double* W, const double* mu_in,
                             double* mu_out, const int* nact, const SolveOut* so, const double* fac, int ld,
                             long pstride, int batch, int n_hi) {
   // throughput form: a workgroup is four independent waves of 64 state indices sharing one staging
@@ -1203,7 +1215,7 @@ static void launch_panels_t(hipStream_t st, const double* P, double* V, double* 
                        mu_out, nact, so, fac, ld, pstride);
 }
 
-void launch_panels(hipStream_t st, int mcap, const double* P, double* V, double* W, const double* mu_in,
+void launch_panels(hipStream_t st, int mcap, double* P, double* V, double* W, const double* mu_in,
                    double* mu_out, const int* nact, const SolveOut* so, const double* fac, int ld, long pstride,
                    int batch, int n_hi) {
   switch (mcap) {
@@ -1235,10 +1247,10 @@ void launch_flush(hipStream_t st, bool streaming, double* P, const double* V, co
     if (streaming) launch_flush_t<N, true>(st, P, V, W, dacc, nact, so, ld, pstride, batch, n_hi, nkt, rows_per_block); \
     else launch_flush_t<N, false>(st, P, V, W, dacc, nact, so, ld, pstride, batch, n_hi, nkt, rows_per_block);          \
   } while (0)
-  if (nkt <= 5) EKF_FLUSH(5);
-  else if (nkt <= 9) EKF_FLUSH(9);
-  else if (nkt <= 14) EKF_FLUSH(14);
-  else if (nkt <= 18) EKF_FLUSH(18);
+  if (nkt <= 4) EKF_FLUSH(4);
+  else if (nkt <= 8) EKF_FLUSH(8);
+  else if (nkt <= 12) EKF_FLUSH(12);
+  else if (nkt <= 16) EKF_FLUSH(16);
   else EKF_FLUSH(20);
 #undef EKF_FLUSH
 }
