@@ -186,7 +186,8 @@ def main():
         avg_s = (pass_ms / max(launches, 1)) * 1e-3
         achieved = alg_bytes / avg_s / 1e9 if avg_s > 0 else 0.0
         steps_per_launch = args.steps / max(launches, 1)
-        ranks = steps_per_launch * (2 * args.obs + 2)
+        mcap = next(c for c in (1, 2, 4, 8, 16) if c >= min(args.obs, 16))   # rank slots a step takes: 2 per landmark,
+        ranks = steps_per_launch * 2 * mcap                                   # landmark count rounded up to 1/2/4/8/16
         out = {
             "metric": "EKF update steps/sec", "value": value, "unit": "steps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -212,7 +213,7 @@ def main():
                                  "SURVEY 8(d)'s 16 n^2 bytes per step become 8 n(n+1) bytes per LAUNCH; achieved/frac "
                                  "count the bytes this launch must move (one read + one write of the triangle), "
                                  "step_equivalent_GBs = SURVEY's 16 n^2 per step x steps folded in / launch time; "
-                                 "at 4 steps (72 ranks) per launch the kernel sits on the ridge (2K flop per 16 B), "
+                                 "at 4 steps (64 ranks) per launch the kernel is bound by the fp64 matrix cores (2K flop per 16 B), "
                                  "see `mfma`"},
             "device_ms_per_step": dev_ms / args.steps,
         }

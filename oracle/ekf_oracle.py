@@ -407,6 +407,118 @@ def ekf_step_structured(mean, cov, lin, ang, idx, ranges, bearings, cfg: EkfConf
     return new_mean, new_cov
 
 
+class DeferredSymmetricFilter:
+    """NumPy restatement of the algebra the HIP kernels run (DESIGN.md "Formulation"), for the CPU tests.
+
+    The covariance is symmetric and only its upper triangle is stored; pending low-rank terms are folded
+    into the stored matrix once every few steps:
+
+        P(a, b) = B[a, b] + sum_k W[a, k] V[k, b] + [a == b < 3] dacc[a]      for a <= b,   P(b, a) := P(a, b)
+
+    One step (reference lines in src/replay_no_ros.py):
+      * gather x[a, i] = P(C[a], i) for the c = 3+2m gathered rows C = [0,1,2, t_0,t_0+1, ...]  (k_solve / k_panels)
+      * prediction P' = G_F P G_F^T + F^T R F (:430) changes rows 0,1 of the stored triangle only; those
+        entries are added to B in place, the pose noise joins dacc
+      * per observed landmark j (sequential, :436-480):  u = H_j P_j (rows from the panel),
+        S = u[:, sel] h5^T + Q,  K_j = u^T S^-1  (P symmetric, so P H^T is the transpose of H P),
+        mean += K_j y_j (:476),  panel -= K_j[C] u (:480),  appended ranks V = u, W = -K_j
+      * flush: B[a, b] += W[a, :] V[:, b] on the upper triangle, B[a, a] += dacc[a]  (k_flush)
+    The lower triangle of B is kept at NaN so that any read below the diagonal poisons the result.
+    """
+
+    def __init__(self, mean, cov_diag, cfg: EkfConfig, rank_limit: int = 64):
+        n = len(mean)
+        self.n, self.cfg, self.rank_limit = n, cfg, rank_limit
+        self.mean = np.array(mean, dtype=float)
+        self.B = np.full((n, n), np.nan)
+        self.B[np.triu_indices(n)] = 0.0
+        self.B[np.arange(n), np.arange(n)] = cov_diag
+        self.W = np.zeros((n, 0))
+        self.V = np.zeros((0, n))
+        self.dacc = np.zeros(3)
+
+    def _gather(self, C):
+        ar = np.arange(self.n)
+        X = np.empty((len(C), self.n))
+        for a, ca in enumerate(C):
+            lo, hi = np.minimum(ca, ar), np.maximum(ca, ar)
+            X[a] = self.B[lo, hi]
+            if self.W.shape[1]:
+                X[a] += np.einsum("ik,ki->i", self.W[lo, :], self.V[:, hi])
+            if ca < 3:
+                X[a, ca] += self.dacc[ca]
+        return X
+
+    def flush(self):
+        if self.W.shape[1]:
+            iu = np.triu_indices(self.n)
+            self.B[iu] += (self.W @ self.V)[iu]
+        for a in range(3):
+            self.B[a, a] += self.dacc[a]
+        self.W, self.V, self.dacc = np.zeros((self.n, 0)), np.zeros((0, self.n)), np.zeros(3)
+
+    def covariance(self):
+        self.flush()
+        up = np.triu(self.B)
+        return up + np.triu(self.B, 1).T
+
+    def step(self, lin, ang, idx, ranges, bearings):
+        cfg, n = self.cfg, self.n
+        idx = [int(j) for j in idx] if cfg.enable_measurement_model else []
+        m = len(idx)
+        if self.W.shape[1] + 2 * m > self.rank_limit:
+            self.flush()
+        C = [0, 1, 2]
+        for j in idx:
+            C += [3 + 2 * j, 4 + 2 * j]
+        C = np.array(C)
+        X = self._gather(C)
+        pose, G = motion_model(self.mean[0:3], lin, ang, cfg)
+        mu = self.mean.copy()
+        if not cfg.disable_motion_model:
+            mu[0:3] = pose
+        g0, g1 = G[0, 2], G[1, 2]
+        # prediction on the panel: row ops on rows 0,1, then the column ops of columns 0,1
+        d0, d1 = g0 * X[2], g1 * X[2]
+        col2 = X[:, 2].copy()
+        col2[0] += g0 * X[2, 2]
+        col2[1] += g1 * X[2, 2]
+        d0[0] += g0 * col2[0]
+        d0[1] += g1 * col2[0]
+        d1[0] += g0 * col2[1]
+        d1[1] += g1 * col2[1]
+        X[2:, 0] += g0 * col2[2:]
+        X[2:, 1] += g1 * col2[2:]
+        X[0] += d0
+        X[1] += d1
+        self.B[0, :] += d0                                   # entries (0, i)
+        self.B[1, 1:] += d1[1:]                              # entries (1, i), i >= 1
+        rd = cfg.motion_noise_diag()
+        for a in range(3):
+            X[a, a] += rd[a]
+        self.dacc += rd
+        Qd = cfg.meas_noise_diag()
+        Wn, Vn = np.zeros((n, 2 * m)), np.zeros((2 * m, n))
+        for j in range(m):
+            a = 3 + 2 * j
+            sel = [0, 1, 2, a, a + 1]
+            y, h5 = innovation_and_h5(mu[0:3], mu[C[a]:C[a] + 2], ranges[j], bearings[j])
+            u = h5 @ X[sel, :]
+            S = u[:, C[sel]] @ h5.T
+            S[0, 0] += Qd[0]
+            S[1, 1] += Qd[1]
+            det = S[0, 0] * S[1, 1] - S[0, 1] * S[1, 0]
+            Si = np.array([[S[1, 1], -S[0, 1]], [-S[1, 0], S[0, 0]]]) / det
+            K = u.T @ Si
+            mu = mu + K @ y
+            X = X - K[C] @ u
+            Vn[2 * j:2 * j + 2] = u
+            Wn[:, 2 * j:2 * j + 2] = -K
+        self.W = np.concatenate([self.W, Wn], axis=1)
+        self.V = np.concatenate([self.V, Vn], axis=0)
+        self.mean = mu
+
+
 # --------------------------------------------------------------------------
 # Synthetic stream of SURVEY.md section 8(d) / BASELINE.md section 3
 # --------------------------------------------------------------------------

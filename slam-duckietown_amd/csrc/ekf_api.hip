@@ -373,7 +373,7 @@ static int cap_for(int m) { return m <= 1 ? 1 : m <= 2 ? 2 : m <= 4 ? 4 : m <= 8
 // the block must be long where many ranks are pending, and short enough to give every CU several waves.
 static int flush_rows_per_block(const ekf_handle* h, bool streaming) {
   if (h->opt_rows_per_block > 0) return (h->opt_rows_per_block + 15) / 16 * 16;
-  return streaming ? 256 : 128;
+  return streaming ? 256 : 96;
 }
 
 // The covariances of the batch stream through HBM when they cannot stay in the 256 MiB Infinity Cache.

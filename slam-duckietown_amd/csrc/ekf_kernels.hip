@@ -840,7 +840,7 @@ __device__ __forceinline__ void st2(double* a, double2 v) {
 
 constexpr int FTS = 80;                 // LDS row stride of a wave's 16 x 64 tile image (doubles)
 
-template <int NKTM, bool NT>
+template <int NKTM, int NKL, bool NT>
 __global__ __launch_bounds__(256, 2) void k_flush(double* __restrict__ P, const double* __restrict__ V,
                                                   const double* __restrict__ W,
                                                   const double* __restrict__ dacc,
@@ -848,6 +848,9 @@ __global__ __launch_bounds__(256, 2) void k_flush(double* __restrict__ P, const 
                                                   const SolveOut* __restrict__ so, int ld, long pstride,
                                                   int nkt, int rows_per_block, int gx) {
   __shared__ double tiles[4][16 * FTS];
+  // k-tiles NKTM.. of the V strip live in LDS (B fragments, lane-linear): the register file holds 16 k-tiles
+  // at 2 waves/SIMD, the remaining LDS holds 4 more per wave
+  __shared__ double vlds[NKL > 0 ? 4 : 1][NKL > 0 ? NKL * 4 * 64 : 1];
   const int b = blockIdx.z;
   const int n = min(nact[b], so[b].neff);              // rows/cols beyond the active bound are untouched
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -893,6 +896,16 @@ __global__ __launch_bounds__(256, 2) void k_flush(double* __restrict__ P, const 
 #pragma unroll
     for (int ct = 0; ct < 4; ++ct)
       vf[t][ct] = (t < nkt && ct < nct) ? Vb[(long)(4 * t + lq) * ld + j0 + ct * 16 + li] : 0.0;
+  double* VL = vlds[NKL > 0 ? wave : 0];
+  if (NKL > 0) {
+#pragma unroll
+    for (int t = 0; t < NKL; ++t)
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct)
+        VL[(t * 4 + ct) * 64 + lane] =
+            (NKTM + t < nkt && ct < nct) ? Vb[(long)(4 * (NKTM + t) + lq) * ld + j0 + ct * 16 + li] : 0.0;
+    WAVE_SYNC();
+  }
 
   double2 g[8];                                        // row-major registers of the tile in flight
   auto gload = [&](int i0) {
@@ -936,6 +949,18 @@ __global__ __launch_bounds__(256, 2) void k_flush(double* __restrict__ P, const 
         for (int ct = 0; ct < 4; ++ct)
           acc[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(wf[t - WH], vf[t][ct], acc[ct], 0, 0, 0);
       }
+    if (NKL > 0) {                                     // k-tiles whose B fragments come from LDS
+      double wl[NKL > 0 ? NKL : 1];
+#pragma unroll
+      for (int t = 0; t < NKL; ++t) wl[t] = (NKTM + t < nkt) ? wsrc[(long)(NKTM + t) * ld16 * 64] : 0.0;
+#pragma unroll
+      for (int t = 0; t < NKL; ++t)
+        if (NKTM + t < nkt) {
+#pragma unroll
+          for (int ct = 0; ct < 4; ++ct)
+            acc[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(wl[t], VL[(t * 4 + ct) * 64 + lane], acc[ct], 0, 0, 0);
+        }
+    }
     if (i0 == 0 && j0 == 0) {                          // pose-block noise accumulated since the last flush
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -1227,14 +1252,14 @@ void launch_panels(hipStream_t st, int mcap, double* P, double* V, double* W, co
   }
 }
 
-template <int NKTM, bool NT>
+template <int NKTM, int NKL, bool NT>
 static void launch_flush_t(hipStream_t st, double* P, const double* V, const double* W, const double* dacc,
                            const int* nact, const SolveOut* so, int ld, long pstride, int batch, int n_hi,
                            int nkt, int rows_per_block) {
   const int gx = (n_hi + 255) / 256, gy = (n_hi + rows_per_block - 1) / rows_per_block;
   int total = 0;                                       // workgroups that reach the upper triangle
   for (int by = 0; by < gy; ++by) total += std::max(0, gx - (by * rows_per_block) / 256);
-  hipLaunchKernelGGL((k_flush<NKTM, NT>), dim3(total, 1, batch), dim3(256), 0, st, P, V, W, dacc, nact, so, ld,
+  hipLaunchKernelGGL((k_flush<NKTM, NKL, NT>), dim3(total, 1, batch), dim3(256), 0, st, P, V, W, dacc, nact, so, ld,
                      pstride, nkt, rows_per_block, gx);
 }
 
@@ -1242,16 +1267,16 @@ static void launch_flush_t(hipStream_t st, double* P, const double* V, const dou
 void launch_flush(hipStream_t st, bool streaming, double* P, const double* V, const double* W,
                   const double* dacc, const int* nact, const SolveOut* so, int ld, long pstride, int batch,
                   int n_hi, int nkt, int rows_per_block) {
-#define EKF_FLUSH(N)                                                                                      \
+#define EKF_FLUSH(N, L)                                                                                   \
   do {                                                                                                    \
-    if (streaming) launch_flush_t<N, true>(st, P, V, W, dacc, nact, so, ld, pstride, batch, n_hi, nkt, rows_per_block); \
-    else launch_flush_t<N, false>(st, P, V, W, dacc, nact, so, ld, pstride, batch, n_hi, nkt, rows_per_block);          \
+    if (streaming) launch_flush_t<N, L, true>(st, P, V, W, dacc, nact, so, ld, pstride, batch, n_hi, nkt, rows_per_block); \
+    else launch_flush_t<N, L, false>(st, P, V, W, dacc, nact, so, ld, pstride, batch, n_hi, nkt, rows_per_block);          \
   } while (0)
-  if (nkt <= 4) EKF_FLUSH(4);
-  else if (nkt <= 8) EKF_FLUSH(8);
-  else if (nkt <= 12) EKF_FLUSH(12);
-  else if (nkt <= 16) EKF_FLUSH(16);
-  else EKF_FLUSH(20);
+  if (nkt <= 4) EKF_FLUSH(4, 0);
+  else if (nkt <= 8) EKF_FLUSH(8, 0);
+  else if (nkt <= 12) EKF_FLUSH(12, 0);
+  else if (nkt <= 16) EKF_FLUSH(16, 0);
+  else EKF_FLUSH(16, 4);
 #undef EKF_FLUSH
 }
 

@@ -125,3 +125,34 @@ def test_odometry():
         r = orc.delta_phi(int(c), int(d), int(g["resolution"]))
         assert (l, r) == tuple(dphi)
         assert orc.displacement(float(g["wheel_radius"]), float(g["baseline"]), l, r) == tuple(disp)
+
+
+# ---------------------------------------------------------------------------------------------
+# the algebra the HIP kernels run (upper triangle + deferred ranks), restated in NumPy
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("case,rank_limit", [("stream_n20_m8", 64), ("stream_n20_m8", 16), ("stream_n20_m1", 64),
+                                             ("stream_n50_m8", 48)])
+def test_deferred_symmetric_restatement_golden(case, rank_limit):
+    g = gu.load(case)
+    f = orc.DeferredSymmetricFilter(g["mean0"], g["diag0"], orc.EkfConfig(), rank_limit)
+    kept = {int(s): i for i, s in enumerate(g["out_cov_steps"])}
+    for k in range(len(g["lin"])):
+        f.step(g["lin"][k], g["ang"][k], g["idx"][k], g["zr"][k], g["zb"][k])
+        assert orc.rel_fro(f.mean, g["out_mean"][k]) < TOL_S
+        if k in kept:
+            assert orc.rel_fro(f.covariance(), g["out_cov"][kept[k]]) < TOL_S
+
+
+def test_deferred_symmetric_long_run_stays_on_the_dense_path():
+    """1500 steps: no drift between the symmetric deferred form and the reference-shaped dense update."""
+    N, steps, m = 20, 1500, 8
+    mean0, diag0, lin, ang, idx, zr, zb = orc.synthetic_stream(N, steps, m, 2)
+    cfg = orc.EkfConfig()
+    f = orc.DeferredSymmetricFilter(mean0, diag0, cfg)
+    om, oP = mean0.copy(), np.diag(diag0)
+    for k in range(steps):
+        om, oP = orc.ekf_step_dense(om, oP, lin[k], ang[k], idx[k], zr[k], zb[k], cfg)
+        f.step(lin[k], ang[k], idx[k], zr[k], zb[k])
+        if k % 250 == 249:
+            assert orc.rel_fro(f.mean, om) < 1e-10
+            assert orc.rel_fro(f.covariance(), oP) < 1e-10
