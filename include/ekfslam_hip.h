@@ -59,7 +59,10 @@ int ekf_device_count(int *count);
 int ekf_create(int device, int n_max, int batch, const ekf_config *cfg, ekf_handle **out);
 int ekf_destroy(ekf_handle *h);
 
-/* Whole state in / out for trajectory b (checkpoint, parity checks).  Blocking. */
+/* Whole state in / out for trajectory b (checkpoint, parity checks).  Blocking.
+ * A covariance is symmetric: the device keeps its upper triangle only, so of an uploaded P the upper
+ * triangle is authoritative, and a download returns that triangle mirrored (the reference's own Sigma is
+ * symmetric to rounding). */
 int ekf_upload_state(ekf_handle *h, int b, const double *mu, const double *P, int n);
 int ekf_upload_state_diag(ekf_handle *h, int b, const double *mu, const double *diagP, int n);
 int ekf_download_state(ekf_handle *h, int b, double *mu, double *P, int n);
@@ -113,10 +116,11 @@ int ekf_run_stream(ekf_handle *h, int steps, const double *lin, const double *an
  * arbitrary Jacobian. */
 int ekf_predict_dense(ekf_handle *h, int b, const double *F, const double *Q);
 
-/* The covariance is held as P_base + (pending low-rank update of the last few steps); the O(n^2) pass
- * over P_base is paid once per `flush_every` steps (option; default 0 = as many steps as fit 72 pending
- * ranks: 4 steps at 8 observations per step, 18 at one).  ekf_flush applies what is
- * pending now (asynchronous).  Every call that reads or rewrites the covariance flushes by itself. */
+/* The covariance is held as P_base + (pending low-rank update of the last few steps, 2 ranks per observed
+ * landmark); the O(n^2) pass over P_base is paid once per `flush_every` steps (option; default 0 = as many
+ * steps as fit `rank_limit` = 64 pending ranks: 4 steps at 8 observations per step, 32 at one).  ekf_flush
+ * applies what is pending now (asynchronous).  Every call that reads or rewrites the covariance flushes by
+ * itself. */
 int ekf_flush(ekf_handle *h);
 int ekf_sync(ekf_handle *h);
 int ekf_status_flags(ekf_handle *h, int b, unsigned *flags);
@@ -130,8 +134,9 @@ int ekf_timer_end(ekf_handle *h, double *elapsed_ms);          /* synchronises *
 /* When enabled every launch of the covariance pass (flush) kernel is bracketed by an event pair. */
 int ekf_profile_enable(ekf_handle *h, int on);
 int ekf_profile_read(ekf_handle *h, double *pass_ms_total, long long *pass_launches); /* and resets */
-/* Tuning knobs: "flush_every" (steps per covariance pass, 0 = auto), "pass_rows_per_block",
- * "pass_streaming" (-1 auto / 0 resident / 1 nontemporal); unknown names fail. */
+/* Tuning knobs: "flush_every" (steps per covariance pass, 0 = auto), "rank_limit" (auto cadence: pending
+ * ranks that trigger the pass, 2..80), "pass_rows_per_block", "pass_streaming" (-1 auto / 0 resident /
+ * 1 nontemporal), "active_bound" (0 = treat every state index as correlated); unknown names fail. */
 int ekf_set_option(ekf_handle *h, const char *name, int value);
 
 #ifdef __cplusplus
