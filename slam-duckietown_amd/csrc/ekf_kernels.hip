@@ -643,34 +643,51 @@ __global__ __launch_bounds__(64 * NW) void k_panels(double* __restrict__ P, doub
   for (int k0 = 8 * kw; k0 < kb; k0 += KSTEP) {
     double vn[8], wn[8];
     if (k0 + KSTEP < kb) load_vw(k0 + KSTEP, vn, wn);
+    // four gathered rows at a time: their 16 coefficient reads are in flight together, and each row's eight
+    // FMAs run as two independent chains (the branch per row is wave-uniform)
 #pragma unroll
-    for (int a = 0; a < CC; ++a) {
-      if (a < c) {
-        const int row = sC[a];
-        const double2* wa = reinterpret_cast<const double2*>(&sF[0][a][k0]);
-        const double2* va = reinterpret_cast<const double2*>(&sF[1][a][k0]);
-        if (row <= i0) {                               // stored as (C[a], i) for the whole wave
+    for (int g = 0; g < CC; g += 4) {
+      double cf[4][8];                                 // (plain doubles: arrays of double2 end up in scratch)
 #pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const double2 f = wa[u];
-            X[a] = fma(f.x, v[2 * u], X[a]);
-            X[a] = fma(f.y, v[2 * u + 1], X[a]);
+      for (int q = 0; q < 4; ++q) {
+        const int a = min(g + q, CC - 1);              // (rows c.. of a short step hold stale, unused data)
+        const double2* src = reinterpret_cast<const double2*>(&sF[sC[a] <= i0 ? 0 : 1][a][k0]);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const double2 t = src[u];
+          cf[q][2 * u] = t.x;
+          cf[q][2 * u + 1] = t.y;
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int a = g + q;
+        if (a < CC) {
+          const int row = sC[a];
+          double s0 = X[a], s1 = 0.0;
+          if (row <= i0) {                             // stored as (C[a], i) for the whole wave
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              s0 = fma(cf[q][2 * u], v[2 * u], s0);
+              s1 = fma(cf[q][2 * u + 1], v[2 * u + 1], s1);
+            }
+          } else if (row > i0 + 63) {                  // mirrored for the whole wave
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              s0 = fma(w[2 * u], cf[q][2 * u], s0);
+              s1 = fma(w[2 * u + 1], cf[q][2 * u + 1], s1);
+            }
+          } else {                                     // the wave straddles C[a]: both forms, chosen per lane
+            const double2* wa = reinterpret_cast<const double2*>(&sF[0][a][k0]);
+            const bool up = row <= ii;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              const double2 fw2 = wa[u];
+              s0 = fma(up ? fw2.x : w[2 * u], up ? v[2 * u] : cf[q][2 * u], s0);
+              s1 = fma(up ? fw2.y : w[2 * u + 1], up ? v[2 * u + 1] : cf[q][2 * u + 1], s1);
+            }
           }
-        } else if (row > i0 + 63) {                    // mirrored for the whole wave
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const double2 f = va[u];
-            X[a] = fma(w[2 * u], f.x, X[a]);
-            X[a] = fma(w[2 * u + 1], f.y, X[a]);
-          }
-        } else {
-          const bool up = row <= ii;
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const double2 fw2 = wa[u], fv2 = va[u];
-            X[a] = fma(up ? fw2.x : w[2 * u], up ? v[2 * u] : fv2.x, X[a]);
-            X[a] = fma(up ? fw2.y : w[2 * u + 1], up ? v[2 * u + 1] : fv2.y, X[a]);
-          }
+          X[a] = s0 + s1;
         }
       }
     }
