@@ -1,18 +1,22 @@
 // Hand-written HIP kernels of the EKF-SLAM step for MI355X (gfx950, wave64).
 //
-// The covariance is kept as   P = P_base + W V + diag(dacc)   with up to KTOT pending ranks:
-// every step appends its own 2m+2 ranks (the m sequential landmark updates of
-// src/replay_no_ros.py:436-480 plus the two rank-1 pairs of G_F P G_F^T, :430) and the O(n^2) pass
-// over P_base ("flush") is paid once per few steps instead of (2+m) dense n x n GEMMs per step:
-//   k_solve    sequential part on the compressed c x c system (c = 3+2m): gathers the CURRENT
-//              P[C,C] (base + pending ranks), one wave runs the recurrences
-//   k_panels   thread i replays the m rank-2 down-dates on column i of the row panel P'[C,:] and on
-//              row i of the column panel P'[:,C] (both of the current P) and appends
+// The covariance is symmetric and only its upper triangle is kept, as
+//     P(a, b) = P_base[a][b] + sum_k W[a][k] V[k][b] + [a == b < 3] dacc[a]      (a <= b),   P(b, a) := P(a, b)
+// with up to KTOT pending ranks: every step appends 2 ranks per observed landmark (the m sequential updates
+// of src/replay_no_ros.py:436-480; with P symmetric K_j = (H_j P_j)^T S_j^-1, so V = H_j P_j, W = -K_j come
+// from one recurrence) and the O(n^2) pass over P_base ("flush") is paid once per few steps instead of
+// (2+m) dense n x n GEMMs per step.  The prediction G_F P G_F^T + F^T R F (:430) changes rows 0,1 of the
+// stored triangle only and is applied to P_base in place.
+//   k_solve    sequential part on the compressed c x c system (c = 3+2m): gathers the CURRENT P[C,C]
+//              (base + pending ranks), one wave runs the recurrences
+//   k_panels   thread i replays the step on P(C, i), the column of the current P at its own state index:
+//              prediction (rows 0,1 of P_base updated in place), m rank-2 down-dates; appends
 //              V = stacked H_j P_j (rank-major, coalesced) and W = -stacked K_j (MFMA-tiled); mean update
-//   k_flush    P_base <- P_base + W V + diag(dacc): one streaming read-modify-write of P_base with
-//              the rank-K product on the fp64 matrix cores (v_mfma_f64_16x16x4_f64)
-// With nothing observed and nothing pending, k_predict_rc touches rows/cols 0,1 of P only (O(n)).
-// The algebra is restated on the CPU in oracle/ekf_oracle.py::ekf_step_structured.
+//   k_flush    P_base <- P_base + W V + diag(dacc) on the upper triangle: one streaming read-modify-write
+//              with the rank-K product on the fp64 matrix cores (v_mfma_f64_16x16x4_f64)
+//   k_mirror   lower triangle <- upper (before a download or the dense product)
+// With nothing observed and nothing pending, k_predict_rc touches rows 0,1 of P only (O(n)).
+// The algebra is restated on the CPU in oracle/ekf_oracle.py::DeferredSymmetricFilter.
 #include <algorithm>
 
 #include "ekf_device.h"
@@ -134,11 +138,6 @@ __device__ __forceinline__ void stage_factors(const double* __restrict__ Vb, con
 // of a step reads an entry another workgroup of the same step writes).  `its` receives the
 // per-landmark records.
 // ---------------------------------------------------------------------------------------------
-struct SolveHdr {
-  double g[2], rd[3], p22h, dacc_old[3];
-  int c, m, kbase, neff;
-};
-
 struct SolveLds {
   double Pc[CPAD][PCS];
   double muc[CPAD];
@@ -148,7 +147,6 @@ struct SolveLds {
   double Vc[KTOT][PCS];
   double2 hS[6];                                       // next linearisation: {h[0][k], h[1][k]} k<5, {y0, y1}
   double xs[CPAD];                                     // column 2 of the row-updated block (prediction)
-  SolveHdr hdr;
 };
 
 __device__ __forceinline__ void solve_body(SolveLds& L, const double* __restrict__ Pb,
@@ -335,41 +333,24 @@ __device__ __forceinline__ void solve_body(SolveLds& L, const double* __restrict
       }
   }
   double mu_cur = mu_pred;                             // (wave 1 published it in muc)
-  if (lane == 0) {
-    SolveHdr hd;
-    hd.g[0] = g0;
-    hd.g[1] = g1;
-    hd.rd[0] = rd0;
-    hd.rd[1] = rd1;
-    hd.rd[2] = rd2;
-    hd.p22h = 0.5 * p22;
-    hd.dacc_old[0] = d0;
-    hd.dacc_old[1] = d1;
-    hd.dacc_old[2] = d2;
-    hd.c = c;
-    hd.m = m;
-    hd.kbase = kbase;
-    hd.neff = s.neff;
-    L.hdr = hd;
-    if (writer) {
-      o.cmax = cmax;
-      o.g[0] = g0;
-      o.g[1] = g1;
-      o.rd[0] = rd0;
-      o.rd[1] = rd1;
-      o.rd[2] = rd2;
-      o.p22h = hd.p22h;
-      o.dacc_old[0] = d0;
-      o.dacc_old[1] = d1;
-      o.dacc_old[2] = d2;
-      o.c = c;
-      o.m = m;
-      o.kbase = kbase;
-      o.neff = s.neff;
-      dacc_out[0] = d0 + rd0;                        // the pose-block noise joins the pending update
-      dacc_out[1] = d1 + rd1;
-      dacc_out[2] = d2 + rd2;
-    }
+  if (lane == 0 && writer) {
+    o.cmax = cmax;
+    o.g[0] = g0;
+    o.g[1] = g1;
+    o.rd[0] = rd0;
+    o.rd[1] = rd1;
+    o.rd[2] = rd2;
+    o.p22h = 0.5 * p22;
+    o.dacc_old[0] = d0;
+    o.dacc_old[1] = d1;
+    o.dacc_old[2] = d2;
+    o.c = c;
+    o.m = m;
+    o.kbase = kbase;
+    o.neff = s.neff;
+    dacc_out[0] = d0 + rd0;                            // the pose-block noise joins the pending update
+    dacc_out[1] = d1 + rd1;
+    dacc_out[2] = d2 + rd2;
   }
   __syncthreads();                                    // S0 (helper waves wait here too)
 

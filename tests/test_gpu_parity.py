@@ -515,3 +515,43 @@ def test_device_association_overflow_flag(sd):
         f.step_detections(0.01, 0.0, [(0.0, [mk(5, 0.1, 0.5), mk(6, -0.1, 0.6), mk(7, 0.0, 0.7)])])
         assert f.size() == 7 and f.tag_index() == {5: 0, 6: 1}
         assert f.flags() & 2                              # EKF_FLAG_ASSOC: the third tag did not fit
+
+
+def test_scattered_landmarks_varying_m(sd):
+    """Observed landmarks scattered over the whole map, 1..16 per step, two trajectories with different lists:
+    every wave of the panel kernel sees gathered rows below, inside and above its own 64 state indices, and
+    steps of different rank counts are packed into one pending update."""
+    N, steps, B = 700, 14, 2
+    n = 3 + 2 * N
+    cfg = orc.EkfConfig()
+    rng = np.random.default_rng(11)
+    world = [orc.synthetic_world(N, t) for t in range(B)]
+    om = [w[2].copy() for w in world]
+    oP = [np.diag(w[3]) for w in world]
+    pose = [np.zeros(3) for _ in range(B)]
+    with sd.EkfSlam(n, batch=B) as f:
+        for b in range(B):
+            f.set_state_diag(world[b][2], world[b][3], b)
+        for k in range(steps):
+            m_b = [int(rng.integers(1, 17)), int(rng.integers(1, 17))]
+            lin, ang = 0.004 + 0.001 * k, (0.02 if k % 3 else 0.004)
+            idx, zr, zb = [], [], []
+            for b in range(B):
+                pose[b], _ = orc.motion_model(pose[b], lin, ang, cfg)
+                vis = rng.choice(N, size=m_b[b], replace=False)
+                d = world[b][1][vis] - pose[b][0:2]
+                cth, sth = np.cos(pose[b][2]), np.sin(pose[b][2])
+                xr = cth * d[:, 0] + sth * d[:, 1] + rng.normal(0, 0.01, m_b[b])
+                yr = -sth * d[:, 0] + cth * d[:, 1] + rng.normal(0, 0.01, m_b[b])
+                idx.append(vis)
+                zr.append(np.sqrt(xr ** 2 + yr ** 2))
+                zb.append(np.arctan2(yr, xr))
+                om[b], oP[b] = orc.ekf_step_structured(om[b], oP[b], lin, ang, vis, zr[b], zb[b], cfg)
+            f.step([lin] * B, [ang] * B, idx, zr, zb)
+            if k in (0, 5, steps - 1):
+                for b in range(B):
+                    mu, P = f.state(b)
+                    close(mu, om[b])
+                    close(P, oP[b])
+                    assert np.array_equal(P, P.T)
+        assert f.flags(0) == 0 and f.flags(1) == 0
