@@ -102,25 +102,43 @@ constexpr int WCS = KTOT + 1;   // row stride of the staged W[C,:] (81 doubles: 
 
 // Stage the pending factors restricted to C into LDS: Wc[a][k] = W[C[a]][k], Vc[k][a] = V[k][C[a]]; with
 // `fac` they are also written out compactly (facW[a][k], facV[a][k], zero-filled to a multiple of 8 ranks) for
-// the panel kernel, whose waves read them through the scalar cache.
-__device__ __forceinline__ void stage_factors(const double* __restrict__ Vb, const double* __restrict__ Wb,
-                                              const int* Cs, int c, int kb, int ld, int tid, int nthreads,
-                                              double (*Wc)[WCS], double (*Vc)[PCS], double* __restrict__ fac) {
+// the panel kernel.  Split in two so that the caller can compute under the gathers' latency: `issue` puts
+// all loads of the thread in flight (ranks [kofs, kofs+64)), `commit` stores them.
+constexpr int SQ = (CMAX + 3) / 4;                     // rows per wave with four waves
+struct StageRegs {
+  double wv[SQ], vv[SQ];
+};
+__device__ __forceinline__ void stage_issue(StageRegs& R, const double* __restrict__ Vb,
+                                            const double* __restrict__ Wb, const int* Cs, int c, int kb, int kofs,
+                                            int ld, int tid) {
   const int ld16 = ld >> 4;
+  const int wave = tid >> 6;
+  const int k = kofs + (tid & 63);
+#pragma unroll
+  for (int q = 0; q < SQ; ++q) {
+    const int a = wave + 4 * q;
+    const int row = Cs[min(a, CPAD - 1)];
+    const bool in = k < kb && a < c;
+    R.wv[q] = in ? Wb[wm_index(ld16, k, row)] : 0.0;
+    R.vv[q] = in ? Vb[(long)k * ld + row] : 0.0;
+  }
+}
+__device__ __forceinline__ void stage_commit(const StageRegs& R, int c, int kb, int kofs, int tid,
+                                             double (*Wc)[WCS], double (*Vc)[PCS], double* __restrict__ fac) {
+  const int wave = tid >> 6;
+  const int k = kofs + (tid & 63);
   const int k8 = (kb + 7) & ~7;
-  for (int a = tid >> 6; a < c; a += nthreads >> 6) {
-    const int row = Cs[a];
-    for (int k = tid & 63; k < k8; k += 64) {
-      const bool in = k < kb;
-      const double wv = in ? Wb[wm_index(ld16, k, row)] : 0.0;
-      const double vv = in ? Vb[(long)k * ld + row] : 0.0;
-      if (in) {
-        Wc[a][k] = wv;
-        Vc[k][a] = vv;
+#pragma unroll
+  for (int q = 0; q < SQ; ++q) {
+    const int a = wave + 4 * q;
+    if (a < c && k < k8) {
+      if (k < kb) {
+        Wc[a][k] = R.wv[q];
+        Vc[k][a] = R.vv[q];
       }
       if (fac) {
-        fac[a * KTOT + k] = wv;
-        fac[CMAX * KTOT + a * KTOT + k] = vv;
+        fac[a * KTOT + k] = R.wv[q];
+        fac[CMAX * KTOT + a * KTOT + k] = R.vv[q];
       }
     }
   }
@@ -189,10 +207,6 @@ __device__ __forceinline__ void solve_body(SolveLds& L, const double* __restrict
 #pragma unroll
   for (int sh = 32; sh > 0; sh >>= 1) cmax = max(cmax, __shfl_xor(cmax, sh));
   __syncthreads();
-  if (kbase > 0) {
-    stage_factors(Vb, Wb, Cs, c, kbase, ld, tid, 256, Wc, Vc, writer ? fac_b : nullptr);
-    __syncthreads();
-  }
   STAMP(o, 1);
   // current P[C,C] = P_base[C,C] + W[C,:] V[:,C] + diag(dacc): the base loads are issued first ...
   // (thread = (wave w, lane): column C[lane] of rows w, w+4, ...: no integer division on the path)
@@ -205,6 +219,8 @@ __device__ __forceinline__ void solve_body(SolveLds& L, const double* __restrict
     const int Cr = (r < c) ? Cs[r] : 0;
     gv[q] = (on && r < c) ? Pb[(long)min(Cr, Cl) * ld + max(Cr, Cl)] : 0.0;   // the upper triangle is authoritative
   }
+  StageRegs SR;                                        // ... then the gathers of the pending factors at C ...
+  if (kbase > 0) stage_issue(SR, Vb, Wb, Cs, c, kbase, 0, ld, tid);
   // ---- ... and the motion model (src/replay_no_ros.py:368-417) runs under their latency, redundantly in
   // every lane of every wave (wave 1 needs the predicted pose for the first linearisation) ----
   const double th = __shfl(mu_l, 2);
@@ -231,15 +247,53 @@ __device__ __forceinline__ void solve_body(SolveLds& L, const double* __restrict
     }
   }
   const double mu_pred = (lane == 0) ? nx : ((lane == 1) ? ny : ((lane == 2) ? nth : mu_l));
+  if (kbase > 0) {
+    stage_commit(SR, c, kbase, 0, tid, Wc, Vc, writer ? fac_b : nullptr);
+    if (kbase > 64) {                                  // (more than 64 pending ranks: second pass)
+      stage_issue(SR, Vb, Wb, Cs, c, kbase, 64, ld, tid);
+      stage_commit(SR, c, kbase, 64, tid, Wc, Vc, writer ? fac_b : nullptr);
+    }
+    __syncthreads();
+  }
+  // pending ranks: M = W[C,:] V[:,C] (c x c, 16x16 tiles dealt to the four waves, v_mfma_f64_16x16x4 with both
+  // operands straight from the staged factors), parked in Pc; entry (r, l) of the gathered block then takes
+  // M[r][l] where P(C[r], C[l]) is stored that way round and M[l][r] where it is stored mirrored
+  double mcor[GQ];
+#pragma unroll
+  for (int q = 0; q < GQ; ++q) mcor[q] = 0.0;
+  if (kbase > 0) {
+    const int T = (c + 15) >> 4, nkt = (kbase + 3) >> 2;
+    const int li = lane & 15, lq = lane >> 4;
+    for (int t = gw; t < T * T; t += 4) {
+      const int rt = (t >= 2 * T) ? 2 : ((t >= T) ? 1 : 0), ct = t - rt * T;   // T <= 3
+      const int ar = 16 * rt + li, bc = 16 * ct + li;
+      const double* wr = Wc[min(ar, CMAX - 1)];
+      double4_t acc = {0.0, 0.0, 0.0, 0.0};
+      for (int kt = 0; kt < nkt; ++kt) {
+        const int kk = 4 * kt + lq;
+        const double av = wr[min(kk, KTOT - 1)], bv = Vc[min(kk, KTOT - 1)][min(bc, PCS - 1)];
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64((ar < c && kk < kbase) ? av : 0.0,
+                                                   (bc < c && kk < kbase) ? bv : 0.0, acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int r = 16 * rt + lq + 4 * reg, l = 16 * ct + li;
+        if (r < c && l < c) Pc[r][l] = acc[reg];
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < GQ; ++q) {
+      const int r = gw + 4 * q;
+      if (on && r < c) mcor[q] = (Cs[r] <= Cl) ? Pc[r][lane] : Pc[lane][r];
+    }
+    __syncthreads();
+  }
 #pragma unroll
   for (int q = 0; q < GQ; ++q) {
     const int r = gw + 4 * q;
     if (on && r < c) {
-      double v = gv[q];
-      const bool up = Cs[r] <= Cl;                      // entry (C[r], C[lane]) or its mirror (C[lane], C[r])
-      const double* wrow = Wc[up ? r : lane];
-      const int vcol = up ? lane : r;
-      for (int k = 0; k < kbase; ++k) v = fma(wrow[k], Vc[k][vcol], v);
+      double v = gv[q] + mcor[q];
       if (r == lane && r < 3) v += (r == 0) ? d0 : ((r == 1) ? d1 : d2);
       Pc[r][lane] = v;
     }
