@@ -35,7 +35,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 MFMA_F64_SPEC_TF = 78.6        # public datasheet figure (the local guide lists no fp64 matrix peak)
-MFMA_F64_MEASURED_TF = 47.3    # sustained v_mfma_f64_16x16x4 on this part: profiles/mfma_probe.txt
+MFMA_F64_MEASURED_TF = 77.9    # sustained v_mfma_f64_16x16x4 on this part (accumulators in VGPRs): profiles/mfma_probe.txt
 
 
 def make_streams(sd_syn, traj_ids, n_landmarks, steps, m):
@@ -213,7 +213,7 @@ def main():
                                  "SURVEY 8(d)'s 16 n^2 bytes per step become 8 n(n+1) bytes per LAUNCH; achieved/frac "
                                  "count the bytes this launch must move (one read + one write of the triangle), "
                                  "step_equivalent_GBs = SURVEY's 16 n^2 per step x steps folded in / launch time; "
-                                 "at 4 steps (64 ranks) per launch the kernel is bound by the fp64 matrix cores (2K flop per 16 B), "
+                                 "at 4 steps (64 ranks) per launch its memory side alone takes 0.82 ms and its MFMA side 0.73 ms (profiles/mfma_probe.txt), "
                                  "see `mfma`"},
             "device_ms_per_step": dev_ms / args.steps,
         }

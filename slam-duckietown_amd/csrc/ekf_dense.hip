@@ -20,7 +20,15 @@ constexpr int BM = 128, BN = 128, BK = 16, LS = 144;
 // Load 8 consecutive k-entries of one row (row-major source, k contiguous): rows >= n or k >= n -> 0.
 __device__ __forceinline__ void load_row8(const double* __restrict__ src, int ld, int n, int row, int k0,
                                           double (&r)[8]) {
-  if (row < n) {
+  if (row < n && k0 + 8 <= n) {                        // interior: four unconditional 16-byte loads
+    const double2* p = reinterpret_cast<const double2*>(src + (long)row * ld + k0);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const double2 t = p[q];
+      r[2 * q] = t.x;
+      r[2 * q + 1] = t.y;
+    }
+  } else if (row < n) {
     const double2* p = reinterpret_cast<const double2*>(src + (long)row * ld + k0);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -37,7 +45,7 @@ __device__ __forceinline__ void load_row8(const double* __restrict__ src, int ld
 // TRANS_B = false: C = A * B     (B row-major [k][j])
 // TRANS_B = true : C = A * B^T + Q  (B row-major [j][k])
 template <bool TRANS_B>
-__global__ __launch_bounds__(256) void k_gemm_f64(const double* __restrict__ A,
+__global__ __launch_bounds__(256, 2) void k_gemm_f64(const double* __restrict__ A,
                                                   const double* __restrict__ B,
                                                   const double* __restrict__ Q, double* __restrict__ C,
                                                   int n, int ld) {
