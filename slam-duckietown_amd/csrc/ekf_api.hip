@@ -156,7 +156,7 @@ extern "C" int ekf_create(int device, int n_max, int batch, const ekf_config* cf
   ekf_handle* h = new ekf_handle();
   h->device = device;
   h->n_max = n_max;
-  h->ld = (n_max + 15) / 16 * 16;
+  h->ld = (n_max + 63) / 64 * 64;                      // every 64-column strip of k_flush lies inside the row (512-B aligned)
   h->batch = batch;
   h->pstride = (long)h->ld * h->ld;
   if (cfg) h->cfg = *cfg; else ekf_config_default(&h->cfg);

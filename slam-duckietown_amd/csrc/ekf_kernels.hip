@@ -939,8 +939,6 @@ __global__ __launch_bounds__(256, 2) void k_flush(double* __restrict__ P, const 
   double* T = tiles[wave];
   int nct = (n - j0 + 15) >> 4;                        // column tiles of this strip that start below n
   if (nct > 4) nct = 4;
-  const bool colok = (j0 + rc + 1) < ld;               // the 16-byte access stays inside the row
-  const bool col0 = (j0 + rc) < n, col1 = (j0 + rc + 1) < n;
 
   double vf[NKTM][4];
 #pragma unroll
@@ -959,25 +957,30 @@ __global__ __launch_bounds__(256, 2) void k_flush(double* __restrict__ P, const 
     WAVE_SYNC();
   }
 
+  // Every global access of the row loop is unconditional (rows and columns up to the padded size ld exist, their
+  // W rows / V columns are zero, so padding is read and written back unchanged): with no branch around a load or a
+  // store the compiler can count them, and waits for the tile it needs instead of draining the queue
+  // (s_waitcnt vmcnt(0) would expose the previous tile's store latency and the W round trip every tile).
   double2 g[8];                                        // row-major registers of the tile in flight
+  const int jc = j0 + rc;                              // ld is a multiple of 64: the strip lies inside the row
   auto gload = [&](int i0) {
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const int row = i0 + 2 * q + rr;
-      g[q] = (row < n && colok) ? ld2<NT>(Pb + (long)row * ld + j0 + rc) : make_double2(0.0, 0.0);
-    }
+    for (int q = 0; q < 8; ++q) g[q] = ld2<NT>(Pb + (long)(i0 + 2 * q + rr) * ld + jc);
   };
   gload(i_begin);
-  constexpr int WH = (NKTM + 1) / 2;                   // W fragments are fetched in two halves (registers)
+  const int i_last = i_begin + ((i_end - 1 - i_begin) & ~15);
+  // W fragments of the tile: one batch at the top of the iteration.  (Loads complete in order: a second batch
+  // issued behind the P prefetch could only be waited for together with that prefetch.)
+  constexpr int WH = NKTM;
   for (int i0 = i_begin; i0 < i_end; i0 += 16) {
     const double* wsrc = Wb + (long)(i0 >> 4) * 64 + lane;
     double wf[WH];
 #pragma unroll
-    for (int t = 0; t < WH; ++t) wf[t] = (t < nkt) ? wsrc[(long)t * ld16 * 64] : 0.0;
+    for (int t = 0; t < WH; ++t) wf[t] = wsrc[(long)min(t, nkt - 1) * ld16 * 64];
 #pragma unroll
     for (int q = 0; q < 8; ++q) *reinterpret_cast<double2*>(&T[(2 * q + rr) * FTS + rc]) = g[q];
     WAVE_SYNC();
-    if (i0 + 16 < i_end) gload(i0 + 16);               // prefetch under the MFMAs
+    gload(min(i0 + 16, i_last));                       // prefetch under the MFMAs (the last tile re-reads itself)
     double4_t acc[4];
 #pragma unroll
     for (int ct = 0; ct < 4; ++ct)
@@ -993,7 +996,7 @@ __global__ __launch_bounds__(256, 2) void k_flush(double* __restrict__ P, const 
       }
     // second half: the loads reuse the registers as soon as the first half's MFMAs have issued
 #pragma unroll
-    for (int t = WH; t < NKTM; ++t) wf[t - WH] = (t < nkt) ? wsrc[(long)t * ld16 * 64] : 0.0;
+    for (int t = WH; t < NKTM; ++t) wf[t - WH] = wsrc[(long)min(t, nkt - 1) * ld16 * 64];
 #pragma unroll
     for (int t = WH; t < NKTM; ++t)
       if (t < nkt) {
@@ -1004,7 +1007,7 @@ __global__ __launch_bounds__(256, 2) void k_flush(double* __restrict__ P, const 
     if (NKL > 0) {                                     // k-tiles whose B fragments come from LDS
       double wl[NKL > 0 ? NKL : 1];
 #pragma unroll
-      for (int t = 0; t < NKL; ++t) wl[t] = (NKTM + t < nkt) ? wsrc[(long)(NKTM + t) * ld16 * 64] : 0.0;
+      for (int t = 0; t < NKL; ++t) wl[t] = wsrc[(long)min(NKTM + t, nkt - 1) * ld16 * 64];
 #pragma unroll
       for (int t = 0; t < NKL; ++t)
         if (NKTM + t < nkt) {
@@ -1029,11 +1032,7 @@ __global__ __launch_bounds__(256, 2) void k_flush(double* __restrict__ P, const 
     for (int q = 0; q < 8; ++q) {
       const int row = i0 + 2 * q + rr;
       const double2 o = *reinterpret_cast<const double2*>(&T[(2 * q + rr) * FTS + rc]);
-      if (row < n) {
-        double* dst = Pb + (long)row * ld + j0 + rc;
-        if (col1) st2<NT>(dst, o);
-        else if (col0) *dst = o.x;
-      }
+      st2<NT>(Pb + (long)row * ld + jc, o);
     }
     WAVE_SYNC();
   }
