@@ -18,6 +18,7 @@
 // With nothing observed and nothing pending, k_predict_rc touches rows 0,1 of P only (O(n)).
 // The algebra is restated on the CPU in oracle/ekf_oracle.py::DeferredSymmetricFilter.
 #include <algorithm>
+#include <type_traits>
 
 #include "ekf_device.h"
 
@@ -653,31 +654,36 @@ __global__ __launch_bounds__(64 * NW) void k_panels(double* __restrict__ P, doub
   }
 
   // ---- pending ranks of the gather ----
-  const bool need_w = o.cmax > i0;                     // some gathered index lies beyond this wave's first one
-  double v[8], w[8];
+  // The loop exists in two forms, with and without the W[i,:] loads (needed only where some gathered index lies
+  // beyond this wave's first state index).  Inside a form no load sits under a branch -- the group of 8 ranks
+  // after the last one is fetched too (rank rows up to KTOT exist) and masked -- so the compiler can count the
+  // outstanding loads and the next group really is in flight under this group's FMAs.
   const double* vlane = Vb + ii;
   const double* wlane = Wb + (long)(ii >> 4) * 64 + (ii & 15);   // wm_index = rank part + lane part
-  auto load_vw = [&](int k0, double (&vv)[8], double (&ww)[8]) {   // ranks up to KTOT exist: no clamping
+  auto gather_pending = [&](auto need_w_tag) {
+  constexpr bool NEEDW = decltype(need_w_tag)::value;
+  double v[8], w[8];
+  auto load_vw = [&](int k0, double (&vv)[8], double (&ww)[8]) {
+    const int kc = min(k0, KTOT - 8);                  // stay inside the rank slots
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
-      const double x = vlane[(long)(k0 + u) * ld];
+      const double x = vlane[(long)(kc + u) * ld];
       vv[u] = (k0 + u < kb) ? x : 0.0;
     }
-    if (need_w) {
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const double x = wlane[((long)((k0 + u) >> 2) * ld16) * 64 + ((k0 + u) & 3) * 16];
+    for (int u = 0; u < 8; ++u) {
+      if (NEEDW) {
+        const double x = wlane[((long)((kc + u) >> 2) * ld16) * 64 + ((kc + u) & 3) * 16];
         ww[u] = (k0 + u < kb) ? x : 0.0;
+      } else {
+        ww[u] = 0.0;
       }
-    } else {
-#pragma unroll
-      for (int u = 0; u < 8; ++u) ww[u] = 0.0;
     }
   };
-  if (8 * kw < kb) load_vw(8 * kw, v, w);
+  load_vw(8 * kw, v, w);
   for (int k0 = 8 * kw; k0 < kb; k0 += KSTEP) {
     double vn[8], wn[8];
-    if (k0 + KSTEP < kb) load_vw(k0 + KSTEP, vn, wn);
+    load_vw(k0 + KSTEP, vn, wn);
     // four gathered rows at a time: their 16 coefficient reads are in flight together, and each row's eight
     // FMAs run as two independent chains (the branch per row is wave-uniform)
 #pragma unroll
@@ -726,14 +732,15 @@ __global__ __launch_bounds__(64 * NW) void k_panels(double* __restrict__ P, doub
         }
       }
     }
-    if (k0 + KSTEP < kb) {
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        v[u] = vn[u];
-        w[u] = wn[u];
-      }
+    for (int u = 0; u < 8; ++u) {
+      v[u] = vn[u];
+      w[u] = wn[u];
     }
   }
+  };
+  if (o.cmax > i0) gather_pending(std::true_type{});
+  else gather_pending(std::false_type{});
   if (KSPLIT) {                                        // waves 1.. hand their partial sums to wave 0 and leave
     if (kw > 0) {
 #pragma unroll
