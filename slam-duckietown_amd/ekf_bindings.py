@@ -239,6 +239,8 @@ class EkfSlam:
         return n.value
 
     def set_state(self, mean, cov, b: int = 0):
+        """Upload mean and covariance of trajectory b (the upper triangle of `cov` is authoritative: the device
+        stores a covariance as its upper triangle and returns it mirrored)."""
         mean = _f64(mean)
         n = mean.shape[0]
         cov = _f64(cov, (n, n))
