@@ -831,11 +831,14 @@ __global__ __launch_bounds__(64 * NW) void k_panels(double* __restrict__ P, doub
         Wb[wm_index(ld16, kr + 1, i)] = -f1;
       }
       if (it + 1 < m) {                                // x[a] -= K_j[C[a],:] . (H_j P_j)[:, i]
+        // only the rows a later landmark still reads: the pose rows and the rows of landmarks it+1..
 #pragma unroll
         for (int a = 0; a < CC; ++a) {
-          const double2 kc = *reinterpret_cast<const double2*>(I.kc[a]);
-          X[a] = fma(-kc.x, e0, X[a]);
-          X[a] = fma(-kc.y, e1, X[a]);
+          if (a < 3 || a >= a0 + 2) {
+            const double2 kc = *reinterpret_cast<const double2*>(I.kc[a]);
+            X[a] = fma(-kc.x, e0, X[a]);
+            X[a] = fma(-kc.y, e1, X[a]);
+          }
         }
       }
     } else if (act) {
