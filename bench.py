@@ -213,7 +213,7 @@ def main():
                                  "SURVEY 8(d)'s 16 n^2 bytes per step become 8 n(n+1) bytes per LAUNCH; achieved/frac "
                                  "count the bytes this launch must move (one read + one write of the triangle), "
                                  "step_equivalent_GBs = SURVEY's 16 n^2 per step x steps folded in / launch time; "
-                                 "at 4 steps (64 ranks) per launch its memory side alone takes 0.82 ms and its MFMA side 0.73 ms (profiles/mfma_probe.txt), "
+                                 "at the default 5 steps (80 ranks = 10 flop/B, the ridge of this part) per launch neither side is saturated; its memory side alone takes 0.80 ms (profiles/mfma_probe.txt, DESIGN.md section 4), "
                                  "see `mfma`"},
             "device_ms_per_step": dev_ms / args.steps,
         }

@@ -118,7 +118,7 @@ int ekf_predict_dense(ekf_handle *h, int b, const double *F, const double *Q);
 
 /* The covariance is held as P_base + (pending low-rank update of the last few steps, 2 ranks per observed
  * landmark); the O(n^2) pass over P_base is paid once per `flush_every` steps (option; default 0 = as many
- * steps as fit `rank_limit` = 64 pending ranks: 4 steps at 8 observations per step, 32 at one).  ekf_flush
+ * steps as fit `rank_limit` = 80 pending ranks: 5 steps at 8 observations per step, 40 at one).  ekf_flush
  * applies what is pending now (asynchronous).  Every call that reads or rewrites the covariance flushes by
  * itself. */
 int ekf_flush(ekf_handle *h);

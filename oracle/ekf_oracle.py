@@ -426,7 +426,7 @@ class DeferredSymmetricFilter:
     The lower triangle of B is kept at NaN so that any read below the diagonal poisons the result.
     """
 
-    def __init__(self, mean, cov_diag, cfg: EkfConfig, rank_limit: int = 64):
+    def __init__(self, mean, cov_diag, cfg: EkfConfig, rank_limit: int = 80):
         n = len(mean)
         self.n, self.cfg, self.rank_limit = n, cfg, rank_limit
         self.mean = np.array(mean, dtype=float)

@@ -72,8 +72,8 @@ struct ekf_handle {
   bool profile = false;
   std::vector<hipEvent_t> prof_pool;
   size_t prof_used = 0;
-  int opt_rank_limit = 64;        // automatic cadence: flush when the next step would exceed this many ranks
-                                  // (16 MFMA k-tiles: the largest k_flush instantiation without register spills)
+  int opt_rank_limit = KTOT;      // automatic cadence: flush when the next step would exceed this many ranks
+                                  // (20 MFMA k-tiles: 16 of the V strip in registers, 4 in LDS)
   int opt_rows_per_block = 0;     // 0 = auto (flush kernel: rows per workgroup, multiple of 16)
   int opt_flush_every = 0;        // 0 = auto; k = flush the pending low-rank update after k steps
   int opt_streaming = -1;         // -1 = auto (by working-set size), 0 = resident kernel, 1 = nontemporal kernel
@@ -451,7 +451,7 @@ static int enqueue_pass(ekf_handle* h, const StepIn* d_in, int m_hi) {
   h->pending_k += ktp;
   h->pending_steps += 1;
   // cadence of the covariance pass: a fixed number of steps if asked for, otherwise as many steps as fit
-  // `rank_limit` pending ranks (default 64) -- 4 steps at m = 8, 8 at m = 4, 32 at m = 1
+  // `rank_limit` pending ranks (default 80) -- 5 steps at m = 8, 10 at m = 4, 40 at m = 1
   const bool due = h->opt_flush_every > 0 ? h->pending_steps >= h->opt_flush_every : h->pending_k + ktp > h->opt_rank_limit;
   if (due || h->pending_k + 2 > KTOT)
     if (int rc = flush_pending(h)) return rc;

@@ -981,12 +981,12 @@ __global__ __launch_bounds__(256, 2) void k_flush(double* __restrict__ P, const 
   const int i_last = i_begin + ((i_end - 1 - i_begin) & ~15);
   // W fragments of the tile: one batch at the top of the iteration.  (Loads complete in order: a second batch
   // issued behind the P prefetch could only be waited for together with that prefetch.)
-  constexpr int WH = NKTM;
+  constexpr int NKT_ALL = NKTM + NKL;
   for (int i0 = i_begin; i0 < i_end; i0 += 16) {
     const double* wsrc = Wb + (long)(i0 >> 4) * 64 + lane;
-    double wf[WH];
+    double wf[NKT_ALL];
 #pragma unroll
-    for (int t = 0; t < WH; ++t) wf[t] = wsrc[(long)min(t, nkt - 1) * ld16 * 64];
+    for (int t = 0; t < NKT_ALL; ++t) wf[t] = wsrc[(long)min(t, nkt - 1) * ld16 * 64];
 #pragma unroll
     for (int q = 0; q < 8; ++q) *reinterpret_cast<double2*>(&T[(2 * q + rr) * FTS + rc]) = g[q];
     WAVE_SYNC();
@@ -998,34 +998,19 @@ __global__ __launch_bounds__(256, 2) void k_flush(double* __restrict__ P, const 
       for (int r = 0; r < 4; ++r) acc[ct][r] = T[(lq + 4 * r) * FTS + ct * 16 + li];
     WAVE_SYNC();
 #pragma unroll
-    for (int t = 0; t < WH; ++t)
+    for (int t = 0; t < NKTM; ++t)
       if (t < nkt) {
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct)
           acc[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(wf[t], vf[t][ct], acc[ct], 0, 0, 0);
       }
-    // second half: the loads reuse the registers as soon as the first half's MFMAs have issued
 #pragma unroll
-    for (int t = WH; t < NKTM; ++t) wf[t - WH] = wsrc[(long)min(t, nkt - 1) * ld16 * 64];
-#pragma unroll
-    for (int t = WH; t < NKTM; ++t)
-      if (t < nkt) {
+    for (int t = 0; t < NKL; ++t)                      // k-tiles whose B fragments come from LDS
+      if (NKTM + t < nkt) {
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct)
-          acc[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(wf[t - WH], vf[t][ct], acc[ct], 0, 0, 0);
+          acc[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(wf[NKTM + t], VL[(t * 4 + ct) * 64 + lane], acc[ct], 0, 0, 0);
       }
-    if (NKL > 0) {                                     // k-tiles whose B fragments come from LDS
-      double wl[NKL > 0 ? NKL : 1];
-#pragma unroll
-      for (int t = 0; t < NKL; ++t) wl[t] = wsrc[(long)min(NKTM + t, nkt - 1) * ld16 * 64];
-#pragma unroll
-      for (int t = 0; t < NKL; ++t)
-        if (NKTM + t < nkt) {
-#pragma unroll
-          for (int ct = 0; ct < 4; ++ct)
-            acc[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(wl[t], VL[(t * 4 + ct) * 64 + lane], acc[ct], 0, 0, 0);
-        }
-    }
     if (i0 == 0 && j0 == 0) {                          // pose-block noise accumulated since the last flush
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
