@@ -145,6 +145,11 @@ def main():
     ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE",
                     help="ekf_set_option knob, e.g. flush_every=3 (default: library defaults)")
     args = ap.parse_args()
+    # stdout carries exactly ONE line, the JSON: libraries that chat on fd 1 (gloo prints its peer count there)
+    # are sent to stderr for the whole run, the result is written to the saved descriptor at the end
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     # Headline numbers are steady state: every landmark has been observed, the whole covariance is dense.
     # The active-bound shortcut (rows/cols never correlated yet are skipped, exact) would make the first
     # N/m steps of a block-diagonal start cheaper than that, so it is off unless asked for.
@@ -246,7 +251,8 @@ def main():
     if rank == 0:
         if "cpu_baseline" not in out:
             out["cpu_baseline"] = None
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     grp.close()
 
 
