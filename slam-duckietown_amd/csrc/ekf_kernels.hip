@@ -860,9 +860,9 @@ __global__ __launch_bounds__(64 * NW) void k_panels(double* __restrict__ P, doub
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_flush: P_base[i][j] += sum_{k < 4 nkt} W[i][k] V[k][j] + dacc on the pose diagonal, in place:
-// one read + one write of P_base (16 n^2 bytes per trajectory) for ALL pending steps, with the
-// rank-K product on the fp64 matrix cores.
+// k_flush: P_base[i][j] += sum_{k < 4 nkt} W[i][k] V[k][j] + dacc on the pose diagonal, in place, on the
+// stored (upper) triangle: one read + one write of it (8 n(n+1) bytes per trajectory) for ALL pending
+// steps, with the rank-K product on the fp64 matrix cores.
 // A wave owns a strip of 64 columns; the V strip lives in registers as MFMA B fragments (nkt x 4
 // doubles per lane) for the whole row block.  Per 16-row tile:
 //   global -> registers   8 x global_load_dwordx4: every instruction is two full 512-B row segments
@@ -876,8 +876,9 @@ __global__ __launch_bounds__(64 * NW) void k_panels(double* __restrict__ P, doub
 // Going through LDS keeps every HBM access 16 B per lane; loading the C/D layout straight from global
 // memory (8 B per lane, 128-B segments) ran at 0.6x the streaming rate.
 // NT: nontemporal loads/stores for working sets beyond the 256 MiB Infinity Cache.
-// Bound: HBM up to ~48 pending ranks, fp64 MFMA beyond (2 K flop per 16 B; v_mfma_f64_16x16x4 sustains
-// 47 TFLOP/s on this part, profiles/mfma_probe.txt).
+// Bound: HBM up to ~48 pending ranks (0.80 ms for 32 x N=2000: 5.1 TB/s); beyond, the MFMA phase of a
+// wave no longer hides under its own memory wait (0.885 ms at 64 ranks, 0.99 ms at 80; the matrix pipe is
+// 55 % busy there -- v_mfma_f64_16x16x4 sustains 77.9 TFLOP/s on this part, profiles/mfma_probe.txt).
 // ---------------------------------------------------------------------------------------------
 template <bool NT>
 __device__ __forceinline__ double2 ld2(const double* a) {
