@@ -29,6 +29,7 @@ extern "C" {
 
 /* sticky per-trajectory flags, ekf_status_flags() */
 #define EKF_FLAG_NONFINITE 1u /* a non-finite mean entry was produced (q = 0 at :466-469, singular S at :473) */
+#define EKF_FLAG_INTERNAL 4u  /* a bounded wait inside the covariance pass timed out (must never happen) */
 #define EKF_FLAG_ASSOC 2u     /* device-side association dropped a detection: tag id outside [0, 1024), state full,
                                  or more than EKF_MMAX distinct tags in one window */
 #define EKF_DMAX 64           /* detections per window for ekf_step_detections */
@@ -136,7 +137,8 @@ int ekf_profile_enable(ekf_handle *h, int on);
 int ekf_profile_read(ekf_handle *h, double *pass_ms_total, long long *pass_launches); /* and resets */
 /* Tuning knobs: "flush_every" (steps per covariance pass, 0 = auto), "rank_limit" (auto cadence: pending
  * ranks that trigger the pass, 2..80), "pass_rows_per_block", "pass_streaming" (-1 auto / 0 resident /
- * 1 nontemporal), "active_bound" (0 = treat every state index as correlated); unknown names fail. */
+ * 1 nontemporal), "active_bound" (0 = treat every state index as correlated), "pass_kernel" (0 = k_flush,
+ * 1 = k_flush_pc, the producer/consumer form of the pass; same result bit for bit); unknown names fail. */
 int ekf_set_option(ekf_handle *h, const char *name, int value);
 
 #ifdef __cplusplus

@@ -16,6 +16,8 @@ void launch_panels(hipStream_t, int, double*, double*, double*, const double*, d
                    const SolveOut*, const double*, int, long, int, int);
 void launch_flush(hipStream_t, bool, double*, const double*, const double*, const double*, const int*,
                   const SolveOut*, int, long, int, int, int, int);
+void launch_flush_pc(hipStream_t, bool, double*, const double*, const double*, const double*, const int*,
+                     const SolveOut*, int, long, int, int, int, int, unsigned*);
 void launch_predict_rc(hipStream_t, double*, const double*, double*, const int*, const SolveOut*, int, long,
                        int, int);
 void launch_add_landmarks(hipStream_t, double*, double*, int, int, int, double, const double*);
@@ -74,6 +76,7 @@ struct ekf_handle {
   size_t prof_used = 0;
   int opt_rank_limit = KTOT;      // automatic cadence: flush when the next step would exceed this many ranks
                                   // (20 MFMA k-tiles: 16 of the V strip in registers, 4 in LDS)
+  int opt_pass_kernel = 0;        // 0 = k_flush, 1 = k_flush_pc (producer/consumer waves)
   int opt_rows_per_block = 0;     // 0 = auto (flush kernel: rows per workgroup, multiple of 16)
   int opt_flush_every = 0;        // 0 = auto; k = flush the pending low-rank update after k steps
   int opt_streaming = -1;         // -1 = auto (by working-set size), 0 = resident kernel, 1 = nontemporal kernel
@@ -405,8 +408,13 @@ static int flush_pending(ekf_handle* h) {
   int e_hi = 3;                                        // grid covers the largest active bound of the batch
   for (int b = 0; b < h->batch; ++b) e_hi = std::max(e_hi, std::min(h->n[b], h->neff_enq[b]));
   if (h->sizes_dirty) e_hi = h->n_max;
-  launch_flush(h->stream, streaming_pass(h, n_hi), h->dP, h->dV, h->dW, h->ddacc2[h->dcur], h->dn, h->dso, h->ld, h->pstride,
-               h->batch, e_hi, (h->pending_k + 3) / 4, flush_rows_per_block(h, streaming_pass(h, n_hi)));
+  if (h->opt_pass_kernel == 1)
+    launch_flush_pc(h->stream, streaming_pass(h, n_hi), h->dP, h->dV, h->dW, h->ddacc2[h->dcur], h->dn, h->dso, h->ld,
+                    h->pstride, h->batch, e_hi, (h->pending_k + 3) / 4, flush_rows_per_block(h, streaming_pass(h, n_hi)),
+                    h->dflags);
+  else
+    launch_flush(h->stream, streaming_pass(h, n_hi), h->dP, h->dV, h->dW, h->ddacc2[h->dcur], h->dn, h->dso, h->ld, h->pstride,
+                 h->batch, e_hi, (h->pending_k + 3) / 4, flush_rows_per_block(h, streaming_pass(h, n_hi)));
   if (h->profile) HIP_TRY(h, hipEventRecord(e1, h->stream));
   HIP_TRY(h, hipGetLastError());
   HIP_TRY(h, hipMemsetAsync(h->ddacc2[0], 0, sizeof(double) * 4 * h->batch, h->stream));
@@ -834,6 +842,11 @@ extern "C" int ekf_profile_read(ekf_handle* h, double* pass_ms_total, long long*
 
 extern "C" int ekf_set_option(ekf_handle* h, const char* name, int value) {
   if (!h || !name) return EKF_ERR_ARG;
+  if (std::strcmp(name, "pass_kernel") == 0) {
+    if (value < 0 || value > 1) return fail(h, EKF_ERR_ARG, "pass_kernel: 0 or 1");
+    h->opt_pass_kernel = value;
+    return EKF_OK;
+  }
   if (std::strcmp(name, "rank_limit") == 0) {
     if (value < 2 || value > KTOT) return fail(h, EKF_ERR_ARG, "rank_limit out of range");
     h->opt_rank_limit = value;

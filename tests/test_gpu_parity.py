@@ -555,3 +555,28 @@ def test_scattered_landmarks_varying_m(sd):
                     close(P, oP[b])
                     assert np.array_equal(P, P.T)
         assert f.flags(0) == 0 and f.flags(1) == 0
+
+
+def test_producer_consumer_pass_is_bit_identical(sd):
+    """`pass_kernel=1` (k_flush_pc: matrix waves and memory waves hand tiles over through an LDS ring) applies the
+    same update as k_flush, bit for bit, over several cadences, and raises no internal flag."""
+    N, B, steps, m = 300, 2, 13, 8
+    n = 3 + 2 * N
+    streams = [orc.synthetic_stream(N, steps, m, t) for t in range(B)]
+    out = {}
+    for kernel in (0, 1):
+        for limit in (16, 64, 80):
+            with sd.EkfSlam(n, batch=B) as f:
+                f.set_option("pass_kernel", kernel)
+                f.set_option("rank_limit", limit)
+                for b, s in enumerate(streams):
+                    f.set_state_diag(s[0], s[1], b)
+                for k in range(steps):
+                    f.step([s[2][k] for s in streams], [s[3][k] for s in streams], [s[4][k] for s in streams],
+                           [s[5][k] for s in streams], [s[6][k] for s in streams])
+                out[kernel, limit] = [f.state(b) for b in range(B)]
+                assert [f.flags(b) for b in range(B)] == [0] * B
+    for limit in (16, 64, 80):
+        for b in range(B):
+            assert np.array_equal(out[0, limit][b][0], out[1, limit][b][0])
+            assert np.array_equal(out[0, limit][b][1], out[1, limit][b][1])
