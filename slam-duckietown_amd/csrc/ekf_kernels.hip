@@ -990,18 +990,29 @@ __global__ __launch_bounds__(256, 2) void k_flush(double* __restrict__ P, const 
   };
   gload(i_begin);
   const int i_last = i_begin + ((i_end - 1 - i_begin) & ~15);
-  // W fragments of the tile: one batch at the top of the iteration.  (Loads complete in order: a second batch
-  // issued behind the P prefetch could only be waited for together with that prefetch.)
+  // W fragments: one batch per tile, issued as soon as the previous tile's MFMAs have issued (they free the
+  // registers), i.e. a tile's LDS phases and stores ahead of their first use: an L2 round trip of W no longer
+  // sits between the accumulator read and the first MFMA.  Loads complete in order; this batch sits between the
+  // P prefetch of the next tile (older) and the one after it (younger), so waiting for it leaves the younger
+  // prefetch and the stores in flight.
+  // (Only where the registers allow: with 20 k-tiles the second set of live fragments spills, and below 12 the
+  // MFMA phase is too short to matter; those forms fetch the batch at the top of the tile.)
   constexpr int NKT_ALL = NKTM + NKL;
-  for (int i0 = i_begin; i0 < i_end; i0 += 16) {
+  constexpr bool EARLYW = (NKL == 0) && (NKTM >= 12);
+  double wf[NKT_ALL];
+  auto wload = [&](int i0) {
     const double* wsrc = Wb + (long)(i0 >> 4) * 64 + lane;
-    double wf[NKT_ALL];
 #pragma unroll
     for (int t = 0; t < NKT_ALL; ++t) wf[t] = wsrc[(long)min(t, nkt - 1) * ld16 * 64];
+  };
+  if (EARLYW) wload(i_begin);
+  for (int i0 = i_begin; i0 < i_end; i0 += 16) {
+    const int i_next = min(i0 + 16, i_last);           // (the last tile re-reads itself)
+    if (!EARLYW) wload(i0);
 #pragma unroll
     for (int q = 0; q < 8; ++q) *reinterpret_cast<double2*>(&T[(2 * q + rr) * FTS + rc]) = g[q];
     WAVE_SYNC();
-    gload(min(i0 + 16, i_last));                       // prefetch under the MFMAs (the last tile re-reads itself)
+    gload(i_next);                                     // prefetch under the MFMAs
     double4_t acc[4];
 #pragma unroll
     for (int ct = 0; ct < 4; ++ct)
@@ -1033,6 +1044,7 @@ __global__ __launch_bounds__(256, 2) void k_flush(double* __restrict__ P, const 
     for (int ct = 0; ct < 4; ++ct)
 #pragma unroll
       for (int r = 0; r < 4; ++r) T[(lq + 4 * r) * FTS + ct * 16 + li] = acc[ct][r];
+    if (EARLYW) wload(i_next);                         // (the accumulators are dead: their registers are not needed twice)
     WAVE_SYNC();
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
