@@ -75,7 +75,7 @@ struct ekf_handle {
   std::vector<hipEvent_t> prof_pool;
   size_t prof_used = 0;
   int opt_rank_limit = KTOT;      // automatic cadence: flush when the next step would exceed this many ranks
-                                  // (20 MFMA k-tiles: 16 of the V strip in registers, 4 in LDS)
+                                  // (20 MFMA k-tiles: 15 of the V strip in registers, 5 in LDS)
   int opt_pass_kernel = 0;        // 0 = k_flush, 1 = k_flush_pc (producer/consumer waves)
   int opt_rows_per_block = 0;     // 0 = auto (flush kernel: rows per workgroup, multiple of 16)
   int opt_flush_every = 0;        // 0 = auto; k = flush the pending low-rank update after k steps

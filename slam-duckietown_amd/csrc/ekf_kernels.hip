@@ -917,8 +917,8 @@ __global__ __launch_bounds__(256, 2) void k_flush(double* __restrict__ P, const 
                                                   const SolveOut* __restrict__ so, int ld, long pstride,
                                                   int nkt, int rows_per_block, int gx) {
   __shared__ double tiles[4][16 * FTS];
-  // k-tiles NKTM.. of the V strip live in LDS (B fragments, lane-linear): the register file holds 16 k-tiles
-  // at 2 waves/SIMD, the remaining LDS holds 4 more per wave
+  // k-tiles NKTM.. of the V strip live in LDS (B fragments, lane-linear): the register file holds 15-16 k-tiles
+  // at 2 waves/SIMD, the remaining LDS holds 5 more per wave
   __shared__ double vlds[NKL > 0 ? 4 : 1][NKL > 0 ? NKL * 4 * 64 : 1];
   const int b = blockIdx.z;
   const int n = min(nact[b], so[b].neff);              // rows/cols beyond the active bound are untouched
@@ -995,10 +995,11 @@ __global__ __launch_bounds__(256, 2) void k_flush(double* __restrict__ P, const 
   // sits between the accumulator read and the first MFMA.  Loads complete in order; this batch sits between the
   // P prefetch of the next tile (older) and the one after it (younger), so waiting for it leaves the younger
   // prefetch and the stores in flight.
-  // (Only where the registers allow: with 20 k-tiles the second set of live fragments spills, and below 12 the
-  // MFMA phase is too short to matter; those forms fetch the batch at the top of the tile.)
+  // (Below 12 k-tiles the MFMA phase is too short to matter: the batch is fetched at the top of the tile.  The
+  // 20-k-tile form keeps 15 k-tiles of the V strip in registers and 5 in LDS -- 80 KB of LDS per workgroup, two
+  // workgroups per CU -- so that this second live set of fragments fits without spilling.)
   constexpr int NKT_ALL = NKTM + NKL;
-  constexpr bool EARLYW = (NKL == 0) && (NKTM >= 12);
+  constexpr bool EARLYW = NKTM >= 12;
   double wf[NKT_ALL];
   auto wload = [&](int i0) {
     const double* wsrc = Wb + (long)(i0 >> 4) * 64 + lane;
@@ -1613,7 +1614,7 @@ void launch_flush(hipStream_t st, bool streaming, double* P, const double* V, co
   else if (nkt <= 8) EKF_FLUSH(8, 0);
   else if (nkt <= 12) EKF_FLUSH(12, 0);
   else if (nkt <= 16) EKF_FLUSH(16, 0);
-  else EKF_FLUSH(16, 4);
+  else EKF_FLUSH(15, 5);
 #undef EKF_FLUSH
 }
 
