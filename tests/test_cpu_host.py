@@ -165,3 +165,29 @@ def test_two_rank_gloo_sharding_and_timing(tmp_path):
     assert outs[0]["ids"] + outs[1]["ids"] == list(range(10))
     assert abs(outs[0]["dt"] - outs[1]["dt"]) < 1e-12 and outs[0]["dt"] >= 0.1     # slower rank's time on both
     assert abs(outs[0]["total"] - 70.0) < 1e-9
+
+
+def test_header_is_plain_c_and_links_against_the_library(tmp_path):
+    """include/ekfslam_hip.h is the drop-in boundary: it must compile as C (no C++, no torch types) and a C program
+    using it must link against the shared library (no device call is made: there is no GPU here)."""
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(root, "slam-duckietown_amd", "libekfslam_hip.so")
+    if shutil.which("gcc") is None or not os.path.exists(lib):
+        pytest.skip("gcc or the built library is not available")
+    src = tmp_path / "abi.c"
+    src.write_text(
+        '#include "ekfslam_hip.h"\n'
+        "#include <stdio.h>\n"
+        "int main(void) {\n"
+        "  ekf_config cfg;\n"
+        "  ekf_config_default(&cfg);\n"
+        '  printf("%g %g %d %d\\n", cfg.motion_sigma, cfg.meas_sigma, EKF_MMAX, (int)EKF_FLAG_NONFINITE);\n'
+        "  return (void*)ekf_step == (void*)0 || (void*)ekf_flush == (void*)0;\n"
+        "}\n")
+    exe = tmp_path / "abi"
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(root, "include"), str(src), "-o", str(exe),
+                    lib, "-Wl,-rpath," + os.path.dirname(lib)], check=True, capture_output=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()
+    assert float(out[0]) == 0.1 and float(out[1]) == 0.7 and int(out[2]) == 16 and int(out[3]) == 1
