@@ -48,8 +48,10 @@ def make_streams(sd_syn, traj_ids, n_landmarks, steps, m):
     return streams, lin, ang, idx, zr, zb
 
 
-def time_filter(sd, sd_syn, device, traj_ids, n_landmarks, m, steps, warmup, barrier, profile_leg=True, options=()):
-    """Returns (seconds for `steps` steps on this rank, pass_ms_total, pass_launches, device_ms)."""
+def time_filter(sd, sd_syn, shard, grp, device, traj_ids, n_landmarks, m, steps, warmup, profile_leg=True, options=()):
+    """Returns (max-over-ranks seconds for `steps` steps, pass_ms_total, pass_launches, device_ms).
+    The timed region is sharding.timed_region (device sync + barrier on both sides, max over ranks): the function
+    the world_size-2 gloo test covers."""
     n = 3 + 2 * n_landmarks
     total = warmup + steps + (steps if profile_leg else 0)
     streams, lin, ang, idx, zr, zb = make_streams(sd_syn, traj_ids, n_landmarks, total, m)
@@ -62,16 +64,16 @@ def time_filter(sd, sd_syn, device, traj_ids, n_landmarks, m, steps, warmup, bar
     f.stream_upload(lin, ang, idx, zr, zb)
     f.stream_run(0, warmup)
     f.flush()
-    f.sync()
-    barrier()
-    t0 = time.perf_counter()
-    f.timer_begin()
-    f.stream_run(warmup, steps)
-    f.flush()                         # any covariance pass still pending belongs to the timed steps
-    dev_ms = f.timer_end()            # synchronises the stream
-    f.sync()
-    dt = time.perf_counter() - t0
-    barrier()
+    dev = {}
+
+    def run():
+        f.timer_begin()
+        f.stream_run(warmup, steps)
+        f.flush()                     # any covariance pass still pending belongs to the timed steps
+        dev["ms"] = f.timer_end()     # HIP events on the handle's stream (synchronises it)
+
+    dt = shard.timed_region(grp, run, f.sync, time.perf_counter)
+    dev_ms = dev["ms"]
     pass_ms, launches = 0.0, 0
     if profile_leg:
         f.profile_enable(True)
@@ -84,6 +86,37 @@ def time_filter(sd, sd_syn, device, traj_ids, n_landmarks, m, steps, warmup, bar
     assert not any(flags) and np.isfinite(mu).all(), "filter diverged during the benchmark"
     f.close()
     return dt, pass_ms, launches, dev_ms
+
+
+def kernel_source_sha():
+    import hashlib
+    src = os.path.join(ROOT, "slam-duckietown_amd", "csrc", "ekf_kernels.hip")
+    return hashlib.sha256(open(src, "rb").read()).hexdigest()[:16]
+
+
+def pmc_traffic(key, options):
+    """HBM bytes per launch of the pass kernel from the committed PMC summary (profiles/pass_traffic.json, written by
+    tools/update_traffic.py from `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes).  The figure is only
+    reported while the kernel source it was measured on is the one in the tree, and for the default options."""
+    path = os.path.join(ROOT, "profiles", "pass_traffic.json")
+    out = {"traffic": None}
+    try:
+        entry = json.load(open(path))[key]
+    except Exception:
+        out["traffic_note"] = "no PMC measurement committed for this configuration"
+        return out
+    sha = kernel_source_sha()
+    if entry.get("kernel_source_sha256_16") != sha:
+        out["traffic_note"] = (f"stale: profiles/pass_traffic.json was measured on kernel source "
+                               f"{entry.get('kernel_source_sha256_16')}, the tree has {sha}")
+    elif [o for o in options if o != "active_bound=0"]:
+        out["traffic_note"] = "PMC traffic is measured for the default options only"
+    else:
+        out["traffic"] = entry["hbm_bytes_per_launch"]
+        out["traffic_source"] = entry.get("source", "profiles/pass_traffic.json")
+        out["traffic_kernel"] = entry.get("kernel")
+        out["traffic_over_algorithmic"] = entry["hbm_bytes_per_launch"] / entry["algorithmic_bytes_per_launch"]
+    return out
 
 
 def dense_propagate_leg(sd, device, n_landmarks, reps=3):
@@ -161,7 +194,6 @@ def main():
     rank, local_rank, world = grp.rank, grp.local_rank, grp.world
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    barrier = grp.barrier
 
     import slam_duckietown_amd as sd
     import slam_duckietown_amd.synthetic as sd_syn
@@ -176,14 +208,12 @@ def main():
     B = args.trajectories
     n = 3 + 2 * args.landmarks
     traj_ids = shard.shard_trajectories(B * world, world, rank)
-    dt, pass_ms, launches, dev_ms = time_filter(sd, sd_syn, local_rank, traj_ids, args.landmarks, args.obs,
-                                                args.steps, args.warmup, barrier, options=args.option)
-    dt = grp.max_over_ranks(dt)
-    total_units = grp.sum_over_ranks(len(traj_ids) * args.steps)
+    dt, pass_ms, launches, dev_ms = time_filter(sd, sd_syn, shard, grp, local_rank, traj_ids, args.landmarks, args.obs,
+                                                args.steps, args.warmup, options=args.option)
+    value = shard.aggregate_steps_per_second(len(traj_ids) * args.steps, grp, dt)
 
     out = None
     if rank == 0:
-        value = total_units / dt
         # The covariance pass (k_flush) reads and writes the stored (upper) triangle of every trajectory's P
         # exactly once per launch, whatever the number of steps it folds in: 2 * 8 * n(n+1)/2 bytes each.
         tri = n * (n + 1) / 2.0
@@ -222,29 +252,24 @@ def main():
                                  "see `mfma`"},
             "device_ms_per_step": dev_ms / args.steps,
         }
-        traffic_file = os.path.join(ROOT, "profiles", "pass_traffic.json")
-        if os.path.exists(traffic_file):
-            try:
-                tr = json.load(open(traffic_file))
-                key = f"N{args.landmarks}_B{B}"
-                if key in tr:
-                    out["roofline"]["traffic"] = tr[key]["hbm_bytes_per_launch"]
-                    out["roofline"]["traffic_source"] = tr[key].get("source", "profiles/pass_traffic.json")
-            except Exception:
-                pass
+        out["roofline"].update(pmc_traffic(f"N{args.landmarks}_B{B}", args.option))
     if world == 1 and rank == 0:
         if not args.no_single:
-            dt1, p1, l1, _ = time_filter(sd, sd_syn, local_rank, [0], args.landmarks, args.obs, args.steps,
-                                         args.warmup, lambda: None, options=args.option)
+            dt1, p1, l1, _ = time_filter(sd, sd_syn, shard, grp, local_rank, [0], args.landmarks, args.obs, args.steps,
+                                         args.warmup, options=args.option)
             a1 = 16.0 * tri / ((p1 / max(l1, 1)) * 1e-3) / 1e9 if p1 > 0 else 0.0
             out["single_trajectory"] = {"workload": f"N={args.landmarks}, m={args.obs}, 1 trajectory (BASELINE config 3)",
                                         "value": args.steps / dt1, "unit": "steps/s",
                                         "pass_avg_launch_ms": p1 / max(l1, 1), "pass_launches": l1,
                                         "pass_achieved_GBs": a1, "pass_frac_of_hbm_peak": a1 / HBM_PEAK_GBS}
-            dtm, _, _, _ = time_filter(sd, sd_syn, local_rank, traj_ids, args.landmarks, 1, args.steps, args.warmup,
-                                       lambda: None, profile_leg=False, options=args.option)
-            out["obs_1_per_step"] = {"workload": f"N={args.landmarks}, m=1 obs/step, {B} trajectories",
-                                     "value": len(traj_ids) * args.steps / dtm, "unit": "steps/s"}
+            # one observation per step: 2 ranks per step, a covariance pass every 40 steps -- timed over whole
+            # cadences only (a shorter run would charge a full pass to a fraction of the steps it serves)
+            steps_m1 = -(-args.steps // 40) * 40
+            dtm, _, _, _ = time_filter(sd, sd_syn, shard, grp, local_rank, traj_ids, args.landmarks, 1, steps_m1, 40,
+                                       profile_leg=False, options=args.option)
+            out["obs_1_per_step"] = {"workload": f"N={args.landmarks}, m=1 obs/step, {B} trajectories, {steps_m1} steps "
+                                                 "(whole 40-step pass cadences)",
+                                     "value": len(traj_ids) * steps_m1 / dtm, "unit": "steps/s"}
             out["dense_propagate"] = dense_propagate_leg(sd, local_rank, args.landmarks)
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.landmarks, args.obs)

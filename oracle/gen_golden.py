@@ -251,10 +251,11 @@ def make_events_csv(seed: int, duration: float, n_tags: int):
     return text, frames
 
 
-def run_reference_replay(slam, text, frames, tmpdir):
+def run_reference_replay(slam, text, frames, tmpdir, fast_mode=False):
     """Execute the reference's own replay() (src/replay_no_ros.py:66-248) on the synthetic log.  Its I/O
     boundary is replaced: frames are looked up in `frames` instead of cv2.imread + dt_apriltags
-    (:587-597), and plot_path (:499-580) records what it is handed instead of drawing."""
+    (:587-597), and plot_path (:499-580) records what it is handed instead of drawing.
+    fast_mode: the reference's ENABLE_FAST_MODE (:32, :122-123, :216-227)."""
     os.makedirs(tmpdir, exist_ok=True)
     with open(os.path.join(tmpdir, "events.csv"), "w") as fh:
         fh.write(text)
@@ -271,10 +272,11 @@ def run_reference_replay(slam, text, frames, tmpdir):
         rec["tag_index"] = dict(tag_index)
 
     saved = {k: slam.get(k) for k in ("load_grayscale", "detect_tags", "plot_path", "plt", "visualize_bounding_boxes",
-                                      "ENABLE_CAMERA_VISUALIZATION", "os", "image_list", "print")}
+                                      "ENABLE_CAMERA_VISUALIZATION", "os", "image_list", "print", "ENABLE_FAST_MODE")}
     slam.update(load_grayscale=lambda path: path, detect_tags=fake_detect, plot_path=fake_plot,
                 plt=SimpleNamespace(pause=lambda *_a: None), visualize_bounding_boxes=lambda *_a: None,
-                ENABLE_CAMERA_VISUALIZATION=False, os=os, image_list=[], print=lambda *_a: None)
+                ENABLE_CAMERA_VISUALIZATION=False, os=os, image_list=[], print=lambda *_a: None,
+                ENABLE_FAST_MODE=bool(fast_mode))
     try:
         slam["replay"](tmpdir)
     finally:
@@ -286,15 +288,86 @@ def run_reference_replay(slam, text, frames, tmpdir):
     return rec
 
 
+def pack_replay(rec):
+    nmax = max(len(m) for m in rec["mean"])
+    W = len(rec["mean"])
+    M = np.zeros((W, nmax)); Pm = np.zeros((W, nmax, nmax)); sizes = np.zeros(W, dtype=np.int64)
+    for k in range(W):
+        n = len(rec["mean"][k]); sizes[k] = n
+        M[k, :n] = rec["mean"][k]; Pm[k, :n, :n] = rec["cov"][k]
+    return dict(out_mean=M, out_cov=Pm, out_size=sizes, out_path=np.array(rec["path"], dtype=float),
+                out_ntags=np.array(rec["ntags"]), out_gt_count=np.array(rec["gt"]),
+                out_tag_index=np.array(sorted(rec["tag_index"].items(), key=lambda kv: kv[1]), dtype=np.int64).reshape(-1, 2))
+
+
+def scaled_ints(rows, width):
+    """Decimal fields of a Vicon CSV as int64 of value * 1e12 (missing -> INT64_MIN): the CSV's decimals have at most
+    12 places, so int / 1e12 (a correctly rounded division of two exact doubles) gives back exactly the double
+    float(text) gives."""
+    from decimal import Decimal
+    out = np.full((len(rows), width), np.iinfo(np.int64).min, dtype=np.int64)
+    for r, row in enumerate(rows):
+        for c, field in enumerate(row[:width]):
+            if field != "":
+                v = Decimal(field) * 1000000000000
+                assert v == v.to_integral_value() and abs(int(v)) < 2 ** 53 and float(int(v)) / 1e12 == float(field)
+                out[r, c] = int(v)
+    return out
+
+
+def run_reference_vicon(ref_root: str):
+    """The reference's own ground-truth decoder, scripts/decode_bag_file.py:107-253 (`rotate_around`,
+    `get_ground_truth`), executed on the recorded Vicon data under bags/ (robot track + marker trajectories +
+    the .xcp capture times).  The matching .bag is an absent LFS blob, so `first_timestamp` (the first bag event,
+    which the decoder only uses to pick the Vicon frame that defines the origin) is set 1.234 s into the capture.
+    Only plot_path (:257-, matplotlib) is replaced, by a no-op."""
+    import datetime as _dt
+    import xml.etree.ElementTree as ET
+    path = os.path.join(ref_root, "scripts", "decode_bag_file.py")
+    tree = ast.parse(open(path).read())
+    keep = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in ("rotate_around", "get_ground_truth")]
+    ns = {"os": os, "plot_path": lambda *_a: None, "print": lambda *_a: None}
+    exec(compile(ast.Module(body=keep, type_ignores=[]), "decode_bag_file.py", "exec"), ns)
+    prefix = os.path.join(ref_root, "bags", "quackgpt_small_town_joystick")
+    cap = ET.parse(prefix + ".xcp").getroot().find("Camera/Capture")
+    # the decoder's own expressions (:131-132), evaluated here only to choose first_timestamp and to record what the
+    # time axis was in this container (naive local time + 5 h)
+    start = _dt.datetime.fromisoformat(cap.get("START_TIME")).timestamp() + _dt.timedelta(hours=5).total_seconds()
+    end = _dt.datetime.fromisoformat(cap.get("END_TIME")).timestamp() + _dt.timedelta(hours=5).total_seconds()
+    first_timestamp, delay = start + 1.234, 0.0
+    events = ns["get_ground_truth"](first_timestamp, prefix, delay)
+    assert events[0][1] == "landmarks" and all(e[1] == "ground_truth" for e in events[1:])
+    landmarks = np.array(ast.literal_eval(events[0][2]), dtype=float)
+    gt_t = np.array([e[0] for e in events[1:]])
+    gt_xy = np.array([[float(v) for v in e[2].split(",")] for e in events[1:]])
+
+    def rows_of(path):
+        with open(path) as fh:
+            for _ in range(5):
+                fh.readline()
+            return [ln.split(",") for ln in fh.read().strip().splitlines()]
+    robot_rows, marker_rows = rows_of(prefix + ".csv"), rows_of(prefix + "_trajectories.csv")
+    width = max(len(r) for r in marker_rows)
+    return dict(robot_fields=scaled_ints(robot_rows, 8), robot_len=np.array([len(r) for r in robot_rows]),
+                marker_fields=scaled_ints(marker_rows, width), marker_len=np.array([len(r) for r in marker_rows]),
+                start_capture_time=start, end_capture_time=end, first_timestamp=first_timestamp, delay=delay,
+                out_landmarks=landmarks, out_landmarks_time=np.float64(events[0][0]), out_gt_time=gt_t, out_gt_xy=gt_xy)
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default="", help="comma-separated fixture names to (re)generate; default all")
     ap.add_argument("--ref", default="/root/reference")
     ap.add_argument("--out", default=os.path.join(os.path.dirname(HERE), "tests", "golden"))
     args = ap.parse_args()
     os.makedirs(args.out, exist_ok=True)
     slam, proto = load_reference(args.ref)
 
+    only = set(filter(None, args.only.split(",")))
+
     def save(name, **arrs):
+        if only and name not in only:
+            return
         path = os.path.join(args.out, name + ".npz")
         np.savez_compressed(path, **arrs)
         print(f"{name}: {os.path.getsize(path) / 1024:.0f} KiB")
@@ -347,6 +420,16 @@ def main():
          out_tag_index=np.array(sorted(rec["tag_index"].items(), key=lambda kv: kv[1]), dtype=np.int64).reshape(-1, 2),
          out_camera_params=np.array(rec["camera_params"], dtype=float),
          out_landmarks=np.array(rec["landmarks"], dtype=float))
+
+    # 2c. the same log with ENABLE_FAST_MODE (:32): detection deferred to the window boundary, last 5 images of the
+    # ever-growing image list (:216-227).  Inputs are replay_events.npz's; only the outputs are stored.
+    with tempfile.TemporaryDirectory() as tmp:
+        rec_fast = run_reference_replay(slam, text, frames, tmp, fast_mode=True)
+    save("replay_events_fast", **pack_replay(rec_fast))
+
+    # 2d. Vicon ground-truth alignment on the recorded data
+    if not only or "vicon_alignment" in only:
+        save("vicon_alignment", **run_reference_vicon(args.ref))
 
     # 3. 3-state predict/update prototype
     save("proto3", **run_proto(proto, 7, 60))

@@ -11,7 +11,8 @@
 
 namespace ekf {
 void launch_solve(hipStream_t, const double*, const double*, const double*, const double*, double*, const double*,
-                  double*, const int*, const StepIn*, SolveOut*, unsigned*, double*, const DeviceConfig&, int, long, int, int);
+                  double*, const int*, const StepIn*, SolveOut*, unsigned*, double*, const int*, const DeviceConfig&, int,
+                  long, int, int);
 void launch_panels(hipStream_t, int, double*, double*, double*, const double*, double*, const int*,
                    const SolveOut*, const double*, int, long, int, int);
 void launch_flush(hipStream_t, bool, double*, const double*, const double*, const double*, const int*,
@@ -57,7 +58,10 @@ struct ekf_handle {
   size_t stream_cap = 0;
   int stream_steps = 0;
   std::vector<int> stream_mhi;
-  std::vector<int> stream_neff;   // per (step, trajectory) active bound of the uploaded stream
+  std::vector<int> stream_own;    // per (step, trajectory): active bound from the stream's OWN observations up to that step
+  std::vector<int> stream_maxlm;  // per trajectory: landmarks the stream needs in the state (largest index + 1)
+  int* dfloor = nullptr;          // per trajectory floor of the active bound, applied by k_solve (see push_floor)
+  std::vector<int> floor_host;    // what dfloor holds
   double *dF = nullptr, *dQ = nullptr, *dTmp = nullptr;   // dense path, allocated on first use
   // device-side association (allocated on first use)
   int *dtagmap = nullptr, *dneff = nullptr;
@@ -126,7 +130,7 @@ static void free_all(ekf_handle* h) {
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   void* ptrs[] = {h->dP, h->dmu2[0], h->dmu2[1], h->dV, h->dW, h->ddacc2[0], h->ddacc2[1], h->dscratch, h->dn, h->dflags, h->dso, h->dfac,
-                  h->d_ring, h->d_stream, h->dF, h->dQ, h->dTmp, h->dtagmap, h->dneff, h->d_det, h->d_assoc_step,
+                  h->d_ring, h->d_stream, h->dF, h->dQ, h->dTmp, h->dtagmap, h->dneff, h->d_det, h->d_assoc_step, h->dfloor,
                   h->d_assoc_out};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (h->h_ring) (void)hipHostFree(h->h_ring);
@@ -180,6 +184,7 @@ extern "C" int ekf_create(int device, int n_max, int batch, const ekf_config* cf
   h->n.assign(batch, 3);
   h->neff.assign(batch, 3);
   h->neff_enq.assign(batch, 3);
+  h->floor_host.assign(batch, 3);
 
 #define CREATE_TRY(expr)                                                                  \
   do {                                                                                    \
@@ -203,6 +208,7 @@ extern "C" int ekf_create(int device, int n_max, int batch, const ekf_config* cf
   CREATE_TRY(hipMalloc(&h->dscratch, sizeof(double) * ldz * 2));
   CREATE_TRY(hipMalloc(&h->dn, sizeof(int) * batch));
   CREATE_TRY(hipMalloc(&h->dflags, sizeof(unsigned) * batch));
+  CREATE_TRY(hipMalloc(&h->dfloor, sizeof(int) * batch));
   CREATE_TRY(hipMalloc(&h->dso, sizeof(SolveOut) * batch));
   CREATE_TRY(hipMalloc(&h->dfac, sizeof(double) * FACS * batch));
   CREATE_TRY(hipMalloc(&h->d_ring, sizeof(StepIn) * batch * RING));
@@ -228,6 +234,7 @@ extern "C" int ekf_create(int device, int n_max, int batch, const ekf_config* cf
       CREATE_TRY(hipMemcpy2DAsync(h->dP + (size_t)b * h->pstride, sizeof(double) * ldz, p3.data(),
                                   sizeof(double) * 3, sizeof(double) * 3, 3, hipMemcpyHostToDevice, h->stream));
     CREATE_TRY(hipMemcpyAsync(h->dn, h->n.data(), sizeof(int) * batch, hipMemcpyHostToDevice, h->stream));
+    CREATE_TRY(hipMemcpyAsync(h->dfloor, h->floor_host.data(), sizeof(int) * batch, hipMemcpyHostToDevice, h->stream));
     CREATE_TRY(hipStreamSynchronize(h->stream));
   }
 #undef CREATE_TRY
@@ -263,6 +270,25 @@ static int check_b(ekf_handle* h, int b, const char* fn) {
 static int set_size(ekf_handle* h, int b, int n) {
   h->n[b] = n;
   HIP_TRY(h, hipMemcpyAsync(h->dn + b, &h->n[b], sizeof(int), hipMemcpyHostToDevice, h->stream));
+  return EKF_OK;
+}
+
+// The active bound a step record carries (StepIn.neff) comes from the observations the host saw when the record was
+// made.  k_solve raises it to this per-trajectory floor = the bound of the state when the enqueueing call starts
+// (or n where the shortcut is switched off), so that a stream uploaded before the state changed -- a dense
+// upload, ekf_predict_dense, other steps, a replay of the same stream -- still covers everything correlated.
+// exact: the floor must equal the current bound (streams); otherwise it only must not exceed it (single steps
+// carry the current bound themselves).
+static int push_floor(ekf_handle* h, bool exact) {
+  if (h->sizes_dirty) return EKF_OK;                   // device-side association keeps the bound on the device
+  bool need = false;
+  for (int b = 0; b < h->batch; ++b) {
+    const int want = h->opt_active_bound ? h->neff[b] : h->n[b];
+    if ((exact || !h->opt_active_bound) ? h->floor_host[b] != want : h->floor_host[b] > want) need = true;
+  }
+  if (!need) return EKF_OK;
+  for (int b = 0; b < h->batch; ++b) h->floor_host[b] = h->opt_active_bound ? h->neff[b] : h->n[b];
+  HIP_TRY(h, hipMemcpyAsync(h->dfloor, h->floor_host.data(), sizeof(int) * h->batch, hipMemcpyHostToDevice, h->stream));
   return EKF_OK;
 }
 
@@ -436,7 +462,7 @@ static int enqueue_pass(ekf_handle* h, const StepIn* d_in, int m_hi) {
   if (m_hi == 0 && h->pending_k == 0) {
     // prediction only, nothing pending: rows/cols 0,1 of P_base directly, O(n)
     launch_solve(h->stream, h->dP, h->dV, h->dW, dacc_in, dacc_out, mu_in, mu_out, h->dn, d_in, h->dso, h->dflags,
-                 h->dfac, h->dcfg, h->ld, h->pstride, h->batch, 0);
+                 h->dfac, h->dfloor, h->dcfg, h->ld, h->pstride, h->batch, 0);
     launch_predict_rc(h->stream, h->dP, mu_in, mu_out, h->dn, h->dso, h->ld, h->pstride, h->batch, n_hi);
     // k_predict_rc applied the noise itself
     HIP_TRY(h, hipMemsetAsync(h->ddacc2[0], 0, sizeof(double) * 4 * h->batch, h->stream));
@@ -450,7 +476,7 @@ static int enqueue_pass(ekf_handle* h, const StepIn* d_in, int m_hi) {
   dacc_in = h->ddacc2[h->dcur];
   dacc_out = h->ddacc2[h->dcur ^ 1];
   launch_solve(h->stream, h->dP, h->dV, h->dW, dacc_in, dacc_out, mu_in, mu_out, h->dn, d_in, h->dso, h->dflags,
-               h->dfac, h->dcfg, h->ld, h->pstride, h->batch, h->pending_k);
+               h->dfac, h->dfloor, h->dcfg, h->ld, h->pstride, h->batch, h->pending_k);
   launch_panels(h->stream, mcap, h->dP, h->dV, h->dW, mu_in, mu_out, h->dn, h->dso, h->dfac, h->ld, h->pstride,
                 h->batch, n_hi);
   HIP_TRY(h, hipGetLastError());
@@ -466,32 +492,40 @@ static int enqueue_pass(ekf_handle* h, const StepIn* d_in, int m_hi) {
   return EKF_OK;
 }
 
-// Validate one trajectory's observation list and fill StepIn for pass `p` (landmarks [p*MMAX, ...)).
-static int fill_step(ekf_handle* h, StepIn& s, int b, double lin, double ang, int flags, const int* idx,
-                     const double* range, const double* bearing, int m, int p) {
+// Validate one trajectory's whole observation list (all device passes of it) before any handle state changes:
+// indices inside the current state, no index twice (the reference keys observations by landmark index,
+// replay_no_ros.py:312-313).
+static int validate_obs(ekf_handle* h, int b, const int* idx, int m, std::vector<unsigned char>& seen) {
+  const int n_lm = (h->n[b] - 3) / 2;
+  seen.assign((size_t)std::max(n_lm, 1), 0);
+  for (int i = 0; i < m; ++i) {
+    const int id = idx[i];
+    if (id < 0 || id >= n_lm) return fail(h, EKF_ERR_ARG, "landmark index outside the current state (add_landmarks first)");
+    if (seen[id]) return fail(h, EKF_ERR_ARG, "duplicate landmark index in one update (the reference keys observations by index, replay_no_ros.py:312-313)");
+    seen[id] = 1;
+  }
+  return EKF_OK;
+}
+
+// Fill StepIn for pass `p` (landmarks [p*MMAX, ...)) of a validated list; `bound` is the trajectory's running
+// active bound (monotone): an observed landmark and everything below it may be correlated from now on.
+static void fill_step(StepIn& s, int n_b, int& bound, double lin, double ang, int flags, const int* idx,
+                      const double* range, const double* bearing, int m, int p) {
   s.lin = lin;
   s.ang = ang;
   s.flags = flags;
   const int lo = p * MMAX, cnt = std::max(0, std::min(m - lo, MMAX));
   s.m = cnt;
-  const int n_lm = (h->n[b] - 3) / 2;
   for (int i = 0; i < cnt; ++i) {
-    const int id = idx[lo + i];
-    if (id < 0 || id >= n_lm) return fail(h, EKF_ERR_ARG, "landmark index outside the current state (add_landmarks first)");
-    for (int k = 0; k < i; ++k)
-      if (s.idx[k] == id) return fail(h, EKF_ERR_ARG, "duplicate landmark index in one update (the reference keys observations by index, replay_no_ros.py:312-313)");
-    s.idx[i] = id;
+    s.idx[i] = idx[lo + i];
     s.range[i] = range[lo + i];
     s.bearing[i] = bearing[lo + i];
   }
   for (int i = cnt; i < MMAX; ++i) { s.idx[i] = 0; s.range[i] = 0.0; s.bearing[i] = 0.0; }
-  // active bound (monotone): an observed landmark and everything below it may be correlated from now on
-  int bound = h->neff[b];
   for (int i = 0; i < cnt; ++i) bound = std::max(bound, 3 + 2 * (s.idx[i] + 1));
-  h->neff[b] = std::min(bound, h->n[b]);
-  s.neff = h->opt_active_bound ? h->neff[b] : h->n[b];
+  bound = std::min(bound, n_b);
+  s.neff = bound;                                      // (k_solve raises it to the handle's floor, see push_floor)
   s.pad = 0;
-  return EKF_OK;
 }
 
 static int do_step(ekf_handle* h, int base_flags, const double* lin, const double* ang, const int* idx,
@@ -508,7 +542,13 @@ static int do_step(ekf_handle* h, int base_flags, const double* lin, const doubl
       m_hi = std::max(m_hi, m[b]);
     }
   if (m_hi > 0 && (!idx || !range || !bearing)) return fail(h, EKF_ERR_ARG, "NULL observation arrays");
+  if (m_hi > 0) {                                      // everything is checked before any handle state changes
+    std::vector<unsigned char> seen;
+    for (int b = 0; b < h->batch; ++b)
+      if (int rc = validate_obs(h, b, idx + (long)b * stride, m[b], seen)) return rc;
+  }
   HIP_TRY(h, hipSetDevice(h->device));
+  if (int rc = push_floor(h, false)) return rc;
   const int passes = std::max(1, (m_hi + MMAX - 1) / MMAX);
   for (int p = 0; p < passes; ++p) {
     const int slot = h->ring_pos;
@@ -521,13 +561,11 @@ static int do_step(ekf_handle* h, int base_flags, const double* lin, const doubl
     for (int b = 0; b < h->batch; ++b) {
       const int mb = (upd && h->cfg.enable_measurement_model) ? m[b] : 0;
       const long off = (long)b * stride;
-      if (int rc = fill_step(h, hs[b], b, pred ? lin[b] : 0.0, pred ? ang[b] : 0.0, flags,
-                             idx ? idx + off : nullptr, range ? range + off : nullptr,
-                             bearing ? bearing + off : nullptr, mb, p))
-        return rc;
+      fill_step(hs[b], h->n[b], h->neff[b], pred ? lin[b] : 0.0, pred ? ang[b] : 0.0, flags,
+                idx ? idx + off : nullptr, range ? range + off : nullptr, bearing ? bearing + off : nullptr, mb, p);
       m_pass_hi = std::max(m_pass_hi, hs[b].m);
+      h->neff_enq[b] = h->opt_active_bound ? h->neff[b] : h->n[b];
     }
-    for (int b = 0; b < h->batch; ++b) h->neff_enq[b] = hs[b].neff;
     HIP_TRY(h, hipMemcpyAsync(ds, hs, sizeof(StepIn) * h->batch, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipEventRecord(h->ring_ev[slot], h->stream));
     h->ring_used[slot] = true;
@@ -567,6 +605,7 @@ extern "C" int ekf_step_detections(ekf_handle* h, const double* lin, const doubl
   if (!lin || !ang || !count || stride < 0) return fail(h, EKF_ERR_ARG, "ekf_step_detections: NULL array");
   if (int rc = assoc_init(h)) return rc;
   HIP_TRY(h, hipSetDevice(h->device));
+  if (int rc = push_floor(h, false)) return rc;
   // an upper bound of the landmarks observed this window (distinct tag ids) selects the kernel instantiation
   int m_hi = 0;
   const int slot = h->ring_pos;
@@ -622,6 +661,7 @@ extern "C" int ekf_download_tags(ekf_handle* h, int b, int* m, int* idx, int* ta
                                  double* err, double* range, double* bearing) {
   if (int rc = check_b(h, b, "ekf_download_tags")) return rc;
   if (!h->d_assoc_out) return fail(h, EKF_ERR_STATE, "ekf_download_tags: no device-side association has run");
+  HIP_TRY(h, hipSetDevice(h->device));
   AssocOut a;
   HIP_TRY(h, hipMemcpyAsync(&a, h->d_assoc_out + b, sizeof(a), hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -642,6 +682,7 @@ extern "C" int ekf_download_tag_index(ekf_handle* h, int b, int* tag_of_index, i
   if (int rc = check_b(h, b, "ekf_download_tag_index")) return rc;
   if (!n_landmarks) return fail(h, EKF_ERR_ARG, "ekf_download_tag_index: NULL");
   if (int rc = assoc_init(h)) return rc;
+  HIP_TRY(h, hipSetDevice(h->device));
   std::vector<int> tm(TAGMAX);
   HIP_TRY(h, hipMemcpyAsync(tm.data(), h->dtagmap + (size_t)b * TAGMAX, sizeof(int) * TAGMAX, hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -659,6 +700,7 @@ extern "C" int ekf_upload_tag_index(ekf_handle* h, int b, const int* tag_of_inde
   if (int rc = check_b(h, b, "ekf_upload_tag_index")) return rc;
   if (n_landmarks < 0 || (n_landmarks > 0 && !tag_of_index)) return fail(h, EKF_ERR_ARG, "ekf_upload_tag_index: bad arguments");
   if (int rc = assoc_init(h)) return rc;
+  HIP_TRY(h, hipSetDevice(h->device));
   std::vector<int> tm(TAGMAX, -1);
   for (int i = 0; i < n_landmarks; ++i) {
     if (tag_of_index[i] < 0 || tag_of_index[i] >= TAGMAX) return fail(h, EKF_ERR_ARG, "ekf_upload_tag_index: tag id outside [0, 1024)");
@@ -691,22 +733,34 @@ extern "C" int ekf_stream_upload(ekf_handle* h, int steps, const double* lin, co
   if (!lin || !ang || !m || stride < 0) return fail(h, EKF_ERR_ARG, "ekf_stream_upload: NULL array");
   if (stride > MMAX) return fail(h, EKF_ERR_ARG, "ekf_stream_upload: stride must be <= EKF_MMAX");
   const size_t count = (size_t)steps * h->batch;
-  std::vector<StepIn> host(count);
-  h->stream_mhi.assign(steps, 0);
-  h->stream_neff.assign(count, 3);
-  h->stream_steps = 0;
+  // validate the whole stream before anything of the previous one is replaced
+  std::vector<unsigned char> seen;
   for (int k = 0; k < steps; ++k)
     for (int b = 0; b < h->batch; ++b) {
       const size_t e = (size_t)k * h->batch + b;
-      int mb = h->cfg.enable_measurement_model ? m[e] : 0;
-      if (mb < 0 || mb > stride) return fail(h, EKF_ERR_ARG, "ekf_stream_upload: m out of range");
+      const int mb = h->cfg.enable_measurement_model ? m[e] : 0;
+      if (m[e] < 0 || m[e] > stride) return fail(h, EKF_ERR_ARG, "ekf_stream_upload: m out of range");
       if (mb > 0 && (!idx || !range || !bearing)) return fail(h, EKF_ERR_ARG, "ekf_stream_upload: NULL observation arrays");
-      if (int rc = fill_step(h, host[e], b, lin[e], ang[e], FLAG_PREDICT | FLAG_UPDATE,
-                             idx ? idx + e * stride : nullptr, range ? range + e * stride : nullptr,
-                             bearing ? bearing + e * stride : nullptr, mb, 0))
-        return rc;
+      if (mb > 0)
+        if (int rc = validate_obs(h, b, idx + e * stride, mb, seen)) return rc;
+    }
+  std::vector<StepIn> host(count);
+  h->stream_mhi.assign(steps, 0);
+  h->stream_own.assign(count, 3);
+  h->stream_maxlm.assign(h->batch, 0);
+  h->stream_steps = 0;
+  // The records carry the bound that follows from the stream's own observations; what the state already
+  // correlates when the stream is RUN (possibly later, possibly more than once) is added there (push_floor).
+  std::vector<int> own(h->batch, 3);
+  for (int k = 0; k < steps; ++k)
+    for (int b = 0; b < h->batch; ++b) {
+      const size_t e = (size_t)k * h->batch + b;
+      const int mb = h->cfg.enable_measurement_model ? m[e] : 0;
+      fill_step(host[e], h->n[b], own[b], lin[e], ang[e], FLAG_PREDICT | FLAG_UPDATE, idx ? idx + e * stride : nullptr,
+                range ? range + e * stride : nullptr, bearing ? bearing + e * stride : nullptr, mb, 0);
       h->stream_mhi[k] = std::max(h->stream_mhi[k], mb);
-      h->stream_neff[e] = host[e].neff;
+      h->stream_own[e] = own[b];
+      for (int i = 0; i < mb; ++i) h->stream_maxlm[b] = std::max(h->stream_maxlm[b], host[e].idx[i] + 1);
     }
   HIP_TRY(h, hipSetDevice(h->device));
   if (h->stream_cap < count) {
@@ -725,13 +779,22 @@ extern "C" int ekf_stream_upload(ekf_handle* h, int steps, const double* lin, co
 
 extern "C" int ekf_stream_run(ekf_handle* h, int first, int count) {
   if (!h) return EKF_ERR_ARG;
+  if (int rc = refresh_sizes(h)) return rc;
   if (first < 0 || count < 0 || first + count > h->stream_steps)
     return fail(h, EKF_ERR_STATE, "ekf_stream_run: range outside the uploaded stream");
+  for (int b = 0; b < h->batch; ++b)                   // the state may have been replaced since the upload
+    if (h->stream_maxlm[b] > (h->n[b] - 3) / 2)
+      return fail(h, EKF_ERR_STATE, "ekf_stream_run: the uploaded stream observes landmarks the current state does not have");
   HIP_TRY(h, hipSetDevice(h->device));
+  if (int rc = push_floor(h, true)) return rc;
   for (int k = first; k < first + count; ++k) {
-    for (int b = 0; b < h->batch; ++b) h->neff_enq[b] = h->stream_neff[(size_t)k * h->batch + b];
+    for (int b = 0; b < h->batch; ++b)
+      h->neff_enq[b] = std::min(h->n[b], std::max(h->floor_host[b], h->stream_own[(size_t)k * h->batch + b]));
     if (int rc = enqueue_pass(h, h->d_stream + (size_t)k * h->batch, h->stream_mhi[k])) return rc;
   }
+  if (count > 0)
+    for (int b = 0; b < h->batch; ++b)
+      h->neff[b] = std::max(h->neff[b], std::min(h->n[b], h->stream_own[(size_t)(first + count - 1) * h->batch + b]));
   return EKF_OK;
 }
 
@@ -859,6 +922,7 @@ extern "C" int ekf_set_option(ekf_handle* h, const char* name, int value) {
   }
   if (std::strcmp(name, "active_bound") == 0) {
     if (value != 0 && value != 1) return fail(h, EKF_ERR_ARG, "active_bound must be 0 or 1");
+    HIP_TRY(h, hipSetDevice(h->device));
     if (int rc = flush_pending(h)) return rc;
     h->opt_active_bound = value;
     return EKF_OK;

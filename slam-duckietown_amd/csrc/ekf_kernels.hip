@@ -180,7 +180,7 @@ __device__ __forceinline__ void solve_body(SolveLds& L, const double* __restrict
                                            const double* __restrict__ mu_in_b, double* __restrict__ mu_out_b,
                                            const StepIn& s, SolveOut& o, SolveIter* its, unsigned* flag_b,
                                            double* __restrict__ fac_b, const DeviceConfig& cfg, int ld, int kbase,
-                                           bool writer) {
+                                           bool writer, int neff_eff) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   auto& Pc = L.Pc;
@@ -408,7 +408,7 @@ __device__ __forceinline__ void solve_body(SolveLds& L, const double* __restrict
     o.c = c;
     o.m = m;
     o.kbase = kbase;
-    o.neff = s.neff;
+    o.neff = neff_eff;
     dacc_out[0] = d0 + rd0;                            // the pose-block noise joins the pending update
     dacc_out[1] = d1 + rd1;
     dacc_out[2] = d2 + rd2;
@@ -539,12 +539,16 @@ __global__ __launch_bounds__(256) void k_solve(const double* __restrict__ P, con
                                                const StepIn* __restrict__ in,
                                                SolveOut* __restrict__ out,
                                                unsigned* __restrict__ flags, double* __restrict__ fac,
+                                               const int* __restrict__ neff_floor,
                                                DeviceConfig cfg, int ld, long pstride, int kbase) {
   __shared__ SolveLds L;
   const int b = blockIdx.x;
+  // active bound of this step: what the host baked into the record, raised to the handle's floor (the bound the
+  // state had when the enqueueing call started: a stream uploaded earlier knows only its own observations)
+  const int neff_eff = min(nact[b], max(in[b].neff, neff_floor[b]));
   solve_body(L, P + (long)b * pstride, V + (long)b * KTOT * ld, W + (long)b * KTOT * ld, dacc_in + 4 * b,
              dacc_out + 4 * b, mu_in + (long)b * ld, mu_out + (long)b * ld, in[b], out[b], out[b].it,
-             flags + b, fac + (long)b * FACS, cfg, ld, kbase, true);
+             flags + b, fac + (long)b * FACS, cfg, ld, kbase, true, neff_eff);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1404,16 +1408,19 @@ __global__ __launch_bounds__(64) void k_associate(const DetIn* __restrict__ det,
       const double tx = d.pose_t[q][0], tz = d.pose_t[q][2];
       if (tz * tz + tx * tx > cfg.gate2) continue;                                // :289
       int lm = tm[id];
-      if (lm < 0) {                                                               // :294-295
-        if (3 + 2 * (nl + 1) > n_max) { bad |= EKF_FLAG_ASSOC; continue; }
-        lm = nl++;
-        tm[id] = lm;
-      }
       int slot = -1;
-      for (int u = 0; u < m; ++u)
-        if (s_idx[u] == lm) slot = u;
+      if (lm >= 0)
+        for (int u = 0; u < m; ++u)
+          if (s_idx[u] == lm) slot = u;
       if (slot < 0) {
+        // a detection that cannot be taken is dropped BEFORE it gets a landmark index: an index handed out here
+        // with no measurement behind it would leave an uninitialised landmark in the state
         if (m >= MMAX) { bad |= EKF_FLAG_ASSOC; continue; }
+        if (lm < 0) {                                                             // :294-295
+          if (3 + 2 * (nl + 1) > n_max) { bad |= EKF_FLAG_ASSOC; continue; }
+          lm = nl++;
+          tm[id] = lm;
+        }
         slot = m++;
         s_idx[slot] = lm;
         s_tag[slot] = id;
@@ -1532,10 +1539,10 @@ __global__ __launch_bounds__(256) void k_fill_diag(double* __restrict__ Pb, int 
 // ---------------------------------------------------------------------------------------------
 void launch_solve(hipStream_t st, const double* P, const double* V, const double* W, const double* dacc_in,
                   double* dacc_out, const double* mu_in, double* mu_out, const int* nact, const StepIn* in,
-                  SolveOut* out, unsigned* flags, double* fac, const DeviceConfig& cfg, int ld, long pstride,
-                  int batch, int kbase) {
+                  SolveOut* out, unsigned* flags, double* fac, const int* neff_floor, const DeviceConfig& cfg,
+                  int ld, long pstride, int batch, int kbase) {
   hipLaunchKernelGGL(k_solve, dim3(batch), dim3(256), 0, st, P, V, W, dacc_in, dacc_out, mu_in, mu_out, nact, in,
-                     out, flags, fac, cfg, ld, pstride, kbase);
+                     out, flags, fac, neff_floor, cfg, ld, pstride, kbase);
 }
 
 template <int MCAP>

@@ -31,6 +31,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_NAME = "libekfslam_hip.so"
 EKF_MMAX = 16
 EKF_FLAG_NONFINITE = 1
+EKF_FLAG_ASSOC = 2
+EKF_DMAX = 64
+EKF_TAGMAX = 1024
 
 
 class EkfError(RuntimeError):
@@ -321,7 +324,13 @@ class EkfSlam:
     def step_detections(self, lin, ang, detections):
         """One window of raw detections per trajectory: the reference's ``[(timestamp, [tag, ...])]`` list
         (src/replay_no_ros.py:280-284), or a list of such lists for a batch.  Association, the 1.5 m gate,
-        per-tag averaging, augmentation, prediction and update all run on the GPU."""
+        per-tag averaging, augmentation, prediction and update all run on the GPU.
+
+        Limits of the device front end (the reference has none): tag ids in [0, 1024), at most 64 detections
+        and 16 distinct tags per window, and the map must fit ``n_max``.  A detection beyond them is dropped
+        and the sticky ``EKF_FLAG_ASSOC`` is raised on the device; ``tags_positions()`` (which synchronises
+        anyway) then raises ``EkfError``.  ``replay.GpuBackend`` checks the limits on the host first and
+        regrows the state / takes the host association for such a window instead."""
         lin, ang = self._per_traj(lin, "lin"), self._per_traj(ang, "ang")
         if self.batch == 1 and (len(detections) == 0 or isinstance(detections[0], tuple)):
             detections = [detections]
@@ -347,6 +356,10 @@ class EkfSlam:
         idx, tid = np.zeros(EKF_MMAX, dtype=np.int32), np.zeros(EKF_MMAX, dtype=np.int32)
         arrs = [np.zeros(EKF_MMAX) for _ in range(5)]
         self._check(self._lib.ekf_download_tags(self._h, b, C.byref(m), _p(idx, _ip), _p(tid, _ip), *[_p(a) for a in arrs]))
+        if self.flags(b) & EKF_FLAG_ASSOC:
+            raise EkfError("device-side association dropped a detection (tag id outside [0, 1024), more than "
+                           f"{EKF_MMAX} distinct tags in one window, or the state is full): the map no longer matches "
+                           "the reference's; use a larger n_max or the host association")
         xw, yw, err, rng, brg = arrs
         return {int(idx[i]): [xw[i], yw[i], err[i], int(tid[i]), rng[i], brg[i]] for i in range(m.value)}
 
@@ -425,21 +438,26 @@ class EkfSlam:
 class _DropInState:
     """Device state kept between EKF_pose_estimation calls so the covariance need not be re-uploaded
     when the caller passes back exactly what the previous call returned (the reference loop does,
-    src/replay_no_ros.py:229-237)."""
+    src/replay_no_ros.py:229-237).  "Exactly" is checked against PRIVATE records of what was returned
+    (a copy of the mean, row and column sums of the covariance), never against the returned arrays
+    themselves: the caller owns those and may edit them in place."""
     filt: Optional[EkfSlam] = None
-    mean: Optional[np.ndarray] = None
-    cov: Optional[np.ndarray] = None
-    sample: Optional[np.ndarray] = None
+    mean_obj: Optional[np.ndarray] = None      # the objects handed to the caller (identity test only)
+    cov_obj: Optional[np.ndarray] = None
+    mean_copy: Optional[np.ndarray] = None     # private records of their contents
+    cov_sums: Optional[np.ndarray] = None
 
 
 _drop = _DropInState()
 DROP_IN_CONFIG = EkfConfig()      # edit like the reference's module constants
-DROP_IN_ALWAYS_UPLOAD = False     # True: never trust array identity
+DROP_IN_ALWAYS_UPLOAD = False     # True: never trust the records, upload mean and covariance every call
 DROP_IN_MIN_CAPACITY = 203        # n_max of the first handle (100 landmarks); grows by doubling
 
 
-def _cov_sample(cov: np.ndarray) -> np.ndarray:
-    return np.concatenate([np.diag(cov), cov[:3].ravel(), cov[:, :3].ravel()])
+def _cov_sums(cov: np.ndarray) -> np.ndarray:
+    """Row sums and column sums: any edit of a single entry changes one of each, an edit of several entries
+    goes unnoticed only if it cancels in every row and every column it touches."""
+    return np.concatenate([cov.sum(axis=0), cov.sum(axis=1)])
 
 
 def EKF_pose_estimation(angular_displacement, linear_displacement, motion_model_mean, motion_model_covariance,
@@ -463,9 +481,10 @@ def EKF_pose_estimation(angular_displacement, linear_displacement, motion_model_
         new_xy.append((tags_positions[j][0], tags_positions[j][1]))   # KeyError like the reference
 
     d = _drop
-    resident = (not DROP_IN_ALWAYS_UPLOAD and d.filt is not None and d.mean is motion_model_mean
-                and d.cov is motion_model_covariance and d.filt.size() == n_old
-                and np.array_equal(d.sample, _cov_sample(cov_in)) and np.array_equal(d.mean, mean_in))
+    resident = (not DROP_IN_ALWAYS_UPLOAD and d.filt is not None and d.mean_obj is motion_model_mean
+                and d.cov_obj is motion_model_covariance and d.filt.size() == n_old
+                and cov_in.shape == (n_old, n_old)
+                and np.array_equal(d.mean_copy, mean_in) and np.array_equal(d.cov_sums, _cov_sums(cov_in)))
     if d.filt is None or d.filt.n_max < n_new or d.filt.config != cfg:
         cap = max(DROP_IN_MIN_CAPACITY, n_new if d.filt is None else max(n_new, 2 * d.filt.n_max - 3))
         cap |= 1
@@ -484,7 +503,8 @@ def EKF_pose_estimation(angular_displacement, linear_displacement, motion_model_
     mean, cov = f.state()
     if f.flags() & EKF_FLAG_NONFINITE:
         warnings.warn("EKF_pose_estimation: non-finite state (q == 0 or singular S)", RuntimeWarning)
-    d.mean, d.cov, d.sample = mean, cov, _cov_sample(cov)
+    d.mean_obj, d.cov_obj = mean, cov
+    d.mean_copy, d.cov_sums = mean.copy(), _cov_sums(cov)
     return mean, cov, tags_positions
 
 

@@ -52,7 +52,10 @@ class GpuBackend:
 
     def __init__(self, config=None, capacity: int = 203, device: int = 0, device_association: bool = False):
         """device_association=True: association / gate / averaging / augmentation run on the GPU too
-        (`EkfSlam.step_detections`); the capacity must then cover the whole map (no regrowth)."""
+        (`EkfSlam.step_detections`).  The device front end has limits the reference does not (16 distinct tags
+        and 64 detections per window, tag ids below 1024, a fixed capacity): every window is checked against them
+        on the host first; the state is regrown when the map would not fit, and a window beyond the per-window
+        limits takes the host association (which has none) for that window."""
         from .ekf_bindings import EkfConfig, EkfSlam
         self.config = config or EkfConfig()
         self.device_association = device_association
@@ -66,13 +69,20 @@ class GpuBackend:
         if n > self.filt.n_max:
             self.filt.close()
             self.filt = self._make(max(n, 2 * self.filt.n_max - 3))
+            if self.device_association:
+                self.filt.set_association(self.config.gate_range, self.config.ignore_tags)
         self.filt.set_state(mean, cov)
 
     def _grow(self, n_needed):
         mean, cov = self.filt.state()
+        index = self.filt.tag_index() if self.device_association else None
         self.filt.close()
         self.filt = self._make(max(n_needed, 2 * self.filt.n_max - 3))
         self.filt.set_state(mean, cov)
+        if self.device_association:
+            self.filt.set_association(self.config.gate_range, self.config.ignore_tags)
+            if index:
+                self.filt.set_tag_index(index)
 
     def pose(self) -> np.ndarray:
         return self.filt.mean()[:3]
@@ -80,15 +90,39 @@ class GpuBackend:
     def state(self):
         return self.filt.state()
 
+    def _window_tags(self, detections):
+        """Tag ids of the window that pass IGNORE_TAGS and the gate (:286-289), in order of first appearance."""
+        ids, count = [], 0
+        gate2 = self.config.gate_range ** 2
+        for _stamp, tags in detections:
+            for tag in tags:
+                count += 1
+                t = np.asarray(tag.pose_t, dtype=np.float64).ravel()
+                if tag.tag_id in self.config.ignore_tags or t[2] ** 2 + t[0] ** 2 > gate2:
+                    continue
+                if tag.tag_id not in ids:
+                    ids.append(tag.tag_id)
+        return ids, count
+
     def step(self, ang, lin, detections, tag_index) -> dict:
+        from .ekf_bindings import EKF_DMAX, EKF_MMAX, EKF_TAGMAX
         if self.device_association:
-            if tag_index and not self.filt.tag_index():           # a pre-filled TAG_INDEX (god mode) goes to the device
+            dev_index = self.filt.tag_index()
+            if tag_index and not dev_index:                       # a pre-filled TAG_INDEX (god mode) goes to the device
                 self.filt.set_tag_index(tag_index)
-            self.filt.step_detections(lin, ang, detections)
-            tags = self.filt.tags_positions()
-            tag_index.clear()
-            tag_index.update(self.filt.tag_index())
-            return tags
+                dev_index = dict(tag_index)
+            ids, count = self._window_tags(detections)
+            n_need = 3 + 2 * (len(dev_index) + sum(1 for t in ids if t not in dev_index))
+            if n_need > self.filt.n_max:
+                self._grow(n_need)
+            if len(ids) <= EKF_MMAX and count <= EKF_DMAX and all(0 <= t < EKF_TAGMAX for t in ids):
+                self.filt.step_detections(lin, ang, detections)
+                tags = self.filt.tags_positions()                 # raises if the device still had to drop something
+                tag_index.clear()
+                tag_index.update(self.filt.tag_index())
+                return tags
+            tag_index.clear()                                     # this window: host association, no limits
+            tag_index.update(dev_index)
         pose = self.pose()                                        # world guesses use the pre-step pose (:331-332)
         tags = associate(detections, tag_index, pose, self.config.gate_range, self.config.ignore_tags)
         n_old = self.filt.size()
@@ -100,6 +134,8 @@ class GpuBackend:
             self.filt.add_landmarks(np.array(new_xy))
         idx = list(tags.keys())
         self.filt.step(lin, ang, idx, [tags[k][4] for k in idx], [tags[k][5] for k in idx])
+        if self.device_association and all(0 <= t < EKF_TAGMAX for t in tag_index):
+            self.filt.set_tag_index(tag_index)                    # the device table follows the host's for the next window
         return tags
 
     def close(self):
@@ -122,11 +158,15 @@ def _payload(line: str) -> str:
 
 def replay(source, backend=None, delta_time: float = 0.7, detector: Optional[Callable] = None,
            god_key: Optional[Sequence[int]] = None, wheel_radius: float = 0.0318, baseline: float = 0.1,
-           resolution: int = 135, motion_sigma: float = 0.1, on_window: Optional[Callable] = None) -> ReplayResult:
+           resolution: int = 135, motion_sigma: float = 0.1, on_window: Optional[Callable] = None,
+           fast_mode: bool = False) -> ReplayResult:
     """Replay an ``events.csv`` (directory, file path, or an iterable of lines) through the EKF.
 
     ``backend`` defaults to ``GpuBackend()``; it needs ``set_state / pose / state / step`` (tests inject a
     CPU double).  ``on_window(result_so_far_dict)`` is called after every EKF step (the reference plots there).
+    ``fast_mode`` is the reference's ``ENABLE_FAST_MODE`` (:32): frames are only queued when they arrive
+    (:122-123) and, at every window boundary, the detector runs on the LAST FIVE frames queued so far -- the
+    queue is never emptied, so a window with fewer than five frames reaches back into earlier ones (:216-227).
     """
     base_dir = None
     if isinstance(source, (str, os.PathLike)):
@@ -148,6 +188,7 @@ def replay(source, backend=None, delta_time: float = 0.7, detector: Optional[Cal
     prev_stamp = False                                                           # :81
     tag_index: Dict[int, int] = {}
     window: list = []
+    image_list: list = []                                                        # fast mode: every frame so far (:123)
     poses, path_xy, measured = [], [(0, 0)], []
     ground_truth, landmarks = [], None
     camera_params = [340, 336, 328, 257]                                         # :93
@@ -173,9 +214,16 @@ def replay(source, backend=None, delta_time: float = 0.7, detector: Optional[Cal
                 if detector is None:
                     raise ValueError("'image' event needs a detector(path, camera_params) callable")
                 img_path = os.path.join(base_dir, data) if base_dir else data
-                window.append((stamp_s, detector(img_path, camera_params)))
+                if fast_mode:
+                    image_list.append((stamp_s, lambda cp, p=img_path: detector(p, cp)))
+                else:
+                    window.append((stamp_s, detector(img_path, camera_params)))
             elif event == "detections":
-                window.append((stamp_s, _tags_from_literal(ast.literal_eval(_payload(line.strip())))))
+                tags_now = _tags_from_literal(ast.literal_eval(_payload(line.strip())))
+                if fast_mode:
+                    image_list.append((stamp_s, lambda cp, t=tags_now: t))
+                else:
+                    window.append((stamp_s, tags_now))
             elif event == "landmarks":
                 landmarks = ast.literal_eval(_payload(line.strip()))
                 if god_key is not None:                                          # ENABLE_GOD_EKF, :140-157
@@ -205,6 +253,8 @@ def replay(source, backend=None, delta_time: float = 0.7, detector: Optional[Cal
                 d_r = delta_phi(curr_rtick, prev_rtick, resolution)
                 prev_ltick, prev_rtick = curr_ltick, curr_rtick
                 ang, lin = displacement(wheel_radius, baseline, d_l, d_r)
+                if fast_mode:                                                    # :216-227
+                    window = [(stamp, detect(camera_params)) for _stamp, detect in image_list[-5:]]
                 tags = backend.step(ang, lin, window, tag_index)
                 window = []                                                      # :238
                 pose = np.array(backend.pose(), dtype=float)

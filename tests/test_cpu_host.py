@@ -191,3 +191,38 @@ def test_header_is_plain_c_and_links_against_the_library(tmp_path):
                     lib, "-Wl,-rpath," + os.path.dirname(lib)], check=True, capture_output=True)
     out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()
     assert float(out[0]) == 0.1 and float(out[1]) == 0.7 and int(out[2]) == 16 and int(out[3]) == 1
+
+
+def test_every_entry_point_selects_its_device():
+    """A host thread may own handles on several GPUs: every exported function that
+    enqueues work on the handle's stream must call hipSetDevice(h->device) first -- itself or through the
+    function it delegates to.  Source audit of csrc/ekf_api.hip."""
+    text = open(os.path.join(ROOT, "slam-duckietown_amd", "csrc", "ekf_api.hip")).read()
+    text = re.sub(r"//[^\n]*", "", text)
+    bodies = {}
+    for mt in re.finditer(r'^(?:extern "C" |static )[^\n;{]*?\b([A-Za-z_][A-Za-z0-9_]*)\s*\(([^)]*)\)\s*\{', text, flags=re.M):
+        depth, i = 1, mt.end()
+        while depth:
+            depth += {"{": 1, "}": -1}.get(text[i], 0)
+            i += 1
+        bodies[mt.group(1)] = (mt.group(0).startswith("extern"), mt.group(2), text[mt.end():i])
+    exported = {k for k, v in bodies.items() if v[0] and "ekf_handle* h" in v[1]}
+    assert {"ekf_step", "ekf_stream_run", "ekf_download_tags", "ekf_set_option", "ekf_flush"} <= exported
+    gpu = re.compile(r"\bhip(?!SetDevice)[A-Z]\w*\s*\(|\blaunch_\w+\s*\(|\bdense_propagate\s*\(")
+
+    def callees(name):
+        return [c for c in set(re.findall(r"\b([A-Za-z_]\w*)\s*\(", bodies[name][2])) if c in bodies and c != name]
+
+    def touches(name, seen=()):
+        return bool(gpu.search(bodies[name][2])) or any(touches(c, seen + (name,)) for c in callees(name) if c not in seen)
+
+    def selects(name, seen=()):
+        body = bodies[name][2]
+        if "hipSetDevice(h->device)" in body:
+            return True
+        if gpu.search(body):
+            return False
+        return all(selects(c, seen + (name,)) for c in callees(name) if c not in seen and touches(c))
+
+    missing = sorted(n for n in exported if touches(n) and not selects(n))
+    assert not missing, f"entry points that use the stream without hipSetDevice(h->device): {missing}"

@@ -1,0 +1,220 @@
+"""GPU regression tests of the host-side state tracking around the HIP path (round-1 advisor findings):
+the drop-in's "is this what I returned?" test, the active bound of an uploaded stream, the limits of the
+device-side association, argument validation that must not leave the handle half-updated."""
+from types import SimpleNamespace as NS
+
+import numpy as np
+import pytest
+
+from oracle import ekf_oracle as orc
+from tests import golden_util as gu
+
+pytestmark = pytest.mark.gpu
+
+REL_TOL = 1e-6
+TIGHT = 1e-9
+
+
+@pytest.fixture(scope="module")
+def sd():
+    import slam_duckietown_amd as sd
+    sd.load_library()
+    return sd
+
+
+def close(a, b, tol=TIGHT):
+    r = orc.rel_fro(a, b)
+    assert r < REL_TOL, f"rel Frobenius {r:.3e} exceeds the 1e-6 bar"
+    assert r < tol, f"rel Frobenius {r:.3e} exceeds the expected {tol:g}"
+
+
+def test_drop_in_sees_in_place_edits_of_returned_arrays(sd):
+    """The caller owns the arrays EKF_pose_estimation returned and may edit them IN PLACE (a pose reset, a wrapped
+    angle, an inflated landmark-landmark entry far from the pose block): the next call must start from the edited
+    values like the reference does (src/replay_no_ros.py:229-237 passes them straight back in)."""
+    from slam_duckietown_amd import ekf_bindings as eb
+    g = gu.load("replay_default")
+    mean = np.array([0.0, 0.0, 0.0])
+    cov = np.eye(3) * 0.1
+    ti, oti = {}, {}
+    ocfg = orc.EkfConfig()
+    omean, ocov = mean.copy(), cov.copy()
+    edits = 0
+    for k in range(16):
+        det = gu.detections_for_step(g, k)
+        mean, cov, _ = eb.EKF_pose_estimation(g["ang"][k], g["lin"][k], mean, cov, 0.7, det, ti)
+        omean, ocov, _ = orc.ekf_pose_estimation_dense(g["ang"][k], g["lin"][k], omean, ocov, 0.7, det, oti, ocfg)
+        close(mean, omean)
+        close(cov, ocov)
+        n = len(mean)
+        if k % 3 == 1:                               # same objects, new contents
+            mean[2] = mean[2] + 0.25
+            omean[2] = omean[2] + 0.25
+            edits += 1
+        if k % 4 == 2 and n >= 9:                    # an entry the old diag + pose-rows sample never looked at
+            i, j = n - 1, n - 4
+            cov[i, j] += 0.125
+            cov[j, i] += 0.125
+            ocov[i, j] += 0.125
+            ocov[j, i] += 0.125
+            edits += 1
+    assert edits >= 6
+
+
+def test_uploaded_stream_follows_later_state_changes(sd):
+    """ekf_stream_upload bakes the active bound that follows from the stream's own observations; a dense upload, a
+    second run of the same stream or a toggled option between upload and run must still give the dense reference
+    result (the bound is completed at run time)."""
+    N, steps, m = 120, 12, 4
+    mean0, diag0, lin, ang, idx, zr, zb = orc.synthetic_stream(N, steps, m, 21)
+    idx = idx % 30                                   # the stream itself only ever observes landmarks 0..29
+    for k in range(steps):
+        assert len(set(idx[k].tolist())) == m
+    n = len(mean0)
+    cfg = orc.EkfConfig()
+    rng = np.random.default_rng(2)
+    A = rng.normal(size=(n, 6)) * 0.4
+    Pd = A @ A.T + np.diag(rng.uniform(0.5, 1.5, n))      # dense: everything correlated with everything
+
+    def oracle_run(mu, P, k0, k1):
+        for k in range(k0, k1):
+            mu, P = orc.ekf_step_dense(mu, P, lin[k], ang[k], idx[k], zr[k], zb[k], cfg)
+        return mu, P
+
+    with sd.EkfSlam(n) as f:
+        # 1. upload on a diagonal state, then replace the state by a dense one, then run
+        f.set_state_diag(mean0, diag0)
+        f.stream_upload(lin, ang, idx, zr, zb)
+        f.set_state(mean0, Pd)
+        f.stream_run(0, steps)
+        mu, P = f.state()
+        om, oP = oracle_run(mean0.copy(), Pd.copy(), 0, steps)
+        close(mu, om)
+        close(P, oP)
+        # 2. run the first half of the same stream again on the state it left behind
+        f.stream_run(0, 6)
+        mu, P = f.state()
+        om, oP = oracle_run(om, oP, 0, 6)
+        close(mu, om)
+        close(P, oP)
+        # 3. the option changes after the upload
+        f.set_option("active_bound", 0)
+        f.stream_run(6, 6)
+        f.set_option("active_bound", 1)
+        f.stream_run(0, 3)
+        mu, P = f.state()
+        om, oP = oracle_run(om, oP, 6, 12)
+        om, oP = oracle_run(om, oP, 0, 3)
+        close(mu, om)
+        close(P, oP)
+        # 4. a state that lacks the stream's landmarks is refused, not indexed out of range
+        f.set_state(mean0[:3 + 2 * 10], Pd[:23, :23])
+        with pytest.raises(sd.EkfError):
+            f.stream_run(0, 1)
+
+
+def test_step_interleaved_with_predict_dense_keeps_the_bound(sd):
+    """A general dense F correlates every state with every other: steps after ekf_predict_dense must treat the
+    whole state as active, whatever the observations so far said."""
+    N, steps, m = 60, 6, 4
+    mean0, diag0, lin, ang, idx, zr, zb = orc.synthetic_stream(N, steps, m, 5)
+    idx = idx % 10
+    n = len(mean0)
+    cfg = orc.EkfConfig()
+    rng = np.random.default_rng(8)
+    F = np.eye(n) + rng.normal(size=(n, n)) * 0.02
+    Q = np.eye(n) * 0.01
+    om, oP = mean0.copy(), np.diag(diag0)
+    with sd.EkfSlam(n) as f:
+        f.set_state_diag(mean0, diag0)
+        f.stream_upload(lin, ang, idx, zr, zb)
+        f.stream_run(0, 3)
+        f.predict_dense(F, Q)
+        f.stream_run(3, 3)
+        mu, P = f.state()
+    for k in range(3):
+        om, oP = orc.ekf_step_dense(om, oP, lin[k], ang[k], idx[k], zr[k], zb[k], cfg)
+    oP = F @ oP @ F.T + Q
+    for k in range(3, 6):
+        om, oP = orc.ekf_step_dense(om, oP, lin[k], ang[k], idx[k], zr[k], zb[k], cfg)
+    close(mu, om)
+    close(P, oP)
+
+
+def test_rejected_update_leaves_the_handle_untouched(sd):
+    """A duplicate index anywhere in a long list (also across the 16-landmark device passes) is refused before any
+    handle state changes: the following valid steps still match the reference."""
+    N = 40
+    mean0, diag0, lin, ang, idx, zr, zb = orc.synthetic_stream(N, 4, 20, 13)
+    cfg = orc.EkfConfig()
+    om, oP = mean0.copy(), np.diag(diag0)
+    with sd.EkfSlam(len(mean0), batch=2) as f:
+        for b in range(2):
+            f.set_state_diag(mean0, diag0, b)
+        bad = idx[0].copy()
+        bad[18] = bad[2]                              # the repeat sits in the second device pass
+        with pytest.raises(sd.EkfError):
+            f.step([lin[0]] * 2, [ang[0]] * 2, [idx[0], bad], [zr[0]] * 2, [zb[0]] * 2)
+        far = idx[0].copy()
+        far[19] = N                                   # outside the state, trajectory 1 only
+        with pytest.raises(sd.EkfError):
+            f.step([lin[0]] * 2, [ang[0]] * 2, [idx[0], far], [zr[0]] * 2, [zb[0]] * 2)
+        for k in range(4):
+            f.step([lin[k]] * 2, [ang[k]] * 2, [idx[k][:6]] * 2, [zr[k][:6]] * 2, [zb[k][:6]] * 2)
+            om, oP = orc.ekf_step_dense(om, oP, lin[k], ang[k], idx[k][:6], zr[k][:6], zb[k][:6], cfg)
+        for b in range(2):
+            mu, P = f.state(b)
+            close(mu, om)
+            close(P, oP)
+
+
+def _tag(i, x, z):
+    return NS(tag_id=i, pose_R=np.eye(3), pose_t=np.array([[x], [0.0], [z]]), pose_err=0.0)
+
+
+def test_device_association_drops_before_indexing(sd):
+    """17 distinct tags in one window: the 17th is dropped BEFORE it is given a landmark index (no uninitialised
+    landmark enters the state), the sticky flag is raised and tags_positions() reports it."""
+    tags = [_tag(100 + i, -0.4 + 0.05 * i, 0.6 + 0.01 * i) for i in range(17)]
+    with sd.EkfSlam(3 + 2 * 40) as f:
+        f.step_detections(0.01, 0.0, [(0.0, tags)])
+        assert f.size() == 3 + 2 * 16
+        assert f.tag_index() == {100 + i: i for i in range(16)}
+        assert f.flags() & 2
+        with pytest.raises(sd.EkfError):
+            f.tags_positions()
+        mu = f.mean()
+        assert np.isfinite(mu).all() and (np.abs(mu[3:]) > 0).any()
+
+
+def test_gpu_backend_device_association_beyond_the_device_limits(sd):
+    """replay.GpuBackend(device_association=True) against the host-association backend on windows the device
+    front end cannot take alone: more than 16 distinct tags in a window, and a map that outgrows the capacity."""
+    from slam_duckietown_amd.replay import GpuBackend
+    rng = np.random.default_rng(4)
+    windows = []
+    for k in range(10):
+        count = 20 if k in (2, 6) else 5
+        ids = rng.choice(60, size=count, replace=False)
+        tags = [_tag(int(i), float(rng.uniform(-0.5, 0.5)), float(rng.uniform(0.4, 1.2))) for i in ids]
+        windows.append([(float(k), tags)])
+    res = []
+    for dev in (False, True):
+        be = GpuBackend(capacity=3 + 2 * 20, device_association=dev)     # 20 landmarks: regrowth needed
+        be.set_state(np.zeros(3), np.eye(3) * 0.1)
+        ti = {}
+        for k, w in enumerate(windows):
+            be.step(0.02 if k % 2 else 0.004, 0.004, w, ti)
+        res.append(be.state() + (dict(ti), be.filt.flags()))
+        be.close()
+    assert res[0][2] == res[1][2] and res[1][3] == 0
+    close(res[1][0], res[0][0])
+    close(res[1][1], res[0][1])
+    # and the host path itself is the reference's: the oracle's dense EKF_pose_estimation on the same windows
+    om, oP, oti = np.zeros(3), np.eye(3) * 0.1, {}
+    cfg = orc.EkfConfig()
+    for k, w in enumerate(windows):
+        om, oP, _ = orc.ekf_pose_estimation_dense(0.02 if k % 2 else 0.004, 0.004, om, oP, 0.7, w, oti, cfg)
+    assert oti == res[0][2]
+    close(res[0][0], om)
+    close(res[0][1], oP)

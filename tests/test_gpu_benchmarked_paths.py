@@ -1,0 +1,199 @@
+"""GPU parity of the EXACT kernel instantiations and sizes bench.py runs (BASELINE configs 3, 4, 5):
+
+* N=2000 x 32 trajectories, default cadence: the streaming 80-rank covariance pass `k_flush<15,5,true>`
+  (two full passes + an odd tail), dense covariances, against `oracle.ekf_step_structured`;
+* the same instantiation forced at N=300 against the reference-shaped dense path;
+* `ekf_predict_dense` at n=4003 against NumPy dgemm;
+* N=8000 with and without the active bound, bit for bit;
+* two handles driven from two host threads.
+Reference: src/replay_no_ros.py:430 (propagation), :473-480 (gain, mean and covariance update).
+"""
+import threading
+
+import numpy as np
+import pytest
+
+from oracle import ekf_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+REL_TOL = 1e-6
+TIGHT = 1e-9
+
+
+@pytest.fixture(scope="module")
+def sd():
+    import slam_duckietown_amd as sd
+    sd.load_library()
+    return sd
+
+
+def close(a, b, tol=TIGHT):
+    r = orc.rel_fro(a, b)
+    assert r < REL_TOL, f"rel Frobenius {r:.3e} exceeds the 1e-6 bar"
+    assert r < tol, f"rel Frobenius {r:.3e} exceeds the expected {tol:g}"
+
+
+def dense_start(n, seed):
+    """A dense SPD covariance (diagonal + rank 8) so that every tile of the pass receives a non-zero update."""
+    rng = np.random.default_rng(seed)
+    A = rng.normal(size=(n, 8)) * 0.3
+    P = A @ A.T
+    P[np.arange(n), np.arange(n)] += rng.uniform(0.5, 2.0, n)
+    return P
+
+
+def test_config4_shard_n2000_x32_default_cadence(sd):
+    """BASELINE config 4's per-GPU shard exactly as bench.py runs it (N=2000, m=8, 32 trajectories, active bound
+    off, default cadence = 5 steps per 80-rank streaming pass): 11 steps = two full `k_flush<15,5,true>` launches
+    plus a one-step tail.  Trajectories 0-2 start from three different dense covariances and are compared with
+    the O(n^2) oracle; trajectory b > 2 repeats trajectory b % 3, so all 32 are checked -- bit for bit -- against
+    an oracle-checked one, wherever they sit in the launch (blockIdx.z)."""
+    N, steps, m, B, K = 2000, 11, 8, 32, 3
+    n = 3 + 2 * N
+    cfg = orc.EkfConfig()
+    streams = [orc.synthetic_stream(N, steps, m, 40 + t) for t in range(K)]
+    starts = [dense_start(n, 7 + t) for t in range(K)]
+    ref = []
+    for t in range(K):
+        om, oP = streams[t][0].copy(), starts[t].copy()
+        for k in range(steps):
+            s = streams[t]
+            om, oP = orc.ekf_step_structured(om, oP, s[2][k], s[3][k], s[4][k], s[5][k], s[6][k], cfg)
+        ref.append((om, oP))
+    pick = [streams[b % K] for b in range(B)]
+    with sd.EkfSlam(n, batch=B) as f:
+        f.set_option("active_bound", 0)
+        for b in range(B):
+            f.set_state(pick[b][0], starts[b % K], b)
+        f.run_stream(np.stack([s[2] for s in pick], 1), np.stack([s[3] for s in pick], 1),
+                     np.stack([s[4] for s in pick], 1), np.stack([s[5] for s in pick], 1),
+                     np.stack([s[6] for s in pick], 1))
+        got = {}
+        for b in range(B):
+            mu, P = f.state(b)
+            assert f.flags(b) == 0
+            assert np.array_equal(P, P.T)
+            d = np.diag(P)
+            assert (d > 0).all() and (d[3:] <= np.diag(starts[b % K])[3:] * (1 + 1e-12)).all()   # updates never add variance
+            if b < K:
+                close(mu, ref[b][0])
+                close(P, ref[b][1])
+                close(P.sum(axis=1), ref[b][1].sum(axis=1))
+                got[b] = (mu, P)
+            else:
+                assert np.array_equal(mu, got[b % K][0]) and np.array_equal(P, got[b % K][1])
+
+
+def test_streaming_80_rank_pass_small(sd):
+    """The same instantiation (nontemporal, 15 k-tiles of the V strip in registers + 5 in LDS) forced on a small
+    state, every step against the reference-shaped dense path."""
+    N, steps, m, B = 300, 12, 8, 2
+    cfg = orc.EkfConfig()
+    streams = [orc.synthetic_stream(N, steps, m, 60 + t) for t in range(B)]
+    n = 3 + 2 * N
+    ref = [(s[0].copy(), dense_start(n, 3 + b)) for b, s in enumerate(streams)]
+    with sd.EkfSlam(n, batch=B) as f:
+        f.set_option("pass_streaming", 1)
+        f.set_option("rank_limit", 80)
+        for b in range(B):
+            f.set_state(ref[b][0], ref[b][1], b)
+        for k in range(steps):
+            f.step([s[2][k] for s in streams], [s[3][k] for s in streams], [s[4][k] for s in streams],
+                   [s[5][k] for s in streams], [s[6][k] for s in streams])
+            for b, s in enumerate(streams):
+                ref[b] = orc.ekf_step_dense(ref[b][0], ref[b][1], s[2][k], s[3][k], s[4][k], s[5][k], s[6][k], cfg)
+            if k in (4, 9, 11):                       # after the first pass, the second, and with a tail pending
+                for b in range(B):
+                    mu, P = f.state(b)
+                    close(mu, ref[b][0])
+                    close(P, ref[b][1])
+
+
+def test_predict_dense_n4003(sd):
+    """`ekf_predict_dense` at the size bench.py times it (n = 4003) against NumPy dgemm (src/replay_no_ros.py:430
+    with a general F)."""
+    n = 4003
+    rng = np.random.default_rng(5)
+    P0 = dense_start(n, 11)
+    F = np.eye(n) + rng.normal(size=(n, n)) * (0.1 / np.sqrt(n))
+    Nq = rng.normal(size=(n, 8)) * 0.05
+    Q = Nq @ Nq.T + np.diag(rng.uniform(0.01, 0.1, n))
+    with sd.EkfSlam(n) as f:
+        f.set_state(np.zeros(n), P0)
+        f.predict_dense(F, Q)
+        P = f.covariance()
+    close(P, F @ P0 @ F.T + Q, 1e-12)
+
+
+def test_config5_n8000_active_bound_bit_identical(sd):
+    """BASELINE config 5 at full size (n = 16003): the skip-unobserved pass (active bound on) against the dense pass
+    (off) -- bit for bit on the whole matrix -- plus the O(n^2) oracle on sampled rows."""
+    N, steps, m = 8000, 12, 8
+    mean0, diag0, lin, ang, idx, zr, zb = orc.synthetic_stream(N, steps, m, 9)
+    idx = (idx * 37 + 5) % 3000                      # observations stay inside the first 3000 landmarks
+    for k in range(steps):
+        assert len(set(idx[k].tolist())) == m
+    n = len(mean0)
+    top = 3 + 2 * (int(idx.max()) + 1)
+    out = []
+    for bound in (1, 0):
+        with sd.EkfSlam(n) as f:
+            f.set_option("active_bound", bound)
+            f.set_state_diag(mean0, diag0)
+            f.run_stream(lin, ang, idx, zr, zb)
+            mu, P = f.state()
+            assert f.flags() == 0
+            out.append((mu, P))
+    assert np.array_equal(out[0][0], out[1][0])
+    assert np.array_equal(out[0][1], out[1][1])
+    P = out[0][1]
+    del out[1:]
+    assert not P[top:, :top].any() and not P[:top, top:].any()            # never correlated: untouched
+    assert np.array_equal(np.diag(P)[top:], diag0[top:])
+    cfg = orc.EkfConfig()
+    om, oP = mean0[:top].copy(), np.diag(diag0[:top])                     # the active part is a closed system
+    for k in range(steps):
+        om, oP = orc.ekf_step_structured(om, oP, lin[k], ang[k], idx[k], zr[k], zb[k], cfg)
+    close(out[0][0][:top], om)
+    close(P[:top, :top], oP)
+
+
+def test_two_handles_from_two_host_threads(sd):
+    """one handle per host thread, driven concurrently (ctypes releases the GIL).  Each
+    handle's result equals its own single-threaded run bit for bit."""
+    N, steps, m = 300, 40, 8
+    streams = [orc.synthetic_stream(N, steps, m, 70 + t) for t in range(2)]
+    n = 3 + 2 * N
+
+    def run(s, out, slot, barrier=None):
+        with sd.EkfSlam(n, batch=1) as f:
+            f.set_state_diag(s[0], s[1])
+            if barrier is not None:
+                barrier.wait()
+            for k in range(steps):
+                f.step(s[2][k], s[3][k], s[4][k], s[5][k], s[6][k])
+                if k % 7 == 0:
+                    f.mean()                       # a blocking call in the middle of the other thread's work
+            out[slot] = f.state() + (f.flags(),)
+
+    alone, together = [None, None], [None, None]
+    for t in range(2):
+        run(streams[t], alone, t)
+    barrier = threading.Barrier(2)
+    threads = [threading.Thread(target=run, args=(streams[t], together, t, barrier)) for t in range(2)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join(timeout=300)
+        assert not th.is_alive()
+    for t in range(2):
+        assert together[t] is not None and together[t][2] == 0
+        assert np.array_equal(alone[t][0], together[t][0]) and np.array_equal(alone[t][1], together[t][1])
+    cfg = orc.EkfConfig()
+    s = streams[0]
+    om, oP = s[0].copy(), np.diag(s[1])
+    for k in range(steps):
+        om, oP = orc.ekf_step_dense(om, oP, s[2][k], s[3][k], s[4][k], s[5][k], s[6][k], cfg)
+    close(together[0][0], om)
+    close(together[0][1], oP)

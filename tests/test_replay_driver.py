@@ -78,6 +78,20 @@ def test_replay_loop_matches_reference_cpu():
     assert sizes == list(g["out_ntags"])
 
 
+def test_fast_mode_matches_reference_cpu():
+    """ENABLE_FAST_MODE (src/replay_no_ros.py:32, :122-123, :216-227): the reference's own replay() with the flag
+    set, on the same log (tests/golden/replay_events_fast.npz)."""
+    import slam_duckietown_amd.replay as rp
+    g, gf = gu.load("replay_events"), gu.load("replay_events_fast")
+    detect, seen = fixture_detector(g)
+    res = rp.replay(str(g["events_csv"]).splitlines(), backend=OracleBackend(), detector=detect, fast_mode=True)
+    merged = dict(g)
+    merged.update(gf)
+    check_against_reference_loop(res, merged, seen, 1e-11)
+    slow = gu.load("replay_events")
+    assert not np.array_equal(gf["out_mean"][-1], slow["out_mean"][-1])          # the flag changes the result
+
+
 def test_detections_event_replaces_images_cpu():
     """The `detections` extension carries the tags in the log itself: same result without a detector."""
     import slam_duckietown_amd.replay as rp
@@ -120,6 +134,17 @@ def test_replay_loop_matches_reference_gpu():
     detect, seen = fixture_detector(g)
     res = rp.replay(str(g["events_csv"]).splitlines(), detector=detect)        # GpuBackend
     check_against_reference_loop(res, g, seen, 1e-9)
+
+
+@pytest.mark.gpu
+def test_fast_mode_matches_reference_gpu():
+    import slam_duckietown_amd.replay as rp
+    g, gf = gu.load("replay_events"), gu.load("replay_events_fast")
+    detect, seen = fixture_detector(g)
+    res = rp.replay(str(g["events_csv"]).splitlines(), detector=detect, fast_mode=True)     # GpuBackend
+    merged = dict(g)
+    merged.update(gf)
+    check_against_reference_loop(res, merged, seen, 1e-9)
 
 
 @pytest.mark.gpu
