@@ -19,6 +19,9 @@ void launch_flush(hipStream_t, bool, double*, const double*, const double*, cons
                   const SolveOut*, int, long, int, int, int, int);
 void launch_flush_pc(hipStream_t, bool, double*, const double*, const double*, const double*, const int*,
                      const SolveOut*, int, long, int, int, int, int, unsigned*);
+void launch_flush_rs(hipStream_t, bool, double*, const double*, const double*, const double*, const int*,
+                     const SolveOut*, int, long, int, int, int, int, unsigned*);
+int flush_rs_queue_words();
 void launch_predict_rc(hipStream_t, double*, const double*, double*, const int*, const SolveOut*, int, long,
                        int, int);
 void launch_add_landmarks(hipStream_t, double*, double*, int, int, int, double, const double*);
@@ -80,7 +83,9 @@ struct ekf_handle {
   size_t prof_used = 0;
   int opt_rank_limit = KTOT;      // automatic cadence: flush when the next step would exceed this many ranks
                                   // (20 MFMA k-tiles: 15 of the V strip in registers, 5 in LDS)
-  int opt_pass_kernel = 0;        // 0 = k_flush, 1 = k_flush_pc (producer/consumer waves)
+  int opt_pass_kernel = -1;       // -1 = auto, 0 = k_flush, 1 = k_flush_pc (producer/consumer waves), 2 = k_flush_rs (row slabs)
+  unsigned* dqueue = nullptr;     // work-queue heads of k_flush_rs (zeroed before every launch)
+  int cu_count = 0;
   int opt_rows_per_block = 0;     // 0 = auto (flush kernel: rows per workgroup, multiple of 16)
   int opt_flush_every = 0;        // 0 = auto; k = flush the pending low-rank update after k steps
   int opt_streaming = -1;         // -1 = auto (by working-set size), 0 = resident kernel, 1 = nontemporal kernel
@@ -130,7 +135,7 @@ static void free_all(ekf_handle* h) {
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   void* ptrs[] = {h->dP, h->dmu2[0], h->dmu2[1], h->dV, h->dW, h->ddacc2[0], h->ddacc2[1], h->dscratch, h->dn, h->dflags, h->dso, h->dfac,
-                  h->d_ring, h->d_stream, h->dF, h->dQ, h->dTmp, h->dtagmap, h->dneff, h->d_det, h->d_assoc_step, h->dfloor,
+                  h->d_ring, h->d_stream, h->dF, h->dQ, h->dTmp, h->dtagmap, h->dneff, h->d_det, h->d_assoc_step, h->dfloor, h->dqueue,
                   h->d_assoc_out};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (h->h_ring) (void)hipHostFree(h->h_ring);
@@ -162,6 +167,7 @@ extern "C" int ekf_create(int device, int n_max, int batch, const ekf_config* cf
                                           ", kernels are built for gfx950 only");
   ekf_handle* h = new ekf_handle();
   h->device = device;
+  h->cu_count = prop.multiProcessorCount;
   h->n_max = n_max;
   h->ld = (n_max + 63) / 64 * 64;                      // every 64-column strip of k_flush lies inside the row (512-B aligned)
   h->batch = batch;
@@ -209,6 +215,7 @@ extern "C" int ekf_create(int device, int n_max, int batch, const ekf_config* cf
   CREATE_TRY(hipMalloc(&h->dn, sizeof(int) * batch));
   CREATE_TRY(hipMalloc(&h->dflags, sizeof(unsigned) * batch));
   CREATE_TRY(hipMalloc(&h->dfloor, sizeof(int) * batch));
+  CREATE_TRY(hipMalloc(&h->dqueue, sizeof(unsigned) * flush_rs_queue_words()));
   CREATE_TRY(hipMalloc(&h->dso, sizeof(SolveOut) * batch));
   CREATE_TRY(hipMalloc(&h->dfac, sizeof(double) * FACS * batch));
   CREATE_TRY(hipMalloc(&h->d_ring, sizeof(StepIn) * batch * RING));
@@ -434,13 +441,23 @@ static int flush_pending(ekf_handle* h) {
   int e_hi = 3;                                        // grid covers the largest active bound of the batch
   for (int b = 0; b < h->batch; ++b) e_hi = std::max(e_hi, std::min(h->n[b], h->neff_enq[b]));
   if (h->sizes_dirty) e_hi = h->n_max;
-  if (h->opt_pass_kernel == 1)
-    launch_flush_pc(h->stream, streaming_pass(h, n_hi), h->dP, h->dV, h->dW, h->ddacc2[h->dcur], h->dn, h->dso, h->ld,
-                    h->pstride, h->batch, e_hi, (h->pending_k + 3) / 4, flush_rows_per_block(h, streaming_pass(h, n_hi)),
-                    h->dflags);
-  else
-    launch_flush(h->stream, streaming_pass(h, n_hi), h->dP, h->dV, h->dW, h->ddacc2[h->dcur], h->dn, h->dso, h->ld, h->pstride,
-                 h->batch, e_hi, (h->pending_k + 3) / 4, flush_rows_per_block(h, streaming_pass(h, n_hi)));
+  const bool streaming = streaming_pass(h, n_hi);
+  const int nkt = (h->pending_k + 3) / 4;
+  int kernel = h->opt_pass_kernel;
+  if (kernel < 0)                                      // auto: the row-slab form needs enough slabs to fill every CU
+    kernel = (streaming && (long)h->batch * ((e_hi + 127) / 128) >= 2L * h->cu_count) ? 2 : 0;
+  if (kernel == 2) {
+    HIP_TRY(h, hipMemsetAsync(h->dqueue, 0, sizeof(unsigned) * flush_rs_queue_words(), h->stream));
+    if (h->profile) HIP_TRY(h, hipEventRecord(e0, h->stream));      // (time the kernel, not the 1 KB memset)
+    launch_flush_rs(h->stream, streaming, h->dP, h->dV, h->dW, h->ddacc2[h->dcur], h->dn, h->dso, h->ld, h->pstride,
+                    h->batch, e_hi, nkt, h->cu_count, h->dqueue);
+  } else if (kernel == 1) {
+    launch_flush_pc(h->stream, streaming, h->dP, h->dV, h->dW, h->ddacc2[h->dcur], h->dn, h->dso, h->ld, h->pstride,
+                    h->batch, e_hi, nkt, flush_rows_per_block(h, streaming), h->dflags);
+  } else {
+    launch_flush(h->stream, streaming, h->dP, h->dV, h->dW, h->ddacc2[h->dcur], h->dn, h->dso, h->ld, h->pstride, h->batch,
+                 e_hi, nkt, flush_rows_per_block(h, streaming));
+  }
   if (h->profile) HIP_TRY(h, hipEventRecord(e1, h->stream));
   HIP_TRY(h, hipGetLastError());
   HIP_TRY(h, hipMemsetAsync(h->ddacc2[0], 0, sizeof(double) * 4 * h->batch, h->stream));
@@ -906,7 +923,7 @@ extern "C" int ekf_profile_read(ekf_handle* h, double* pass_ms_total, long long*
 extern "C" int ekf_set_option(ekf_handle* h, const char* name, int value) {
   if (!h || !name) return EKF_ERR_ARG;
   if (std::strcmp(name, "pass_kernel") == 0) {
-    if (value < 0 || value > 1) return fail(h, EKF_ERR_ARG, "pass_kernel: 0 or 1");
+    if (value < -1 || value > 2) return fail(h, EKF_ERR_ARG, "pass_kernel: -1 (auto), 0, 1 or 2");
     h->opt_pass_kernel = value;
     return EKF_OK;
   }

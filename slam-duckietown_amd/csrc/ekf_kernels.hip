@@ -1304,6 +1304,321 @@ __global__ __launch_bounds__(512, 1) void k_flush_pc(double* __restrict__ P, con
 #undef PC_STORE
 
 // ---------------------------------------------------------------------------------------------
+// k_flush_rs: the same update, "row slab" form (the default for batches that stream through HBM).
+// The roles of the two operands are swapped with respect to k_flush: a wave keeps the W fragments of ITS 16 rows
+// in registers (A operands: 2 VGPRs per k-tile instead of the 8 a 64-column V strip costs) and walks along those
+// rows one 16 x 64 tile at a time; the V strip of the current 64 columns (B operands) lives in LDS and is shared
+// by the eight waves of the workgroup, which cover 128 consecutive rows.  With 40 instead of 160 operand registers
+// there is room to software-pipeline the tiles inside one wave, so that no MFMA ever waits for memory or for the
+// LDS transposes:
+//   while tile t is in the matrix pipe (4 * NKT MFMAs on `acc`), the same wave
+//     . sends the result of tile t-1 (parked in its LDS image) to HBM as 16-byte row segments,
+//     . turns tile t+1 (already in registers, row-major) into the C/D layout through the image -> `accn`,
+//     . issues the HBM loads of tile t+2,
+//     . stages its share of the V strip of step t+1 into the other half of the strip buffer;
+//   at the tile boundary: one workgroup barrier (s_barrier only: nothing in flight is drained), acc -> image,
+//   acc <- accn.
+// Every global access inside the pipelined loop is unconditional (loads beyond the end of a slab are pointed at a
+// small cache-resident dummy, by a select, not a branch) so that the compiler can count what is in flight.
+// Work distribution: persistent workgroups (one per CU: 144 KB of LDS), units = (trajectory, 128-row slab) handed
+// out longest first from per-XCD queues (trajectory b belongs to queue b % 8: the slabs of a trajectory share V and
+// run on one L2; an idle workgroup steals from the other queues).  A slab is walked from the right end of its rows
+// towards the diagonal: the slabs of a trajectory start on the same V strip.
+// The accumulation order per element is k_flush's (k-tiles ascending): the two kernels agree bit for bit.
+// ---------------------------------------------------------------------------------------------
+constexpr int RS_ROWS = 128;            // rows of a slab = 8 waves x 16
+constexpr int RS_QSTRIDE = 32;          // words between the per-XCD queue heads (one cache line each)
+typedef unsigned int uint4v_t __attribute__((ext_vector_type(4)));
+typedef unsigned int uint2v_t __attribute__((ext_vector_type(2)));
+
+// Global accesses of k_flush_rs are buffer instructions: (128-bit resource in SGPRs: wave-uniform base) + (SGPR byte
+// offset: the tile) + (ONE 32-bit VGPR: the lane's place inside the tile).  64-bit per-lane pointers for the eight
+// rows of a tile would cost the registers the pipeline needs (the compiler does not form the saddr + voffset
+// global instructions when the lane offset is defined outside the loop).  Offsets are unsigned 32-bit: a
+// trajectory's P is at most 4 GB.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t rs_rsrc(const void* base) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, -1, 0x00020000);
+}
+template <bool NT>
+__device__ __forceinline__ double2 ldb16(__amdgpu_buffer_rsrc_t rs, unsigned lane_bytes, unsigned tile_bytes) {
+  const uint4v_t v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)lane_bytes, (int)tile_bytes, NT ? 2 : 0);
+  double2 r;
+  r.x = __builtin_bit_cast(double, uint2v_t{v.x, v.y});
+  r.y = __builtin_bit_cast(double, uint2v_t{v.z, v.w});
+  return r;
+}
+template <bool NT>
+__device__ __forceinline__ void stb16(__amdgpu_buffer_rsrc_t rs, unsigned lane_bytes, unsigned tile_bytes, double2 v) {
+  const uint2v_t a = __builtin_bit_cast(uint2v_t, v.x), b = __builtin_bit_cast(uint2v_t, v.y);
+  __builtin_amdgcn_raw_buffer_store_b128(uint4v_t{a.x, a.y, b.x, b.y}, rs, (int)lane_bytes, (int)tile_bytes, NT ? 2 : 0);
+}
+__device__ __forceinline__ double ldb8(__amdgpu_buffer_rsrc_t rs, unsigned lane_bytes, unsigned row_bytes) {
+  return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs, (int)lane_bytes, (int)row_bytes, 0));
+}
+
+#define RS_CBAR() asm volatile("" ::: "memory")
+
+template <int NKT, bool NT>
+__global__ __launch_bounds__(512, 2) void k_flush_rs(double* __restrict__ P, const double* __restrict__ V,
+                                                     const double* __restrict__ W,
+                                                     const double* __restrict__ dacc,
+                                                     const int* __restrict__ nact,
+                                                     const SolveOut* __restrict__ so, int ld, long pstride,
+                                                     int nkt, int batch, int nrb, unsigned* __restrict__ queue) {
+  constexpr int RPW = NKT / 2;                         // ranks of a V strip each of the 8 waves stages
+  __shared__ __attribute__((aligned(16))) double vbuf[2][NKT * 256];   // V strip as B fragments: [k-tile][col tile][lane]
+  __shared__ __attribute__((aligned(16))) double img[8][16 * 64];      // per wave: 16 x 64 tile image (swizzled)
+  __shared__ int s_unit;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  const int li = lane & 15, lq = lane >> 4;            // C/D layout coordinates
+  const int rr = lane >> 5, rc = (lane & 31) * 2;      // row-major image: 2 rows per instruction
+  const int ld16 = ld >> 4;
+  const int grp = blockIdx.x & 7;                      // workgroups with equal blockIdx % 8 share an XCD (speed only)
+  double* T = img[wave];
+  // Image of a tile: element (r, c) at r * 64 + (c ^ ((r & 1) << 4)): both the row-major 16-byte accesses and the
+  // 8-byte accesses in the C/D layout (two rows of opposite parity per 32 lanes) are bank-conflict free at 8 KB.
+  const int rm_base = rr * 64 + (rc ^ (rr << 4));      // + 128 q  for rows 2q + rr
+  // C/D layout, element (lq + 4 reg, ct * 16 + li):  (lq + 4 reg) * 64 + ((ct * 16 + li) ^ ((lq & 1) << 4)), written as
+  // one of two lane bases plus a compile-time offset (the swizzle swaps column tiles 2u, 2u + 1 in odd rows)
+  const int cd_even = lq * 64 + li + 16 * (lq & 1), cd_odd = lq * 64 + li + 16 * (1 - (lq & 1));
+  auto cd_index = [&](int ct, int reg) { return ((ct & 1) ? cd_odd : cd_even) + 16 * (ct & ~1) + 256 * reg; };
+  const int k0 = wave * RPW;                           // first rank this wave stages
+  const unsigned loff = (unsigned)(rr * ld + rc) * 8u; // lane part of a tile address, bytes (rows 2q + rr, columns rc, rc + 1)
+  const unsigned lane8 = (unsigned)lane * 8u;
+
+  for (;;) {
+    // ---- next unit: own queue first, then the others ----
+    if (threadIdx.x == 0) {
+      int found = -1;
+      for (int a = 0; a < 8 && found < 0; ++a) {
+        const int g2 = (grp + a) & 7;
+        const int cnt = (g2 < batch) ? ((batch - g2 + 7) >> 3) * nrb : 0;
+        if (cnt == 0) continue;
+        unsigned* head = queue + g2 * RS_QSTRIDE;
+        if (__hip_atomic_load(head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)cnt) continue;
+        const unsigned u = atomicAdd(head, 1u);
+        if (u < (unsigned)cnt) found = (g2 + 8 * (int)(u / (unsigned)nrb)) * nrb + (int)(u % (unsigned)nrb);
+      }
+      s_unit = found;
+    }
+    __syncthreads();
+    const int unit = __builtin_amdgcn_readfirstlane(s_unit);   // (an LDS load is a vector value to the compiler)
+    __syncthreads();
+    if (unit < 0) return;                              // every queue is empty: all eight waves leave together
+    const int b = unit / nrb, rb = unit - b * nrb;
+    const int n = min(nact[b], so[b].neff);            // rows/cols beyond the active bound are untouched
+    const int i0 = rb * RS_ROWS;
+    if (i0 >= n) continue;
+    const int j_last = ((n - 1) >> 6) << 6;            // rightmost strip that starts below n
+    const int S = ((j_last - i0) >> 6) + 1;            // strips from the right end down to the one holding the diagonal
+    const int i0w = i0 + 16 * wave;
+    // tiles of this wave: none if its rows lie beyond n; in the last strip (columns i0..i0+63) the rows of waves 4-7
+    // lie strictly below the diagonal
+    const int Sw = (i0w < n) ? (wave < 4 ? S : S - 1) : 0;
+    double* Pb = P + (long)b * pstride;
+    const double* Vb = V + (long)b * KTOT * ld;
+    const double* Wb = W + (long)b * KTOT * ld;
+    const __amdgpu_buffer_rsrc_t rsV = rs_rsrc(Vb), rsW = rs_rsrc(Wb);
+    const unsigned ld8 = (unsigned)ld * 8u;            // bytes per row
+    const unsigned prow = (unsigned)i0w * ld8;         // byte offset of this wave's first row inside the trajectory's P
+    const double dd0 = dacc[4 * b], dd1 = dacc[4 * b + 1], dd2 = dacc[4 * b + 2];
+
+    // ranks [k0 + i0, k0 + i0 + CNT) of the strip of step t (clamped to an existing one) -> registers -> B fragments
+    auto stage_load = [&](int t, auto i0_tag, auto cnt_tag, double* vs) {
+      constexpr int I0 = decltype(i0_tag)::value, CNT = decltype(cnt_tag)::value;
+      const int j = j_last - 64 * min(t, S - 1);
+#pragma unroll
+      for (int i = 0; i < CNT; ++i) vs[i] = ldb8(rsV, lane8, (unsigned)(k0 + I0 + i) * ld8 + (unsigned)j * 8u);
+    };
+    auto stage_store = [&](double* dst, auto i0_tag, auto cnt_tag, const double* vs) {
+      constexpr int I0 = decltype(i0_tag)::value, CNT = decltype(cnt_tag)::value;
+#pragma unroll
+      for (int i = 0; i < CNT; ++i) {
+        const int k = k0 + I0 + i;                      // rank slots beyond the pending ones hold stale data: zero
+        dst[((k >> 2) * 4 + lq) * 64 + (k & 3) * 16 + li] = (k < 4 * nkt) ? vs[i] : 0.0;   // (masked here, not at the load:
+      }                                                 //  the select would wait for the load where it is issued)
+    };
+    using I0_ = std::integral_constant<int, 0>;
+    using IH_ = std::integral_constant<int, RPW / 2>;
+    using IR_ = std::integral_constant<int, RPW>;
+    auto wg_barrier = [&]() {                          // LDS stores landed, then s_barrier: global accesses stay in flight
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      RS_CBAR();
+    };
+
+    if (Sw == 0) {                                     // (wave-uniform) staging and barriers only
+      double vs[RPW];
+      stage_load(0, I0_{}, IR_{}, vs);
+      stage_store(vbuf[0], I0_{}, IR_{}, vs);
+      wg_barrier();
+      for (int t = 0; t < S - 1; ++t) {
+        stage_load(t + 1, I0_{}, IR_{}, vs);
+        stage_store(vbuf[(t + 1) & 1], I0_{}, IR_{}, vs);
+        wg_barrier();
+      }
+      continue;
+    }
+
+    double2 g[8];                                      // row-major registers of the tile in flight
+    // tile t of this wave; beyond its last tile the loads are pointed at the first 16 ranks of V (valid, cache
+    // resident, same row stride): a select on the uniform base and offset, no branch
+    auto tile_off = [&](int t) -> unsigned { return prow + (unsigned)(j_last - 64 * t) * 8u; };
+    auto gload = [&](int t) {
+      const bool ok = t < Sw;
+      const __amdgpu_buffer_rsrc_t rs = rs_rsrc(ok ? (const void*)Pb : (const void*)Vb);
+      const unsigned off = ok ? tile_off(t) : 0u;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) g[q] = ldb16<NT>(rs, loff, off + (unsigned)q * 2u * ld8);
+    };
+    // two accumulator sets: tile t accumulates in accs[t & 1] while tile t+1 is brought into accs[(t + 1) & 1]
+    // (compile-time roles -- the tile loop is unrolled by two -- so that no register copies sit between the MFMAs)
+    double4_t accs[2][4];
+    double wf[NKT];
+
+    // ---- prologue: W fragments, strip 0, tile 0 -> acc, tile 1 in flight ----
+    {
+      double vs[RPW];
+      stage_load(0, I0_{}, IR_{}, vs);
+      gload(0);
+#pragma unroll
+      for (int t = 0; t < NKT; ++t) {
+        const double x = ldb8(rsW, lane8, ((unsigned)t * ld16 + (unsigned)(i0w >> 4)) * 512u);
+        wf[t] = (t < nkt) ? x : 0.0;
+      }
+      stage_store(vbuf[0], I0_{}, IR_{}, vs);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) *reinterpret_cast<double2*>(&T[rm_base + 128 * q]) = g[q];
+      RS_CBAR();
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) accs[0][ct][r] = T[cd_index(ct, r)];
+      RS_CBAR();
+      gload(1);
+      wg_barrier();
+    }
+
+    // ---- one tile: MFMAs of tile t with everything else of tiles t-1, t+1, t+2 issued between them ----
+    auto body = [&](auto first_tag, auto stage_tag, auto par_tag, int t) {
+      constexpr bool FIRST = decltype(first_tag)::value, STAGE = decltype(stage_tag)::value;
+      constexpr int PAR = decltype(par_tag)::value;    // t & 1
+      double4_t (&acc)[4] = accs[PAR];
+      double4_t (&accn)[4] = accs[1 - PAR];
+      const double* vb = vbuf[t & 1];
+      double vs[RPW / 2];                              // the strip is staged in two halves through the same registers
+      double2 r[4];                                    // ... and so is the result of tile t-1
+      // side operations in issue order; slot kt executes the ops [kt * NSIDE / NKT, (kt + 1) * NSIDE / NKT)
+      constexpr int NE = FIRST ? 0 : 4, NV = STAGE ? 1 : 0;
+      constexpr int OVA = 0, OE1A = OVA + NV, OE2A = OE1A + NE, OE1B = OE2A + NE, OE2B = OE1B + NE, OVB = OE2B + NE,
+                    ON1 = OVB + NV, ON2 = ON1 + 8, ON3 = ON2 + 16, OWB = ON3 + 8, NSIDE = OWB + NV;
+      const __amdgpu_buffer_rsrc_t rsP = rs_rsrc(Pb);
+      const unsigned off_prev = tile_off(t - 1);       // tile t-1 (FIRST: unused)
+      const bool ok2 = t + 2 < Sw;
+      const __amdgpu_buffer_rsrc_t rs2 = rs_rsrc(ok2 ? (const void*)Pb : (const void*)Vb);
+      const unsigned off2 = ok2 ? tile_off(t + 2) : 0u;
+      double* vnext = vbuf[(t + 1) & 1];
+      auto side = [&](int o) {
+        if constexpr (STAGE) {
+          if (o == OVA) stage_load(t + 1, I0_{}, IH_{}, vs);
+          if (o == OVB) {
+            stage_store(vnext, I0_{}, IH_{}, vs);
+            stage_load(t + 1, IH_{}, IH_{}, vs);
+          }
+          if (o == OWB) stage_store(vnext, IH_{}, IH_{}, vs);
+        }
+        if constexpr (!FIRST) {                        // result of tile t-1: image -> row-major registers -> HBM
+          if (o >= OE1A && o < OE2A) r[o - OE1A] = *reinterpret_cast<const double2*>(&T[rm_base + 128 * (o - OE1A)]);
+          if (o >= OE2A && o < OE1B) stb16<NT>(rsP, loff, off_prev + (unsigned)(o - OE2A) * 2u * ld8, r[o - OE2A]);
+          if (o >= OE1B && o < OE2B) r[o - OE1B] = *reinterpret_cast<const double2*>(&T[rm_base + 128 * (o - OE1B + 4)]);
+          if (o >= OE2B && o < OVB) stb16<NT>(rsP, loff, off_prev + (unsigned)(o - OE2B + 4) * 2u * ld8, r[o - OE2B]);
+        }
+        if (o >= ON1 && o < ON2) {                     // tile t+1: row-major registers -> image
+          const int q = o - ON1;
+          if (q == 0) RS_CBAR();
+          *reinterpret_cast<double2*>(&T[rm_base + 128 * q]) = g[q];
+          if (q == 7) RS_CBAR();
+        } else if (o >= ON2 && o < ON3) {              // ... -> C/D layout
+          const int e = o - ON2;
+          accn[e >> 2][e & 3] = T[cd_index(e >> 2, e & 3)];
+          if (e == 15) RS_CBAR();
+        } else if (o >= ON3 && o < OWB) {              // tile t+2: HBM -> row-major registers
+          const int q = o - ON3;
+          g[q] = ldb16<NT>(rs2, loff, off2 + (unsigned)q * 2u * ld8);
+        }
+      };
+      // B fragments: two register sets with compile-time roles (k-tile kt multiplies out of set kt & 1 while set
+      // (kt + 1) & 1 is being read): the reads of the next k-tile are in flight under this one's MFMAs
+      double bf[2][4];
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) bf[0][ct] = vb[ct * 64 + lane];
+#pragma unroll
+      for (int kt = 0; kt < NKT; ++kt) {
+        if (kt + 1 < NKT) {
+#pragma unroll
+          for (int ct = 0; ct < 4; ++ct) bf[(kt + 1) & 1][ct] = vb[((kt + 1) * 4 + ct) * 64 + lane];
+        }
+        __builtin_amdgcn_sched_barrier(0);             // (the scheduler would sink the reads below the MFMAs to reuse registers)
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct)
+          acc[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(wf[kt], bf[kt & 1][ct], acc[ct], 0, 0, 0);
+#pragma unroll
+        for (int o = kt * NSIDE / NKT; o < (kt + 1) * NSIDE / NKT; ++o) side(o);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      // ---- tile boundary ----
+      if (STAGE) wg_barrier();
+      if (i0w == 0 && t == S - 1) {                    // (uniform) pose-block noise accumulated since the last pass
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          const int row = lq + 4 * rg;
+          if (row < 3 && li == row) acc[0][rg] += (row == 0) ? dd0 : ((row == 1) ? dd1 : dd2);
+        }
+      }
+      RS_CBAR();
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) T[cd_index(ct, rg)] = acc[ct][rg];
+      RS_CBAR();
+    };
+    using T_ = std::true_type;
+    using F_ = std::false_type;
+    using P0 = std::integral_constant<int, 0>;
+    using P1 = std::integral_constant<int, 1>;
+    if (S == 1) {
+      body(T_{}, F_{}, P0{}, 0);
+    } else {
+      body(T_{}, T_{}, P0{}, 0);
+      int t = 1;
+      for (; t + 1 < S - 1; t += 2) {
+        body(F_{}, T_{}, P1{}, t);
+        body(F_{}, T_{}, P0{}, t + 1);
+      }
+      if (t < S - 1) {                                 // (t is odd here)
+        body(F_{}, T_{}, P1{}, t);
+        ++t;
+      }
+      if (Sw == S) {                                   // waves 0-3: the strip that holds the diagonal, no staging after it
+        if ((S - 1) & 1) body(F_{}, F_{}, P1{}, S - 1);
+        else body(F_{}, F_{}, P0{}, S - 1);
+      }
+    }
+    // ---- drain: the last result of this wave ----
+    {
+      const __amdgpu_buffer_rsrc_t rsP = rs_rsrc(Pb);
+      const unsigned off_last = tile_off(Sw - 1);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const double2 o = *reinterpret_cast<const double2*>(&T[rm_base + 128 * q]);
+        stb16<NT>(rsP, loff, off_last + (unsigned)q * 2u * ld8, o);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // k_predict_rc: prediction with no observation and nothing pending touches only rows/cols 0,1 and
 // the pose diagonal (src/replay_no_ros.py:428-430 with G_F = I outside the 3x3 block).  O(n).
 // ---------------------------------------------------------------------------------------------
@@ -1624,6 +1939,35 @@ void launch_flush(hipStream_t st, bool streaming, double* P, const double* V, co
   else EKF_FLUSH(15, 5);
 #undef EKF_FLUSH
 }
+
+// the row-slab form of the pass (k_flush_rs): persistent workgroups, `queue` = 8 x RS_QSTRIDE zeroed words
+template <int NKT, bool NT>
+static void launch_flush_rs_t(hipStream_t st, double* P, const double* V, const double* W, const double* dacc,
+                              const int* nact, const SolveOut* so, int ld, long pstride, int batch, int n_hi, int nkt,
+                              int workgroups, unsigned* queue) {
+  const int nrb = (n_hi + RS_ROWS - 1) / RS_ROWS;
+  const int units = nrb * batch;
+  hipLaunchKernelGGL((k_flush_rs<NKT, NT>), dim3(std::min(workgroups, units)), dim3(512), 0, st, P, V, W, dacc, nact, so,
+                     ld, pstride, nkt, batch, nrb, queue);
+}
+
+void launch_flush_rs(hipStream_t st, bool streaming, double* P, const double* V, const double* W, const double* dacc,
+                     const int* nact, const SolveOut* so, int ld, long pstride, int batch, int n_hi, int nkt,
+                     int workgroups, unsigned* queue) {
+#define EKF_FLUSH_RS(N)                                                                                   \
+  do {                                                                                                    \
+    if (streaming) launch_flush_rs_t<N, true>(st, P, V, W, dacc, nact, so, ld, pstride, batch, n_hi, nkt, workgroups, queue); \
+    else launch_flush_rs_t<N, false>(st, P, V, W, dacc, nact, so, ld, pstride, batch, n_hi, nkt, workgroups, queue);          \
+  } while (0)
+  if (nkt <= 4) EKF_FLUSH_RS(4);
+  else if (nkt <= 8) EKF_FLUSH_RS(8);
+  else if (nkt <= 12) EKF_FLUSH_RS(12);
+  else if (nkt <= 16) EKF_FLUSH_RS(16);
+  else EKF_FLUSH_RS(20);
+#undef EKF_FLUSH_RS
+}
+
+int flush_rs_queue_words() { return 8 * RS_QSTRIDE; }
 
 void launch_predict_rc(hipStream_t st, double* P, const double* mu_in, double* mu_out, const int* nact,
                        const SolveOut* so, int ld, long pstride, int batch, int n_hi) {

@@ -580,3 +580,67 @@ def test_producer_consumer_pass_is_bit_identical(sd):
         for b in range(B):
             assert np.array_equal(out[0, limit][b][0], out[1, limit][b][0])
             assert np.array_equal(out[0, limit][b][1], out[1, limit][b][1])
+
+
+@pytest.mark.parametrize("N,B,m", [(300, 2, 8), (531, 3, 5), (64, 9, 8), (1100, 2, 3)])
+def test_row_slab_pass_is_bit_identical(sd, N, B, m):
+    """`pass_kernel=2` (k_flush_rs: W fragments in registers, the V strip shared through LDS, software-pipelined
+    tiles, persistent workgroups on a work queue) applies the same update as k_flush, bit for bit: all rank counts
+    (4..20 k-tiles), both cache policies, slabs that end inside a 128-row block, states smaller than one slab."""
+    steps = 11
+    n = 3 + 2 * N
+    streams = [orc.synthetic_stream(N, steps, m, 30 + t) for t in range(B)]
+    starts = []
+    for t in range(B):
+        rng = np.random.default_rng(90 + t)
+        A = rng.normal(size=(n, 6)) * 0.3
+        starts.append(A @ A.T + np.diag(rng.uniform(0.5, 2.0, n)))
+    out = {}
+    for kernel in (0, 2):
+        for limit, streaming in ((2 * m, 0), (6 * m, 1), (80, 1), (80, 0)):
+            with sd.EkfSlam(n, batch=B) as f:
+                f.set_option("pass_kernel", kernel)
+                f.set_option("rank_limit", limit)
+                f.set_option("pass_streaming", streaming)
+                f.set_option("active_bound", 0)
+                for b, s in enumerate(streams):
+                    f.set_state(s[0], starts[b], b)
+                for k in range(steps):
+                    f.step([s[2][k] for s in streams], [s[3][k] for s in streams], [s[4][k] for s in streams],
+                           [s[5][k] for s in streams], [s[6][k] for s in streams])
+                out[kernel, limit, streaming] = [f.state(b) for b in range(B)]
+                assert [f.flags(b) for b in range(B)] == [0] * B
+    for key in [k[1:] for k in out if k[0] == 0]:
+        for b in range(B):
+            assert np.array_equal(out[(0,) + key][b][0], out[(2,) + key][b][0])
+            assert np.array_equal(out[(0,) + key][b][1], out[(2,) + key][b][1]), (key, b)
+    # and the result itself is the reference's
+    cfg = orc.EkfConfig()
+    s = streams[0]
+    om, oP = s[0].copy(), starts[0].copy()
+    for k in range(steps):
+        om, oP = orc.ekf_step_dense(om, oP, s[2][k], s[3][k], s[4][k], s[5][k], s[6][k], cfg)
+    close(out[2, 80, 1][0][0], om)
+    close(out[2, 80, 1][0][1], oP)
+
+
+def test_row_slab_pass_with_active_bound_and_growing_state(sd):
+    """k_flush_rs on a block-diagonal start with the active bound on (slabs beyond the bound are skipped, the last slab
+    ends inside a block) and with trajectories of different sizes in one batch."""
+    N, steps, m, B = 400, 14, 8, 3
+    streams = [orc.synthetic_stream(N, steps, m, 50 + t) for t in range(B)]
+    sizes = [3 + 2 * N, 3 + 2 * 150, 3 + 2 * 333]
+    out = {}
+    for kernel in (0, 2):
+        with sd.EkfSlam(3 + 2 * N, batch=B) as f:
+            f.set_option("pass_kernel", kernel)
+            f.set_option("pass_streaming", 1)
+            for b, s in enumerate(streams):
+                f.set_state_diag(s[0][:sizes[b]], s[1][:sizes[b]], b)
+            for k in range(steps):
+                idx = [(s[4][k] * 3 + 1) % ((sizes[b] - 3) // 2 // 2) for b, s in enumerate(streams)]
+                f.step([s[2][k] for s in streams], [s[3][k] for s in streams], idx,
+                       [s[5][k] for s in streams], [s[6][k] for s in streams])
+            out[kernel] = [f.state(b) for b in range(B)]
+    for b in range(B):
+        assert np.array_equal(out[0][b][0], out[2][b][0]) and np.array_equal(out[0][b][1], out[2][b][1])
