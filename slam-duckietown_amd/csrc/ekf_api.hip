@@ -38,7 +38,7 @@ static thread_local std::string g_create_error;
 constexpr int RING = 16;
 
 struct ekf_handle {
-  int device = 0, n_max = 0, ld = 0, batch = 0;
+  int device = 0, n_max = 0, ld = 0, rows = 0, batch = 0;
   long pstride = 0;
   ekf_config cfg{};
   DeviceConfig dcfg{};
@@ -169,9 +169,20 @@ extern "C" int ekf_create(int device, int n_max, int batch, const ekf_config* cf
   h->device = device;
   h->cu_count = prop.multiProcessorCount;
   h->n_max = n_max;
-  h->ld = (n_max + 63) / 64 * 64;                      // every 64-column strip of k_flush lies inside the row (512-B aligned)
+  // Row stride of P: a multiple of 64 doubles (every 64-column strip of the pass lies inside the row, 512-B aligned)
+  // and, up to 4096, a power of two: with rows exactly 32 KB (or 16, 8 ... KB) apart the sixteen 512-byte row
+  // segments of a tile fall into the same DRAM pages instead of sixteen different ones -- measured on the pass at
+  // N=2000 x 32: 775 us with ld = 4032, 729 us with ld = 4096; N=1500: 767 -> 696 us; larger strides (ld = 8192) are
+  // slower than the plain round-up, so beyond 4096 the stride is n_max rounded up to 64 (profiles/r02_ld_sweep.txt).
+  h->rows = (n_max + 63) / 64 * 64;                    // rows allocated per trajectory
+  h->ld = h->rows;
+  if (n_max <= 4096) {
+    int p2 = 64;
+    while (p2 < n_max) p2 *= 2;
+    h->ld = p2;
+  }
   h->batch = batch;
-  h->pstride = (long)h->ld * h->ld;
+  h->pstride = (long)h->rows * h->ld;
   if (cfg) h->cfg = *cfg; else ekf_config_default(&h->cfg);
   const double s = h->cfg.motion_sigma, q = h->cfg.meas_sigma;
   h->dcfg.rd[0] = s * s;                        // src/replay_no_ros.py:421
@@ -204,7 +215,8 @@ extern "C" int ekf_create(int device, int n_max, int batch, const ekf_config* cf
   CREATE_TRY(hipSetDevice(device));
   CREATE_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
   const size_t ldz = (size_t)h->ld;
-  CREATE_TRY(hipMalloc(&h->dP, sizeof(double) * ldz * ldz * batch));
+  const size_t rowz = (size_t)h->rows;
+  CREATE_TRY(hipMalloc(&h->dP, sizeof(double) * rowz * ldz * batch));
   CREATE_TRY(hipMalloc(&h->dmu2[0], sizeof(double) * ldz * batch));
   CREATE_TRY(hipMalloc(&h->dmu2[1], sizeof(double) * ldz * batch));
   CREATE_TRY(hipMalloc(&h->dV, sizeof(double) * ldz * KTOT * batch));
@@ -223,7 +235,7 @@ extern "C" int ekf_create(int device, int n_max, int batch, const ekf_config* cf
   for (auto& ev : h->ring_ev) CREATE_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
   CREATE_TRY(hipEventCreate(&h->t0));
   CREATE_TRY(hipEventCreate(&h->t1));
-  CREATE_TRY(hipMemsetAsync(h->dP, 0, sizeof(double) * ldz * ldz * batch, h->stream));
+  CREATE_TRY(hipMemsetAsync(h->dP, 0, sizeof(double) * rowz * ldz * batch, h->stream));
   CREATE_TRY(hipMemsetAsync(h->dmu2[0], 0, sizeof(double) * ldz * batch, h->stream));
   CREATE_TRY(hipMemsetAsync(h->dmu2[1], 0, sizeof(double) * ldz * batch, h->stream));
   CREATE_TRY(hipMemsetAsync(h->dV, 0, sizeof(double) * ldz * KTOT * batch, h->stream));
@@ -827,7 +839,7 @@ extern "C" int ekf_predict_dense(ekf_handle* h, int b, const double* F, const do
   if (int rc = check_b(h, b, "ekf_predict_dense")) return rc;
   if (!F || !Q) return fail(h, EKF_ERR_ARG, "ekf_predict_dense: NULL matrix");
   const int n = h->n[b];
-  const size_t bytes = sizeof(double) * (size_t)h->ld * h->ld;
+  const size_t bytes = sizeof(double) * (size_t)h->rows * h->ld;
   HIP_TRY(h, hipSetDevice(h->device));
   if (int rc = materialize(h, b)) return rc;           // the product needs the full matrix
   if (!h->dF) {

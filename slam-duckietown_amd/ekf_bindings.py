@@ -67,7 +67,10 @@ class EkfConfig:
 
 
 def library_path() -> str:
-    return os.path.join(_HERE, _LIB_NAME)
+    """The in-tree library.  EKFSLAM_HIP_VARIANT=<tag> selects a diagnostic build libekfslam_hip_<tag>.so made with
+    `make -C csrc variant TAG=<tag> EXTRA=...` (kernel experiments; never set in production)."""
+    tag = os.environ.get("EKFSLAM_HIP_VARIANT")
+    return os.path.join(_HERE, f"libekfslam_hip_{tag}.so" if tag else _LIB_NAME)
 
 
 def build_library(force: bool = False) -> str:
