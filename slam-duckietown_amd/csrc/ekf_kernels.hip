@@ -1355,6 +1355,13 @@ __device__ __forceinline__ void stb16(__amdgpu_buffer_rsrc_t rs, unsigned lane_b
   {
   const uint2v_t a = __builtin_bit_cast(uint2v_t, v.x), b = __builtin_bit_cast(uint2v_t, v.y);
   __builtin_amdgcn_raw_buffer_store_b128(uint4v_t{a.x, a.y, b.x, b.y}, rs, (int)lane_bytes, (int)tile_bytes, NT ? 2 : 0);
+  // A 16-byte store reads its data registers in two passes; a VALU instruction issued right behind it that writes
+  // one of them can overtake the second pass (dwords 2-3 of the last lanes).  The compiler's hazard recogniser adds
+  // the wait state for global/flat stores and for buffer stores WITHOUT an SGPR offset only (it assumes the SGPR read
+  // covers it); on gfx950 the form used here (offen + SGPR soffset) was caught corrupting the low mantissa bits of the
+  // odd columns of a tile's last row pair (`buffer_store_dwordx4 v[76:79]` followed by `v_add_u32 v78`): keep two
+  // wait states behind every such store.
+  asm volatile("s_nop 1" ::: "memory");
   }
 }
 __device__ __forceinline__ double ldb8(__amdgpu_buffer_rsrc_t rs, unsigned lane_bytes, unsigned row_bytes) {
@@ -1388,7 +1395,8 @@ __global__ __launch_bounds__(512, 2) void k_flush_rs(double* __restrict__ P, con
   // one of two lane bases plus a compile-time offset (the swizzle swaps column tiles 2u, 2u + 1 in odd rows)
   const int cd_even = lq * 64 + li + 16 * (lq & 1), cd_odd = lq * 64 + li + 16 * (1 - (lq & 1));
   auto cd_index = [&](int ct, int reg) { return ((ct & 1) ? cd_odd : cd_even) + 16 * (ct & ~1) + 256 * reg; };
-  const int k0 = wave * RPW;                           // first rank this wave stages
+  // rank k = wave + 8 i of a strip: k-tile 2 i + (wave >> 2), row wave & 3 of the fragment
+  const int stage_base = ((wave >> 2) * 4 + lq) * 64 + (wave & 3) * 16 + li;
   const unsigned loff = (unsigned)(rr * ld + rc) * 8u; // lane part of a tile address, bytes (rows 2q + rr, columns rc, rc + 1)
   const unsigned lane8 = (unsigned)lane * 8u;
 
@@ -1429,20 +1437,23 @@ __global__ __launch_bounds__(512, 2) void k_flush_rs(double* __restrict__ P, con
     const unsigned prow = (unsigned)i0w * ld8;         // byte offset of this wave's first row inside the trajectory's P
     const double dd0 = dacc[4 * b], dd1 = dacc[4 * b + 1], dd2 = dacc[4 * b + 2];
 
-    // ranks [k0 + i0, k0 + i0 + CNT) of the strip of step t (clamped to an existing one) -> registers -> B fragments
+    // Staging of a V strip: wave w moves the ranks w, w + 8, w + 16, ... (RPW of them) of the strip of step t (clamped
+    // to an existing one) global -> registers -> B fragments in LDS.  With that interleaving the LDS address of rank
+    // w + 8 i is ONE lane base plus the compile-time offset i * 4 KB (ranks k0 .. k0 + RPW - 1 would need a VGPR
+    // address each, kept live across the whole tile loop).
     auto stage_load = [&](int t, auto i0_tag, auto cnt_tag, double* vs) {
       constexpr int I0 = decltype(i0_tag)::value, CNT = decltype(cnt_tag)::value;
       const int j = j_last - 64 * min(t, S - 1);
 #pragma unroll
-      for (int i = 0; i < CNT; ++i) vs[i] = ldb8(rsV, lane8, (unsigned)(k0 + I0 + i) * ld8 + (unsigned)j * 8u);
+      for (int i = 0; i < CNT; ++i) vs[i] = ldb8(rsV, lane8, (unsigned)(wave + 8 * (I0 + i)) * ld8 + (unsigned)j * 8u);
     };
     auto stage_store = [&](double* dst, auto i0_tag, auto cnt_tag, const double* vs) {
       constexpr int I0 = decltype(i0_tag)::value, CNT = decltype(cnt_tag)::value;
+      double* d0 = dst + stage_base;                   // B fragment slot of rank `wave`, this lane
 #pragma unroll
-      for (int i = 0; i < CNT; ++i) {
-        const int k = k0 + I0 + i;                      // rank slots beyond the pending ones hold stale data: zero
-        dst[((k >> 2) * 4 + lq) * 64 + (k & 3) * 16 + li] = (k < 4 * nkt) ? vs[i] : 0.0;   // (masked here, not at the load:
-      }                                                 //  the select would wait for the load where it is issued)
+      for (int i = 0; i < CNT; ++i) {                  // rank slots beyond the pending ones hold stale data: zero
+        d0[(I0 + i) * 512] = (wave + 8 * (I0 + i) < 4 * nkt) ? vs[i] : 0.0;   // (masked here, not at the load: the select
+      }                                                 //  would wait for the load where it is issued)
     };
     using I0_ = std::integral_constant<int, 0>;
     using IH_ = std::integral_constant<int, RPW / 2>;
@@ -1467,8 +1478,8 @@ __global__ __launch_bounds__(512, 2) void k_flush_rs(double* __restrict__ P, con
     }
 
     double2 g[8];                                      // row-major registers of the tile in flight
-    // tile t of this wave; beyond its last tile the loads are pointed at the first 16 ranks of V (valid, cache
-    // resident, same row stride): a select on the uniform base and offset, no branch
+    // tile t of this wave; beyond its last tile the loads are pointed at 1 KB of the (read-only, cache resident)
+    // SolveOut record instead: a select on the uniform base, offset and stride, no branch
     auto tile_off = [&](int t) -> unsigned { return prow + (unsigned)(j_last - 64 * t) * 8u; };
     auto gload = [&](int t) {
 #ifdef RS_SKIP_PMEM                                     /* diagnostic build: the compute side alone */
@@ -1476,17 +1487,21 @@ __global__ __launch_bounds__(512, 2) void k_flush_rs(double* __restrict__ P, con
 #else
       const bool ok = t < Sw;
 #endif
-      const __amdgpu_buffer_rsrc_t rs = rs_rsrc(ok ? (const void*)Pb : (const void*)Vb);
-      const unsigned off = ok ? tile_off(t) : 0u;
+      const __amdgpu_buffer_rsrc_t rs = rs_rsrc(ok ? (const void*)Pb : (const void*)so);
+      const unsigned off = ok ? tile_off(t) : 0u, ld8d = ok ? ld8 : 0u, loffd = ok ? loff : lane8 * 2u;
 #pragma unroll
-      for (int q = 0; q < 8; ++q) g[q] = ldb16<NT>(rs, loff, off + (unsigned)q * 2u * ld8);
+      for (int q = 0; q < 8; ++q) g[q] = ldb16<NT>(rs, loffd, off + (unsigned)q * 2u * ld8d);
     };
     // two accumulator sets: tile t accumulates in accs[t & 1] while tile t+1 is brought into accs[(t + 1) & 1]
     // (compile-time roles -- the tile loop is unrolled by two -- so that no register copies sit between the MFMAs)
     double4_t accs[2][4];
     double wf[NKT];
+    // B fragments: two register sets with compile-time roles (k-tile kt multiplies out of set kt & 1 while set
+    // (kt + 1) & 1 is being read; NKT is even, so set 0 is also where the last k-tile of a tile prefetches the first
+    // fragments of the NEXT tile): the reads of the next k-tile are always in flight under this one's MFMAs
+    double bf[2][4];
 
-    // ---- prologue: W fragments, strip 0, tile 0 -> acc, tile 1 in flight ----
+    // ---- prologue: W fragments, strip 0, tile 0 -> accs[0], tile 1 in flight ----
     {
       double vs[RPW];
       stage_load(0, I0_{}, IR_{}, vs);
@@ -1507,21 +1522,29 @@ __global__ __launch_bounds__(512, 2) void k_flush_rs(double* __restrict__ P, con
       RS_CBAR();
       gload(1);
       wg_barrier();
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) bf[0][ct] = vbuf[0][ct * 64 + lane];
     }
 
-    // ---- one tile: MFMAs of tile t with everything else of tiles t-1, t+1, t+2 issued between them ----
+    // ---- one tile: the MFMAs of tile t with everything else of tiles t-1, t+1, t+2 issued between them.
+    // No instruction of the tile boundary sits between the last MFMA of tile t and the first of tile t+1: the
+    // result of tile t stays in its accumulator set and goes to the image at the start of tile t+1 (which
+    // accumulates in the other set); the workgroup barrier that publishes the next V strip comes one k-tile
+    // early (every B fragment of this tile has been read by then) and the last k-tile prefetches the first
+    // fragments of the next tile.
     auto body = [&](auto first_tag, auto stage_tag, auto par_tag, int t) {
       constexpr bool FIRST = decltype(first_tag)::value, STAGE = decltype(stage_tag)::value;
       constexpr int PAR = decltype(par_tag)::value;    // t & 1
       double4_t (&acc)[4] = accs[PAR];
-      double4_t (&accn)[4] = accs[1 - PAR];
+      double4_t (&accn)[4] = accs[1 - PAR];            // result of tile t-1 first, then the start values of tile t+1
       const double* vb = vbuf[t & 1];
       double vs[RPW / 2];                              // the strip is staged in two halves through the same registers
       double2 r[4];                                    // ... and so is the result of tile t-1
-      // side operations in issue order; slot kt executes the ops [kt * NSIDE / NKT, (kt + 1) * NSIDE / NKT)
+      // side operations in issue order: k-tile 0 issues only the loads of the strip (the result of tile t-1 is still
+      // leaving the matrix pipe), the k-tiles [1, NKT - 1) share the rest evenly, the last k-tile only prefetches
       constexpr int NE = FIRST ? 0 : 4, NV = STAGE ? 1 : 0;
-      constexpr int OVA = 0, OE1A = OVA + NV, OE2A = OE1A + NE, OE1B = OE2A + NE, OE2B = OE1B + NE, OVB = OE2B + NE,
-                    ON1 = OVB + NV, ON2 = ON1 + 8, ON3 = ON2 + 16, OWB = ON3 + 8, NSIDE = OWB + NV;
+      constexpr int OVA = 0, OW0 = OVA + NV, OE1A = OW0 + NE, OE2A = OE1A + NE, OE1B = OE2A + NE, OE2B = OE1B + NE,
+                    OVB = OE2B + NE, ON1 = OVB + NV, ON2 = ON1 + 8, OWB = ON2 + 16, ON3 = OWB + NV, NSIDE = ON3 + 8;
       const __amdgpu_buffer_rsrc_t rsP = rs_rsrc(Pb);
       const unsigned off_prev = tile_off(t - 1);       // tile t-1 (FIRST: unused)
 #ifdef RS_SKIP_PMEM
@@ -1529,8 +1552,8 @@ __global__ __launch_bounds__(512, 2) void k_flush_rs(double* __restrict__ P, con
 #else
       const bool ok2 = t + 2 < Sw;
 #endif
-      const __amdgpu_buffer_rsrc_t rs2 = rs_rsrc(ok2 ? (const void*)Pb : (const void*)Vb);
-      const unsigned off2 = ok2 ? tile_off(t + 2) : 0u;
+      const __amdgpu_buffer_rsrc_t rs2 = rs_rsrc(ok2 ? (const void*)Pb : (const void*)so);
+      const unsigned off2 = ok2 ? tile_off(t + 2) : 0u, ld8d = ok2 ? ld8 : 0u, loffd = ok2 ? loff : lane8 * 2u;
       double* vnext = vbuf[(t + 1) & 1];
       auto side = [&](int o) {
         if constexpr (STAGE) {
@@ -1541,7 +1564,14 @@ __global__ __launch_bounds__(512, 2) void k_flush_rs(double* __restrict__ P, con
           }
           if (o == OWB) stage_store(vnext, IH_{}, IH_{}, vs);
         }
-        if constexpr (!FIRST) {                        // result of tile t-1: image -> row-major registers -> HBM
+        if constexpr (!FIRST) {                        // result of tile t-1: accumulators -> image -> row-major -> HBM
+          if (o >= OW0 && o < OE1A) {
+            const int ct = o - OW0;
+            if (ct == 0) RS_CBAR();
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) T[cd_index(ct, rg)] = accn[ct][rg];
+            if (ct == 3) RS_CBAR();
+          }
           if (o >= OE1A && o < OE2A) r[o - OE1A] = *reinterpret_cast<const double2*>(&T[rm_base + 128 * (o - OE1A)]);
           if (o >= OE2A && o < OE1B) stb16<NT>(rsP, loff, off_prev + (unsigned)(o - OE2A) * 2u * ld8, r[o - OE2A]);
           if (o >= OE1B && o < OE2B) r[o - OE1B] = *reinterpret_cast<const double2*>(&T[rm_base + 128 * (o - OE1B + 4)]);
@@ -1552,25 +1582,23 @@ __global__ __launch_bounds__(512, 2) void k_flush_rs(double* __restrict__ P, con
           if (q == 0) RS_CBAR();
           *reinterpret_cast<double2*>(&T[rm_base + 128 * q]) = g[q];
           if (q == 7) RS_CBAR();
-        } else if (o >= ON2 && o < ON3) {              // ... -> C/D layout
+        } else if (o >= ON2 && o < OWB) {              // ... -> C/D layout
           const int e = o - ON2;
           accn[e >> 2][e & 3] = T[cd_index(e >> 2, e & 3)];
           if (e == 15) RS_CBAR();
-        } else if (o >= ON3 && o < OWB) {              // tile t+2: HBM -> row-major registers
+        } else if (o >= ON3 && o < NSIDE) {            // tile t+2: HBM -> row-major registers
           const int q = o - ON3;
-          g[q] = ldb16<NT>(rs2, loff, off2 + (unsigned)q * 2u * ld8);
+          g[q] = ldb16<NT>(rs2, loffd, off2 + (unsigned)q * 2u * ld8d);
         }
       };
-      // B fragments: two register sets with compile-time roles (k-tile kt multiplies out of set kt & 1 while set
-      // (kt + 1) & 1 is being read): the reads of the next k-tile are in flight under this one's MFMAs
-      double bf[2][4];
-#pragma unroll
-      for (int ct = 0; ct < 4; ++ct) bf[0][ct] = vb[ct * 64 + lane];
 #pragma unroll
       for (int kt = 0; kt < NKT; ++kt) {
         if (kt + 1 < NKT) {
 #pragma unroll
           for (int ct = 0; ct < 4; ++ct) bf[(kt + 1) & 1][ct] = vb[((kt + 1) * 4 + ct) * 64 + lane];
+        } else if (STAGE) {                            // first fragments of the next tile (published by the barrier below)
+#pragma unroll
+          for (int ct = 0; ct < 4; ++ct) bf[0][ct] = vnext[ct * 64 + lane];
         }
         __builtin_amdgcn_sched_barrier(0);             // (the scheduler would sink the reads below the MFMAs to reuse registers)
 #pragma unroll
@@ -1580,13 +1608,21 @@ __global__ __launch_bounds__(512, 2) void k_flush_rs(double* __restrict__ P, con
 #else
           acc[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(wf[kt], bf[kt & 1][ct], acc[ct], 0, 0, 0);
 #endif
+        if (kt == 0) {
+          if (NV) side(OVA);
+        } else if (kt < NKT - 1) {
 #pragma unroll
-        for (int o = kt * NSIDE / NKT; o < (kt + 1) * NSIDE / NKT; ++o) side(o);
+          for (int o = NV + (kt - 1) * (NSIDE - NV) / (NKT - 2); o < NV + kt * (NSIDE - NV) / (NKT - 2); ++o) side(o);
+        }
+        if (STAGE && kt == NKT - 2) wg_barrier();      // strip t+1 complete; every B fragment of strip t has been read
         __builtin_amdgcn_sched_barrier(0);
       }
-      // ---- tile boundary ----
-      if (STAGE) wg_barrier();
-      if (i0w == 0 && t == S - 1) {                    // (uniform) pose-block noise accumulated since the last pass
+    };
+    // ---- drain: the last result of this wave (still in its accumulators) ----
+    auto drain = [&](auto par_tag) {
+      constexpr int PAR = decltype(par_tag)::value;
+      double4_t (&acc)[4] = accs[PAR];
+      if (i0w == 0 && Sw == S) {                       // (uniform) the tile at (0, 0): pose-block noise accumulated since the last pass
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg) {
           const int row = lq + 4 * rg;
@@ -1598,6 +1634,14 @@ __global__ __launch_bounds__(512, 2) void k_flush_rs(double* __restrict__ P, con
       for (int ct = 0; ct < 4; ++ct)
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg) T[cd_index(ct, rg)] = acc[ct][rg];
+      RS_CBAR();
+      const __amdgpu_buffer_rsrc_t rsP = rs_rsrc(Pb);
+      const unsigned off_last = tile_off(Sw - 1);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const double2 o = *reinterpret_cast<const double2*>(&T[rm_base + 128 * q]);
+        stb16<NT>(rsP, loff, off_last + (unsigned)q * 2u * ld8, o);
+      }
       RS_CBAR();
     };
     using T_ = std::true_type;
@@ -1622,16 +1666,8 @@ __global__ __launch_bounds__(512, 2) void k_flush_rs(double* __restrict__ P, con
         else body(F_{}, F_{}, P0{}, S - 1);
       }
     }
-    // ---- drain: the last result of this wave ----
-    {
-      const __amdgpu_buffer_rsrc_t rsP = rs_rsrc(Pb);
-      const unsigned off_last = tile_off(Sw - 1);
-#pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const double2 o = *reinterpret_cast<const double2*>(&T[rm_base + 128 * q]);
-        stb16<NT>(rsP, loff, off_last + (unsigned)q * 2u * ld8, o);
-      }
-    }
+    if ((Sw - 1) & 1) drain(P1{});
+    else drain(P0{});
   }
 }
 
