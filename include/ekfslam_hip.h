@@ -137,8 +137,10 @@ int ekf_profile_enable(ekf_handle *h, int on);
 int ekf_profile_read(ekf_handle *h, double *pass_ms_total, long long *pass_launches); /* and resets */
 /* Tuning knobs: "flush_every" (steps per covariance pass, 0 = auto), "rank_limit" (auto cadence: pending
  * ranks that trigger the pass, 2..80), "pass_rows_per_block", "pass_streaming" (-1 auto / 0 resident /
- * 1 nontemporal), "active_bound" (0 = treat every state index as correlated), "pass_kernel" (0 = k_flush,
- * 1 = k_flush_pc, the producer/consumer form of the pass; same result bit for bit); unknown names fail. */
+ * 1 nontemporal), "active_bound" (0 = treat every state index as correlated), "pass_kernel" (-1 = auto:
+ * the row-slab kernel for batches that stream through HBM and fill every CU, else k_flush; 0 = k_flush,
+ * 1 = k_flush_pc, the producer/consumer form, 2 = k_flush_rs, the row-slab form; all give the same result
+ * bit for bit); unknown names fail. */
 int ekf_set_option(ekf_handle *h, const char *name, int value);
 
 #ifdef __cplusplus

@@ -642,7 +642,11 @@ __global__ __launch_bounds__(64 * NW) void k_panels(double* __restrict__ P, doub
 #pragma unroll
     for (int a = 0; a < CC; ++a) {
       const int row = o.C[a];
+#ifdef PANELS_SKIP_COLG                                 /* diagnostic build: no column-direction gathers */
+      X[a] = Pb[(long)min(row, i0) * ld + max(row, ii)];
+#else
       X[a] = Pb[(long)min(row, ii) * ld + max(row, ii)];
+#endif
     }
   } else {
 #pragma unroll
@@ -749,8 +753,10 @@ __global__ __launch_bounds__(64 * NW) void k_panels(double* __restrict__ P, doub
     }
   }
   };
+#ifndef PANELS_SKIP_PEND                                  /* diagnostic build: no pending-rank gather */
   if (o.cmax > i0) gather_pending(std::true_type{});
   else gather_pending(std::false_type{});
+#endif
   if (KSPLIT) {                                        // waves 1.. hand their partial sums to wave 0 and leave
     if (kw > 0) {
 #pragma unroll

@@ -14,7 +14,7 @@ agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob("gpurun_out/pmc_pass/*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         name = r["Kernel_Name"].split("(")[0].replace("void ", "")
-        if "k_flush" in name:
+        if any(k in name for k in ("k_flush", "k_panels", "k_solve")):
             agg[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for name, c in agg.items():
     m = {k: sum(v) / len(v) for k, v in c.items()}
