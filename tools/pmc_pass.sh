@@ -5,16 +5,16 @@ export TMPDIR=/tmp
 OUT=gpurun_out/pmc_pass
 rm -rf $OUT; mkdir -p $OUT
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS \
-  --output-format csv -d $OUT/a -o run -- python3 tools/flush_time.py "$@" > $OUT/a.log 2>&1
+  --output-format csv -d $OUT/a -o run -- python3 ${PMC_PROG:-tools/flush_time.py} "$@" > $OUT/a.log 2>&1
 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM SQ_WAVES SQ_INSTS_LDS \
-  --output-format csv -d $OUT/b -o run -- python3 tools/flush_time.py "$@" > $OUT/b.log 2>&1
+  --output-format csv -d $OUT/b -o run -- python3 ${PMC_PROG:-tools/flush_time.py} "$@" > $OUT/b.log 2>&1
 python3 - <<'PY'
 import csv, glob, collections
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob("gpurun_out/pmc_pass/*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         name = r["Kernel_Name"].split("(")[0].replace("void ", "")
-        if any(k in name for k in ("k_flush", "k_panels", "k_solve")):
+        if any(k in name for k in ("k_flush", "k_panels", "k_solve", "k_gemm")):
             agg[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for name, c in agg.items():
     m = {k: sum(v) / len(v) for k, v in c.items()}
