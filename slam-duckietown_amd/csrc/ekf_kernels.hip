@@ -1382,7 +1382,8 @@ __global__ __launch_bounds__(512, 2) void k_flush_rs(double* __restrict__ P, con
                                                      const double* __restrict__ dacc,
                                                      const int* __restrict__ nact,
                                                      const SolveOut* __restrict__ so, int ld, long pstride,
-                                                     int nkt, int batch, int nrb, unsigned* __restrict__ queue) {
+                                                     int nkt, int batch, int nrb, int nch, int cs,
+                                                     unsigned* __restrict__ queue) {
   constexpr int RPW = NKT / 2;                         // ranks of a V strip each of the 8 waves stages
   __shared__ __attribute__((aligned(16))) double vbuf[2][NKT * 256];   // V strip as B fragments: [k-tile][col tile][lane]
   __shared__ __attribute__((aligned(16))) double img[8][16 * 64];      // per wave: 16 x 64 tile image (swizzled)
@@ -1405,6 +1406,7 @@ __global__ __launch_bounds__(512, 2) void k_flush_rs(double* __restrict__ P, con
   const int stage_base = ((wave >> 2) * 4 + lq) * 64 + (wave & 3) * 16 + li;
   const unsigned loff = (unsigned)(rr * ld + rc) * 8u; // lane part of a tile address, bytes (rows 2q + rr, columns rc, rc + 1)
   const unsigned lane8 = (unsigned)lane * 8u;
+  const int upt = nrb * nch;                           // units per trajectory: (chunk of `cs` strips, slab), chunk-major
 
   for (;;) {
     // ---- next unit: own queue first, then the others ----
@@ -1412,12 +1414,12 @@ __global__ __launch_bounds__(512, 2) void k_flush_rs(double* __restrict__ P, con
       int found = -1;
       for (int a = 0; a < 8 && found < 0; ++a) {
         const int g2 = (grp + a) & 7;
-        const int cnt = (g2 < batch) ? ((batch - g2 + 7) >> 3) * nrb : 0;
+        const int cnt = (g2 < batch) ? ((batch - g2 + 7) >> 3) * upt : 0;
         if (cnt == 0) continue;
         unsigned* head = queue + g2 * RS_QSTRIDE;
         if (__hip_atomic_load(head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)cnt) continue;
         const unsigned u = atomicAdd(head, 1u);
-        if (u < (unsigned)cnt) found = (g2 + 8 * (int)(u / (unsigned)nrb)) * nrb + (int)(u % (unsigned)nrb);
+        if (u < (unsigned)cnt) found = (g2 + 8 * (int)(u / (unsigned)upt)) * upt + (int)(u % (unsigned)upt);
       }
       s_unit = found;
     }
@@ -1425,16 +1427,23 @@ __global__ __launch_bounds__(512, 2) void k_flush_rs(double* __restrict__ P, con
     const int unit = __builtin_amdgcn_readfirstlane(s_unit);   // (an LDS load is a vector value to the compiler)
     __syncthreads();
     if (unit < 0) return;                              // every queue is empty: all eight waves leave together
-    const int b = unit / nrb, rb = unit - b * nrb;
+    const int b = unit / upt, chunk = (unit - b * upt) / nrb, rb = unit - b * upt - chunk * nrb;
     const int n = min(nact[b], so[b].neff);            // rows/cols beyond the active bound are untouched
     const int i0 = rb * RS_ROWS;
     if (i0 >= n) continue;
-    const int j_last = ((n - 1) >> 6) << 6;            // rightmost strip that starts below n
-    const int S = ((j_last - i0) >> 6) + 1;            // strips from the right end down to the one holding the diagonal
+    // The slab's strips run from the right end of its rows (the rightmost strip that starts below n) down to the one
+    // holding the diagonal; a unit is `cs` consecutive strips of them (all of them when the batch alone fills the
+    // chip: nch = 1).  Below, j_last / S / Sw describe THIS UNIT's strips.
+    const int j_right = ((n - 1) >> 6) << 6;
+    const int S_slab = ((j_right - i0) >> 6) + 1;
+    if (chunk * cs >= S_slab) continue;
+    const int j_last = j_right - 64 * chunk * cs;      // first (rightmost) strip of the unit
+    const int S = min(cs, S_slab - chunk * cs);
+    const bool has_diag = chunk * cs + S == S_slab;    // the unit ends on the strip that holds the diagonal
     const int i0w = i0 + 16 * wave;
-    // tiles of this wave: none if its rows lie beyond n; in the last strip (columns i0..i0+63) the rows of waves 4-7
-    // lie strictly below the diagonal
-    const int Sw = (i0w < n) ? (wave < 4 ? S : S - 1) : 0;
+    // tiles of this wave: none if its rows lie beyond n; in the strip that holds the diagonal (columns i0..i0+63)
+    // the rows of waves 4-7 lie strictly below it
+    const int Sw = (i0w < n) ? ((wave < 4 || !has_diag) ? S : S - 1) : 0;
     double* Pb = P + (long)b * pstride;
     const double* Vb = V + (long)b * KTOT * ld;
     const double* Wb = W + (long)b * KTOT * ld;
@@ -1628,7 +1637,7 @@ __global__ __launch_bounds__(512, 2) void k_flush_rs(double* __restrict__ P, con
     auto drain = [&](auto par_tag) {
       constexpr int PAR = decltype(par_tag)::value;
       double4_t (&acc)[4] = accs[PAR];
-      if (i0w == 0 && Sw == S) {                       // (uniform) the tile at (0, 0): pose-block noise accumulated since the last pass
+      if (i0w == 0 && has_diag) {                      // (uniform) the tile at (0, 0): pose-block noise accumulated since the last pass
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg) {
           const int row = lq + 4 * rg;
@@ -1667,7 +1676,7 @@ __global__ __launch_bounds__(512, 2) void k_flush_rs(double* __restrict__ P, con
         body(F_{}, T_{}, P1{}, t);
         ++t;
       }
-      if (Sw == S) {                                   // waves 0-3: the strip that holds the diagonal, no staging after it
+      if (Sw == S) {                                   // this wave also has the unit's last strip: no staging after it
         if ((S - 1) & 1) body(F_{}, F_{}, P1{}, S - 1);
         else body(F_{}, F_{}, P0{}, S - 1);
       }
@@ -2005,9 +2014,20 @@ static void launch_flush_rs_t(hipStream_t st, double* P, const double* V, const 
                               const int* nact, const SolveOut* so, int ld, long pstride, int batch, int n_hi, int nkt,
                               int workgroups, unsigned* queue) {
   const int nrb = (n_hi + RS_ROWS - 1) / RS_ROWS;
-  const int units = nrb * batch;
-  hipLaunchKernelGGL((k_flush_rs<NKT, NT>), dim3(std::min(workgroups, units)), dim3(512), 0, st, P, V, W, dacc, nact, so,
-                     ld, pstride, nkt, batch, nrb, queue);
+  // Units: whole slabs while the batch alone gives every CU a few of them; otherwise a slab is cut into chunks of `cs`
+  // strips so that there are about three units per CU (a unit pays a pipeline fill: not below 2 strips).
+  const int s_max = (n_hi + 63) / 64;                  // strips of the longest slab
+  long steps = 0;
+  for (int rb = 0; rb < nrb; ++rb) steps += std::max(1, s_max - 2 * rb);
+  steps *= batch;
+  int cs = s_max, nch = 1;
+  if ((long)nrb * batch < 3L * workgroups) {
+    cs = (int)std::max<long>(2, (steps + 3L * workgroups - 1) / (3L * workgroups));
+    nch = (s_max + cs - 1) / cs;
+  }
+  const long units = (long)nrb * nch * batch;
+  hipLaunchKernelGGL((k_flush_rs<NKT, NT>), dim3((unsigned)std::min<long>(workgroups, units)), dim3(512), 0, st, P, V, W,
+                     dacc, nact, so, ld, pstride, nkt, batch, nrb, nch, cs, queue);
 }
 
 void launch_flush_rs(hipStream_t st, bool streaming, double* P, const double* V, const double* W, const double* dacc,
