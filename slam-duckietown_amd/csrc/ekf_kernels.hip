@@ -677,8 +677,11 @@ __global__ __launch_bounds__(64 * NW) void k_panels(double* __restrict__ P, doub
   auto gather_pending = [&](auto need_w_tag) {
   constexpr bool NEEDW = decltype(need_w_tag)::value;
   double v[8], w[8];
+  // (the group after the last one is "fetched" too so that no load sits under a branch, but it is pointed at the
+  //  last valid group again: rows that were just read, not rank slots nobody needs -- a V row costs a trip to HBM)
+  const int k_last = ((kb - 1) >> 3) << 3;
   auto load_vw = [&](int k0, double (&vv)[8], double (&ww)[8]) {
-    const int kc = min(k0, KTOT - 8);                  // stay inside the rank slots
+    const int kc = min(k0, k_last);
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       const double x = vlane[(long)(kc + u) * ld];
@@ -754,8 +757,10 @@ __global__ __launch_bounds__(64 * NW) void k_panels(double* __restrict__ P, doub
   }
   };
 #ifndef PANELS_SKIP_PEND                                  /* diagnostic build: no pending-rank gather */
-  if (o.cmax > i0) gather_pending(std::true_type{});
-  else gather_pending(std::false_type{});
+  if (kb > 0) {                                        // (uniform) right after a covariance pass nothing is pending
+    if (o.cmax > i0) gather_pending(std::true_type{});
+    else gather_pending(std::false_type{});
+  }
 #endif
   if (KSPLIT) {                                        // waves 1.. hand their partial sums to wave 0 and leave
     if (kw > 0) {
