@@ -20,7 +20,7 @@ void launch_flush(hipStream_t, bool, double*, const double*, const double*, cons
 void launch_flush_pc(hipStream_t, bool, double*, const double*, const double*, const double*, const int*,
                      const SolveOut*, int, long, int, int, int, int, unsigned*);
 void launch_flush_rs(hipStream_t, bool, double*, const double*, const double*, const double*, const int*,
-                     const SolveOut*, int, long, int, int, int, int, unsigned*);
+                     const SolveOut*, int, long, int, int, int, int, unsigned*, int);
 int flush_rs_queue_words();
 void launch_predict_rc(hipStream_t, double*, const double*, double*, const int*, const SolveOut*, int, long,
                        int, int);
@@ -87,6 +87,7 @@ struct ekf_handle {
   unsigned* dqueue = nullptr;     // work-queue heads of k_flush_rs (zeroed before every launch)
   int cu_count = 0;
   int opt_rows_per_block = 0;     // 0 = auto (flush kernel: rows per workgroup, multiple of 16)
+  int opt_pass_chunk = 0;         // 0 = auto (k_flush_rs: strips per unit)
   int opt_flush_every = 0;        // 0 = auto; k = flush the pending low-rank update after k steps
   int opt_streaming = -1;         // -1 = auto (by working-set size), 0 = resident kernel, 1 = nontemporal kernel
   std::string err;
@@ -464,7 +465,7 @@ static int flush_pending(ekf_handle* h) {
     HIP_TRY(h, hipMemsetAsync(h->dqueue, 0, sizeof(unsigned) * flush_rs_queue_words(), h->stream));
     if (h->profile) HIP_TRY(h, hipEventRecord(e0, h->stream));      // (time the kernel, not the 1 KB memset)
     launch_flush_rs(h->stream, streaming, h->dP, h->dV, h->dW, h->ddacc2[h->dcur], h->dn, h->dso, h->ld, h->pstride,
-                    h->batch, e_hi, nkt, h->cu_count, h->dqueue);
+                    h->batch, e_hi, nkt, h->cu_count, h->dqueue, h->opt_pass_chunk);
   } else if (kernel == 1) {
     launch_flush_pc(h->stream, streaming, h->dP, h->dV, h->dW, h->ddacc2[h->dcur], h->dn, h->dso, h->ld, h->pstride,
                     h->batch, e_hi, nkt, flush_rows_per_block(h, streaming), h->dflags);
@@ -949,6 +950,11 @@ extern "C" int ekf_set_option(ekf_handle* h, const char* name, int value) {
   if (std::strcmp(name, "pass_rows_per_block") == 0) {
     if (value < 0 || value > 4096) return fail(h, EKF_ERR_ARG, "pass_rows_per_block out of range");
     h->opt_rows_per_block = value;
+    return EKF_OK;
+  }
+  if (std::strcmp(name, "pass_chunk") == 0) {
+    if (value < 0 || value > 4096) return fail(h, EKF_ERR_ARG, "pass_chunk out of range");
+    h->opt_pass_chunk = value;
     return EKF_OK;
   }
   if (std::strcmp(name, "active_bound") == 0) {

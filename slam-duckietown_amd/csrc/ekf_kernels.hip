@@ -1413,24 +1413,25 @@ __global__ __launch_bounds__(512, 2) void k_flush_rs(double* __restrict__ P, con
   const unsigned lane8 = (unsigned)lane * 8u;
   const int upt = nrb * nch;                           // units per trajectory: (chunk of `cs` strips, slab), chunk-major
 
-  for (;;) {
-    // ---- next unit: own queue first, then the others ----
-    if (threadIdx.x == 0) {
-      int found = -1;
-      for (int a = 0; a < 8 && found < 0; ++a) {
-        const int g2 = (grp + a) & 7;
-        const int cnt = (g2 < batch) ? ((batch - g2 + 7) >> 3) * upt : 0;
-        if (cnt == 0) continue;
-        unsigned* head = queue + g2 * RS_QSTRIDE;
-        if (__hip_atomic_load(head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)cnt) continue;
-        const unsigned u = atomicAdd(head, 1u);
-        if (u < (unsigned)cnt) found = (g2 + 8 * (int)(u / (unsigned)upt)) * upt + (int)(u % (unsigned)upt);
-      }
-      s_unit = found;
+  // next unit: own queue first, then the others (thread 0 only; -1 = every queue is empty)
+  auto pop = [&]() -> int {
+    int found = -1;
+    for (int a = 0; a < 8 && found < 0; ++a) {
+      const int g2 = (grp + a) & 7;
+      const int cnt = (g2 < batch) ? ((batch - g2 + 7) >> 3) * upt : 0;
+      if (cnt == 0) continue;
+      unsigned* head = queue + g2 * RS_QSTRIDE;
+      if (__hip_atomic_load(head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)cnt) continue;
+      const unsigned u = atomicAdd(head, 1u);
+      if (u < (unsigned)cnt) found = (g2 + 8 * (int)(u / (unsigned)upt)) * upt + (int)(u % (unsigned)upt);
     }
+    return found;
+  };
+  for (;;) {
+    __syncthreads();                                   // every wave is done with the LDS of the previous unit
+    if (threadIdx.x == 0) s_unit = pop();
     __syncthreads();
     const int unit = __builtin_amdgcn_readfirstlane(s_unit);   // (an LDS load is a vector value to the compiler)
-    __syncthreads();
     if (unit < 0) return;                              // every queue is empty: all eight waves leave together
     const int b = unit / upt, chunk = (unit - b * upt) / nrb, rb = unit - b * upt - chunk * nrb;
     const int n = min(nact[b], so[b].neff);            // rows/cols beyond the active bound are untouched
@@ -2017,7 +2018,7 @@ void launch_flush(hipStream_t st, bool streaming, double* P, const double* V, co
 template <int NKT, bool NT>
 static void launch_flush_rs_t(hipStream_t st, double* P, const double* V, const double* W, const double* dacc,
                               const int* nact, const SolveOut* so, int ld, long pstride, int batch, int n_hi, int nkt,
-                              int workgroups, unsigned* queue) {
+                              int workgroups, unsigned* queue, int chunk) {
   const int nrb = (n_hi + RS_ROWS - 1) / RS_ROWS;
   // Units: whole slabs while the batch alone gives every CU a few of them; otherwise a slab is cut into chunks of `cs`
   // strips so that there are about three units per CU (a unit pays a pipeline fill: not below 2 strips).
@@ -2026,7 +2027,10 @@ static void launch_flush_rs_t(hipStream_t st, double* P, const double* V, const 
   for (int rb = 0; rb < nrb; ++rb) steps += std::max(1, s_max - 2 * rb);
   steps *= batch;
   int cs = s_max, nch = 1;
-  if ((long)nrb * batch < 3L * workgroups) {
+  if (chunk > 0) {                                     // ("pass_chunk" option)
+    cs = std::min(std::max(chunk, 1), s_max);
+    nch = (s_max + cs - 1) / cs;
+  } else if ((long)nrb * batch < 3L * workgroups) {
     cs = (int)std::max<long>(2, (steps + 3L * workgroups - 1) / (3L * workgroups));
     nch = (s_max + cs - 1) / cs;
   }
@@ -2037,11 +2041,11 @@ static void launch_flush_rs_t(hipStream_t st, double* P, const double* V, const 
 
 void launch_flush_rs(hipStream_t st, bool streaming, double* P, const double* V, const double* W, const double* dacc,
                      const int* nact, const SolveOut* so, int ld, long pstride, int batch, int n_hi, int nkt,
-                     int workgroups, unsigned* queue) {
+                     int workgroups, unsigned* queue, int chunk) {
 #define EKF_FLUSH_RS(N)                                                                                   \
   do {                                                                                                    \
-    if (streaming) launch_flush_rs_t<N, true>(st, P, V, W, dacc, nact, so, ld, pstride, batch, n_hi, nkt, workgroups, queue); \
-    else launch_flush_rs_t<N, false>(st, P, V, W, dacc, nact, so, ld, pstride, batch, n_hi, nkt, workgroups, queue);          \
+    if (streaming) launch_flush_rs_t<N, true>(st, P, V, W, dacc, nact, so, ld, pstride, batch, n_hi, nkt, workgroups, queue, chunk); \
+    else launch_flush_rs_t<N, false>(st, P, V, W, dacc, nact, so, ld, pstride, batch, n_hi, nkt, workgroups, queue, chunk);          \
   } while (0)
   if (nkt <= 4) EKF_FLUSH_RS(4);
   else if (nkt <= 8) EKF_FLUSH_RS(8);
