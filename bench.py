@@ -81,6 +81,7 @@ def time_filter(sd, sd_syn, shard, grp, device, traj_ids, n_landmarks, m, steps,
         f.flush()
         pass_ms, launches = f.profile_read()
         f.profile_enable(False)
+    time_filter.last_pass_kernel = f.last_pass()
     flags = [f.flags(b) for b in range(len(traj_ids))]
     mu = f.mean(0)
     assert not any(flags) and np.isfinite(mu).all(), "filter diverged during the benchmark"
@@ -234,7 +235,8 @@ def main():
                        "trajectories_per_gpu": B, "parallelism": f"trajectory-sharded x{world}, no collective",
                        "options": args.option},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "ekf::k_flush",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": getattr(time_filter, "last_pass_kernel", "") or "ekf::k_flush",
                          "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_s * 1e3, "launches": launches,
                          "steps_per_launch": steps_per_launch,
                          "step_equivalent_GBs": (B * 16.0 * n * n * steps_per_launch / avg_s / 1e9) if avg_s > 0 else 0.0,
@@ -248,8 +250,9 @@ def main():
                                  "SURVEY 8(d)'s 16 n^2 bytes per step become 8 n(n+1) bytes per LAUNCH; achieved/frac "
                                  "count the bytes this launch must move (one read + one write of the triangle), "
                                  "step_equivalent_GBs = SURVEY's 16 n^2 per step x steps folded in / launch time; "
-                                 "at the default 5 steps (80 ranks = 10 flop/B, the ridge of this part) per launch neither side is saturated; its memory side alone takes 0.80 ms (profiles/mfma_probe.txt, DESIGN.md section 4), "
-                                 "see `mfma`"},
+                                 "at the default 5 steps (80 ranks = 10 flop/B, the ridge of this part) per launch the matrix side "
+                                 "(0.65 ms alone) and the memory side (0.68 ms alone, 6.05 TB/s) of the row-slab pass are balanced "
+                                 "(DESIGN.md section 4), see `mfma`"},
             "device_ms_per_step": dev_ms / args.steps,
         }
         out["roofline"].update(pmc_traffic(f"N{args.landmarks}_B{B}", args.option))

@@ -142,6 +142,9 @@ int ekf_profile_read(ekf_handle *h, double *pass_ms_total, long long *pass_launc
  * 1 = k_flush_pc, the producer/consumer form, 2 = k_flush_rs, the row-slab form; all give the same result
  * bit for bit), "pass_chunk" (row-slab pass: strips per work unit, 0 = auto); unknown names fail. */
 int ekf_set_option(ekf_handle *h, const char *name, int value);
+/* Which form of the covariance pass the last launch used (-1 = none yet; values as for "pass_kernel"), how many
+ * MFMA k-tiles (4 pending ranks each) it applied, and whether it took the nontemporal (streaming) path. */
+int ekf_last_pass(ekf_handle *h, int *kernel, int *k_tiles, int *streaming);
 
 #ifdef __cplusplus
 }

@@ -88,6 +88,7 @@ struct ekf_handle {
   int cu_count = 0;
   int opt_rows_per_block = 0;     // 0 = auto (flush kernel: rows per workgroup, multiple of 16)
   int opt_pass_chunk = 0;         // 0 = auto (k_flush_rs: strips per unit)
+  int last_kernel = -1, last_nkt = 0, last_streaming = 0;   // what the last covariance pass launched
   int opt_flush_every = 0;        // 0 = auto; k = flush the pending low-rank update after k steps
   int opt_streaming = -1;         // -1 = auto (by working-set size), 0 = resident kernel, 1 = nontemporal kernel
   std::string err;
@@ -461,6 +462,9 @@ static int flush_pending(ekf_handle* h) {
   // three per CU the slabs are cut into chunks of strips); measured at N=2000: 8 trajectories 256 us against 266 us
   // with k_flush, 4 trajectories 166 / 164 us, 1 trajectory 97 / 52 us (pipeline fills dominate)
   if (kernel < 0) kernel = (streaming && (long)h->batch * ((e_hi + 127) / 128) >= (long)h->cu_count) ? 2 : 0;
+  h->last_kernel = kernel;
+  h->last_nkt = nkt;
+  h->last_streaming = streaming ? 1 : 0;
   if (kernel == 2) {
     HIP_TRY(h, hipMemsetAsync(h->dqueue, 0, sizeof(unsigned) * flush_rs_queue_words(), h->stream));
     if (h->profile) HIP_TRY(h, hipEventRecord(e0, h->stream));      // (time the kernel, not the 1 KB memset)
@@ -932,6 +936,14 @@ extern "C" int ekf_profile_read(ekf_handle* h, double* pass_ms_total, long long*
   *pass_ms_total = total;
   *pass_launches = (long long)(h->prof_used / 2);
   h->prof_used = 0;
+  return EKF_OK;
+}
+
+extern "C" int ekf_last_pass(ekf_handle* h, int* kernel, int* k_tiles, int* streaming) {
+  if (!h) return EKF_ERR_ARG;
+  if (kernel) *kernel = h->last_kernel;
+  if (k_tiles) *k_tiles = h->last_nkt;
+  if (streaming) *streaming = h->last_streaming;
   return EKF_OK;
 }
 

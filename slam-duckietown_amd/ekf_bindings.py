@@ -123,6 +123,7 @@ ABI = {
     "ekf_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "ekf_profile_read": (C.c_int, [C.c_void_p, _dp, C.POINTER(C.c_longlong)]),
     "ekf_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
+    "ekf_last_pass": (C.c_int, [C.c_void_p, _ip, _ip, _ip]),
 }
 
 
@@ -430,6 +431,22 @@ class EkfSlam:
         ms, cnt = C.c_double(), C.c_longlong()
         self._check(self._lib.ekf_profile_read(self._h, C.byref(ms), C.byref(cnt)))
         return ms.value, cnt.value
+
+    def last_pass(self) -> str:
+        """Name of the kernel the last covariance pass launched (e.g. ``ekf::k_flush_rs<20, true>``, as rocprofv3 prints it), '' if none yet."""
+        k, t, st = C.c_int(), C.c_int(), C.c_int()
+        self._check(self._lib.ekf_last_pass(self._h, C.byref(k), C.byref(t), C.byref(st)))
+        if k.value < 0:
+            return ""
+        nt = "true" if st.value else "false"
+        tiles = next(x for x in (4, 8, 12, 16, 20) if x >= t.value)
+        if k.value == 2:
+            return f"ekf::k_flush_rs<{tiles}, {nt}>"
+        regs = {4: (4, 0), 8: (8, 0), 12: (12, 0), 16: (16, 0), 20: (15, 5)}[tiles]
+        if k.value == 1:
+            regs = (8, 0) if tiles <= 8 else ((16, 0) if tiles <= 16 else (16, 4))
+            return f"ekf::k_flush_pc<{regs[0]}, {regs[1]}, {nt}>"
+        return f"ekf::k_flush<{regs[0]}, {regs[1]}, {nt}>"
 
     def set_option(self, name: str, value: int):
         self._check(self._lib.ekf_set_option(self._h, name.encode(), int(value)))
