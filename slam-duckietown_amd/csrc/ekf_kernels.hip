@@ -1413,7 +1413,10 @@ __global__ __launch_bounds__(512, 2) void k_flush_rs(double* __restrict__ P, con
   const unsigned lane8 = (unsigned)lane * 8u;
   const int upt = nrb * nch;                           // units per trajectory: (chunk of `cs` strips, slab), chunk-major
 
-  // next unit: own queue first, then the others (thread 0 only; -1 = every queue is empty)
+  // next unit: own queue first, then the others (thread 0 only; -1 = every queue is empty).  While the own queue has
+  // units the head is bumped without looking first (one round trip instead of two); a queue found empty is only
+  // looked at from then on (the heads are never bumped far beyond their counts).
+  bool own_empty = false;
   auto pop = [&]() -> int {
     int found = -1;
     for (int a = 0; a < 8 && found < 0; ++a) {
@@ -1421,9 +1424,12 @@ __global__ __launch_bounds__(512, 2) void k_flush_rs(double* __restrict__ P, con
       const int cnt = (g2 < batch) ? ((batch - g2 + 7) >> 3) * upt : 0;
       if (cnt == 0) continue;
       unsigned* head = queue + g2 * RS_QSTRIDE;
-      if (__hip_atomic_load(head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)cnt) continue;
+      if (a > 0 || own_empty) {
+        if (__hip_atomic_load(head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)cnt) continue;
+      }
       const unsigned u = atomicAdd(head, 1u);
       if (u < (unsigned)cnt) found = (g2 + 8 * (int)(u / (unsigned)upt)) * upt + (int)(u % (unsigned)upt);
+      else if (a == 0) own_empty = true;
     }
     return found;
   };
