@@ -88,6 +88,7 @@ struct ekf_handle {
   int cu_count = 0;
   int opt_rows_per_block = 0;     // 0 = auto (flush kernel: rows per workgroup, multiple of 16)
   int opt_pass_chunk = 0;         // 0 = auto (k_flush_rs: strips per unit)
+  int opt_pass_workgroups = 0;    // 0 = one per CU (k_flush_rs: persistent workgroups; fewer leaves CUs to other streams)
   int last_kernel = -1, last_nkt = 0, last_streaming = 0;   // what the last covariance pass launched
   int opt_flush_every = 0;        // 0 = auto; k = flush the pending low-rank update after k steps
   int opt_streaming = -1;         // -1 = auto (by working-set size), 0 = resident kernel, 1 = nontemporal kernel
@@ -469,7 +470,8 @@ static int flush_pending(ekf_handle* h) {
     HIP_TRY(h, hipMemsetAsync(h->dqueue, 0, sizeof(unsigned) * flush_rs_queue_words(), h->stream));
     if (h->profile) HIP_TRY(h, hipEventRecord(e0, h->stream));      // (time the kernel, not the 1 KB memset)
     launch_flush_rs(h->stream, streaming, h->dP, h->dV, h->dW, h->ddacc2[h->dcur], h->dn, h->dso, h->ld, h->pstride,
-                    h->batch, e_hi, nkt, h->cu_count, h->dqueue, h->opt_pass_chunk);
+                    h->batch, e_hi, nkt, h->opt_pass_workgroups > 0 ? std::min(h->opt_pass_workgroups, h->cu_count) : h->cu_count,
+                    h->dqueue, h->opt_pass_chunk);
   } else if (kernel == 1) {
     launch_flush_pc(h->stream, streaming, h->dP, h->dV, h->dW, h->ddacc2[h->dcur], h->dn, h->dso, h->ld, h->pstride,
                     h->batch, e_hi, nkt, flush_rows_per_block(h, streaming), h->dflags);
@@ -939,6 +941,17 @@ extern "C" int ekf_profile_read(ekf_handle* h, double* pass_ms_total, long long*
   return EKF_OK;
 }
 
+// (development aid, not declared in the header: the words behind the queue heads, where a -DRS_STAMPS build of
+//  k_flush_rs leaves its time stamps)
+extern "C" int ekf_debug_read(ekf_handle* h, void* dst, long bytes) {
+  if (!h || !dst) return EKF_ERR_ARG;
+  HIP_TRY(h, hipSetDevice(h->device));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  const long have = (long)sizeof(unsigned) * flush_rs_queue_words();
+  HIP_TRY(h, hipMemcpy(dst, h->dqueue, (size_t)std::min(bytes, have), hipMemcpyDeviceToHost));
+  return EKF_OK;
+}
+
 extern "C" int ekf_last_pass(ekf_handle* h, int* kernel, int* k_tiles, int* streaming) {
   if (!h) return EKF_ERR_ARG;
   if (kernel) *kernel = h->last_kernel;
@@ -967,6 +980,11 @@ extern "C" int ekf_set_option(ekf_handle* h, const char* name, int value) {
   if (std::strcmp(name, "pass_chunk") == 0) {
     if (value < 0 || value > 4096) return fail(h, EKF_ERR_ARG, "pass_chunk out of range");
     h->opt_pass_chunk = value;
+    return EKF_OK;
+  }
+  if (std::strcmp(name, "pass_workgroups") == 0) {
+    if (value < 0 || value > 4096) return fail(h, EKF_ERR_ARG, "pass_workgroups out of range");
+    h->opt_pass_workgroups = value;
     return EKF_OK;
   }
   if (std::strcmp(name, "active_bound") == 0) {

@@ -1380,6 +1380,20 @@ __device__ __forceinline__ double ldb8(__amdgpu_buffer_rsrc_t rs, unsigned lane_
 }
 
 #define RS_CBAR() asm volatile("" ::: "memory")
+// Diagnostic build (-DRS_STAMPS): wave 0 of every workgroup records s_memtime at fixed points of its first units into
+// the words behind the queue heads (tools/rs_stamps.py reads them through ekf_debug_read).
+#ifdef RS_STAMPS
+#define RS_STAMP(k)                                                                             \
+  do {                                                                                          \
+    if (wave == 0 && unit_no < 3) {                                                             \
+      unsigned long long t_;                                                                    \
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                \
+      if (lane == 0) stamp_buf[unit_no * 20 + (k)] = t_;                                        \
+    }                                                                                           \
+  } while (0)
+#else
+#define RS_STAMP(k) do { } while (0)
+#endif
 
 template <int NKT, bool NT>
 __global__ __launch_bounds__(512, 2) void k_flush_rs(double* __restrict__ P, const double* __restrict__ V,
@@ -1416,6 +1430,10 @@ __global__ __launch_bounds__(512, 2) void k_flush_rs(double* __restrict__ P, con
   // next unit: own queue first, then the others (thread 0 only; -1 = every queue is empty).  While the own queue has
   // units the head is bumped without looking first (one round trip instead of two); a queue found empty is only
   // looked at from then on (the heads are never bumped far beyond their counts).
+#ifdef RS_STAMPS
+  unsigned long long* stamp_buf = reinterpret_cast<unsigned long long*>(queue + 8 * RS_QSTRIDE) + blockIdx.x * 64;
+  int unit_no = -1;
+#endif
   bool own_empty = false;
   auto pop = [&]() -> int {
     int found = -1;
@@ -1434,9 +1452,15 @@ __global__ __launch_bounds__(512, 2) void k_flush_rs(double* __restrict__ P, con
     return found;
   };
   for (;;) {
+#ifdef RS_STAMPS
+    ++unit_no;
+#endif
+    RS_STAMP(0);
     __syncthreads();                                   // every wave is done with the LDS of the previous unit
+    RS_STAMP(1);
     if (threadIdx.x == 0) s_unit = pop();
     __syncthreads();
+    RS_STAMP(2);
     const int unit = __builtin_amdgcn_readfirstlane(s_unit);   // (an LDS load is a vector value to the compiler)
     if (unit < 0) return;                              // every queue is empty: all eight waves leave together
     const int b = unit / upt, chunk = (unit - b * upt) / nrb, rb = unit - b * upt - chunk * nrb;
@@ -1528,6 +1552,7 @@ __global__ __launch_bounds__(512, 2) void k_flush_rs(double* __restrict__ P, con
     // fragments of the NEXT tile): the reads of the next k-tile are always in flight under this one's MFMAs
     double bf[2][4];
 
+    RS_STAMP(3);
     // ---- prologue: W fragments, strip 0, tile 0 -> accs[0], tile 1 in flight ----
     {
       double vs[RPW];
@@ -1539,9 +1564,11 @@ __global__ __launch_bounds__(512, 2) void k_flush_rs(double* __restrict__ P, con
         wf[t] = (t < nkt) ? x : 0.0;
       }
       stage_store(vbuf[0], I0_{}, IR_{}, vs);
+      RS_STAMP(4);
 #pragma unroll
       for (int q = 0; q < 8; ++q) *reinterpret_cast<double2*>(&T[rm_base + 128 * q]) = g[q];
       RS_CBAR();
+      RS_STAMP(5);
 #pragma unroll
       for (int ct = 0; ct < 4; ++ct)
 #pragma unroll
@@ -1549,6 +1576,7 @@ __global__ __launch_bounds__(512, 2) void k_flush_rs(double* __restrict__ P, con
       RS_CBAR();
       gload(1);
       wg_barrier();
+      RS_STAMP(6);
 #pragma unroll
       for (int ct = 0; ct < 4; ++ct) bf[0][ct] = vbuf[0][ct * 64 + lane];
     }
@@ -1679,11 +1707,17 @@ __global__ __launch_bounds__(512, 2) void k_flush_rs(double* __restrict__ P, con
       body(T_{}, F_{}, P0{}, 0);
     } else {
       body(T_{}, T_{}, P0{}, 0);
+      RS_STAMP(7);
       int t = 1;
       for (; t + 1 < S - 1; t += 2) {
         body(F_{}, T_{}, P1{}, t);
+        if (t == 1) RS_STAMP(8);
         body(F_{}, T_{}, P0{}, t + 1);
+        if (t == 1) RS_STAMP(9);
+        if (t == 3) RS_STAMP(10);
+        if (t == 5) RS_STAMP(11);
       }
+      RS_STAMP(12);
       if (t < S - 1) {                                 // (t is odd here)
         body(F_{}, T_{}, P1{}, t);
         ++t;
@@ -1693,8 +1727,13 @@ __global__ __launch_bounds__(512, 2) void k_flush_rs(double* __restrict__ P, con
         else body(F_{}, F_{}, P0{}, S - 1);
       }
     }
+    RS_STAMP(13);
     if ((Sw - 1) & 1) drain(P1{});
     else drain(P0{});
+    RS_STAMP(14);
+#ifdef RS_STAMPS
+    if (wave == 0 && lane == 0 && unit_no < 3) stamp_buf[unit_no * 20 + 15] = (unsigned long long)S;
+#endif
   }
 }
 
@@ -2061,7 +2100,11 @@ void launch_flush_rs(hipStream_t st, bool streaming, double* P, const double* V,
 #undef EKF_FLUSH_RS
 }
 
+#ifdef RS_STAMPS
+int flush_rs_queue_words() { return 8 * RS_QSTRIDE + 256 * 64 * 2; }
+#else
 int flush_rs_queue_words() { return 8 * RS_QSTRIDE; }
+#endif
 
 void launch_predict_rc(hipStream_t st, double* P, const double* mu_in, double* mu_out, const int* nact,
                        const SolveOut* so, int ld, long pstride, int batch, int n_hi) {
