@@ -50,6 +50,23 @@
 // and stores in flight (a fence drains vmcnt too).
 #define LDS_SYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 
+// Workgroup barrier for data handed over through LDS only: the wave's LDS operations have completed, its global
+// loads and stores stay in flight (`__syncthreads()` and workgroup fences drain vmcnt as well: a store
+// acknowledgement is ~500 cycles away).  WAVE_LDS_SYNC: the same between lanes of one wave, where LDS operations
+// execute in issue order and only the compiler must be kept from reordering them.
+#define WG_LDS_BARRIER()                                         \
+  do {                                                           \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           \
+    __builtin_amdgcn_s_barrier();                                \
+    asm volatile("" ::: "memory");                               \
+  } while (0)
+#define WAVE_LDS_SYNC()                                          \
+  do {                                                           \
+    asm volatile("" ::: "memory");                               \
+    __builtin_amdgcn_wave_barrier();                             \
+    asm volatile("" ::: "memory");                               \
+  } while (0)
+
 namespace ekf {
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
@@ -73,22 +90,26 @@ __device__ __forceinline__ double wrap_pi(double a) {
   return r - M_PI;
 }
 
-// Innovation and 2x5 Jacobian of one range/bearing observation (src/replay_no_ros.py:443-469).
+// Innovation and 2x5 Jacobian of one range/bearing observation (src/replay_no_ros.py:443-469), in two parts: the
+// Jacobian (needed first, by the covariance chain) and the innovation (atan2: twice as long, needed only by the mean).
 // h[r][k] = row r, column k on {x, y, theta, lx, ly}.  q == 0 gives NaN rows like NumPy's 0/0.
-__device__ __forceinline__ void linearize(const double* muc, int a, double z_range, double z_bearing,
-                                          double (&h)[2][5], double& y0, double& y1) {
-  const double dx = muc[a] - muc[0], dy = muc[a + 1] - muc[1];   // :443
-  const double th = muc[2];
+struct LinGeom {
+  double dx, dy, th, sq;
+};
+__device__ __forceinline__ LinGeom linearize_h(double mx, double my, double mth, double lx, double ly, double (&h)[2][5]) {
+  LinGeom g;
+  g.dx = lx - mx;                                                 // :443
+  g.dy = ly - my;
+  g.th = mth;
+  const double dx = g.dx, dy = g.dy;
   const double q = dx * dx + dy * dy;                             // :446
   // 1/sqrt(q) once (hardware estimate + two Newton steps, <= 1 ulp); sqrt(q) = q * rs, 1/q = rs * rs.
   // q == 0 -> rs = inf -> NaN rows below, like NumPy's 0/0 at :466-469.
   double rs = __builtin_amdgcn_rsq(q);
   rs = rs * fma(-0.5 * q * rs, rs, 1.5);
   rs = rs * fma(-0.5 * q * rs, rs, 1.5);
-  const double sq = q * rs;
+  g.sq = q * rs;
   const double rq = rs * rs;
-  y0 = z_range - sq;                                              // :455
-  y1 = wrap_pi(z_bearing - (atan2(dy, dx) - th));                 // :453-458
   const double nanv = __builtin_nan("");
   h[0][0] = -rs * dx;                                             // (-sqrt(q) dx) / q
   h[0][1] = -rs * dy;
@@ -100,6 +121,27 @@ __device__ __forceinline__ void linearize(const double* muc, int a, double z_ran
   h[1][2] = (q > 0.0 && q < __builtin_inf()) ? -1.0 : nanv;       // -q / q
   h[1][3] = -dy * rq;
   h[1][4] = dx * rq;
+  return g;
+}
+typedef unsigned int uint2v_t __attribute__((ext_vector_type(2)));
+typedef unsigned int uint4v_t __attribute__((ext_vector_type(4)));
+// buffer access with a 32-bit byte offset per lane (one instruction, no 64-bit address arithmetic)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t rs_rsrc(const void* base) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, -1, 0x00020000);
+}
+__device__ __forceinline__ double ldb8(__amdgpu_buffer_rsrc_t rs, unsigned lane_bytes, unsigned row_bytes) {
+  return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs, (int)lane_bytes, (int)row_bytes, 0));
+}
+
+// lane `src` (wave-uniform) of a double, through the scalar registers
+__device__ __forceinline__ double read_lane(double v, int src) {
+  const uint2v_t u = __builtin_bit_cast(uint2v_t, v);
+  const unsigned lo = __builtin_amdgcn_readlane(u.x, src), hi = __builtin_amdgcn_readlane(u.y, src);
+  return __builtin_bit_cast(double, uint2v_t{lo, hi});
+}
+__device__ __forceinline__ void innovation(const LinGeom& g, double z_range, double z_bearing, double& y0, double& y1) {
+  y0 = z_range - g.sq;                                            // :455
+  y1 = wrap_pi(z_bearing - (atan2(g.dy, g.dx) - g.th));           // :453-458
 }
 
 constexpr int PCS = CMAX + 2;   // LDS row stride 37 doubles: column reads by 32 lanes are conflict-free
@@ -111,41 +153,48 @@ constexpr int WCS = KTOT + 1;   // row stride of the staged W[C,:] (81 doubles: 
 // `fac` they are also written out compactly (facW[a][k], facV[a][k], zero-filled to a multiple of 8 ranks) for
 // the panel kernel.  Split in two so that the caller can compute under the gathers' latency: `issue` puts
 // all loads of the thread in flight (ranks [kofs, kofs+64)), `commit` stores them.
-constexpr int SQ = (CMAX + 3) / 4;                     // rows per wave with four waves
+constexpr int SQ = (CMAX + 2) / 3;                     // rows per wave with three staging waves (the fourth runs the motion model)
 struct StageRegs {
   double wv[SQ], vv[SQ];
 };
-__device__ __forceinline__ void stage_issue(StageRegs& R, const double* __restrict__ Vb,
-                                            const double* __restrict__ Wb, const int* Cs, int c, int kb, int kofs,
-                                            int ld, int tid) {
-  const int ld16 = ld >> 4;
-  const int wave = tid >> 6;
-  const int k = kofs + (tid & 63);
+// Thread (wave w < 3, lane) takes rank k = kofs + lane of the rows a = w, w + 3, ...  Every load is one buffer
+// instruction: 32-bit lane offset = rank part, scalar offset = row part (C[a] sits in lane a of the caller's Cl);
+// nothing sits under a per-lane condition (lanes beyond the pending ranks read the last pending one again -- one
+// more lane on a line that is fetched anyway -- and are discarded at commit).
+__device__ __forceinline__ void stage_issue(StageRegs& R, __amdgpu_buffer_rsrc_t rsV, __amdgpu_buffer_rsrc_t rsW,
+                                            int Cl, int c, int kb, int kofs, int ld, int wave, int lane) {
+  const int kc = min(kofs + lane, kb - 1);             // (lanes beyond the pending ranks share the last one's line)
+  const unsigned kW = (unsigned)(((kc >> 2) * (ld >> 4)) * 64 + (kc & 3) * 16) * 8u;   // wm_index = rank part + row part
+  const unsigned kV = (unsigned)(kc * ld) * 8u;
 #pragma unroll
   for (int q = 0; q < SQ; ++q) {
-    const int a = wave + 4 * q;
-    const int row = Cs[min(a, CPAD - 1)];
-    const bool in = k < kb && a < c;
-    R.wv[q] = in ? Wb[wm_index(ld16, k, row)] : 0.0;
-    R.vv[q] = in ? Vb[(long)k * ld + row] : 0.0;
+    const int a = wave + 3 * q;
+    if (a < c) {                                       // (wave-uniform; a scattered load costs the CU ~1 cycle per line)
+      const int row = __builtin_amdgcn_readlane(Cl, a);
+      R.wv[q] = ldb8(rsW, kW, (unsigned)((row >> 4) * 64 + (row & 15)) * 8u);
+      R.vv[q] = ldb8(rsV, kV, (unsigned)row * 8u);
+    } else {
+      R.wv[q] = 0.0;
+      R.vv[q] = 0.0;
+    }
   }
 }
-__device__ __forceinline__ void stage_commit(const StageRegs& R, int c, int kb, int kofs, int tid,
+__device__ __forceinline__ void stage_commit(const StageRegs& R, int c, int kb, int kofs, int wave, int lane,
                                              double (*Wc)[WCS], double (*Vc)[PCS], double* __restrict__ fac) {
-  const int wave = tid >> 6;
-  const int k = kofs + (tid & 63);
+  const int k = kofs + lane;
   const int k8 = (kb + 7) & ~7;
+  if (k >= KTOT) return;
 #pragma unroll
   for (int q = 0; q < SQ; ++q) {
-    const int a = wave + 4 * q;
-    if (a < c && k < k8) {
-      if (k < kb) {
-        Wc[a][k] = R.wv[q];
-        Vc[k][a] = R.vv[q];
-      }
-      if (fac) {
-        fac[a * KTOT + k] = R.wv[q];
-        fac[CMAX * KTOT + a * KTOT + k] = R.vv[q];
+    const int a = wave + 3 * q;                        // (a < 3 SQ = 36 <= PCS: rows c.. and ranks kb.. are staged as zeros,
+    if (a < CMAX) {                                    //  so the product below needs no masks)
+      const bool in = a < c && k < kb;
+      const double w = in ? R.wv[q] : 0.0, v = in ? R.vv[q] : 0.0;
+      Wc[a][k] = w;
+      Vc[k][a] = v;
+      if (fac && a < c && k < k8) {
+        fac[a * KTOT + k] = w;
+        fac[CMAX * KTOT + a * KTOT + k] = v;
       }
     }
   }
@@ -156,7 +205,7 @@ __device__ __forceinline__ void stage_commit(const StageRegs& R, int c, int kb, 
 // All four waves gather the current P[C,C] (base + pending ranks); then wave 0 runs the recurrences:
 // lane l < c owns compressed index l and keeps column l of P[C,C] in registers (written through to
 // LDS for the row/column reads of the other lanes); wave 1 linearises the next landmark beside the
-// down-date; waves 2-3 only keep the barrier count.  The chain is latency-bound (a lone wave issues
+// down-date, which waves 0, 2 and 3 share by rows.  The chain is latency-bound (a lone wave issues
 // one fp64 VALU op per ~8 cycles): every phase is written as batches of independent operations.
 // Reads mu_in / dacc_in, and -- only where `writer` -- writes mu_out[C], dacc_out, the flags and the
 // global SolveOut header (the mean and the pending noise are double-buffered so that no workgroup
@@ -165,13 +214,13 @@ __device__ __forceinline__ void stage_commit(const StageRegs& R, int c, int kb, 
 // ---------------------------------------------------------------------------------------------
 struct SolveLds {
   double Pc[CPAD][PCS];
-  double muc[CPAD];
+  double Ms[CPAD][PCS];                                // W[C,:] V[:,C], the pending ranks' share of the gathered block
   double2 hpS[CPAD], kcS[CPAD];
   int Cs[CPAD];
+  double mot[6];                                       // motion model (wave 3): predicted x, y, theta, G[0,2], G[1,2]
   double Wc[CMAX][WCS];
   double Vc[KTOT][PCS];
-  double2 hS[6];                                       // next linearisation: {h[0][k], h[1][k]} k<5, {y0, y1}
-  double xs[CPAD];                                     // column 2 of the row-updated block (prediction)
+  double2 hS[6];                                       // next linearisation: {h[0][k], h[1][k]} k<5
 };
 
 __device__ __forceinline__ void solve_body(SolveLds& L, const double* __restrict__ Pb,
@@ -184,7 +233,6 @@ __device__ __forceinline__ void solve_body(SolveLds& L, const double* __restrict
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   auto& Pc = L.Pc;
-  auto& muc = L.muc;
   auto& hpS = L.hpS;
   auto& kcS = L.kcS;
   auto& Cs = L.Cs;
@@ -210,61 +258,83 @@ __device__ __forceinline__ void solve_body(SolveLds& L, const double* __restrict
   }
   const double mu_l = mu_in_b[Cl];
   const double d0 = dacc_in[0], d1 = dacc_in[1], d2 = dacc_in[2];
+  const double lin_in = s.lin, ang_in = s.ang;         // (fetched with the other inputs: one round trip)
   int cmax = Cl;                                       // largest gathered index (wave-wide maximum)
 #pragma unroll
   for (int sh = 32; sh > 0; sh >>= 1) cmax = max(cmax, __shfl_xor(cmax, sh));
-  __syncthreads();
+  WG_LDS_BARRIER();
   STAMP(o, 1);
   // current P[C,C] = P_base[C,C] + W[C,:] V[:,C] + diag(dacc): the base loads are issued first ...
   // (thread = (wave w, lane): column C[lane] of rows w, w+4, ...: no integer division on the path)
   constexpr int GQ = (CMAX + 3) / 4;                   // 9 rows per wave at most
-  const int gw = tid >> 6;
+  const int gw = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // (lane a of every wave holds C[a]: the row indices come through the scalar registers; idle lanes read entry
+  //  (0, C[r]) and discard it, so that no load sits under a per-lane condition)
   double gv[GQ];
 #pragma unroll
   for (int q = 0; q < GQ; ++q) {
     const int r = gw + 4 * q;
-    const int Cr = (r < c) ? Cs[r] : 0;
-    gv[q] = (on && r < c) ? Pb[(long)min(Cr, Cl) * ld + max(Cr, Cl)] : 0.0;   // the upper triangle is authoritative
-  }
-  StageRegs SR;                                        // ... then the gathers of the pending factors at C ...
-  if (kbase > 0) stage_issue(SR, Vb, Wb, Cs, c, kbase, 0, ld, tid);
-  // ---- ... and the motion model (src/replay_no_ros.py:368-417) runs under their latency, redundantly in
-  // every lane of every wave (wave 1 needs the predicted pose for the first linearisation) ----
-  const double th = __shfl(mu_l, 2);
-  double g0 = 0.0, g1 = 0.0, nx = __shfl(mu_l, 0), ny = __shfl(mu_l, 1), nth = th;
-  if (do_pred && !cfg.disable_motion_model) {
-    const double lin = s.lin, ang = s.ang;
-    double s0, c0;
-    sincos(th, &s0, &c0);
-    if (cfg.enable_circular_interpolation && fabs(ang) > cfg.arc_threshold) {   // :390 arc
-      double s1, c1;
-      sincos(th + ang, &s1, &c1);
-      const double r = lin / ang;
-      nx += -r * s0 + r * s1;
-      ny += r * c0 - r * c1;
-      nth = wrap_pi(th + ang);                            // :397
-      g0 = -r * c0 + r * c1;                              // :401
-      g1 = -r * s0 + r * s1;                              // :402
-    } else {                                              // :376 straight / :405-417 linear mode
-      nx += lin * c0;
-      ny += lin * s0;
-      if (!cfg.enable_circular_interpolation) nth = th + ang;   // no wrap (:409); :381 keeps theta
-      g0 = -lin * s0;
-      g1 = lin * c0;
+    gv[q] = 0.0;
+    if (r < c) {                                       // (wave-uniform)
+      const int Cr = __builtin_amdgcn_readlane(Cl, r);
+      gv[q] = Pb[(long)min(Cr, Cl) * ld + max(Cr, Cl)];                        // the upper triangle is authoritative
     }
   }
-  const double mu_pred = (lane == 0) ? nx : ((lane == 1) ? ny : ((lane == 2) ? nth : mu_l));
+  STAMP(o, 110);
+  // ... then waves 0-2 gather the pending factors at C while wave 3 runs the motion model
+  // (src/replay_no_ros.py:368-417; two sincos, a division and a wrap: ~1900 cycles of a lone wave)
+  StageRegs SR;
+  const __amdgpu_buffer_rsrc_t rsV = rs_rsrc(Vb), rsW = rs_rsrc(Wb);
+  if (gw < 3) {
+    if (kbase > 0) stage_issue(SR, rsV, rsW, Cl, c, kbase, 0, ld, gw, lane);
+  } else {
+    const double th = __shfl(mu_l, 2);
+    double g0 = 0.0, g1 = 0.0, nx = __shfl(mu_l, 0), ny = __shfl(mu_l, 1), nth = th;
+    if (do_pred && !cfg.disable_motion_model) {
+      const double lin = lin_in, ang = ang_in;
+      double s0, c0;
+      sincos(th, &s0, &c0);
+      if (cfg.enable_circular_interpolation && fabs(ang) > cfg.arc_threshold) {   // :390 arc
+        double s1, c1;
+        sincos(th + ang, &s1, &c1);
+        const double r = lin / ang;
+        nx += -r * s0 + r * s1;
+        ny += r * c0 - r * c1;
+        nth = wrap_pi(th + ang);                            // :397
+        g0 = -r * c0 + r * c1;                              // :401
+        g1 = -r * s0 + r * s1;                              // :402
+      } else {                                              // :376 straight / :405-417 linear mode
+        nx += lin * c0;
+        ny += lin * s0;
+        if (!cfg.enable_circular_interpolation) nth = th + ang;   // no wrap (:409); :381 keeps theta
+        g0 = -lin * s0;
+        g1 = lin * c0;
+      }
+    }
+    if (lane == 0) {
+      L.mot[0] = nx;
+      L.mot[1] = ny;
+      L.mot[2] = nth;
+      L.mot[3] = g0;
+      L.mot[4] = g1;
+    }
+  }
+  STAMP(o, 112);
   if (kbase > 0) {
-    stage_commit(SR, c, kbase, 0, tid, Wc, Vc, writer ? fac_b : nullptr);
-    if (kbase > 64) {                                  // (more than 64 pending ranks: second pass)
-      stage_issue(SR, Vb, Wb, Cs, c, kbase, 64, ld, tid);
-      stage_commit(SR, c, kbase, 64, tid, Wc, Vc, writer ? fac_b : nullptr);
+    if (gw < 3) {
+      stage_commit(SR, c, kbase, 0, gw, lane, Wc, Vc, writer ? fac_b : nullptr);
+      if (kbase > 64) {                                // (more than 64 pending ranks: second pass)
+        stage_issue(SR, rsV, rsW, Cl, c, kbase, 64, ld, gw, lane);
+        stage_commit(SR, c, kbase, 64, gw, lane, Wc, Vc, writer ? fac_b : nullptr);
+      }
     }
-    __syncthreads();
+    WG_LDS_BARRIER();
   }
+  STAMP(o, 113);
   // pending ranks: M = W[C,:] V[:,C] (c x c, 16x16 tiles dealt to the four waves, v_mfma_f64_16x16x4 with both
-  // operands straight from the staged factors), parked in Pc; entry (r, l) of the gathered block then takes
-  // M[r][l] where P(C[r], C[l]) is stored that way round and M[l][r] where it is stored mirrored
+  // operands straight from the staged factors, four k-tiles of fragments fetched per round trip to LDS), parked in
+  // Pc; entry (r, l) of the gathered block then takes M[r][l] where P(C[r], C[l]) is stored that way round and
+  // M[l][r] where it is stored mirrored
   double mcor[GQ];
 #pragma unroll
   for (int q = 0; q < GQ; ++q) mcor[q] = 0.0;
@@ -274,126 +344,193 @@ __device__ __forceinline__ void solve_body(SolveLds& L, const double* __restrict
     for (int t = gw; t < T * T; t += 4) {
       const int rt = (t >= 2 * T) ? 2 : ((t >= T) ? 1 : 0), ct = t - rt * T;   // T <= 3
       const int ar = 16 * rt + li, bc = 16 * ct + li;
-      const double* wr = Wc[min(ar, CMAX - 1)];
-      double4_t acc = {0.0, 0.0, 0.0, 0.0};
-      for (int kt = 0; kt < nkt; ++kt) {
-        const int kk = 4 * kt + lq;
-        const double av = wr[min(kk, KTOT - 1)], bv = Vc[min(kk, KTOT - 1)][min(bc, PCS - 1)];
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64((ar < c && kk < kbase) ? av : 0.0,
-                                                   (bc < c && kk < kbase) ? bv : 0.0, acc, 0, 0, 0);
+      // Operands straight from the staged factors: A[i = li][k = lq] = Wc[ar][4 kt + lq], B[k = lq][j = li] =
+      // Vc[4 kt + lq][bc].  Rows / columns beyond c give rows / columns of the product nobody stores; ranks beyond
+      // the pending ones were staged as zeros.  Four k-tiles of fragments per round trip to LDS, the next four in
+      // flight under the MFMAs; even and odd k-tiles accumulate separately (a dependent v_mfma_f64_16x16x4 waits
+      // for its predecessor).
+      const double* wr = &Wc[min(ar, CMAX - 1)][lq];
+      const double* vc = &Vc[lq][min(bc, PCS - 1)];
+      const int nb = (nkt + 3) >> 2;                   // batches of 4 k-tiles (16 ranks); 16 nb <= KTOT
+      double4_t acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+      double av[4], bv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        av[u] = wr[4 * u];
+        bv[u] = vc[4 * u * PCS];
+      }
+      for (int bt = 0; bt < nb; ++bt) {
+        const int kn = min(16 * (bt + 1), KTOT - 16);  // (the fetch behind the last batch is not used)
+        double an[4], bn[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          an[u] = wr[kn + 4 * u];
+          bn[u] = vc[(kn + 4 * u) * PCS];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[0], bv[0], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[1], bv[1], acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[2], bv[2], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[3], bv[3], acc1, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          av[u] = an[u];
+          bv[u] = bn[u];
+        }
       }
 #pragma unroll
       for (int reg = 0; reg < 4; ++reg) {
         const int r = 16 * rt + lq + 4 * reg, l = 16 * ct + li;
-        if (r < c && l < c) Pc[r][l] = acc[reg];
+        if (r < c && l < c) L.Ms[r][l] = acc0[reg] + acc1[reg];
       }
     }
-    __syncthreads();
+    WG_LDS_BARRIER();
+    STAMP(o, 114);
 #pragma unroll
     for (int q = 0; q < GQ; ++q) {
       const int r = gw + 4 * q;
-      if (on && r < c) mcor[q] = (Cs[r] <= Cl) ? Pc[r][lane] : Pc[lane][r];
+      if (r < c) {                                     // (wave-uniform)
+        const int Cr = __builtin_amdgcn_readlane(Cl, r);
+        const double m_rl = L.Ms[r][ll], m_lr = L.Ms[ll][r];
+        mcor[q] = (Cr <= Cl) ? m_rl : m_lr;
+      }
     }
-    __syncthreads();
   }
 #pragma unroll
   for (int q = 0; q < GQ; ++q) {
     const int r = gw + 4 * q;
     if (on && r < c) {
       double v = gv[q] + mcor[q];
-      if (r == lane && r < 3) v += (r == 0) ? d0 : ((r == 1) ? d1 : d2);
+      if (q == 0 && r == lane && r < 3) v += (r == 0) ? d0 : ((r == 1) ? d1 : d2);   // (r >= 4 for q >= 1)
       Pc[r][lane] = v;
     }
   }
-  __syncthreads();
-  if (tid >= 64) {
-    // Helper waves.  Wave 1 publishes the predicted mean and linearises landmark 0 while wave 0 forms the
-    // predicted covariance block; later it linearises landmark j+1 (atan2, rsqrt: ~1200 cycles of a lone
-    // wave) while wave 0 down-dates for landmark j.  Waves 2-3 only keep the barrier count.
-    const int hw = tid >> 6;
-    if (hw == 1) {
-      if (lane < CPAD) muc[lane] = on ? mu_pred : 0.0;
-      WAVE_SYNC();
-      if (m > 0) {
-        double hn[2][5], yn0, yn1;
-        linearize(muc, 3, s.range[0], s.bearing[0], hn, yn0, yn1);
-        if (lane == 0) {
+  WG_LDS_BARRIER();
+  // (every wave) what wave 3 made of the motion model
+  const double g0 = L.mot[3], g1 = L.mot[4];
+  const double mu_pred = (lane < 3) ? L.mot[lane] : mu_l;
+  // The down-date of one landmark, P[r][l] -= K[r,:] . (H P)[:, l] (:480), on the rows slot, slot + 3, ... of the
+  // block in LDS, column l = lane: waves 0, 2 and 3 each take a third of the rows (a lone wave issues one fp64
+  // operation per ~8 cycles: 2 c of them in a row were the longest phase of an iteration).  Rows >= c have K = 0.
+  auto downdate_rows = [&](int slot, double2 hp) {
+#ifdef PROBE_SKIP_DD
+    return;
+#endif
 #pragma unroll
-          for (int k = 0; k < 5; ++k) hS[k] = make_double2(hn[0][k], hn[1][k]);
-          hS[5] = make_double2(yn0, yn1);
+    for (int q0 = 0; q0 < 14; q0 += 7) {
+      if (slot + 3 * q0 < c) {                         // (uniform) 21 rows per batch over the three waves
+        double2 kr[7];
+        double pv[7];
+#pragma unroll
+        for (int u = 0; u < 7; ++u) {
+          const int r = min(slot + 3 * (q0 + u), CPAD - 1);
+          kr[u] = kcS[r];
+          pv[u] = Pc[r][ll];
+        }
+#pragma unroll
+        for (int u = 0; u < 7; ++u) pv[u] = fma(-kr[u].x, hp.x, pv[u]);
+#pragma unroll
+        for (int u = 0; u < 7; ++u) pv[u] = fma(-kr[u].y, hp.y, pv[u]);
+        if (on) {
+#pragma unroll
+          for (int u = 0; u < 7; ++u) {
+            const int r = slot + 3 * (q0 + u);
+            if (r < CPAD) Pc[r][lane] = pv[u];
+          }
         }
       }
     }
-    __syncthreads();                                  // S0: predicted mean, covariance block and hS published
-    for (int j = 0; j < m; ++j) {
-      __syncthreads();                                // b1(j): mean after landmark j is in muc
-      if (hw == 1 && j + 1 < m) {
-        double hn[2][5], yn0, yn1;
-        linearize(muc, 3 + 2 * (j + 1), s.range[j + 1], s.bearing[j + 1], hn, yn0, yn1);
-        if (lane == 0) {
+  };
+  if (tid >= 64) {
+    // Helper waves.  Wave 1 owns the mean: it publishes the predicted mean and linearises landmark 0 while wave 0
+    // forms the predicted covariance block; in iteration j it adds K_j y_j (:476) as soon as wave 0 has published
+    // K_j, forms the Jacobian of landmark j+1 at the new mean (~350 cycles of a lone wave) while waves 0, 2 and 3
+    // down-date, and computes the innovation of landmark j+1 (atan2, wrap: ~600 cycles) behind the barrier, under
+    // wave 0's next (H P), S and K -- only the mean needs it.
+    const int hw = tid >> 6;
+    double mu_cur = mu_pred, y0 = 0.0, y1 = 0.0;
+    // (wave 1) lane j holds the measurement of landmark j: fetched once, up front
+    const double zr = s.range[lane & (MMAX - 1)], zb = s.bearing[lane & (MMAX - 1)];
+    auto jacobian_at_mean = [&](int a) -> LinGeom {    // mean entries of the pose and of landmark (a - 3) / 2 from the lanes that own them
+      double hn[2][5];
+      const LinGeom g = linearize_h(read_lane(mu_cur, 0), read_lane(mu_cur, 1), read_lane(mu_cur, 2), read_lane(mu_cur, a),
+                                    read_lane(mu_cur, a + 1), hn);
+      if (lane == 0) {
 #pragma unroll
-          for (int k = 0; k < 5; ++k) hS[k] = make_double2(hn[0][k], hn[1][k]);
-          hS[5] = make_double2(yn0, yn1);
-        }
+        for (int k = 0; k < 5; ++k) hS[k] = make_double2(hn[0][k], hn[1][k]);
       }
-      __syncthreads();                                // b2(j): hS ready, covariance block down-dated
+      return g;
+    };
+    if (hw == 1) {
+      LinGeom g{};
+      if (m > 0) g = jacobian_at_mean(3);
+      WG_LDS_BARRIER();                                // S0: predicted covariance block and hS published
+      if (m > 0) innovation(g, read_lane(zr, 0), read_lane(zb, 0), y0, y1);
+    } else {
+      WG_LDS_BARRIER();                                // S0
+    }
+    for (int j = 0; j < m; ++j) {
+      WG_LDS_BARRIER();                                // b1(j): K_j and (H P) of landmark j are in LDS
+      if (hw == 1) {
+        const double2 kj = kcS[ll];
+        if (on) mu_cur += kj.x * y0 + kj.y * y1;      // :476
+        if (lane == 0) *reinterpret_cast<double2*>(its[j].y) = make_double2(y0, y1);
+        LinGeom g{};
+#ifndef PROBE_SKIP_JAC
+        if (j + 1 < m) g = jacobian_at_mean(3 + 2 * (j + 1));
+#endif
+        WG_LDS_BARRIER();                              // b2(j): hS ready, covariance block down-dated
+        if (j + 1 < m) innovation(g, read_lane(zr, j + 1), read_lane(zb, j + 1), y0, y1);
+      } else {
+        if (j + 1 < m) downdate_rows(hw - 1, hpS[ll]);   // waves 2, 3: their third of the rows
+        WG_LDS_BARRIER();                              // b2(j)
+      }
+    }
+    if (hw == 1) {
+      bool bad = false;
+      if (on && writer) {
+        mu_out_b[Cl] = mu_cur;
+        bad = !(fabs(mu_cur) <= 1.79769313486231570815e308);
+      }
+      if (__any(bad) && lane == 0) atomicOr(flag_b, EKF_FLAG_NONFINITE);
     }
   } else {
-  double pcol[CPAD];
-#pragma unroll
-  for (int r0 = 0; r0 < CPAD; r0 += RCH) {
-    if (r0 < c) {
-#pragma unroll
-      for (int r = r0; r < r0 + RCH; ++r) pcol[r] = (on && r < c) ? Pc[r][ll] : 0.0;
-    } else {
-#pragma unroll
-      for (int r = r0; r < r0 + RCH; ++r) pcol[r] = 0.0;
-    }
-  }
   STAMP(o, 2);
   const double rd0 = do_pred ? cfg.rd[0] : 0.0, rd1 = do_pred ? cfg.rd[1] : 0.0,
                rd2 = do_pred ? cfg.rd[2] : 0.0;
   STAMP(o, 3);
-  // P'[C,C] = Gc P[C,C] Gc^T + Rt  (:428-430 restricted to C), column `lane` in registers:
-  // row ops on rows 0,1; column ops need column 2 of the row-updated matrix (lane 2's registers).
-  const double p22 = __shfl(pcol[2], 2);
+  // P'[C,C] = Gc P[C,C] Gc^T + Rt  (:428-430 restricted to C).  Only rows 0,1 and columns 0,1 of the block change
+  // (row ops X = Gc P on rows 0,1 with row 2, then column ops X Gc^T on columns 0,1 with column 2 of X), and the
+  // gathered block is exactly symmetric: lane r holds P[0..2][r] = P[r][0..2] and produces P'[r][0], P'[r][1],
+  // which for r >= 2 are also P'[0][r], P'[1][r].
+  const double p0 = on ? Pc[0][ll] : 0.0, p1 = on ? Pc[1][ll] : 0.0, p2 = on ? Pc[2][ll] : 0.0;
+  const double s20 = __shfl(p2, 0), s21 = __shfl(p2, 1), p22 = __shfl(p2, 2);
   if (writer && lane < CMAX + 1) {                     // rows 0,1 of the gathered block before the step: the panel
-    o.prow[0][lane] = on ? pcol[0] : 0.0;              // kernel's state indices 0,1 start from these (their own
-    o.prow[1][lane] = on ? pcol[1] : 0.0;              // gather would race with the row update of other columns)
+    o.prow[0][lane] = p0;                              // kernel's state indices 0,1 start from these (their own
+    o.prow[1][lane] = p1;                              // gather would race with the row update of other columns)
   }
-  pcol[0] += g0 * pcol[2];
-  pcol[1] += g1 * pcol[2];
-  if (lane == 2) {                                   // X[:,2] after the row ops, for the column ops
-#pragma unroll
-    for (int r0 = 0; r0 < CPAD; r0 += RCH)
-      if (r0 < c) {
-#pragma unroll
-        for (int r = r0; r < r0 + RCH; ++r) L.xs[r] = pcol[r];
+  {
+    const double gr = (lane == 0) ? g0 : ((lane == 1) ? g1 : 0.0);
+    double x0 = p0, x1 = p1, x2 = p2;                  // row r of X, columns 0..2
+    if (lane < 2) {
+      x0 = fma(gr, s20, p0);
+      x1 = fma(gr, s21, p1);
+      x2 = fma(gr, p22, p2);
+    }
+    double c0n = fma(g0, x2, x0), c1n = fma(g1, x2, x1);
+    if (lane == 0) c0n += rd0;
+    if (lane == 1) c1n += rd1;
+    if (on) {
+      Pc[lane][0] = c0n;
+      Pc[lane][1] = c1n;
+      if (lane >= 2) {
+        Pc[0][lane] = c0n;
+        Pc[1][lane] = c1n;
       }
+      if (lane == 2) Pc[2][2] = p2 + rd2;
+    }
   }
-  WAVE_SYNC();
-  if (lane < 2) {
-    const double gl = (lane == 0) ? g0 : g1;
-#pragma unroll
-    for (int r0 = 0; r0 < CPAD; r0 += RCH)
-      if (r0 < c) {
-#pragma unroll
-        for (int r = r0; r < r0 + RCH; ++r) pcol[r] = fma(gl, L.xs[r], pcol[r]);
-      }
-  }
-  if (lane == 0) pcol[0] += rd0;
-  if (lane == 1) pcol[1] += rd1;
-  if (lane == 2) pcol[2] += rd2;
-  WAVE_SYNC();
-  if (on) {
-#pragma unroll
-    for (int r0 = 0; r0 < CPAD; r0 += RCH)
-      if (r0 < c) {
-#pragma unroll
-        for (int r = r0; r < r0 + RCH; ++r) Pc[r][lane] = pcol[r];
-      }
-  }
-  double mu_cur = mu_pred;                             // (wave 1 published it in muc)
   if (lane == 0 && writer) {
     o.cmax = cmax;
     o.g[0] = g0;
@@ -413,11 +550,11 @@ __device__ __forceinline__ void solve_body(SolveLds& L, const double* __restrict
     dacc_out[1] = d1 + rd1;
     dacc_out[2] = d2 + rd2;
   }
-  __syncthreads();                                    // S0 (helper waves wait here too)
+  WG_LDS_BARRIER();                                    // S0 (helper waves wait here too)
 
   STAMP(o, 4);
   // ---- sequential per-landmark recurrences (:436-480) on the compressed system ----
-  double h[2][5], y0 = 0.0, y1 = 0.0;
+  double h[2][5];
   if (m > 0) {                                         // landmark 0 was linearised by wave 1
 #pragma unroll
     for (int k = 0; k < 5; ++k) {
@@ -425,9 +562,6 @@ __device__ __forceinline__ void solve_body(SolveLds& L, const double* __restrict
       h[0][k] = t.x;
       h[1][k] = t.y;
     }
-    const double2 t = hS[5];
-    y0 = t.x;
-    y1 = t.y;
   }
   STAMP(o, 5);
   for (int j = 0; j < m; ++j) {
@@ -448,7 +582,7 @@ __device__ __forceinline__ void solve_body(SolveLds& L, const double* __restrict
       hp1 = fma(h[1][k], pr[k], hp1);
     }
     if (on) hpS[lane] = make_double2(hp0, hp1);
-    WAVE_SYNC();
+    WAVE_LDS_SYNC();
     STAMP(o, 9 + 6 * j);
     // phase B: S = H P H^T + Q (:473), every lane redundantly
     double2 hv[5];
@@ -466,45 +600,21 @@ __device__ __forceinline__ void solve_body(SolveLds& L, const double* __restrict
     const double i00 = S11 * rdet, i01 = -S01 * rdet, i10 = -S10 * rdet, i11 = S00 * rdet;
     const double k0 = hp0 * i00 + hp1 * i10;                            // K_j[C[lane], :] = (H P)[:, C[lane]]^T S^-1
     const double k1 = hp0 * i01 + hp1 * i11;
-    if (on) {
-      kcS[lane] = make_double2(k0, k1);
-      mu_cur += k0 * y0 + k1 * y1;                                      // :476
-      muc[lane] = mu_cur;
-    }
+    if (on) kcS[lane] = make_double2(k0, k1);                           // (wave 1 adds K_j y_j to the mean, :476)
     if (lane < CMAX) *reinterpret_cast<double2*>(it.kc[lane]) = on ? make_double2(k0, k1) : make_double2(0.0, 0.0);
     if (lane == 0) {
 #pragma unroll
       for (int k = 0; k < 5; ++k) *reinterpret_cast<double2*>(it.h5t[k]) = make_double2(h[0][k], h[1][k]);
       *reinterpret_cast<double2*>(&it.si[0]) = make_double2(i00, i01);
       *reinterpret_cast<double2*>(&it.si[2]) = make_double2(i10, i11);
-      *reinterpret_cast<double2*>(it.y) = make_double2(y0, y1);
     }
-    __syncthreads();                                  // b1(j): wave 1 starts the next linearisation
+    WG_LDS_BARRIER();                                  // b1(j): wave 1 starts the next linearisation
     STAMP(o, 10 + 6 * j);
-    // phase C: down-date (:480) as batches of independent FMAs while wave 1 linearises landmark j+1
-    if (j + 1 < m) {
-      double2 kr[CPAD];
-#pragma unroll
-      for (int r0 = 0; r0 < CPAD; r0 += RCH)
-        if (r0 < c) {
-#pragma unroll
-          for (int u = 0; u < RCH; ++u) kr[r0 + u] = kcS[r0 + u];
-        }
-      STAMP(o, 11 + 6 * j);
-#pragma unroll
-      for (int r0 = 0; r0 < CPAD; r0 += RCH)
-        if (r0 < c) {
-#pragma unroll
-          for (int u = 0; u < RCH; ++u) pcol[r0 + u] = fma(-kr[r0 + u].x, hp0, pcol[r0 + u]);
-#pragma unroll
-          for (int u = 0; u < RCH; ++u) pcol[r0 + u] = fma(-kr[r0 + u].y, hp1, pcol[r0 + u]);
-          if (on) {
-#pragma unroll
-            for (int u = 0; u < RCH; ++u) Pc[r0 + u][lane] = pcol[r0 + u];
-          }
-        }
-    }
-    __syncthreads();                                  // b2(j)
+    // phase C: down-date (:480), this wave's third of the rows (waves 2, 3 take the others, wave 1 linearises
+    // landmark j+1 meanwhile)
+    STAMP(o, 11 + 6 * j);
+    if (j + 1 < m) downdate_rows(0, make_double2(hp0, hp1));
+    WG_LDS_BARRIER();                                  // b2(j)
     if (j + 1 < m) {
 #pragma unroll
       for (int k = 0; k < 5; ++k) {
@@ -512,20 +622,10 @@ __device__ __forceinline__ void solve_body(SolveLds& L, const double* __restrict
         h[0][k] = t.x;
         h[1][k] = t.y;
       }
-      const double2 t = hS[5];
-      y0 = t.x;
-      y1 = t.y;
     }
     STAMP(o, 12 + 6 * j);
   }
-
   STAMP(o, 6);
-  bool bad = false;
-  if (on && writer) {
-    mu_out_b[Cl] = mu_cur;
-    bad = !(fabs(mu_cur) <= 1.79769313486231570815e308);
-  }
-  if (__any(bad) && lane == 0) atomicOr(flag_b, EKF_FLAG_NONFINITE);
   }   // wave 0
 }
 
@@ -1339,17 +1439,12 @@ __global__ __launch_bounds__(512, 1) void k_flush_pc(double* __restrict__ P, con
 // ---------------------------------------------------------------------------------------------
 constexpr int RS_ROWS = 128;            // rows of a slab = 8 waves x 16
 constexpr int RS_QSTRIDE = 32;          // words between the per-XCD queue heads (one cache line each)
-typedef unsigned int uint4v_t __attribute__((ext_vector_type(4)));
-typedef unsigned int uint2v_t __attribute__((ext_vector_type(2)));
 
 // Global accesses of k_flush_rs are buffer instructions: (128-bit resource in SGPRs: wave-uniform base) + (SGPR byte
 // offset: the tile) + (ONE 32-bit VGPR: the lane's place inside the tile).  64-bit per-lane pointers for the eight
 // rows of a tile would cost the registers the pipeline needs (the compiler does not form the saddr + voffset
 // global instructions when the lane offset is defined outside the loop).  Offsets are unsigned 32-bit: a
 // trajectory's P is at most 4 GB.
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t rs_rsrc(const void* base) {
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, -1, 0x00020000);
-}
 template <bool NT>
 __device__ __forceinline__ double2 ldb16(__amdgpu_buffer_rsrc_t rs, unsigned lane_bytes, unsigned tile_bytes) {
   const uint4v_t v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)lane_bytes, (int)tile_bytes, NT ? 2 : 0);
@@ -1375,10 +1470,6 @@ __device__ __forceinline__ void stb16(__amdgpu_buffer_rsrc_t rs, unsigned lane_b
   asm volatile("s_nop 1" ::: "memory");
   }
 }
-__device__ __forceinline__ double ldb8(__amdgpu_buffer_rsrc_t rs, unsigned lane_bytes, unsigned row_bytes) {
-  return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs, (int)lane_bytes, (int)row_bytes, 0));
-}
-
 #define RS_CBAR() asm volatile("" ::: "memory")
 // Diagnostic build (-DRS_STAMPS): wave 0 of every workgroup records s_memtime at fixed points of its first units into
 // the words behind the queue heads (tools/rs_stamps.py reads them through ekf_debug_read).

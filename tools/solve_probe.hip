@@ -7,10 +7,10 @@
 using namespace ekf;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1;} } while (0)
 int main(int argc, char** argv) {
-  const int N = 2000, n = 3 + 2 * N, ld = (n + 15) / 16 * 16, m = argc > 1 ? atoi(argv[1]) : 8;
+  const int N = 2000, n = 3 + 2 * N, ld = (n + 15) / 16 * 16, m = argc > 1 ? atoi(argv[1]) : 8, kbase = argc > 2 ? atoi(argv[2]) : 0;
   double *P, *mu0, *mu1, *V, *W, *dacc, *fac; int* dn; StepIn* din; SolveOut* dso; unsigned* dfl;
   CK(hipMalloc(&P, sizeof(double) * ld * ld)); CK(hipMalloc(&mu0, sizeof(double) * ld)); CK(hipMalloc(&mu1, sizeof(double) * ld));
-  CK(hipMalloc(&V, sizeof(double) * KTOT * ld)); CK(hipMalloc(&W, sizeof(double) * KTOT * ld)); CK(hipMalloc(&dacc, 64)); CK(hipMemset(dacc, 0, 64));
+  CK(hipMalloc(&V, sizeof(double) * KTOT * ld)); CK(hipMalloc(&W, sizeof(double) * KTOT * ld)); CK(hipMemset(V, 0, sizeof(double) * KTOT * ld)); CK(hipMemset(W, 0, sizeof(double) * KTOT * ld)); CK(hipMalloc(&dacc, 64)); CK(hipMemset(dacc, 0, 64));
   CK(hipMalloc(&fac, sizeof(double) * FACS)); CK(hipMalloc(&dn, 4)); CK(hipMalloc(&din, sizeof(StepIn))); CK(hipMalloc(&dso, sizeof(SolveOut))); CK(hipMalloc(&dfl, 4));
   std::vector<double> hP((size_t)ld * ld, 0.0), hmu(ld, 0.0);
   for (int i = 0; i < n; ++i) { hP[(size_t)i * ld + i] = i < 3 ? 0.1 : 1e4; if (i >= 3) hmu[i] = 0.3 + 0.001 * i * ((i & 1) ? 1 : -1); }
@@ -24,13 +24,15 @@ int main(int argc, char** argv) {
   cfg.enable_measurement_model = 1; cfg.enable_circular_interpolation = 1; cfg.disable_motion_model = 0;
   SolveOut ho;
   for (int rep = 0; rep < 3; ++rep) {
-    launch_solve(0, P, V, W, dacc, dacc + 4, mu0, mu1, dn, din, dso, dfl, fac, dn, cfg, ld, (long)ld * ld, 1, 0);   // (floor := n)
+    launch_solve(0, P, V, W, dacc, dacc + 4, mu0, mu1, dn, din, dso, dfl, fac, dn, cfg, ld, (long)ld * ld, 1, kbase);   // (floor := n)
     CK(hipDeviceSynchronize());
   }
   CK(hipMemcpy(&ho, dso, sizeof(ho), hipMemcpyDeviceToHost));
   auto d = [&](int a, int b) { return (long long)(ho.stamps[b] - ho.stamps[a]); };
-  printf("m=%d  total %lld cycles\n", m, d(0, 6));
+  printf("m=%d  pending ranks %d  total %lld cycles\n", m, kbase, d(0, 6));
   printf("inputs+sync %lld | gather %lld | motion %lld | predict+writeLDS %lld | first linearize %lld\n", d(0, 1), d(1, 2), d(2, 3), d(3, 4), d(4, 5));
+  printf("   inside gather: base loads issued %lld | factor loads issued %lld | motion model %lld | factors staged+barrier %lld | MFMA+barrier %lld | rest %lld\n",
+         d(1, 110), 0LL, d(110, 112), d(112, 113), kbase > 0 ? d(113, 114) : 0LL, kbase > 0 ? d(114, 2) : d(113, 2));
   for (int j = 0; j < m; ++j) {
     int b0 = 8 + 6 * j;
     long long prev = j == 0 ? (long long)ho.stamps[5] : (long long)ho.stamps[12 + 6 * (j - 1)];
