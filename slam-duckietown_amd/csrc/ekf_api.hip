@@ -11,8 +11,8 @@
 
 namespace ekf {
 void launch_solve(hipStream_t, const double*, const double*, const double*, const double*, double*, const double*,
-                  double*, const int*, const StepIn*, SolveOut*, unsigned*, double*, const int*, const DeviceConfig&, int,
-                  long, int, int);
+                  double*, const int*, const StepIn*, SolveOut*, unsigned*, double*, const int*, unsigned*, const DeviceConfig&,
+                  int, long, int, int);
 void launch_panels(hipStream_t, int, double*, double*, double*, const double*, double*, const int*,
                    const SolveOut*, const double*, int, long, int, int);
 void launch_flush(hipStream_t, bool, double*, const double*, const double*, const double*, const int*,
@@ -466,9 +466,7 @@ static int flush_pending(ekf_handle* h) {
   h->last_kernel = kernel;
   h->last_nkt = nkt;
   h->last_streaming = streaming ? 1 : 0;
-  if (kernel == 2) {
-    HIP_TRY(h, hipMemsetAsync(h->dqueue, 0, sizeof(unsigned) * flush_rs_queue_words(), h->stream));
-    if (h->profile) HIP_TRY(h, hipEventRecord(e0, h->stream));      // (time the kernel, not the 1 KB memset)
+  if (kernel == 2) {                                   // (k_solve of the last step left the queue heads at zero)
     launch_flush_rs(h->stream, streaming, h->dP, h->dV, h->dW, h->ddacc2[h->dcur], h->dn, h->dso, h->ld, h->pstride,
                     h->batch, e_hi, nkt, h->opt_pass_workgroups > 0 ? std::min(h->opt_pass_workgroups, h->cu_count) : h->cu_count,
                     h->dqueue, h->opt_pass_chunk);
@@ -481,9 +479,7 @@ static int flush_pending(ekf_handle* h) {
   }
   if (h->profile) HIP_TRY(h, hipEventRecord(e1, h->stream));
   HIP_TRY(h, hipGetLastError());
-  HIP_TRY(h, hipMemsetAsync(h->ddacc2[0], 0, sizeof(double) * 4 * h->batch, h->stream));
-  HIP_TRY(h, hipMemsetAsync(h->ddacc2[1], 0, sizeof(double) * 4 * h->batch, h->stream));
-  h->pending_k = 0;
+  h->pending_k = 0;                                    // (with no rank pending k_solve takes the pending noise as zero: no clearing)
   h->pending_steps = 0;
   return EKF_OK;
 }
@@ -500,11 +496,9 @@ static int enqueue_pass(ekf_handle* h, const StepIn* d_in, int m_hi) {
   if (m_hi == 0 && h->pending_k == 0) {
     // prediction only, nothing pending: rows/cols 0,1 of P_base directly, O(n)
     launch_solve(h->stream, h->dP, h->dV, h->dW, dacc_in, dacc_out, mu_in, mu_out, h->dn, d_in, h->dso, h->dflags,
-                 h->dfac, h->dfloor, h->dcfg, h->ld, h->pstride, h->batch, 0);
+                 h->dfac, h->dfloor, h->dqueue, h->dcfg, h->ld, h->pstride, h->batch, 0);
     launch_predict_rc(h->stream, h->dP, mu_in, mu_out, h->dn, h->dso, h->ld, h->pstride, h->batch, n_hi);
-    // k_predict_rc applied the noise itself
-    HIP_TRY(h, hipMemsetAsync(h->ddacc2[0], 0, sizeof(double) * 4 * h->batch, h->stream));
-    HIP_TRY(h, hipMemsetAsync(h->ddacc2[1], 0, sizeof(double) * 4 * h->batch, h->stream));
+    // k_predict_rc applied the noise itself (and nothing reads the pending-noise buffers while no rank is pending)
     HIP_TRY(h, hipGetLastError());
     h->cur ^= 1;
     return EKF_OK;
@@ -514,7 +508,7 @@ static int enqueue_pass(ekf_handle* h, const StepIn* d_in, int m_hi) {
   dacc_in = h->ddacc2[h->dcur];
   dacc_out = h->ddacc2[h->dcur ^ 1];
   launch_solve(h->stream, h->dP, h->dV, h->dW, dacc_in, dacc_out, mu_in, mu_out, h->dn, d_in, h->dso, h->dflags,
-               h->dfac, h->dfloor, h->dcfg, h->ld, h->pstride, h->batch, h->pending_k);
+               h->dfac, h->dfloor, h->dqueue, h->dcfg, h->ld, h->pstride, h->batch, h->pending_k);
   launch_panels(h->stream, mcap, h->dP, h->dV, h->dW, mu_in, mu_out, h->dn, h->dso, h->dfac, h->ld, h->pstride,
                 h->batch, n_hi);
   HIP_TRY(h, hipGetLastError());

@@ -144,6 +144,7 @@ __device__ __forceinline__ void innovation(const LinGeom& g, double z_range, dou
   y1 = wrap_pi(z_bearing - (atan2(g.dy, g.dx) - g.th));           // :453-458
 }
 
+constexpr int RS_QSTRIDE = 32;          // k_flush_rs: words between the per-XCD queue heads (one cache line each)
 constexpr int PCS = CMAX + 2;   // LDS row stride 37 doubles: column reads by 32 lanes are conflict-free
 constexpr int RCH = 8;          // rows per batch of the down-date
 constexpr int CPAD = (CMAX + RCH - 1) / RCH * RCH;   // 40
@@ -257,7 +258,9 @@ __device__ __forceinline__ void solve_body(SolveLds& L, const double* __restrict
     if (writer && tid < CMAX + 1) o.C[tid] = Cl;
   }
   const double mu_l = mu_in_b[Cl];
-  const double d0 = dacc_in[0], d1 = dacc_in[1], d2 = dacc_in[2];
+  // pose-block noise pending since the last covariance pass; with no rank pending there is none (the buffers are
+  // not cleared after a pass: that would be two more launches per pass)
+  const double d0 = kbase > 0 ? dacc_in[0] : 0.0, d1 = kbase > 0 ? dacc_in[1] : 0.0, d2 = kbase > 0 ? dacc_in[2] : 0.0;
   const double lin_in = s.lin, ang_in = s.ang;         // (fetched with the other inputs: one round trip)
   int cmax = Cl;                                       // largest gathered index (wave-wide maximum)
 #pragma unroll
@@ -640,9 +643,12 @@ __global__ __launch_bounds__(256) void k_solve(const double* __restrict__ P, con
                                                SolveOut* __restrict__ out,
                                                unsigned* __restrict__ flags, double* __restrict__ fac,
                                                const int* __restrict__ neff_floor,
+                                               unsigned* __restrict__ queue,
                                                DeviceConfig cfg, int ld, long pstride, int kbase) {
   __shared__ SolveLds L;
   const int b = blockIdx.x;
+  // the work-queue heads of the row-slab covariance pass start every pass at zero: some step precedes every pass
+  if (b == 0 && threadIdx.x < 8) queue[threadIdx.x * RS_QSTRIDE] = 0u;
   // active bound of this step: what the host baked into the record, raised to the handle's floor (the bound the
   // state had when the enqueueing call started: a stream uploaded earlier knows only its own observations)
   const int neff_eff = min(nact[b], max(in[b].neff, neff_floor[b]));
@@ -1438,7 +1444,6 @@ __global__ __launch_bounds__(512, 1) void k_flush_pc(double* __restrict__ P, con
 // The accumulation order per element is k_flush's (k-tiles ascending): the two kernels agree bit for bit.
 // ---------------------------------------------------------------------------------------------
 constexpr int RS_ROWS = 128;            // rows of a slab = 8 waves x 16
-constexpr int RS_QSTRIDE = 32;          // words between the per-XCD queue heads (one cache line each)
 
 // Global accesses of k_flush_rs are buffer instructions: (128-bit resource in SGPRs: wave-uniform base) + (SGPR byte
 // offset: the tile) + (ONE 32-bit VGPR: the lane's place inside the tile).  64-bit per-lane pointers for the eight
@@ -2064,10 +2069,10 @@ __global__ __launch_bounds__(256) void k_fill_diag(double* __restrict__ Pb, int 
 // ---------------------------------------------------------------------------------------------
 void launch_solve(hipStream_t st, const double* P, const double* V, const double* W, const double* dacc_in,
                   double* dacc_out, const double* mu_in, double* mu_out, const int* nact, const StepIn* in,
-                  SolveOut* out, unsigned* flags, double* fac, const int* neff_floor, const DeviceConfig& cfg,
-                  int ld, long pstride, int batch, int kbase) {
+                  SolveOut* out, unsigned* flags, double* fac, const int* neff_floor, unsigned* queue,
+                  const DeviceConfig& cfg, int ld, long pstride, int batch, int kbase) {
   hipLaunchKernelGGL(k_solve, dim3(batch), dim3(256), 0, st, P, V, W, dacc_in, dacc_out, mu_in, mu_out, nact, in,
-                     out, flags, fac, neff_floor, cfg, ld, pstride, kbase);
+                     out, flags, fac, neff_floor, queue, cfg, ld, pstride, kbase);
 }
 
 template <int MCAP>

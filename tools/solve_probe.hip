@@ -11,7 +11,7 @@ int main(int argc, char** argv) {
   double *P, *mu0, *mu1, *V, *W, *dacc, *fac; int* dn; StepIn* din; SolveOut* dso; unsigned* dfl;
   CK(hipMalloc(&P, sizeof(double) * ld * ld)); CK(hipMalloc(&mu0, sizeof(double) * ld)); CK(hipMalloc(&mu1, sizeof(double) * ld));
   CK(hipMalloc(&V, sizeof(double) * KTOT * ld)); CK(hipMalloc(&W, sizeof(double) * KTOT * ld)); CK(hipMemset(V, 0, sizeof(double) * KTOT * ld)); CK(hipMemset(W, 0, sizeof(double) * KTOT * ld)); CK(hipMalloc(&dacc, 64)); CK(hipMemset(dacc, 0, 64));
-  CK(hipMalloc(&fac, sizeof(double) * FACS)); CK(hipMalloc(&dn, 4)); CK(hipMalloc(&din, sizeof(StepIn))); CK(hipMalloc(&dso, sizeof(SolveOut))); CK(hipMalloc(&dfl, 4));
+  CK(hipMalloc(&fac, sizeof(double) * FACS)); CK(hipMalloc(&dn, 4)); CK(hipMalloc(&din, sizeof(StepIn))); CK(hipMalloc(&dso, sizeof(SolveOut))); CK(hipMalloc(&dfl, 4)); unsigned* dq; CK(hipMalloc(&dq, 4 * 8 * RS_QSTRIDE));
   std::vector<double> hP((size_t)ld * ld, 0.0), hmu(ld, 0.0);
   for (int i = 0; i < n; ++i) { hP[(size_t)i * ld + i] = i < 3 ? 0.1 : 1e4; if (i >= 3) hmu[i] = 0.3 + 0.001 * i * ((i & 1) ? 1 : -1); }
   CK(hipMemcpy(P, hP.data(), sizeof(double) * ld * ld, hipMemcpyHostToDevice));
@@ -24,7 +24,7 @@ int main(int argc, char** argv) {
   cfg.enable_measurement_model = 1; cfg.enable_circular_interpolation = 1; cfg.disable_motion_model = 0;
   SolveOut ho;
   for (int rep = 0; rep < 3; ++rep) {
-    launch_solve(0, P, V, W, dacc, dacc + 4, mu0, mu1, dn, din, dso, dfl, fac, dn, cfg, ld, (long)ld * ld, 1, kbase);   // (floor := n)
+    launch_solve(0, P, V, W, dacc, dacc + 4, mu0, mu1, dn, din, dso, dfl, fac, dn, dq, cfg, ld, (long)ld * ld, 1, kbase);   // (floor := n)
     CK(hipDeviceSynchronize());
   }
   CK(hipMemcpy(&ho, dso, sizeof(ho), hipMemcpyDeviceToHost));
