@@ -417,9 +417,6 @@ __device__ __forceinline__ void solve_body(SolveLds& L, const double* __restrict
   // block in LDS, column l = lane: waves 0, 2 and 3 each take a third of the rows (a lone wave issues one fp64
   // operation per ~8 cycles: 2 c of them in a row were the longest phase of an iteration).  Rows >= c have K = 0.
   auto downdate_rows = [&](int slot, double2 hp) {
-#ifdef PROBE_SKIP_DD
-    return;
-#endif
 #pragma unroll
     for (int q0 = 0; q0 < 14; q0 += 7) {
       if (slot + 3 * q0 < c) {                         // (uniform) 21 rows per batch over the three waves
@@ -480,9 +477,7 @@ __device__ __forceinline__ void solve_body(SolveLds& L, const double* __restrict
         if (on) mu_cur += kj.x * y0 + kj.y * y1;      // :476
         if (lane == 0) *reinterpret_cast<double2*>(its[j].y) = make_double2(y0, y1);
         LinGeom g{};
-#ifndef PROBE_SKIP_JAC
         if (j + 1 < m) g = jacobian_at_mean(3 + 2 * (j + 1));
-#endif
         WG_LDS_BARRIER();                              // b2(j): hS ready, covariance block down-dated
         if (j + 1 < m) innovation(g, read_lane(zr, j + 1), read_lane(zb, j + 1), y0, y1);
       } else {
