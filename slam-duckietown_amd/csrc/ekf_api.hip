@@ -422,9 +422,36 @@ static int cap_for(int m) { return m <= 1 ? 1 : m <= 2 ? 2 : m <= 4 ? 4 : m <= 8
 
 // Rows per workgroup of k_flush: every wave re-reads its V strip (K x 1 KiB, from L2) per row block, so
 // the block must be long where many ranks are pending, and short enough to give every CU several waves.
-static int flush_rows_per_block(const ekf_handle* h, bool streaming) {
+// Streaming launches with at least four 256-row workgroups per CU (big batches when k_flush is forced; N=8000): 256
+// rows, tuned in round 1 (N=8000, 1 trajectory: 445 us against 488 us with 96 rows).
+// Launches of several rounds of workgroups per CU: 96 rows.  Small launches leave the CUs with one to three workgroups
+// each (two resident at a time) and the pass takes as long as the busiest CU, roughly (rows of a block) x (0.2 + load),
+// load = workgroups per CU, rounded up to the next half where it is below that: the block height minimising it is
+// taken.  N=2000, 1 trajectory: 80 rows (441 workgroups) 46 us, against 52 us with 96 rows (367) and 55 us with 64
+// (543); N=500, 1 trajectory: 64 rows, 23 us against 30 us; N=2000, 2 / 4 / 6 trajectories (streaming): 96 rows 84 /
+// 135 / 199 us against 108 / 164 / 208 us with 256 (profiles/r02_rows_per_block.txt).
+static int flush_workgroups(int n_hi, int rows_per_block) {
+  const int gx = (n_hi + 255) / 256, gy = (n_hi + rows_per_block - 1) / rows_per_block;
+  int total = 0;                                       // (the launcher's count: workgroups that reach the upper triangle)
+  for (int by = 0; by < gy; ++by) total += std::max(0, gx - (by * rows_per_block) / 256);
+  return total;
+}
+static int flush_rows_per_block(const ekf_handle* h, bool streaming, int n_hi) {
   if (h->opt_rows_per_block > 0) return (h->opt_rows_per_block + 15) / 16 * 16;
-  return streaming ? 256 : 96;
+  const long cus = h->cu_count;
+  if (streaming && (long)flush_workgroups(n_hi, 256) * h->batch >= 4 * cus) return 256;
+  if ((long)flush_workgroups(n_hi, 96) * h->batch > 5 * cus / 2) return 96;
+  int best = 96;
+  double best_cost = 0.0;
+  for (int r = 64; r <= 256; r += 16) {
+    const double load = (double)flush_workgroups(n_hi, r) * h->batch / (double)cus;
+    const double cost = r * (0.2 + std::max(load, std::ceil(load) - 0.5));
+    if (best_cost == 0.0 || cost < best_cost) {
+      best_cost = cost;
+      best = r;
+    }
+  }
+  return best;
 }
 
 // The covariances of the batch stream through HBM when they cannot stay in the 256 MiB Infinity Cache.
@@ -472,10 +499,10 @@ static int flush_pending(ekf_handle* h) {
                     h->dqueue, h->opt_pass_chunk);
   } else if (kernel == 1) {
     launch_flush_pc(h->stream, streaming, h->dP, h->dV, h->dW, h->ddacc2[h->dcur], h->dn, h->dso, h->ld, h->pstride,
-                    h->batch, e_hi, nkt, flush_rows_per_block(h, streaming), h->dflags);
+                    h->batch, e_hi, nkt, flush_rows_per_block(h, streaming, e_hi), h->dflags);
   } else {
     launch_flush(h->stream, streaming, h->dP, h->dV, h->dW, h->ddacc2[h->dcur], h->dn, h->dso, h->ld, h->pstride, h->batch,
-                 e_hi, nkt, flush_rows_per_block(h, streaming));
+                 e_hi, nkt, flush_rows_per_block(h, streaming, e_hi));
   }
   if (h->profile) HIP_TRY(h, hipEventRecord(e1, h->stream));
   HIP_TRY(h, hipGetLastError());
