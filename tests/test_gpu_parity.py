@@ -644,3 +644,42 @@ def test_row_slab_pass_with_active_bound_and_growing_state(sd):
             out[kernel] = [f.state(b) for b in range(B)]
     for b in range(B):
         assert np.array_equal(out[0][b][0], out[2][b][0]) and np.array_equal(out[0][b][1], out[2][b][1])
+
+
+def test_pass_scheduling_knobs_do_not_change_the_result(sd):
+    """How the covariance pass is cut into work -- strips per unit of the row-slab kernel (`pass_chunk`), its number of
+    persistent workgroups (`pass_workgroups`: fewer than units, so that the queues and the stealing are exercised),
+    rows per workgroup of the column-strip kernel (`pass_rows_per_block`, also what the automatic rule varies) --
+    never changes a bit of mean or covariance."""
+    N, B, m, steps = 531, 3, 5, 9
+    n = 3 + 2 * N
+    streams = [orc.synthetic_stream(N, steps, m, 60 + t) for t in range(B)]
+    starts = []
+    for t in range(B):
+        rng = np.random.default_rng(190 + t)
+        A = rng.normal(size=(n, 5)) * 0.3
+        starts.append(A @ A.T + np.diag(rng.uniform(0.5, 2.0, n)))
+
+    def run(options):
+        with sd.EkfSlam(n, batch=B) as f:
+            f.set_option("active_bound", 0)
+            for name, value in options:
+                f.set_option(name, value)
+            for b, s in enumerate(streams):
+                f.set_state(s[0], starts[b], b)
+            for k in range(steps):
+                f.step([s[2][k] for s in streams], [s[3][k] for s in streams], [s[4][k] for s in streams],
+                       [s[5][k] for s in streams], [s[6][k] for s in streams])
+            assert [f.flags(b) for b in range(B)] == [0] * B
+            return [f.state(b) for b in range(B)]
+
+    ref = run([("pass_kernel", 0)])
+    variants = [[("pass_kernel", 2), ("pass_chunk", c)] for c in (1, 2, 5, 64)]
+    variants += [[("pass_kernel", 2), ("pass_workgroups", w)] for w in (1, 7, 100)]
+    variants += [[("pass_kernel", 2), ("pass_chunk", 3), ("pass_workgroups", 5), ("pass_streaming", 1)]]
+    variants += [[("pass_kernel", 0), ("pass_rows_per_block", r)] for r in (16, 64, 160, 256)]
+    for opts in variants:
+        got = run(opts)
+        for b in range(B):
+            assert np.array_equal(got[b][0], ref[b][0]), opts
+            assert np.array_equal(got[b][1], ref[b][1]), opts
