@@ -11,11 +11,10 @@
 
 namespace ekf {
 void launch_solve(hipStream_t, const double*, const double*, const double*, const double*, double*, const double*,
-                  const double*, double*, const int*, const StepIn*, SolveOut*, unsigned*, double*, const int*, unsigned*, const DeviceConfig&,
+                  double*, const int*, const StepIn*, SolveOut*, unsigned*, double*, const int*, unsigned*, const DeviceConfig&,
                   int, long, int, int);
-void launch_apply_rows(hipStream_t, double*, const double*, const int*, int, long, int, int);
 void launch_panels(hipStream_t, int, double*, double*, double*, const double*, double*, const int*,
-                   const SolveOut*, const double*, const double*, double*, int, long, int, int);
+                   const SolveOut*, const double*, int, long, int, int);
 void launch_flush(hipStream_t, bool, double*, const double*, const double*, const double*, const int*,
                   const SolveOut*, int, long, int, int, int, int);
 void launch_flush_pc(hipStream_t, bool, double*, const double*, const double*, const double*, const int*,
@@ -46,7 +45,6 @@ struct ekf_handle {
   hipStream_t stream = nullptr;
   double *dP = nullptr, *dV = nullptr, *dW = nullptr, *dscratch = nullptr;
   double* ddacc2[2] = {nullptr, nullptr};  // pending pose-block noise, double-buffered like the mean
-  double* drowp2[2] = {nullptr, nullptr};  // pending patch of rows 0,1 of P_base (the predictions' part), batch x 2 x ld, same index
   int dcur = 0;
   int pending_k = 0, pending_steps = 0;   // ranks / steps appended to (V, W) since the last flush
   double* dmu2[2] = {nullptr, nullptr};   // the mean is double-buffered: a step reads [cur], writes [cur^1]
@@ -139,7 +137,7 @@ static void free_all(ekf_handle* h) {
   if (!h) return;
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
-  void* ptrs[] = {h->dP, h->dmu2[0], h->dmu2[1], h->dV, h->dW, h->ddacc2[0], h->ddacc2[1], h->drowp2[0], h->drowp2[1], h->dscratch, h->dn, h->dflags, h->dso, h->dfac,
+  void* ptrs[] = {h->dP, h->dmu2[0], h->dmu2[1], h->dV, h->dW, h->ddacc2[0], h->ddacc2[1], h->dscratch, h->dn, h->dflags, h->dso, h->dfac,
                   h->d_ring, h->d_stream, h->dF, h->dQ, h->dTmp, h->dtagmap, h->dneff, h->d_det, h->d_assoc_step, h->dfloor, h->dqueue,
                   h->d_assoc_out};
   for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -228,8 +226,6 @@ extern "C" int ekf_create(int device, int n_max, int batch, const ekf_config* cf
   CREATE_TRY(hipMalloc(&h->dW, sizeof(double) * ldz * KTOT * batch));
   CREATE_TRY(hipMalloc(&h->ddacc2[0], sizeof(double) * 4 * batch));
   CREATE_TRY(hipMalloc(&h->ddacc2[1], sizeof(double) * 4 * batch));
-  CREATE_TRY(hipMalloc(&h->drowp2[0], sizeof(double) * 2 * ldz * batch));
-  CREATE_TRY(hipMalloc(&h->drowp2[1], sizeof(double) * 2 * ldz * batch));
   CREATE_TRY(hipMalloc(&h->dscratch, sizeof(double) * ldz * 2));
   CREATE_TRY(hipMalloc(&h->dn, sizeof(int) * batch));
   CREATE_TRY(hipMalloc(&h->dflags, sizeof(unsigned) * batch));
@@ -249,8 +245,6 @@ extern "C" int ekf_create(int device, int n_max, int batch, const ekf_config* cf
   CREATE_TRY(hipMemsetAsync(h->dW, 0, sizeof(double) * ldz * KTOT * batch, h->stream));
   CREATE_TRY(hipMemsetAsync(h->ddacc2[0], 0, sizeof(double) * 4 * batch, h->stream));
   CREATE_TRY(hipMemsetAsync(h->ddacc2[1], 0, sizeof(double) * 4 * batch, h->stream));
-  CREATE_TRY(hipMemsetAsync(h->drowp2[0], 0, sizeof(double) * 2 * ldz * batch, h->stream));
-  CREATE_TRY(hipMemsetAsync(h->drowp2[1], 0, sizeof(double) * 2 * ldz * batch, h->stream));
   CREATE_TRY(hipMemsetAsync(h->dflags, 0, sizeof(unsigned) * batch, h->stream));
   CREATE_TRY(hipMemsetAsync(h->dso, 0, sizeof(SolveOut) * batch, h->stream));
   CREATE_TRY(hipMemsetAsync(h->dfac, 0, sizeof(double) * FACS * batch, h->stream));
@@ -295,15 +289,6 @@ static int check_b(ekf_handle* h, int b, const char* fn) {
   return EKF_OK;
 }
 
-// The pending row patch is only read while ranks are pending and is rewritten for every state index below n at the
-// first step after a pass; entries at and beyond n are never written, so after a state has been replaced (possibly by
-// a smaller one that grows again) they must be zero.
-static int clear_row_patch(ekf_handle* h, int b) {
-  for (int k = 0; k < 2; ++k)
-    HIP_TRY(h, hipMemsetAsync(h->drowp2[k] + (size_t)b * 2 * h->ld, 0, sizeof(double) * 2 * h->ld, h->stream));
-  return EKF_OK;
-}
-
 static int set_size(ekf_handle* h, int b, int n) {
   h->n[b] = n;
   HIP_TRY(h, hipMemcpyAsync(h->dn + b, &h->n[b], sizeof(int), hipMemcpyHostToDevice, h->stream));
@@ -339,7 +324,6 @@ extern "C" int ekf_upload_state(ekf_handle* h, int b, const double* mu, const do
                               sizeof(double) * n, n, hipMemcpyHostToDevice, h->stream));
   HIP_TRY(h, hipMemcpyAsync(h->dmu2[h->cur] + (size_t)b * h->ld, mu, sizeof(double) * n, hipMemcpyHostToDevice, h->stream));
   if (int rc = set_size(h, b, n)) return rc;
-  if (int rc = clear_row_patch(h, b)) return rc;
   h->neff[b] = n;                                      // arbitrary dense covariance: everything is active
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   return EKF_OK;
@@ -357,7 +341,6 @@ extern "C" int ekf_upload_state_diag(ekf_handle* h, int b, const double* mu, con
   h->neff[b] = 3;                                      // diagonal covariance: nothing is correlated yet
   HIP_TRY(h, hipMemcpyAsync(h->dmu2[h->cur] + (size_t)b * h->ld, mu, sizeof(double) * n, hipMemcpyHostToDevice, h->stream));
   if (int rc = set_size(h, b, n)) return rc;
-  if (int rc = clear_row_patch(h, b)) return rc;
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   return EKF_OK;
 }
@@ -510,9 +493,6 @@ static int flush_pending(ekf_handle* h) {
   h->last_kernel = kernel;
   h->last_nkt = nkt;
   h->last_streaming = streaming ? 1 : 0;
-  // the predictions' pending patch of rows 0,1 first (every form of the pass then adds its part to the same entries)
-  launch_apply_rows(h->stream, h->dP, h->drowp2[h->dcur], h->dn, h->ld, h->pstride, h->batch, n_hi);
-  if (h->profile) HIP_TRY(h, hipEventRecord(e0, h->stream));        // (time the pass kernel alone)
   if (kernel == 2) {                                   // (k_solve of the last step left the queue heads at zero)
     launch_flush_rs(h->stream, streaming, h->dP, h->dV, h->dW, h->ddacc2[h->dcur], h->dn, h->dso, h->ld, h->pstride,
                     h->batch, e_hi, nkt, h->opt_pass_workgroups > 0 ? std::min(h->opt_pass_workgroups, h->cu_count) : h->cu_count,
@@ -542,8 +522,8 @@ static int enqueue_pass(ekf_handle* h, const StepIn* d_in, int m_hi) {
   double* dacc_out = h->ddacc2[h->dcur ^ 1];
   if (m_hi == 0 && h->pending_k == 0) {
     // prediction only, nothing pending: rows/cols 0,1 of P_base directly, O(n)
-    launch_solve(h->stream, h->dP, h->dV, h->dW, dacc_in, dacc_out, h->drowp2[h->dcur], mu_in, mu_out, h->dn, d_in, h->dso,
-                 h->dflags, h->dfac, h->dfloor, h->dqueue, h->dcfg, h->ld, h->pstride, h->batch, 0);
+    launch_solve(h->stream, h->dP, h->dV, h->dW, dacc_in, dacc_out, mu_in, mu_out, h->dn, d_in, h->dso, h->dflags,
+                 h->dfac, h->dfloor, h->dqueue, h->dcfg, h->ld, h->pstride, h->batch, 0);
     launch_predict_rc(h->stream, h->dP, mu_in, mu_out, h->dn, h->dso, h->ld, h->pstride, h->batch, n_hi);
     // k_predict_rc applied the noise itself (and nothing reads the pending-noise buffers while no rank is pending)
     HIP_TRY(h, hipGetLastError());
@@ -554,10 +534,10 @@ static int enqueue_pass(ekf_handle* h, const StepIn* d_in, int m_hi) {
     if (int rc = flush_pending(h)) return rc;
   dacc_in = h->ddacc2[h->dcur];
   dacc_out = h->ddacc2[h->dcur ^ 1];
-  launch_solve(h->stream, h->dP, h->dV, h->dW, dacc_in, dacc_out, h->drowp2[h->dcur], mu_in, mu_out, h->dn, d_in, h->dso,
-               h->dflags, h->dfac, h->dfloor, h->dqueue, h->dcfg, h->ld, h->pstride, h->batch, h->pending_k);
-  launch_panels(h->stream, mcap, h->dP, h->dV, h->dW, mu_in, mu_out, h->dn, h->dso, h->dfac, h->drowp2[h->dcur],
-                h->drowp2[h->dcur ^ 1], h->ld, h->pstride, h->batch, n_hi);
+  launch_solve(h->stream, h->dP, h->dV, h->dW, dacc_in, dacc_out, mu_in, mu_out, h->dn, d_in, h->dso, h->dflags,
+               h->dfac, h->dfloor, h->dqueue, h->dcfg, h->ld, h->pstride, h->batch, h->pending_k);
+  launch_panels(h->stream, mcap, h->dP, h->dV, h->dW, mu_in, mu_out, h->dn, h->dso, h->dfac, h->ld, h->pstride,
+                h->batch, n_hi);
   HIP_TRY(h, hipGetLastError());
   h->dcur ^= 1;
   h->cur ^= 1;

@@ -227,7 +227,6 @@ struct SolveLds {
 __device__ __forceinline__ void solve_body(SolveLds& L, const double* __restrict__ Pb,
                                            const double* __restrict__ Vb, const double* __restrict__ Wb,
                                            const double* __restrict__ dacc_in, double* __restrict__ dacc_out,
-                                           const double* __restrict__ rowp_in,
                                            const double* __restrict__ mu_in_b, double* __restrict__ mu_out_b,
                                            const StepIn& s, SolveOut& o, SolveIter* its, unsigned* flag_b,
                                            double* __restrict__ fac_b, const DeviceConfig& cfg, int ld, int kbase,
@@ -281,11 +280,7 @@ __device__ __forceinline__ void solve_body(SolveLds& L, const double* __restrict
     gv[q] = 0.0;
     if (r < c) {                                       // (wave-uniform)
       const int Cr = __builtin_amdgcn_readlane(Cl, r);
-      const int lo = min(Cr, Cl), hi = max(Cr, Cl);
-      gv[q] = Pb[(long)lo * ld + hi];                                          // the upper triangle is authoritative
-      // Rows 0,1 of P_base carry a pending patch (the predictions' part).  Only the ROW entries (r <= 1) need it: what
-      // lanes 0,1 gather for r >= 2 (the same entries, as columns) is overwritten below from the row entries.
-      if (r < 2 && kbase > 0) gv[q] += rowp_in[lo * ld + hi];
+      gv[q] = Pb[(long)min(Cr, Cl) * ld + max(Cr, Cl)];                        // the upper triangle is authoritative
     }
   }
   STAMP(o, 110);
@@ -507,9 +502,7 @@ __device__ __forceinline__ void solve_body(SolveLds& L, const double* __restrict
   // (row ops X = Gc P on rows 0,1 with row 2, then column ops X Gc^T on columns 0,1 with column 2 of X), and the
   // gathered block is exactly symmetric: lane r holds P[0..2][r] = P[r][0..2] and produces P'[r][0], P'[r][1],
   // which for r >= 2 are also P'[0][r], P'[1][r].
-  // (entries (2, 0) and (2, 1) are taken from their mirrors in rows 0,1: only the row entries r <= 1 carry the pending
-  //  row patch, see the gather)
-  const double p0 = on ? Pc[0][ll] : 0.0, p1 = on ? Pc[1][ll] : 0.0, p2 = on ? (lane < 2 ? Pc[lane][2] : Pc[2][ll]) : 0.0;
+  const double p0 = on ? Pc[0][ll] : 0.0, p1 = on ? Pc[1][ll] : 0.0, p2 = on ? Pc[2][ll] : 0.0;
   const double s20 = __shfl(p2, 0), s21 = __shfl(p2, 1), p22 = __shfl(p2, 2);
   if (writer && lane < CMAX + 1) {                     // rows 0,1 of the gathered block before the step: the panel
     o.prow[0][lane] = p0;                              // kernel's state indices 0,1 start from these (their own
@@ -638,7 +631,6 @@ __global__ __launch_bounds__(256) void k_solve(const double* __restrict__ P, con
                                                const double* __restrict__ W,
                                                const double* __restrict__ dacc_in,
                                                double* __restrict__ dacc_out,
-                                               const double* __restrict__ rowp_in,
                                                const double* __restrict__ mu_in,
                                                double* __restrict__ mu_out,
                                                const int* __restrict__ nact,
@@ -656,7 +648,7 @@ __global__ __launch_bounds__(256) void k_solve(const double* __restrict__ P, con
   // state had when the enqueueing call started: a stream uploaded earlier knows only its own observations)
   const int neff_eff = min(nact[b], max(in[b].neff, neff_floor[b]));
   solve_body(L, P + (long)b * pstride, V + (long)b * KTOT * ld, W + (long)b * KTOT * ld, dacc_in + 4 * b,
-             dacc_out + 4 * b, rowp_in + (long)b * 2 * ld, mu_in + (long)b * ld, mu_out + (long)b * ld, in[b], out[b], out[b].it,
+             dacc_out + 4 * b, mu_in + (long)b * ld, mu_out + (long)b * ld, in[b], out[b], out[b].it,
              flags + b, fac + (long)b * FACS, cfg, ld, kbase, true, neff_eff);
 }
 
@@ -680,9 +672,7 @@ __global__ __launch_bounds__(64 * NW) void k_panels(double* __restrict__ P, doub
                                                     double* __restrict__ W, const double* __restrict__ mu_in,
                                                     double* __restrict__ mu_out, const int* __restrict__ nact,
                                                     const SolveOut* __restrict__ so,
-                                                    const double* __restrict__ fac,
-                                                    const double* __restrict__ rowp_in,
-                                                    double* __restrict__ rowp_out, int ld, long pstride) {
+                                                    const double* __restrict__ fac, int ld, long pstride) {
   constexpr int CC = 3 + 2 * MCAP, KTP = ranks_for(MCAP), NT = 64 * NW;
   __shared__ __attribute__((aligned(16))) double sF[2][CC][KTOT];   // [0]: W[C[a]][k], [1]: V[k][C[a]]
   __shared__ SolveIter sIt[MCAP];
@@ -701,10 +691,6 @@ __global__ __launch_bounds__(64 * NW) void k_panels(double* __restrict__ P, doub
   double* Wb = W + (long)b * KTOT * ld;
   const double* mu_in_b = mu_in + (long)b * ld;
   double* mu_out_b = mu_out + (long)b * ld;
-  // pending patch of rows 0,1 of P_base (what the predictions since the last pass added to them), double-buffered
-  // like the mean: [row][state index]
-  const double* rp_in = rowp_in + (long)b * 2 * ld;
-  double* rp_out = rowp_out + (long)b * 2 * ld;
   const int kb = o.kbase, neff = o.neff;
   const int m = min(o.m, MCAP), c = o.c;
   const int i0 = KSPLIT ? w0 : w0 + wave * 64;
@@ -763,10 +749,6 @@ __global__ __launch_bounds__(64 * NW) void k_panels(double* __restrict__ P, doub
       X[a] = Pb[(long)min(row, ii) * ld + max(row, ii)];
 #endif
     }
-    if (kb > 0) {                                      // entries (0, i) and (1, i) [(0, 1) for i = 0] carry the pending patch
-      X[0] += rp_in[ii];
-      X[1] += (ii >= 1) ? rp_in[ld + ii] : rp_in[1];
-    }
   } else {
 #pragma unroll
     for (int a = 0; a < CC; ++a) X[a] = 0.0;
@@ -782,8 +764,6 @@ __global__ __launch_bounds__(64 * NW) void k_panels(double* __restrict__ P, doub
         Wb[wm_index(ld16, k, i)] = 0.0;
       }
       mu_out_b[i] = mu_in_b[i];
-      rp_out[i] = kb > 0 ? rp_in[i] : 0.0;             // (zero here: P(2, i) = 0 beyond the bound)
-      rp_out[ld + i] = kb > 0 ? rp_in[ld + i] : 0.0;
     }
     return;
   }
@@ -933,9 +913,10 @@ __global__ __launch_bounds__(64 * NW) void k_panels(double* __restrict__ P, doub
   }
   X[0] += d0;
   X[1] += d1;
-  if (act) {                                           // entries (0, i) and (1, i): joined to the pending patch
-    rp_out[i] = (kb > 0 ? rp_in[i] : 0.0) + d0;
-    if (i >= 1) rp_out[ld + i] = (kb > 0 ? rp_in[ld + i] : 0.0) + d1;   // (1, 0) lies below the diagonal
+  if (act) {
+    double* p0 = Pb + i;                               // entry (0, i)
+    *p0 += d0;
+    if (i >= 1) p0[ld] += d1;                          // entry (1, i); (1, 0) lies below the diagonal
   }
 #pragma unroll
   for (int a = 0; a < 3; ++a)
@@ -2082,36 +2063,36 @@ __global__ __launch_bounds__(256) void k_fill_diag(double* __restrict__ Pb, int 
 // launchers (called from ekf_api.hip)
 // ---------------------------------------------------------------------------------------------
 void launch_solve(hipStream_t st, const double* P, const double* V, const double* W, const double* dacc_in,
-                  double* dacc_out, const double* rowp_in, const double* mu_in, double* mu_out, const int* nact, const StepIn* in,
+                  double* dacc_out, const double* mu_in, double* mu_out, const int* nact, const StepIn* in,
                   SolveOut* out, unsigned* flags, double* fac, const int* neff_floor, unsigned* queue,
                   const DeviceConfig& cfg, int ld, long pstride, int batch, int kbase) {
-  hipLaunchKernelGGL(k_solve, dim3(batch), dim3(256), 0, st, P, V, W, dacc_in, dacc_out, rowp_in, mu_in, mu_out, nact, in,
+  hipLaunchKernelGGL(k_solve, dim3(batch), dim3(256), 0, st, P, V, W, dacc_in, dacc_out, mu_in, mu_out, nact, in,
                      out, flags, fac, neff_floor, queue, cfg, ld, pstride, kbase);
 }
 
 template <int MCAP>
 static void launch_panels_t(hipStream_t st, double* P, double* V, double* W, const double* mu_in,
-                            double* mu_out, const int* nact, const SolveOut* so, const double* fac,
-                            const double* rowp_in, double* rowp_out, int ld, long pstride, int batch, int n_hi) {
+                            double* mu_out, const int* nact, const SolveOut* so, const double* fac, int ld,
+                            long pstride, int batch, int n_hi) {
   // throughput form: a workgroup is four independent waves of 64 state indices sharing one staging
   const long waves = (long)((n_hi + 63) / 64) * batch;
   if (waves <= 512)                                     // latency-bound: four waves split the pending ranks of 64 indices
     hipLaunchKernelGGL((k_panels<MCAP, 4, true>), dim3((n_hi + 63) / 64, batch), dim3(256), 0, st, P, V, W, mu_in,
-                       mu_out, nact, so, fac, rowp_in, rowp_out, ld, pstride);
+                       mu_out, nact, so, fac, ld, pstride);
   else
     hipLaunchKernelGGL((k_panels<MCAP, 4, false>), dim3((n_hi + 255) / 256, batch), dim3(256), 0, st, P, V, W, mu_in,
-                       mu_out, nact, so, fac, rowp_in, rowp_out, ld, pstride);
+                       mu_out, nact, so, fac, ld, pstride);
 }
 
 void launch_panels(hipStream_t st, int mcap, double* P, double* V, double* W, const double* mu_in,
-                   double* mu_out, const int* nact, const SolveOut* so, const double* fac, const double* rowp_in,
-                   double* rowp_out, int ld, long pstride, int batch, int n_hi) {
+                   double* mu_out, const int* nact, const SolveOut* so, const double* fac, int ld, long pstride,
+                   int batch, int n_hi) {
   switch (mcap) {
-    case 1: launch_panels_t<1>(st, P, V, W, mu_in, mu_out, nact, so, fac, rowp_in, rowp_out, ld, pstride, batch, n_hi); break;
-    case 2: launch_panels_t<2>(st, P, V, W, mu_in, mu_out, nact, so, fac, rowp_in, rowp_out, ld, pstride, batch, n_hi); break;
-    case 4: launch_panels_t<4>(st, P, V, W, mu_in, mu_out, nact, so, fac, rowp_in, rowp_out, ld, pstride, batch, n_hi); break;
-    case 8: launch_panels_t<8>(st, P, V, W, mu_in, mu_out, nact, so, fac, rowp_in, rowp_out, ld, pstride, batch, n_hi); break;
-    default: launch_panels_t<16>(st, P, V, W, mu_in, mu_out, nact, so, fac, rowp_in, rowp_out, ld, pstride, batch, n_hi); break;
+    case 1: launch_panels_t<1>(st, P, V, W, mu_in, mu_out, nact, so, fac, ld, pstride, batch, n_hi); break;
+    case 2: launch_panels_t<2>(st, P, V, W, mu_in, mu_out, nact, so, fac, ld, pstride, batch, n_hi); break;
+    case 4: launch_panels_t<4>(st, P, V, W, mu_in, mu_out, nact, so, fac, ld, pstride, batch, n_hi); break;
+    case 8: launch_panels_t<8>(st, P, V, W, mu_in, mu_out, nact, so, fac, ld, pstride, batch, n_hi); break;
+    default: launch_panels_t<16>(st, P, V, W, mu_in, mu_out, nact, so, fac, ld, pstride, batch, n_hi); break;
   }
 }
 
@@ -2215,23 +2196,6 @@ int flush_rs_queue_words() { return 8 * RS_QSTRIDE + 256 * 64 * 2; }
 #else
 int flush_rs_queue_words() { return 8 * RS_QSTRIDE; }
 #endif
-
-// P_base(0, i) += patch[0][i], P_base(1, i) += patch[1][i] (i >= 1): the predictions since the last pass, applied
-// right before the pass (the step kernels never write P_base, so a step's workgroups may read it in any order).
-__global__ __launch_bounds__(256) void k_apply_rows(double* __restrict__ P, const double* __restrict__ rowp,
-                                                    const int* __restrict__ nact, int ld, long pstride) {
-  const int b = blockIdx.y;
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= nact[b]) return;
-  double* Pb = P + (long)b * pstride;
-  const double* rp = rowp + (long)b * 2 * ld;
-  Pb[i] += rp[i];
-  if (i >= 1) Pb[ld + i] += rp[ld + i];
-}
-void launch_apply_rows(hipStream_t st, double* P, const double* rowp, const int* nact, int ld, long pstride, int batch,
-                       int n_hi) {
-  hipLaunchKernelGGL(k_apply_rows, dim3((n_hi + 255) / 256, batch), dim3(256), 0, st, P, rowp, nact, ld, pstride);
-}
 
 void launch_predict_rc(hipStream_t st, double* P, const double* mu_in, double* mu_out, const int* nact,
                        const SolveOut* so, int ld, long pstride, int batch, int n_hi) {

@@ -24,7 +24,7 @@ int main(int argc, char** argv) {
   cfg.enable_measurement_model = 1; cfg.enable_circular_interpolation = 1; cfg.disable_motion_model = 0;
   SolveOut ho;
   for (int rep = 0; rep < 3; ++rep) {
-    launch_solve(0, P, V, W, dacc, dacc + 4, V /* row patch: any 2 x ld doubles */, mu0, mu1, dn, din, dso, dfl, fac, dn, dq, cfg, ld, (long)ld * ld, 1, kbase);   // (floor := n)
+    launch_solve(0, P, V, W, dacc, dacc + 4, mu0, mu1, dn, din, dso, dfl, fac, dn, dq, cfg, ld, (long)ld * ld, 1, kbase);   // (floor := n)
     CK(hipDeviceSynchronize());
   }
   CK(hipMemcpy(&ho, dso, sizeof(ho), hipMemcpyDeviceToHost));
