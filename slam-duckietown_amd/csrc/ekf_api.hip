@@ -13,6 +13,10 @@ namespace ekf {
 void launch_solve(hipStream_t, const double*, const double*, const double*, const double*, double*, const double*,
                   double*, const int*, const StepIn*, SolveOut*, unsigned*, double*, const int*, unsigned*, const DeviceConfig&,
                   int, long, int, int);
+bool step_is_split(int batch, int n_hi, int cus);
+void launch_step_split(hipStream_t, int, double*, double*, double*, const double*, double*, const double*, double*,
+                       const int*, const StepIn*, SolveOut*, unsigned*, double*, const int*, unsigned*, unsigned*, unsigned,
+                       const DeviceConfig&, int, long, int, int, int);
 void launch_panels(hipStream_t, int, double*, double*, double*, const double*, double*, const int*,
                    const SolveOut*, const double*, int, long, int, int);
 void launch_flush(hipStream_t, bool, double*, const double*, const double*, const double*, const int*,
@@ -85,6 +89,9 @@ struct ekf_handle {
                                   // (20 MFMA k-tiles: 15 of the V strip in registers, 5 in LDS)
   int opt_pass_kernel = -1;       // -1 = auto, 0 = k_flush, 1 = k_flush_pc (producer/consumer waves), 2 = k_flush_rs (row slabs)
   unsigned* dqueue = nullptr;     // work-queue heads of k_flush_rs (zeroed before every launch)
+  unsigned* dready = nullptr;     // per trajectory: sequence number of the last solve that completed (k_step_split)
+  unsigned step_seq = 0;          // sequence number of the last single-launch step
+  int opt_fused_step = 1;         // 1 = one launch per step where the launch is small (k_step_split), 0 = always two
   int cu_count = 0;
   int opt_rows_per_block = 0;     // 0 = auto (flush kernel: rows per workgroup, multiple of 16)
   int opt_pass_chunk = 0;         // 0 = auto (k_flush_rs: strips per unit)
@@ -138,7 +145,7 @@ static void free_all(ekf_handle* h) {
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   void* ptrs[] = {h->dP, h->dmu2[0], h->dmu2[1], h->dV, h->dW, h->ddacc2[0], h->ddacc2[1], h->dscratch, h->dn, h->dflags, h->dso, h->dfac,
-                  h->d_ring, h->d_stream, h->dF, h->dQ, h->dTmp, h->dtagmap, h->dneff, h->d_det, h->d_assoc_step, h->dfloor, h->dqueue,
+                  h->d_ring, h->d_stream, h->dF, h->dQ, h->dTmp, h->dtagmap, h->dneff, h->d_det, h->d_assoc_step, h->dfloor, h->dqueue, h->dready,
                   h->d_assoc_out};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (h->h_ring) (void)hipHostFree(h->h_ring);
@@ -231,6 +238,8 @@ extern "C" int ekf_create(int device, int n_max, int batch, const ekf_config* cf
   CREATE_TRY(hipMalloc(&h->dflags, sizeof(unsigned) * batch));
   CREATE_TRY(hipMalloc(&h->dfloor, sizeof(int) * batch));
   CREATE_TRY(hipMalloc(&h->dqueue, sizeof(unsigned) * flush_rs_queue_words()));
+  CREATE_TRY(hipMalloc(&h->dready, sizeof(unsigned) * batch));
+  CREATE_TRY(hipMemsetAsync(h->dready, 0, sizeof(unsigned) * batch, h->stream));
   CREATE_TRY(hipMalloc(&h->dso, sizeof(SolveOut) * batch));
   CREATE_TRY(hipMalloc(&h->dfac, sizeof(double) * FACS * batch));
   CREATE_TRY(hipMalloc(&h->d_ring, sizeof(StepIn) * batch * RING));
@@ -534,10 +543,17 @@ static int enqueue_pass(ekf_handle* h, const StepIn* d_in, int m_hi) {
     if (int rc = flush_pending(h)) return rc;
   dacc_in = h->ddacc2[h->dcur];
   dacc_out = h->ddacc2[h->dcur ^ 1];
-  launch_solve(h->stream, h->dP, h->dV, h->dW, dacc_in, dacc_out, mu_in, mu_out, h->dn, d_in, h->dso, h->dflags,
-               h->dfac, h->dfloor, h->dqueue, h->dcfg, h->ld, h->pstride, h->batch, h->pending_k);
-  launch_panels(h->stream, mcap, h->dP, h->dV, h->dW, mu_in, mu_out, h->dn, h->dso, h->dfac, h->ld, h->pstride,
-                h->batch, n_hi);
+  if (h->opt_fused_step && step_is_split(h->batch, n_hi, h->cu_count)) {
+    // few workgroups (the latency regime): the whole step as one launch, the panels gathered beside the solve
+    launch_step_split(h->stream, mcap, h->dP, h->dV, h->dW, dacc_in, dacc_out, mu_in, mu_out, h->dn, d_in, h->dso,
+                      h->dflags, h->dfac, h->dfloor, h->dqueue, h->dready, ++h->step_seq, h->dcfg, h->ld, h->pstride,
+                      h->batch, n_hi, h->pending_k);
+  } else {
+    launch_solve(h->stream, h->dP, h->dV, h->dW, dacc_in, dacc_out, mu_in, mu_out, h->dn, d_in, h->dso, h->dflags,
+                 h->dfac, h->dfloor, h->dqueue, h->dcfg, h->ld, h->pstride, h->batch, h->pending_k);
+    launch_panels(h->stream, mcap, h->dP, h->dV, h->dW, mu_in, mu_out, h->dn, h->dso, h->dfac, h->ld, h->pstride,
+                  h->batch, n_hi);
+  }
   HIP_TRY(h, hipGetLastError());
   h->dcur ^= 1;
   h->cur ^= 1;
@@ -1001,6 +1017,11 @@ extern "C" int ekf_set_option(ekf_handle* h, const char* name, int value) {
   if (std::strcmp(name, "pass_chunk") == 0) {
     if (value < 0 || value > 4096) return fail(h, EKF_ERR_ARG, "pass_chunk out of range");
     h->opt_pass_chunk = value;
+    return EKF_OK;
+  }
+  if (std::strcmp(name, "fused_step") == 0) {
+    if (value != 0 && value != 1) return fail(h, EKF_ERR_ARG, "fused_step must be 0 or 1");
+    h->opt_fused_step = value;
     return EKF_OK;
   }
   if (std::strcmp(name, "pass_workgroups") == 0) {

@@ -668,216 +668,159 @@ __global__ __launch_bounds__(256) void k_solve(const double* __restrict__ P, con
 // then read as 16-byte broadcasts; after the single barrier the waves never synchronise again.
 // ---------------------------------------------------------------------------------------------
 template <int MCAP, int NW, bool KSPLIT>
-__global__ __launch_bounds__(64 * NW) void k_panels(double* __restrict__ P, double* __restrict__ V,
-                                                    double* __restrict__ W, const double* __restrict__ mu_in,
-                                                    double* __restrict__ mu_out, const int* __restrict__ nact,
-                                                    const SolveOut* __restrict__ so,
-                                                    const double* __restrict__ fac, int ld, long pstride) {
-  constexpr int CC = 3 + 2 * MCAP, KTP = ranks_for(MCAP), NT = 64 * NW;
-  __shared__ __attribute__((aligned(16))) double sF[2][CC][KTOT];   // [0]: W[C[a]][k], [1]: V[k][C[a]]
-  __shared__ SolveIter sIt[MCAP];
-  __shared__ int sC[CC + 1];
-  __shared__ double sPart[KSPLIT ? NW - 1 : 1][KSPLIT ? CC : 1][64];   // KSPLIT: partial gathers of waves 1..
-  const int b = blockIdx.y;
-  const int n = nact[b];
-  const int w0 = blockIdx.x * (KSPLIT ? 64 : NT);
-  if (w0 >= n) return;
-  const SolveOut& o = so[b];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int ld16 = ld >> 4;
-  double* Pb = P + (long)b * pstride;
-  double* Vb = V + (long)b * KTOT * ld;
-  double* Wb = W + (long)b * KTOT * ld;
-  const double* mu_in_b = mu_in + (long)b * ld;
-  double* mu_out_b = mu_out + (long)b * ld;
-  const int kb = o.kbase, neff = o.neff;
-  const int m = min(o.m, MCAP), c = o.c;
-  const int i0 = KSPLIT ? w0 : w0 + wave * 64;
-  const int i = i0 + lane;
-  const bool act = i < n;
-  const int ii = act ? i : n - 1;                      // idle lanes shadow the last state index (no stores)
-  const int kw = KSPLIT ? wave : 0;                    // KSPLIT: this wave takes every NW-th group of 8 ranks
-  constexpr int KSTEP = KSPLIT ? 8 * NW : 8;
+struct PanelLds {
+  static constexpr int CC = 3 + 2 * MCAP;
+  __attribute__((aligned(16))) double sF[2][CC][KTOT];   // [0]: W[C[a]][k], [1]: V[k][C[a]]
+  SolveIter sIt[MCAP];
+  int sC[CC + 1];
+};
+template <int MCAP, int NPART>
+struct PanelPartLds {
+  double sPart[NPART][3 + 2 * MCAP][64];               // rank-split shapes: partial gathers of the other waves
+};
 
-  if (w0 < neff) {                                     // (uniform) some wave of this workgroup replays the step
-    if (kb > 0) {
-      const double2* src0 = reinterpret_cast<const double2*>(fac + (long)b * FACS);
-      const double2* src1 = src0 + CMAX * KTOT / 2;
-      double2* dst0 = reinterpret_cast<double2*>(&sF[0][0][0]);
-      double2* dst1 = reinterpret_cast<double2*>(&sF[1][0][0]);
-      constexpr int CNT = CC * KTOT / 2, Q = (CNT + NT - 1) / NT;
-      double2 t0[Q], t1[Q];
-#pragma unroll
-      for (int q = 0; q < Q; ++q) {
-        const int t = min(tid + q * NT, CNT - 1);
-        t0[q] = src0[t];
-        t1[q] = src1[t];
-      }
-#pragma unroll
-      for (int q = 0; q < Q; ++q) {
-        const int t = tid + q * NT;
-        if (t < CNT) {
-          dst0[t] = t0[q];
-          dst1[t] = t1[q];
-        }
-      }
-    }
-    {
-      const double2* src = reinterpret_cast<const double2*>(o.it);
-      double2* dst = reinterpret_cast<double2*>(sIt);
-      constexpr int PER = (int)(sizeof(SolveIter) / 16), CNT = MCAP * PER, Q = (CNT + NT - 1) / NT;
-      const int count = m * PER;
-      double2 t0[Q];
-#pragma unroll
-      for (int q = 0; q < Q; ++q) t0[q] = src[min(tid + q * NT, CNT - 1)];
-#pragma unroll
-      for (int q = 0; q < Q; ++q)
-        if (tid + q * NT < count) dst[tid + q * NT] = t0[q];
-    }
-    if (tid < CC + 1) sC[tid] = o.C[tid];
-  }
-  // the base entries of the gather do not depend on the staged data: issue them before the barrier
-  double X[CC];
-  if (i0 < neff && i0 < n && kw == 0) {
-#pragma unroll
-    for (int a = 0; a < CC; ++a) {
-      const int row = o.C[a];
-#ifdef PANELS_SKIP_COLG                                 /* diagnostic build: no column-direction gathers */
-      X[a] = Pb[(long)min(row, i0) * ld + max(row, ii)];
-#else
-      X[a] = Pb[(long)min(row, ii) * ld + max(row, ii)];
-#endif
-    }
-  } else {
-#pragma unroll
-    for (int a = 0; a < CC; ++a) X[a] = 0.0;
-  }
-  __syncthreads();
-  if (i0 >= n) return;
-  if (i0 >= neff) {
-    // beyond the active bound the rows and columns of P are exactly zero off the diagonal: this step's
-    // ranks are zero there and the mean is carried over
-    if (act && kw == 0) {
-      for (int k = kb; k < ((kb + KTP + 3) & ~3); ++k) {
-        Vb[(long)k * ld + i] = 0.0;
-        Wb[wm_index(ld16, k, i)] = 0.0;
-      }
-      mu_out_b[i] = mu_in_b[i];
-    }
-    return;
-  }
-
-  // ---- pending ranks of the gather ----
-  // The loop exists in two forms, with and without the W[i,:] loads (needed only where some gathered index lies
-  // beyond this wave's first state index).  Inside a form no load sits under a branch -- the group of 8 ranks
-  // after the last one is fetched too (rank rows up to KTOT exist) and masked -- so the compiler can count the
-  // outstanding loads and the next group really is in flight under this group's FMAs.
-  const double* vlane = Vb + ii;
-  const double* wlane = Wb + (long)(ii >> 4) * 64 + (ii & 15);   // wm_index = rank part + lane part
-  auto gather_pending = [&](auto need_w_tag) {
-  constexpr bool NEEDW = decltype(need_w_tag)::value;
-  double v[8], w[8];
-  // (the group after the last one is "fetched" too so that no load sits under a branch, but it is pointed at the
-  //  last valid group again: rows that were just read, not rank slots nobody needs -- a V row costs a trip to HBM)
+// ---- the gather of the pending ranks, 8 ranks at a time ----
+// The loads of a group: V[k][i] (coalesced along the state indices) and, where some gathered index lies beyond the
+// wave's first state index (NEEDW), W[i][k].  No load sits under a branch -- the group after the last one is "fetched"
+// too, but pointed at the last valid group again (rows that were just read, not rank slots nobody needs: a V row costs
+// a trip to HBM) and masked -- so the compiler can count the outstanding loads and the next group really is in flight
+// under this group's FMAs.
+template <bool NEEDW>
+__device__ __forceinline__ void pg_load(const double* __restrict__ vlane, const double* __restrict__ wlane, int ld,
+                                        int ld16, int kb, int k0, double (&vv)[8], double (&ww)[8]) {
   const int k_last = ((kb - 1) >> 3) << 3;
-  auto load_vw = [&](int k0, double (&vv)[8], double (&ww)[8]) {
-    const int kc = min(k0, k_last);
+  const int kc = min(k0, k_last);
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const double x = vlane[(long)(kc + u) * ld];
-      vv[u] = (k0 + u < kb) ? x : 0.0;
+  for (int u = 0; u < 8; ++u) {
+    const double x = vlane[(long)(kc + u) * ld];
+    vv[u] = (k0 + u < kb) ? x : 0.0;
+  }
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    if (NEEDW) {
+      const double x = wlane[((long)((kc + u) >> 2) * ld16) * 64 + ((kc + u) & 3) * 16];
+      ww[u] = (k0 + u < kb) ? x : 0.0;
+    } else {
+      ww[u] = 0.0;
     }
+  }
+}
+// X[a] += sum over the group's ranks of W[C[a]][k] V[k][i] where the entry is stored as (C[a], i), of W[i][k] V[k][C[a]]
+// where it is stored mirrored.  Four gathered rows at a time: their 16 coefficient reads (16-byte LDS broadcasts) are in
+// flight together, and each row's eight FMAs run as two independent chains (the branch per row is wave-uniform).
+template <int CC>
+__device__ __forceinline__ void pg_accumulate(double (&X)[CC], const double (&v)[8], const double (&w)[8],
+                                              const double (*sF)[CC][KTOT], const int* sC, int k0, int i0, int ii) {
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      if (NEEDW) {
-        const double x = wlane[((long)((kc + u) >> 2) * ld16) * 64 + ((kc + u) & 3) * 16];
-        ww[u] = (k0 + u < kb) ? x : 0.0;
-      } else {
-        ww[u] = 0.0;
+  for (int g = 0; g < CC; g += 4) {
+    double cf[4][8];                                   // (plain doubles: arrays of double2 end up in scratch)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int a = min(g + q, CC - 1);                // (rows c.. of a short step hold stale, unused data)
+      const double2* src = reinterpret_cast<const double2*>(&sF[sC[a] <= i0 ? 0 : 1][a][k0]);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const double2 t = src[u];
+        cf[q][2 * u] = t.x;
+        cf[q][2 * u + 1] = t.y;
       }
     }
-  };
-  load_vw(8 * kw, v, w);
-  for (int k0 = 8 * kw; k0 < kb; k0 += KSTEP) {
-    double vn[8], wn[8];
-    load_vw(k0 + KSTEP, vn, wn);
-    // four gathered rows at a time: their 16 coefficient reads are in flight together, and each row's eight
-    // FMAs run as two independent chains (the branch per row is wave-uniform)
 #pragma unroll
-    for (int g = 0; g < CC; g += 4) {
-      double cf[4][8];                                 // (plain doubles: arrays of double2 end up in scratch)
+    for (int q = 0; q < 4; ++q) {
+      const int a = g + q;
+      if (a < CC) {
+        const int row = sC[a];
+        double s0 = X[a], s1 = 0.0;
+        if (row <= i0) {                               // stored as (C[a], i) for the whole wave
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int a = min(g + q, CC - 1);              // (rows c.. of a short step hold stale, unused data)
-        const double2* src = reinterpret_cast<const double2*>(&sF[sC[a] <= i0 ? 0 : 1][a][k0]);
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const double2 t = src[u];
-          cf[q][2 * u] = t.x;
-          cf[q][2 * u + 1] = t.y;
-        }
-      }
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int a = g + q;
-        if (a < CC) {
-          const int row = sC[a];
-          double s0 = X[a], s1 = 0.0;
-          if (row <= i0) {                             // stored as (C[a], i) for the whole wave
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-              s0 = fma(cf[q][2 * u], v[2 * u], s0);
-              s1 = fma(cf[q][2 * u + 1], v[2 * u + 1], s1);
-            }
-          } else if (row > i0 + 63) {                  // mirrored for the whole wave
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-              s0 = fma(w[2 * u], cf[q][2 * u], s0);
-              s1 = fma(w[2 * u + 1], cf[q][2 * u + 1], s1);
-            }
-          } else {                                     // the wave straddles C[a]: both forms, chosen per lane
-            const double2* wa = reinterpret_cast<const double2*>(&sF[0][a][k0]);
-            const bool up = row <= ii;
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-              const double2 fw2 = wa[u];
-              s0 = fma(up ? fw2.x : w[2 * u], up ? v[2 * u] : cf[q][2 * u], s0);
-              s1 = fma(up ? fw2.y : w[2 * u + 1], up ? v[2 * u + 1] : cf[q][2 * u + 1], s1);
-            }
+          for (int u = 0; u < 4; ++u) {
+            s0 = fma(cf[q][2 * u], v[2 * u], s0);
+            s1 = fma(cf[q][2 * u + 1], v[2 * u + 1], s1);
           }
-          X[a] = s0 + s1;
+        } else if (row > i0 + 63) {                    // mirrored for the whole wave
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            s0 = fma(w[2 * u], cf[q][2 * u], s0);
+            s1 = fma(w[2 * u + 1], cf[q][2 * u + 1], s1);
+          }
+        } else {                                       // the wave straddles C[a]: both forms, chosen per lane
+          const double2* wa = reinterpret_cast<const double2*>(&sF[0][a][k0]);
+          const bool up = row <= ii;
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const double2 fw2 = wa[u];
+            s0 = fma(up ? fw2.x : w[2 * u], up ? v[2 * u] : cf[q][2 * u], s0);
+            s1 = fma(up ? fw2.y : w[2 * u + 1], up ? v[2 * u + 1] : cf[q][2 * u + 1], s1);
+          }
         }
+        X[a] = s0 + s1;
       }
     }
+  }
+}
+
+// What every shape of the panel code needs to know about its 64 state indices.
+struct PanelIdx {
+  int lane, i0, i, ii, ld, ld16, n;
+  bool act;
+  double *Pb, *Vb, *Wb;
+  const double* mu_in_b;
+  double* mu_out_b;
+};
+__device__ __forceinline__ PanelIdx panel_idx(double* P, double* V, double* W, const double* mu_in, double* mu_out,
+                                              int ld, long pstride, int b, int n, int i0) {
+  PanelIdx t;
+  t.lane = threadIdx.x & 63;
+  t.i0 = i0;
+  t.i = i0 + t.lane;
+  t.act = t.i < n;
+  t.ii = t.act ? t.i : n - 1;                          // idle lanes shadow the last state index (no stores)
+  t.ld = ld;
+  t.ld16 = ld >> 4;
+  t.n = n;
+  t.Pb = P + (long)b * pstride;
+  t.Vb = V + (long)b * KTOT * ld;
+  t.Wb = W + (long)b * KTOT * ld;
+  t.mu_in_b = mu_in + (long)b * ld;
+  t.mu_out_b = mu_out + (long)b * ld;
+  return t;
+}
+// x[a] = P_base(min(C[a], i), max(C[a], i)): the base entries of the gather
+template <int CC>
+__device__ __forceinline__ void panel_base_gather(const PanelIdx& t, const int* Crow, double (&X)[CC]) {
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      v[u] = vn[u];
-      w[u] = wn[u];
-    }
-  }
-  };
-#ifndef PANELS_SKIP_PEND                                  /* diagnostic build: no pending-rank gather */
-  if (kb > 0) {                                        // (uniform) right after a covariance pass nothing is pending
-    if (o.cmax > i0) gather_pending(std::true_type{});
-    else gather_pending(std::false_type{});
-  }
+  for (int a = 0; a < CC; ++a) {
+    const int row = Crow[a];
+#ifdef PANELS_SKIP_COLG                                 /* diagnostic build: no column-direction gathers */
+    X[a] = t.Pb[(long)min(row, t.i0) * t.ld + max(row, t.ii)];
+#else
+    X[a] = t.Pb[(long)min(row, t.ii) * t.ld + max(row, t.ii)];
 #endif
-  if (KSPLIT) {                                        // waves 1.. hand their partial sums to wave 0 and leave
-    if (kw > 0) {
-#pragma unroll
-      for (int a = 0; a < CC; ++a) sPart[kw - 1][a][lane] = X[a];
-    }
-    __syncthreads();
-    if (kw > 0) return;
-#pragma unroll
-    for (int a = 0; a < CC; ++a) {
-      double t = X[a];
-#pragma unroll
-      for (int q = 0; q < NW - 1; ++q) t += sPart[q][a][lane];
-      X[a] = t;
-    }
   }
+}
+// Beyond the active bound the rows and columns of P are exactly zero off the diagonal: this step's ranks are zero
+// there and the mean is carried over.
+template <int MCAP>
+__device__ __forceinline__ void panel_beyond_bound(const PanelIdx& t, int kb) {
+  constexpr int KTP = ranks_for(MCAP);
+  if (!t.act) return;
+  for (int k = kb; k < ((kb + KTP + 3) & ~3); ++k) {
+    t.Vb[(long)k * t.ld + t.i] = 0.0;
+    t.Wb[wm_index(t.ld16, k, t.i)] = 0.0;
+  }
+  t.mu_out_b[t.i] = t.mu_in_b[t.i];
+}
+
+// From the gathered x[a] = P(C[a], i) on: prediction on the panel, the m sequential rank-2 updates, the new rank
+// entries, the mean.  `o`, `sIt` (per-landmark records) and `sC` may live in LDS or (o) in global memory.
+template <int MCAP>
+__device__ __forceinline__ void panels_finish(const PanelIdx& t, const SolveOut& o, const SolveIter* sIt, const int* sC,
+                                              double (&X)[3 + 2 * MCAP]) {
+  constexpr int CC = 3 + 2 * MCAP, KTP = ranks_for(MCAP);
+  const int lane = t.lane, i0 = t.i0, i = t.i, ii = t.ii, ld = t.ld, ld16 = t.ld16;
+  const bool act = t.act;
+  double *Vb = t.Vb, *Wb = t.Wb;
+  const int kb = o.kbase, m = min(o.m, MCAP), c = o.c;
 #pragma unroll
   for (int a = 0; a < 3; ++a)
     if (ii == a) X[a] += o.dacc_old[a];                // pending pose-block noise on the diagonal
@@ -891,7 +834,7 @@ __global__ __launch_bounds__(64 * NW) void k_panels(double* __restrict__ P, doub
   if (i0 == 0) {
     if (lane < 2) {                                    // rows 0,1 of P_base are being rewritten by the other columns:
 #pragma unroll
-      for (int a = 0; a < CC; ++a) X[a] = o.prow[lane][a];   // state indices 0,1 take k_solve's gather
+      for (int a = 0; a < CC; ++a) X[a] = o.prow[lane][a];   // state indices 0,1 take the solve's gather
     }
     const double p22 = __shfl(X[2], 2);
     double col2[CC];                                   // X[:,2] after the row ops, for the column ops of lanes 0,1
@@ -914,7 +857,7 @@ __global__ __launch_bounds__(64 * NW) void k_panels(double* __restrict__ P, doub
   X[0] += d0;
   X[1] += d1;
   if (act) {
-    double* p0 = Pb + i;                               // entry (0, i)
+    double* p0 = t.Pb + i;                             // entry (0, i)
     *p0 += d0;
     if (i >= 1) p0[ld] += d1;                          // entry (1, i); (1, 0) lies below the diagonal
   }
@@ -977,8 +920,306 @@ __global__ __launch_bounds__(64 * NW) void k_panels(double* __restrict__ P, doub
     }
     bool inC = false;
     for (int a = 0; a < c; ++a) inC |= (sC[a] == i);
-    if (!inC) mu_out_b[i] = mu_in_b[i] + dm;           // k_solve wrote the entries in C
+    if (!inC) t.mu_out_b[i] = t.mu_in_b[i] + dm;       // the solve wrote the entries in C
   }
+}
+
+template <int MCAP, int NW, bool KSPLIT>
+__global__ __launch_bounds__(64 * NW) void k_panels(double* __restrict__ P, double* __restrict__ V,
+                                                    double* __restrict__ W, const double* __restrict__ mu_in,
+                                                    double* __restrict__ mu_out, const int* __restrict__ nact,
+                                                    const SolveOut* __restrict__ so,
+                                                    const double* __restrict__ fac, int ld, long pstride) {
+  constexpr int CC = 3 + 2 * MCAP, NT = 64 * NW;
+  __shared__ PanelLds<MCAP, NW, KSPLIT> S;
+  __shared__ PanelPartLds<MCAP, KSPLIT ? NW - 1 : 1> SP;
+  auto& sF = S.sF;
+  auto& sIt = S.sIt;
+  auto& sC = S.sC;
+  const int b = blockIdx.y;
+  const int n = nact[b];
+  const int w0 = blockIdx.x * (KSPLIT ? 64 : NT);
+  if (w0 >= n) return;
+  const SolveOut& o = so[b];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int kb = o.kbase, neff = o.neff;
+  const int m = min(o.m, MCAP);
+  const int i0 = KSPLIT ? w0 : w0 + wave * 64;
+  const PanelIdx t = panel_idx(P, V, W, mu_in, mu_out, ld, pstride, b, n, i0);
+  const int kw = KSPLIT ? wave : 0;                    // KSPLIT: this wave takes every NW-th group of 8 ranks
+  constexpr int KSTEP = KSPLIT ? 8 * NW : 8;
+
+  if (w0 < neff) {                                     // (uniform) some wave of this workgroup replays the step
+    if (kb > 0) {
+      const double2* src0 = reinterpret_cast<const double2*>(fac + (long)b * FACS);
+      const double2* src1 = src0 + CMAX * KTOT / 2;
+      double2* dst0 = reinterpret_cast<double2*>(&sF[0][0][0]);
+      double2* dst1 = reinterpret_cast<double2*>(&sF[1][0][0]);
+      constexpr int CNT = CC * KTOT / 2, Q = (CNT + NT - 1) / NT;
+      double2 t0[Q], t1[Q];
+#pragma unroll
+      for (int q = 0; q < Q; ++q) {
+        const int e = min(tid + q * NT, CNT - 1);
+        t0[q] = src0[e];
+        t1[q] = src1[e];
+      }
+#pragma unroll
+      for (int q = 0; q < Q; ++q) {
+        const int e = tid + q * NT;
+        if (e < CNT) {
+          dst0[e] = t0[q];
+          dst1[e] = t1[q];
+        }
+      }
+    }
+    {
+      const double2* src = reinterpret_cast<const double2*>(o.it);
+      double2* dst = reinterpret_cast<double2*>(sIt);
+      constexpr int PER = (int)(sizeof(SolveIter) / 16), CNT = MCAP * PER, Q = (CNT + NT - 1) / NT;
+      const int count = m * PER;
+      double2 t0[Q];
+#pragma unroll
+      for (int q = 0; q < Q; ++q) t0[q] = src[min(tid + q * NT, CNT - 1)];
+#pragma unroll
+      for (int q = 0; q < Q; ++q)
+        if (tid + q * NT < count) dst[tid + q * NT] = t0[q];
+    }
+    if (tid < CC + 1) sC[tid] = o.C[tid];
+  }
+  // the base entries of the gather do not depend on the staged data: issue them before the barrier
+  double X[CC];
+  if (i0 < neff && i0 < n && kw == 0) {
+    panel_base_gather<CC>(t, o.C, X);
+  } else {
+#pragma unroll
+    for (int a = 0; a < CC; ++a) X[a] = 0.0;
+  }
+  __syncthreads();
+  if (i0 >= n) return;
+  if (i0 >= neff) {
+    if (kw == 0) panel_beyond_bound<MCAP>(t, kb);
+    return;
+  }
+
+  // ---- pending ranks of the gather: with and without the W[i,:] loads ----
+  const double* vlane = t.Vb + t.ii;
+  const double* wlane = t.Wb + (long)(t.ii >> 4) * 64 + (t.ii & 15);   // wm_index = rank part + lane part
+  auto gather_pending = [&](auto need_w_tag) {
+    constexpr bool NEEDW = decltype(need_w_tag)::value;
+    double v[8], w[8];
+    pg_load<NEEDW>(vlane, wlane, ld, t.ld16, kb, 8 * kw, v, w);
+    for (int k0 = 8 * kw; k0 < kb; k0 += KSTEP) {
+      double vn[8], wn[8];
+      pg_load<NEEDW>(vlane, wlane, ld, t.ld16, kb, k0 + KSTEP, vn, wn);
+      pg_accumulate<CC>(X, v, w, sF, sC, k0, i0, t.ii);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        v[u] = vn[u];
+        w[u] = wn[u];
+      }
+    }
+  };
+#ifndef PANELS_SKIP_PEND                                  /* diagnostic build: no pending-rank gather */
+  if (kb > 0) {                                        // (uniform) right after a covariance pass nothing is pending
+    if (o.cmax > i0) gather_pending(std::true_type{});
+    else gather_pending(std::false_type{});
+  }
+#endif
+  if (KSPLIT) {                                        // waves 1.. hand their partial sums to wave 0 and leave
+    if (kw > 0) {
+#pragma unroll
+      for (int a = 0; a < CC; ++a) SP.sPart[kw - 1][a][lane] = X[a];
+    }
+    __syncthreads();
+    if (kw > 0) return;
+#pragma unroll
+    for (int a = 0; a < CC; ++a) {
+      double x = X[a];
+#pragma unroll
+      for (int q = 0; q < NW - 1; ++q) x += SP.sPart[q][a][lane];
+      X[a] = x;
+    }
+  }
+  panels_finish<MCAP>(t, o, sIt, sC, X);
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_step_split: the whole step in ONE launch for launches of few workgroups (the latency regime: at most 512 waves
+// of state indices, where k_panels runs in its rank-split shape).  Workgroup 0 of a trajectory is the sequential solve
+// (exactly k_solve); the others are panel workgroups of 64 state indices, which do NOT wait for it to start: nothing
+// in the gather of the panel depends on the solve -- the gathered indices C come from the step's inputs, the factors
+// at C are staged by every panel workgroup for itself (scattered loads the idle CUs have time for) -- so base entries
+// and pending ranks are gathered while the chain runs.  Only then does a panel workgroup wait for its trajectory's
+// solve (release / acquire at device scope on a per-trajectory step counter: the solve's records travel through
+// global memory), replay the step on the gathered panel and write its ranks.  Every write of a panel workgroup
+// happens after that wait, so the solve never sees a half-written step.  A workgroup only ever waits for one with a
+// smaller linear index (dispatched before it), the wait is bounded, and a timeout raises EKF_FLAG_INTERNAL.
+// ---------------------------------------------------------------------------------------------
+constexpr int SPLIT_SPIN_LIMIT = 1 << 18;              // x (s_sleep + one load from L2): tens of milliseconds
+
+template <int MCAP>
+__global__ __launch_bounds__(256) void k_step_split(double* __restrict__ P, double* __restrict__ V,
+                                                    double* __restrict__ W, const double* __restrict__ dacc_in,
+                                                    double* __restrict__ dacc_out, const double* __restrict__ mu_in,
+                                                    double* __restrict__ mu_out, const int* __restrict__ nact,
+                                                    const StepIn* __restrict__ in, SolveOut* __restrict__ out,
+                                                    unsigned* __restrict__ flags, double* __restrict__ fac,
+                                                    const int* __restrict__ neff_floor, unsigned* __restrict__ queue,
+                                                    unsigned* __restrict__ ready, unsigned seq, DeviceConfig cfg,
+                                                    int ld, long pstride, int kbase) {
+  constexpr int CC = 3 + 2 * MCAP;
+  struct PanelSide {
+    PanelLds<MCAP, 4, true> S;
+    PanelPartLds<MCAP, 3> SP;
+  };
+  __shared__ union {
+    SolveLds L;
+    PanelSide Pn;
+  } U;
+  const int b = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n = nact[b];
+  const int neff_eff = min(n, max(in[b].neff, neff_floor[b]));
+  if (blockIdx.x == 0) {                               // ---- the solve of trajectory b ----
+    if (b == 0 && tid < 8) queue[tid * RS_QSTRIDE] = 0u;   // (see k_solve)
+    solve_body(U.L, P + (long)b * pstride, V + (long)b * KTOT * ld, W + (long)b * KTOT * ld, dacc_in + 4 * b,
+               dacc_out + 4 * b, mu_in + (long)b * ld, mu_out + (long)b * ld, in[b], out[b], out[b].it, flags + b,
+               fac + (long)b * FACS, cfg, ld, kbase, true, neff_eff);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); // this wave's stores are visible device-wide ...
+    __syncthreads();                                   // ... every wave's are ...
+    if (tid == 0) __hip_atomic_store(ready + b, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);   // ... then the word
+    return;
+  }
+  // ---- a panel workgroup: 64 state indices, four waves splitting the pending ranks ----
+  const int w0 = (blockIdx.x - 1) * 64;
+  if (w0 >= n) return;
+  auto& S = U.Pn.S;
+  auto& SP = U.Pn.SP;
+  const StepIn& s = in[b];
+  // the gathered indices, as the solve forms them (lane a holds C[a], 0 beyond c)
+  const int my_idx = (lane >= 3 && lane < CMAX) ? s.idx[(lane - 3) >> 1] : 0;
+  int m = ((s.flags & FLAG_UPDATE) && cfg.enable_measurement_model) ? s.m : 0;
+  m = min(min(m, MMAX), MCAP);
+  const int c = 3 + 2 * m;
+  const int Cl = (lane < 3) ? lane : (lane < c ? 3 + 2 * my_idx + ((lane - 3) & 1) : 0);
+  int cmax = Cl;
+#pragma unroll
+  for (int sh = 32; sh > 0; sh >>= 1) cmax = max(cmax, __shfl_xor(cmax, sh));
+  const int kb = kbase;
+  const PanelIdx t = panel_idx(P, V, W, mu_in, mu_out, ld, pstride, b, n, w0);
+  if (w0 >= neff_eff) {                                // beyond the active bound: nothing to wait for
+    if (wave == 0) panel_beyond_bound<MCAP>(t, kb);
+    return;
+  }
+  if (tid < CC + 1) S.sC[tid] = Cl;
+  // the factors at C for this workgroup: sF[0][a][k] = W[C[a]][k], sF[1][a][k] = V[k][C[a]] (zero up to a whole group
+  // of 8 ranks); wave w takes the rows w, w + 4, ..., lane = rank (see stage_issue for the addressing)
+  if (kb > 0) {
+    const __amdgpu_buffer_rsrc_t rsV = rs_rsrc(t.Vb), rsW = rs_rsrc(t.Wb);
+    constexpr int Q = (CC + 3) / 4;
+    const int k8 = (kb + 7) & ~7;
+    for (int kofs = 0; kofs < kb; kofs += 64) {
+      const int k = kofs + lane, kc = min(k, kb - 1);
+      const unsigned kW = (unsigned)(((kc >> 2) * (ld >> 4)) * 64 + (kc & 3) * 16) * 8u;
+      const unsigned kV = (unsigned)(kc * ld) * 8u;
+      double wv[Q], vv[Q];
+#pragma unroll
+      for (int q = 0; q < Q; ++q) {
+        const int a = wave + 4 * q;
+        wv[q] = 0.0;
+        vv[q] = 0.0;
+        if (a < c) {                                   // (wave-uniform)
+          const int row = __builtin_amdgcn_readlane(Cl, a);
+          wv[q] = ldb8(rsW, kW, (unsigned)((row >> 4) * 64 + (row & 15)) * 8u);
+          vv[q] = ldb8(rsV, kV, (unsigned)row * 8u);
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < Q; ++q) {
+        const int a = wave + 4 * q;
+        if (a < CC && k < k8) {
+          const bool live = a < c && k < kb;
+          S.sF[0][a][k] = live ? wv[q] : 0.0;
+          S.sF[1][a][k] = live ? vv[q] : 0.0;
+        }
+      }
+    }
+  }
+  double X[CC];
+  if (wave == 0) {
+    int Crow[CC];
+#pragma unroll
+    for (int a = 0; a < CC; ++a) Crow[a] = __builtin_amdgcn_readlane(Cl, a);
+    panel_base_gather<CC>(t, Crow, X);
+  } else {
+#pragma unroll
+    for (int a = 0; a < CC; ++a) X[a] = 0.0;
+  }
+  __syncthreads();
+  if (kb > 0) {
+    const double* vlane = t.Vb + t.ii;
+    const double* wlane = t.Wb + (long)(t.ii >> 4) * 64 + (t.ii & 15);   // wm_index = rank part + lane part
+    auto gather_pending = [&](auto need_w_tag) {
+      constexpr bool NEEDW = decltype(need_w_tag)::value;
+      double v[8], w[8];
+      pg_load<NEEDW>(vlane, wlane, ld, t.ld16, kb, 8 * wave, v, w);
+      for (int k0 = 8 * wave; k0 < kb; k0 += 32) {
+        double vn[8], wn[8];
+        pg_load<NEEDW>(vlane, wlane, ld, t.ld16, kb, k0 + 32, vn, wn);
+        pg_accumulate<CC>(X, v, w, S.sF, S.sC, k0, w0, t.ii);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          v[u] = vn[u];
+          w[u] = wn[u];
+        }
+      }
+    };
+    if (cmax > w0) gather_pending(std::true_type{});
+    else gather_pending(std::false_type{});
+    if (wave > 0) {
+#pragma unroll
+      for (int a = 0; a < CC; ++a) SP.sPart[wave - 1][a][lane] = X[a];
+    }
+    __syncthreads();
+    if (wave > 0) return;
+#pragma unroll
+    for (int a = 0; a < CC; ++a) {
+      double x = X[a];
+#pragma unroll
+      for (int q = 0; q < 3; ++q) x += SP.sPart[q][a][lane];
+      X[a] = x;
+    }
+  } else if (wave > 0) {
+    return;
+  }
+  // ---- wave 0: wait for the solve of this trajectory, fetch its records, replay ----
+  {
+    unsigned got = 0;
+    for (int spin = 0; spin < SPLIT_SPIN_LIMIT; ++spin) {
+      got = __hip_atomic_load(ready + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (got == seq) break;
+      __builtin_amdgcn_s_sleep(4);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    if (got != seq && lane == 0) atomicOr(flags + b, EKF_FLAG_INTERNAL);
+  }
+  const SolveOut& o = out[b];
+  {
+    const double2* src = reinterpret_cast<const double2*>(o.it);
+    double2* dst = reinterpret_cast<double2*>(S.sIt);
+    constexpr int PER = (int)(sizeof(SolveIter) / 16), CNT = MCAP * PER, Q = (CNT + 63) / 64;
+    const int count = m * PER;
+    double2 t0[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) t0[q] = src[min(lane + q * 64, CNT - 1)];
+#pragma unroll
+    for (int q = 0; q < Q; ++q)
+      if (lane + q * 64 < count) dst[lane + q * 64] = t0[q];
+  }
+  WAVE_LDS_SYNC();
+  panels_finish<MCAP>(t, o, S.sIt, S.sC, X);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2094,6 +2335,28 @@ void launch_panels(hipStream_t st, int mcap, double* P, double* V, double* W, co
     case 8: launch_panels_t<8>(st, P, V, W, mu_in, mu_out, nact, so, fac, ld, pstride, batch, n_hi); break;
     default: launch_panels_t<16>(st, P, V, W, mu_in, mu_out, nact, so, fac, ld, pstride, batch, n_hi); break;
   }
+}
+
+// Whether a step of this shape is run as one launch (the latency regime, see k_step_split): while every panel
+// workgroup has a CU to itself.  N=2000: 1 trajectory 33.7 k steps/s against 28.0 k with two launches, 4 trajectories
+// 79.2 k against 73.6 k, but 8 trajectories (504 panel workgroups) 85.8 k against 98.8 k.
+bool step_is_split(int batch, int n_hi, int cus) { return (long)((n_hi + 63) / 64) * batch <= (long)cus; }
+void launch_step_split(hipStream_t st, int mcap, double* P, double* V, double* W, const double* dacc_in, double* dacc_out,
+                       const double* mu_in, double* mu_out, const int* nact, const StepIn* in, SolveOut* out,
+                       unsigned* flags, double* fac, const int* neff_floor, unsigned* queue, unsigned* ready, unsigned seq,
+                       const DeviceConfig& cfg, int ld, long pstride, int batch, int n_hi, int kbase) {
+  const dim3 grid(1 + (n_hi + 63) / 64, batch);
+#define EKF_SPLIT(M)                                                                                                \
+  hipLaunchKernelGGL((k_step_split<M>), grid, dim3(256), 0, st, P, V, W, dacc_in, dacc_out, mu_in, mu_out, nact, in, out, \
+                     flags, fac, neff_floor, queue, ready, seq, cfg, ld, pstride, kbase)
+  switch (mcap) {
+    case 1: EKF_SPLIT(1); break;
+    case 2: EKF_SPLIT(2); break;
+    case 4: EKF_SPLIT(4); break;
+    case 8: EKF_SPLIT(8); break;
+    default: EKF_SPLIT(16); break;
+  }
+#undef EKF_SPLIT
 }
 
 template <int NKTM, int NKL, bool NT>
