@@ -683,3 +683,40 @@ def test_pass_scheduling_knobs_do_not_change_the_result(sd):
         for b in range(B):
             assert np.array_equal(got[b][0], ref[b][0]), opts
             assert np.array_equal(got[b][1], ref[b][1]), opts
+
+
+def test_single_launch_step_is_bit_identical(sd):
+    """`fused_step=1` (k_step_split: solve and panel workgroups in one launch, the panels gathered beside the solve and
+    released by a per-trajectory step counter) gives the results of the two-launch path bit for bit: ragged observation
+    counts (0..16, so every instantiation runs), scattered landmarks, three trajectories of different sizes with the
+    active bound on, flags clean (EKF_FLAG_INTERNAL would mean a wait timed out)."""
+    N, steps, B = 300, 17, 3
+    rng = np.random.default_rng(5)
+    world = [orc.synthetic_world(N, 40 + t) for t in range(B)]
+    sizes = [3 + 2 * N, 3 + 2 * 120, 3 + 2 * 211]
+    ms = [[int(rng.integers(0, 17)) for _ in range(B)] for _ in range(steps)]
+    obs = []
+    for k in range(steps):
+        row = []
+        for b in range(B):
+            nl = (sizes[b] - 3) // 2
+            vis = rng.choice(nl, size=ms[k][b], replace=False)
+            row.append((vis, rng.uniform(0.3, 1.4, ms[k][b]), rng.uniform(-1.0, 1.0, ms[k][b])))
+        obs.append(row)
+    out = {}
+    for fused in (0, 1):
+        with sd.EkfSlam(3 + 2 * N, batch=B) as f:
+            f.set_option("fused_step", fused)
+            for b in range(B):
+                f.set_state_diag(world[b][2][:sizes[b]], world[b][3][:sizes[b]], b)
+            for k in range(steps):
+                f.step([0.004 + 0.001 * k] * B, [0.02 if k % 3 else 0.004] * B, [o[0] for o in obs[k]],
+                       [o[1] for o in obs[k]], [o[2] for o in obs[k]])
+                if k == 7:
+                    out[fused, "mid"] = [f.mean(b) for b in range(B)]
+            out[fused, "end"] = [f.state(b) for b in range(B)]
+            assert [f.flags(b) for b in range(B)] == [0] * B
+    for b in range(B):
+        assert np.array_equal(out[0, "mid"][b], out[1, "mid"][b])
+        assert np.array_equal(out[0, "end"][b][0], out[1, "end"][b][0])
+        assert np.array_equal(out[0, "end"][b][1], out[1, "end"][b][1])
