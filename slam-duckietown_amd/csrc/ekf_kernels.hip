@@ -717,7 +717,7 @@ __device__ __forceinline__ void pg_accumulate(double (&X)[CC], const double (&v)
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int a = min(g + q, CC - 1);                // (rows c.. of a short step hold stale, unused data)
-      const double2* src = reinterpret_cast<const double2*>(&sF[sC[a] <= i0 ? 0 : 1][a][k0]);
+      const double2* src = reinterpret_cast<const double2*>(__builtin_assume_aligned(&sF[sC[a] <= i0 ? 0 : 1][a][k0], 16));
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const double2 t = src[u];
@@ -744,7 +744,7 @@ __device__ __forceinline__ void pg_accumulate(double (&X)[CC], const double (&v)
             s1 = fma(w[2 * u + 1], cf[q][2 * u + 1], s1);
           }
         } else {                                       // the wave straddles C[a]: both forms, chosen per lane
-          const double2* wa = reinterpret_cast<const double2*>(&sF[0][a][k0]);
+          const double2* wa = reinterpret_cast<const double2*>(__builtin_assume_aligned(&sF[0][a][k0], 16));
           const bool up = row <= ii;
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
@@ -871,7 +871,7 @@ __device__ __forceinline__ void panels_finish(const PanelIdx& t, const SolveOut&
   for (int it = 0; it < MCAP; ++it) {
     const int kr = kb + 2 * it;
     if (it < m) {
-      const SolveIter& I = sIt[it];
+      const SolveIter& I = *reinterpret_cast<const SolveIter*>(__builtin_assume_aligned(sIt + it, 16));
       const int a0 = 3 + 2 * it;
       double2 hk[5];
 #pragma unroll
@@ -924,18 +924,19 @@ __device__ __forceinline__ void panels_finish(const PanelIdx& t, const SolveOut&
   }
 }
 
+// (k_panels keeps its own copy of the gather and replay code below: routed through the shared helpers above, the
+//  same source compiles to a slower kernel at 32 trajectories -- 35.9 us against 33.7 us, same box)
 template <int MCAP, int NW, bool KSPLIT>
 __global__ __launch_bounds__(64 * NW) void k_panels(double* __restrict__ P, double* __restrict__ V,
                                                     double* __restrict__ W, const double* __restrict__ mu_in,
                                                     double* __restrict__ mu_out, const int* __restrict__ nact,
                                                     const SolveOut* __restrict__ so,
                                                     const double* __restrict__ fac, int ld, long pstride) {
-  constexpr int CC = 3 + 2 * MCAP, NT = 64 * NW;
-  __shared__ PanelLds<MCAP, NW, KSPLIT> S;
-  __shared__ PanelPartLds<MCAP, KSPLIT ? NW - 1 : 1> SP;
-  auto& sF = S.sF;
-  auto& sIt = S.sIt;
-  auto& sC = S.sC;
+  constexpr int CC = 3 + 2 * MCAP, KTP = ranks_for(MCAP), NT = 64 * NW;
+  __shared__ __attribute__((aligned(16))) double sF[2][CC][KTOT];   // [0]: W[C[a]][k], [1]: V[k][C[a]]
+  __shared__ SolveIter sIt[MCAP];
+  __shared__ int sC[CC + 1];
+  __shared__ double sPart[KSPLIT ? NW - 1 : 1][KSPLIT ? CC : 1][64];   // KSPLIT: partial gathers of waves 1..
   const int b = blockIdx.y;
   const int n = nact[b];
   const int w0 = blockIdx.x * (KSPLIT ? 64 : NT);
@@ -943,10 +944,18 @@ __global__ __launch_bounds__(64 * NW) void k_panels(double* __restrict__ P, doub
   const SolveOut& o = so[b];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ld16 = ld >> 4;
+  double* Pb = P + (long)b * pstride;
+  double* Vb = V + (long)b * KTOT * ld;
+  double* Wb = W + (long)b * KTOT * ld;
+  const double* mu_in_b = mu_in + (long)b * ld;
+  double* mu_out_b = mu_out + (long)b * ld;
   const int kb = o.kbase, neff = o.neff;
-  const int m = min(o.m, MCAP);
+  const int m = min(o.m, MCAP), c = o.c;
   const int i0 = KSPLIT ? w0 : w0 + wave * 64;
-  const PanelIdx t = panel_idx(P, V, W, mu_in, mu_out, ld, pstride, b, n, i0);
+  const int i = i0 + lane;
+  const bool act = i < n;
+  const int ii = act ? i : n - 1;                      // idle lanes shadow the last state index (no stores)
   const int kw = KSPLIT ? wave : 0;                    // KSPLIT: this wave takes every NW-th group of 8 ranks
   constexpr int KSTEP = KSPLIT ? 8 * NW : 8;
 
@@ -960,16 +969,16 @@ __global__ __launch_bounds__(64 * NW) void k_panels(double* __restrict__ P, doub
       double2 t0[Q], t1[Q];
 #pragma unroll
       for (int q = 0; q < Q; ++q) {
-        const int e = min(tid + q * NT, CNT - 1);
-        t0[q] = src0[e];
-        t1[q] = src1[e];
+        const int t = min(tid + q * NT, CNT - 1);
+        t0[q] = src0[t];
+        t1[q] = src1[t];
       }
 #pragma unroll
       for (int q = 0; q < Q; ++q) {
-        const int e = tid + q * NT;
-        if (e < CNT) {
-          dst0[e] = t0[q];
-          dst1[e] = t1[q];
+        const int t = tid + q * NT;
+        if (t < CNT) {
+          dst0[t] = t0[q];
+          dst1[t] = t1[q];
         }
       }
     }
@@ -990,7 +999,15 @@ __global__ __launch_bounds__(64 * NW) void k_panels(double* __restrict__ P, doub
   // the base entries of the gather do not depend on the staged data: issue them before the barrier
   double X[CC];
   if (i0 < neff && i0 < n && kw == 0) {
-    panel_base_gather<CC>(t, o.C, X);
+#pragma unroll
+    for (int a = 0; a < CC; ++a) {
+      const int row = o.C[a];
+#ifdef PANELS_SKIP_COLG                                 /* diagnostic build: no column-direction gathers */
+      X[a] = Pb[(long)min(row, i0) * ld + max(row, ii)];
+#else
+      X[a] = Pb[(long)min(row, ii) * ld + max(row, ii)];
+#endif
+    }
   } else {
 #pragma unroll
     for (int a = 0; a < CC; ++a) X[a] = 0.0;
@@ -998,27 +1015,106 @@ __global__ __launch_bounds__(64 * NW) void k_panels(double* __restrict__ P, doub
   __syncthreads();
   if (i0 >= n) return;
   if (i0 >= neff) {
-    if (kw == 0) panel_beyond_bound<MCAP>(t, kb);
+    // beyond the active bound the rows and columns of P are exactly zero off the diagonal: this step's
+    // ranks are zero there and the mean is carried over
+    if (act && kw == 0) {
+      for (int k = kb; k < ((kb + KTP + 3) & ~3); ++k) {
+        Vb[(long)k * ld + i] = 0.0;
+        Wb[wm_index(ld16, k, i)] = 0.0;
+      }
+      mu_out_b[i] = mu_in_b[i];
+    }
     return;
   }
 
-  // ---- pending ranks of the gather: with and without the W[i,:] loads ----
-  const double* vlane = t.Vb + t.ii;
-  const double* wlane = t.Wb + (long)(t.ii >> 4) * 64 + (t.ii & 15);   // wm_index = rank part + lane part
+  // ---- pending ranks of the gather ----
+  // The loop exists in two forms, with and without the W[i,:] loads (needed only where some gathered index lies
+  // beyond this wave's first state index).  Inside a form no load sits under a branch -- the group of 8 ranks
+  // after the last one is fetched too (rank rows up to KTOT exist) and masked -- so the compiler can count the
+  // outstanding loads and the next group really is in flight under this group's FMAs.
+  const double* vlane = Vb + ii;
+  const double* wlane = Wb + (long)(ii >> 4) * 64 + (ii & 15);   // wm_index = rank part + lane part
   auto gather_pending = [&](auto need_w_tag) {
-    constexpr bool NEEDW = decltype(need_w_tag)::value;
-    double v[8], w[8];
-    pg_load<NEEDW>(vlane, wlane, ld, t.ld16, kb, 8 * kw, v, w);
-    for (int k0 = 8 * kw; k0 < kb; k0 += KSTEP) {
-      double vn[8], wn[8];
-      pg_load<NEEDW>(vlane, wlane, ld, t.ld16, kb, k0 + KSTEP, vn, wn);
-      pg_accumulate<CC>(X, v, w, sF, sC, k0, i0, t.ii);
+  constexpr bool NEEDW = decltype(need_w_tag)::value;
+  double v[8], w[8];
+  // (the group after the last one is "fetched" too so that no load sits under a branch, but it is pointed at the
+  //  last valid group again: rows that were just read, not rank slots nobody needs -- a V row costs a trip to HBM)
+  const int k_last = ((kb - 1) >> 3) << 3;
+  auto load_vw = [&](int k0, double (&vv)[8], double (&ww)[8]) {
+    const int kc = min(k0, k_last);
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        v[u] = vn[u];
-        w[u] = wn[u];
+    for (int u = 0; u < 8; ++u) {
+      const double x = vlane[(long)(kc + u) * ld];
+      vv[u] = (k0 + u < kb) ? x : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      if (NEEDW) {
+        const double x = wlane[((long)((kc + u) >> 2) * ld16) * 64 + ((kc + u) & 3) * 16];
+        ww[u] = (k0 + u < kb) ? x : 0.0;
+      } else {
+        ww[u] = 0.0;
       }
     }
+  };
+  load_vw(8 * kw, v, w);
+  for (int k0 = 8 * kw; k0 < kb; k0 += KSTEP) {
+    double vn[8], wn[8];
+    load_vw(k0 + KSTEP, vn, wn);
+    // four gathered rows at a time: their 16 coefficient reads are in flight together, and each row's eight
+    // FMAs run as two independent chains (the branch per row is wave-uniform)
+#pragma unroll
+    for (int g = 0; g < CC; g += 4) {
+      double cf[4][8];                                 // (plain doubles: arrays of double2 end up in scratch)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int a = min(g + q, CC - 1);              // (rows c.. of a short step hold stale, unused data)
+        const double2* src = reinterpret_cast<const double2*>(&sF[sC[a] <= i0 ? 0 : 1][a][k0]);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const double2 t = src[u];
+          cf[q][2 * u] = t.x;
+          cf[q][2 * u + 1] = t.y;
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int a = g + q;
+        if (a < CC) {
+          const int row = sC[a];
+          double s0 = X[a], s1 = 0.0;
+          if (row <= i0) {                             // stored as (C[a], i) for the whole wave
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              s0 = fma(cf[q][2 * u], v[2 * u], s0);
+              s1 = fma(cf[q][2 * u + 1], v[2 * u + 1], s1);
+            }
+          } else if (row > i0 + 63) {                  // mirrored for the whole wave
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              s0 = fma(w[2 * u], cf[q][2 * u], s0);
+              s1 = fma(w[2 * u + 1], cf[q][2 * u + 1], s1);
+            }
+          } else {                                     // the wave straddles C[a]: both forms, chosen per lane
+            const double2* wa = reinterpret_cast<const double2*>(&sF[0][a][k0]);
+            const bool up = row <= ii;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              const double2 fw2 = wa[u];
+              s0 = fma(up ? fw2.x : w[2 * u], up ? v[2 * u] : cf[q][2 * u], s0);
+              s1 = fma(up ? fw2.y : w[2 * u + 1], up ? v[2 * u + 1] : cf[q][2 * u + 1], s1);
+            }
+          }
+          X[a] = s0 + s1;
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      v[u] = vn[u];
+      w[u] = wn[u];
+    }
+  }
   };
 #ifndef PANELS_SKIP_PEND                                  /* diagnostic build: no pending-rank gather */
   if (kb > 0) {                                        // (uniform) right after a covariance pass nothing is pending
@@ -1029,19 +1125,119 @@ __global__ __launch_bounds__(64 * NW) void k_panels(double* __restrict__ P, doub
   if (KSPLIT) {                                        // waves 1.. hand their partial sums to wave 0 and leave
     if (kw > 0) {
 #pragma unroll
-      for (int a = 0; a < CC; ++a) SP.sPart[kw - 1][a][lane] = X[a];
+      for (int a = 0; a < CC; ++a) sPart[kw - 1][a][lane] = X[a];
     }
     __syncthreads();
     if (kw > 0) return;
 #pragma unroll
     for (int a = 0; a < CC; ++a) {
-      double x = X[a];
+      double t = X[a];
 #pragma unroll
-      for (int q = 0; q < NW - 1; ++q) x += SP.sPart[q][a][lane];
-      X[a] = x;
+      for (int q = 0; q < NW - 1; ++q) t += sPart[q][a][lane];
+      X[a] = t;
     }
   }
-  panels_finish<MCAP>(t, o, sIt, sC, X);
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+    if (ii == a) X[a] += o.dacc_old[a];                // pending pose-block noise on the diagonal
+
+  // ---- predict:  P' = G_F P G_F^T + F^T R F  (src/replay_no_ros.py:430) on the panel ----
+  // Of the stored triangle it changes rows 0 and 1 only: thread i adds its two entries to P_base directly
+  // (the pending ranks are unaffected), so the prediction costs no rank of the covariance pass.
+  const double g0 = o.g[0], g1 = o.g[1];
+  const double gj = (ii == 0) ? g0 : ((ii == 1) ? g1 : 0.0);
+  double d0, d1;                                       // P'(0,i) - P(0,i),  P'(1,i) - P(1,i)
+  if (i0 == 0) {
+    if (lane < 2) {                                    // rows 0,1 of P_base are being rewritten by the other columns:
+#pragma unroll
+      for (int a = 0; a < CC; ++a) X[a] = o.prow[lane][a];   // state indices 0,1 take k_solve's gather
+    }
+    const double p22 = __shfl(X[2], 2);
+    double col2[CC];                                   // X[:,2] after the row ops, for the column ops of lanes 0,1
+#pragma unroll
+    for (int a = 0; a < CC; ++a) col2[a] = __shfl(X[a], 2);
+    col2[0] += g0 * p22;
+    col2[1] += g1 * p22;
+    d0 = g0 * X[2];                                    // row ops on rows 0,1
+    d1 = g1 * X[2];
+    if (ii < 2) {
+      d0 += gj * col2[0];
+      d1 += gj * col2[1];
+#pragma unroll
+      for (int a = 2; a < CC; ++a) X[a] += gj * col2[a];
+    }
+  } else {
+    d0 = g0 * X[2];
+    d1 = g1 * X[2];
+  }
+  X[0] += d0;
+  X[1] += d1;
+  if (act) {
+    double* p0 = Pb + i;                               // entry (0, i)
+    *p0 += d0;
+    if (i >= 1) p0[ld] += d1;                          // entry (1, i); (1, 0) lies below the diagonal
+  }
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+    if (a == ii) X[a] += o.rd[a];
+
+  // ---- sequential landmark updates ----
+  double dm = 0.0;
+#pragma unroll
+  for (int it = 0; it < MCAP; ++it) {
+    const int kr = kb + 2 * it;
+    if (it < m) {
+      const SolveIter& I = sIt[it];
+      const int a0 = 3 + 2 * it;
+      double2 hk[5];
+#pragma unroll
+      for (int k = 0; k < 5; ++k) hk[k] = *reinterpret_cast<const double2*>(I.h5t[k]);
+      const double2 s01 = *reinterpret_cast<const double2*>(&I.si[0]);
+      const double2 s23 = *reinterpret_cast<const double2*>(&I.si[2]);
+      const double2 yy = *reinterpret_cast<const double2*>(I.y);
+      double e0 = hk[0].x * X[0], e1 = hk[0].y * X[0];   // (H_j P_j)[:, i] = h5 . x[sel]
+#pragma unroll
+      for (int k = 1; k < 5; ++k) {
+        const double xv = (k < 3) ? X[k] : X[a0 + (k - 3)];
+        e0 = fma(hk[k].x, xv, e0);
+        e1 = fma(hk[k].y, xv, e1);
+      }
+      const double f0 = e0 * s01.x + e1 * s23.x;       // K_j[i,:] = (H_j P_j)[:, i]^T S^-1  (P symmetric)
+      const double f1 = e0 * s01.y + e1 * s23.y;
+      dm += f0 * yy.x + f1 * yy.y;
+      if (act) {
+        Vb[(long)kr * ld + i] = e0;
+        Vb[(long)(kr + 1) * ld + i] = e1;
+        Wb[wm_index(ld16, kr, i)] = -f0;
+        Wb[wm_index(ld16, kr + 1, i)] = -f1;
+      }
+      if (it + 1 < m) {                                // x[a] -= K_j[C[a],:] . (H_j P_j)[:, i]
+        // only the rows a later landmark still reads: the pose rows and the rows of landmarks it+1..
+#pragma unroll
+        for (int a = 0; a < CC; ++a) {
+          if (a < 3 || a >= a0 + 2) {
+            const double2 kc = *reinterpret_cast<const double2*>(I.kc[a]);
+            X[a] = fma(-kc.x, e0, X[a]);
+            X[a] = fma(-kc.y, e1, X[a]);
+          }
+        }
+      }
+    } else if (act) {
+      Vb[(long)kr * ld + i] = 0.0;
+      Vb[(long)(kr + 1) * ld + i] = 0.0;
+      Wb[wm_index(ld16, kr, i)] = 0.0;
+      Wb[wm_index(ld16, kr + 1, i)] = 0.0;
+    }
+  }
+  if (act) {
+    for (int k = kb + KTP; k < ((kb + KTP + 3) & ~3); ++k) {   // k-tile pad
+      Vb[(long)k * ld + i] = 0.0;
+      Wb[wm_index(ld16, k, i)] = 0.0;
+    }
+    bool inC = false;
+    for (int a = 0; a < c; ++a) inC |= (sC[a] == i);
+    if (!inC) mu_out_b[i] = mu_in_b[i] + dm;           // k_solve wrote the entries in C
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
