@@ -142,8 +142,9 @@ int ekf_profile_read(ekf_handle *h, double *pass_ms_total, long long *pass_launc
  * 1 = k_flush_pc, the producer/consumer form, 2 = k_flush_rs, the row-slab form; all give the same result
  * bit for bit), "pass_chunk" (row-slab pass: strips per work unit, 0 = auto), "pass_workgroups" (row-slab pass:
  * persistent workgroups, 0 = one per CU; fewer leaves whole CUs to other streams), "fused_step" (1 = small launches
- * run a step as one kernel, the panels gathered beside the solve -- same results; 0 = always two kernels); unknown
- * names fail. */
+ * run a step as one kernel, the panels gathered beside the solve -- same results; 0 = always two kernels; 2 =
+ * diagnostic: the solve never publishes its completion, every bounded wait times out with EKF_FLAG_INTERNAL);
+ * unknown names fail. */
 int ekf_set_option(ekf_handle *h, const char *name, int value);
 /* Which form of the covariance pass the last launch used (-1 = none yet; values as for "pass_kernel"), how many
  * MFMA k-tiles (4 pending ranks each) it applied, and whether it took the nontemporal (streaming) path. */

@@ -16,7 +16,7 @@ void launch_solve(hipStream_t, const double*, const double*, const double*, cons
 bool step_is_split(int batch, int n_hi, int cus);
 void launch_step_split(hipStream_t, int, double*, double*, double*, const double*, double*, const double*, double*,
                        const int*, const StepIn*, SolveOut*, unsigned*, double*, const int*, unsigned*, unsigned*, unsigned,
-                       const DeviceConfig&, int, long, int, int, int);
+                       int, const DeviceConfig&, int, long, int, int, int);
 void launch_panels(hipStream_t, int, double*, double*, double*, const double*, double*, const int*,
                    const SolveOut*, const double*, int, long, int, int);
 void launch_flush(hipStream_t, bool, double*, const double*, const double*, const double*, const int*,
@@ -546,7 +546,8 @@ static int enqueue_pass(ekf_handle* h, const StepIn* d_in, int m_hi) {
   if (h->opt_fused_step && step_is_split(h->batch, n_hi, h->cu_count)) {
     // few workgroups (the latency regime): the whole step as one launch, the panels gathered beside the solve
     launch_step_split(h->stream, mcap, h->dP, h->dV, h->dW, dacc_in, dacc_out, mu_in, mu_out, h->dn, d_in, h->dso,
-                      h->dflags, h->dfac, h->dfloor, h->dqueue, h->dready, ++h->step_seq, h->dcfg, h->ld, h->pstride,
+                      h->dflags, h->dfac, h->dfloor, h->dqueue, h->dready, ++h->step_seq, h->opt_fused_step == 1, h->dcfg, h->ld,
+                      h->pstride,
                       h->batch, n_hi, h->pending_k);
   } else {
     launch_solve(h->stream, h->dP, h->dV, h->dW, dacc_in, dacc_out, mu_in, mu_out, h->dn, d_in, h->dso, h->dflags,
@@ -1020,7 +1021,9 @@ extern "C" int ekf_set_option(ekf_handle* h, const char* name, int value) {
     return EKF_OK;
   }
   if (std::strcmp(name, "fused_step") == 0) {
-    if (value != 0 && value != 1) return fail(h, EKF_ERR_ARG, "fused_step must be 0 or 1");
+    // (2 = diagnostic: the solve never publishes its completion, so that every panel workgroup's bounded wait must
+    //  time out and raise EKF_FLAG_INTERNAL -- the results of such a step are garbage)
+    if (value < 0 || value > 2) return fail(h, EKF_ERR_ARG, "fused_step must be 0, 1 or 2 (diagnostic)");
     h->opt_fused_step = value;
     return EKF_OK;
   }

@@ -1262,8 +1262,8 @@ __global__ __launch_bounds__(256) void k_step_split(double* __restrict__ P, doub
                                                     const StepIn* __restrict__ in, SolveOut* __restrict__ out,
                                                     unsigned* __restrict__ flags, double* __restrict__ fac,
                                                     const int* __restrict__ neff_floor, unsigned* __restrict__ queue,
-                                                    unsigned* __restrict__ ready, unsigned seq, DeviceConfig cfg,
-                                                    int ld, long pstride, int kbase) {
+                                                    unsigned* __restrict__ ready, unsigned seq, int publish,
+                                                    DeviceConfig cfg, int ld, long pstride, int kbase) {
   constexpr int CC = 3 + 2 * MCAP;
   struct PanelSide {
     PanelLds<MCAP, 4, true> S;
@@ -1285,7 +1285,8 @@ __global__ __launch_bounds__(256) void k_step_split(double* __restrict__ P, doub
                fac + (long)b * FACS, cfg, ld, kbase, true, neff_eff);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); // this wave's stores are visible device-wide ...
     __syncthreads();                                   // ... every wave's are ...
-    if (tid == 0) __hip_atomic_store(ready + b, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);   // ... then the word
+    // ... then the word (publish = 0: a test of the panels' bounded wait -- they must time out, not hang)
+    if (tid == 0 && publish) __hip_atomic_store(ready + b, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     return;
   }
   // ---- a panel workgroup: 64 state indices, four waves splitting the pending ranks ----
@@ -2540,11 +2541,11 @@ bool step_is_split(int batch, int n_hi, int cus) { return (long)((n_hi + 63) / 6
 void launch_step_split(hipStream_t st, int mcap, double* P, double* V, double* W, const double* dacc_in, double* dacc_out,
                        const double* mu_in, double* mu_out, const int* nact, const StepIn* in, SolveOut* out,
                        unsigned* flags, double* fac, const int* neff_floor, unsigned* queue, unsigned* ready, unsigned seq,
-                       const DeviceConfig& cfg, int ld, long pstride, int batch, int n_hi, int kbase) {
+                       int publish, const DeviceConfig& cfg, int ld, long pstride, int batch, int n_hi, int kbase) {
   const dim3 grid(1 + (n_hi + 63) / 64, batch);
 #define EKF_SPLIT(M)                                                                                                \
   hipLaunchKernelGGL((k_step_split<M>), grid, dim3(256), 0, st, P, V, W, dacc_in, dacc_out, mu_in, mu_out, nact, in, out, \
-                     flags, fac, neff_floor, queue, ready, seq, cfg, ld, pstride, kbase)
+                     flags, fac, neff_floor, queue, ready, seq, publish, cfg, ld, pstride, kbase)
   switch (mcap) {
     case 1: EKF_SPLIT(1); break;
     case 2: EKF_SPLIT(2); break;

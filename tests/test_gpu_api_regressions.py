@@ -218,3 +218,21 @@ def test_gpu_backend_device_association_beyond_the_device_limits(sd):
     assert oti == res[0][2]
     close(res[0][0], om)
     close(res[0][1], oP)
+
+
+def test_single_launch_step_wait_is_bounded(sd):
+    """The panel workgroups of the single-launch step wait for their trajectory's solve on a device-scope word.  With
+    the diagnostic setting `fused_step=2` the solve never publishes it: every wait must run into its bound, raise
+    EKF_FLAG_INTERNAL and let the launch finish (no hang); the handle stays usable."""
+    N = 40
+    mean0, diag0, lin, ang, idx, zr, zb = orc.synthetic_stream(N, 3, 4, 3)
+    with sd.EkfSlam(len(mean0)) as f:
+        f.set_state_diag(mean0, diag0)
+        f.set_option("fused_step", 2)
+        f.step(lin[0], ang[0], idx[0], zr[0], zb[0])
+        f.sync()
+        assert f.flags(0) & 4                      # EKF_FLAG_INTERNAL
+        f.set_option("fused_step", 1)
+        f.set_state_diag(mean0, diag0)             # (the step above left garbage)
+        f.step(lin[0], ang[0], idx[0], zr[0], zb[0])
+        assert np.isfinite(f.mean()).all()
