@@ -1930,7 +1930,7 @@ __global__ __launch_bounds__(512, 2) void k_flush_rs(double* __restrict__ P, con
                                                      const double* __restrict__ dacc,
                                                      const int* __restrict__ nact,
                                                      const SolveOut* __restrict__ so, int ld, long pstride,
-                                                     int nkt, int batch, int nrb, int nch, int cs,
+                                                     int nkt, int batch, int nrb, int nch, int cs_arg, int pair,
                                                      unsigned* __restrict__ queue) {
   constexpr int RPW = NKT / 2;                         // ranks of a V strip each of the 8 waves stages
   __shared__ __attribute__((aligned(16))) double vbuf[2][NKT * 256];   // V strip as B fragments: [k-tile][col tile][lane]
@@ -1964,18 +1964,40 @@ __global__ __launch_bounds__(512, 2) void k_flush_rs(double* __restrict__ P, con
   int unit_no = -1;
 #endif
   bool own_empty = false;
+  // Queue g2 (one per XCD) holds the trajectories g2, g2 + 8, ...
+  //   pair form (batches of 8 and more, unless "pass_chunk" is set): one trajectory after the other, whole slabs longest
+  //     first -- the workgroup that got the longest slab of one trajectory gets the shortest of the next -- and if
+  //     their number is odd the last of them finds no partner: its slabs, only they, are cut into `nch` chunks;
+  //   uniform form: every slab of every trajectory in `nch` chunks, chunk-major.
+  //   (Dealing the slabs of the batch-modulo-8 last trajectories over all queues was measured too: no better.)
+  // A unit comes back as (trajectory * nrb + slab) * 1024 + chunk, chunk = 1023 for a whole slab.
   auto pop = [&]() -> int {
     int found = -1;
     for (int a = 0; a < 8 && found < 0; ++a) {
       const int g2 = (grp + a) & 7;
-      const int cnt = (g2 < batch) ? ((batch - g2 + 7) >> 3) * upt : 0;
+      const int tq = (g2 < batch) ? ((batch - g2 + 7) >> 3) : 0;
+      const int lone = (pair && (tq & 1)) ? 1 : 0;
+      const int whole = pair ? (tq - lone) * nrb : 0;
+      const int cnt = pair ? whole + lone * upt : tq * upt;
       if (cnt == 0) continue;
       unsigned* head = queue + g2 * RS_QSTRIDE;
       if (a > 0 || own_empty) {
         if (__hip_atomic_load(head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)cnt) continue;
       }
       const unsigned u = atomicAdd(head, 1u);
-      if (u < (unsigned)cnt) found = (g2 + 8 * (int)(u / (unsigned)upt)) * upt + (int)(u % (unsigned)upt);
+      if (u < (unsigned)cnt) {
+        int r = (int)u;
+        if (!pair) {
+          const int t = r / upt;
+          r -= t * upt;
+          found = ((g2 + 8 * t) * nrb + r % nrb) * 1024 + (nch > 1 ? r / nrb : 1023);
+        } else if (r < whole) {
+          found = ((g2 + 8 * (r / nrb)) * nrb + r % nrb) * 1024 + 1023;
+        } else {
+          r -= whole;
+          found = ((g2 + 8 * (tq - 1)) * nrb + r % nrb) * 1024 + r / nrb;
+        }
+      }
       else if (a == 0) own_empty = true;
     }
     return found;
@@ -1992,7 +2014,9 @@ __global__ __launch_bounds__(512, 2) void k_flush_rs(double* __restrict__ P, con
     RS_STAMP(2);
     const int unit = __builtin_amdgcn_readfirstlane(s_unit);   // (an LDS load is a vector value to the compiler)
     if (unit < 0) return;                              // every queue is empty: all eight waves leave together
-    const int b = unit / upt, chunk = (unit - b * upt) / nrb, rb = unit - b * upt - chunk * nrb;
+    const int code = unit & 1023, b = (unit >> 10) / nrb, rb = (unit >> 10) - b * nrb;
+    const int chunk = code == 1023 ? 0 : code;
+    const int cs = code == 1023 ? (1 << 20) : cs_arg;   // strips per unit: the whole slab, or a chunk of it
     const int n = min(nact[b], so[b].neff);            // rows/cols beyond the active bound are untouched
     const int i0 = rb * RS_ROWS;
     if (i0 >= n) continue;
@@ -2616,23 +2640,37 @@ static void launch_flush_rs_t(hipStream_t st, double* P, const double* V, const 
                               const int* nact, const SolveOut* so, int ld, long pstride, int batch, int n_hi, int nkt,
                               int workgroups, unsigned* queue, int chunk) {
   const int nrb = (n_hi + RS_ROWS - 1) / RS_ROWS;
-  // Units: whole slabs while the batch alone gives every CU a few of them; otherwise a slab is cut into chunks of `cs`
-  // strips so that there are about three units per CU (a unit pays a pipeline fill: not below 2 strips).
+  // Units.  The workgroups of an XCD take the slabs of their queue's trajectories in order (trajectory by trajectory,
+  // longest slab first): with an even number of trajectories per queue the workgroup that got the longest slab of one
+  // trajectory gets the shortest of the next, and whole slabs balance perfectly (16 trajectories: 366 us against
+  // 430 us in chunks of 22 strips); with an odd number (8 trajectories: one per queue; 17-24: three) the last
+  // trajectory of the queue finds no partner, and its slabs -- only its -- are cut in two (N=2000: 8 trajectories 203 us
+  // against 256 us with the former rule and 328 us whole; 24: 557 us against 668 us) -- profiles/r02_chunk_sweep.txt.
+  // Below 8 trajectories (the row-slab kernel then only runs for long ones, N=8000) every slab is cut so that there are
+  // about three units per CU.
   const int s_max = (n_hi + 63) / 64;                  // strips of the longest slab
-  long steps = 0;
-  for (int rb = 0; rb < nrb; ++rb) steps += std::max(1, s_max - 2 * rb);
-  steps *= batch;
-  int cs = s_max, nch = 1;
-  if (chunk > 0) {                                     // ("pass_chunk" option)
+  int cs = s_max, nch = 1, pair = 0;
+  if (chunk > 0) {                                     // ("pass_chunk" option: every slab of every trajectory)
     cs = std::min(std::max(chunk, 1), s_max);
     nch = (s_max + cs - 1) / cs;
-  } else if ((long)nrb * batch < 3L * workgroups) {
-    cs = (int)std::max<long>(2, (steps + 3L * workgroups - 1) / (3L * workgroups));
-    nch = (s_max + cs - 1) / cs;
+  } else if (batch >= 8) {                             // the unpaired trajectory of a queue: slabs cut in two
+    if (s_max >= 4) {
+      cs = (s_max + 1) / 2;
+      nch = 2;
+      pair = 1;
+    }
+  } else {                                             // a few long trajectories (N=8000): about three units per CU
+    long steps = 0;
+    for (int rb = 0; rb < nrb; ++rb) steps += std::max(1, s_max - 2 * rb);
+    steps *= batch;
+    if ((long)nrb * batch < 3L * workgroups) {
+      cs = (int)std::max<long>(2, (steps + 3L * workgroups - 1) / (3L * workgroups));
+      nch = (s_max + cs - 1) / cs;
+    }
   }
-  const long units = (long)nrb * nch * batch;
+  const long units = (long)nrb * (pair ? 1 : nch) * batch;   // (pair: at least; only the grid size depends on it)
   hipLaunchKernelGGL((k_flush_rs<NKT, NT>), dim3((unsigned)std::min<long>(workgroups, units)), dim3(512), 0, st, P, V, W,
-                     dacc, nact, so, ld, pstride, nkt, batch, nrb, nch, cs, queue);
+                     dacc, nact, so, ld, pstride, nkt, batch, nrb, nch, cs, pair, queue);
 }
 
 void launch_flush_rs(hipStream_t st, bool streaming, double* P, const double* V, const double* W, const double* dacc,
