@@ -17,6 +17,9 @@ bool step_is_split(int batch, int n_hi, int cus);
 void launch_step_split(hipStream_t, int, double*, double*, double*, const double*, double*, const double*, double*,
                        const int*, const StepIn*, SolveOut*, unsigned*, double*, const int*, unsigned*, unsigned*, unsigned,
                        int, const DeviceConfig&, int, long, int, int, int);
+void launch_step_split_tp(hipStream_t, int, double*, double*, double*, const double*, double*, const double*, double*,
+                          const int*, const StepIn*, SolveOut*, unsigned*, double*, const int*, unsigned*, SolveOut*,
+                          unsigned*, unsigned, int, const DeviceConfig&, int, long, int, int, int);
 void launch_panels(hipStream_t, int, double*, double*, double*, const double*, double*, const int*,
                    const SolveOut*, const double*, int, long, int, int);
 void launch_flush(hipStream_t, bool, double*, const double*, const double*, const double*, const int*,
@@ -90,6 +93,7 @@ struct ekf_handle {
   int opt_pass_kernel = -1;       // -1 = auto, 0 = k_flush, 1 = k_flush_pc (producer/consumer waves), 2 = k_flush_rs (row slabs)
   unsigned* dqueue = nullptr;     // work-queue heads of k_flush_rs (zeroed before every launch)
   unsigned* dready = nullptr;     // per trajectory: sequence number of the last solve that completed (k_step_split)
+  SolveOut* dmbox = nullptr;      // per trajectory: that solve's header and records, written through (mailbox_publish)
   unsigned step_seq = 0;          // sequence number of the last single-launch step
   int opt_fused_step = 1;         // 1 = one launch per step where the launch is small (k_step_split), 0 = always two
   int cu_count = 0;
@@ -145,7 +149,7 @@ static void free_all(ekf_handle* h) {
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   void* ptrs[] = {h->dP, h->dmu2[0], h->dmu2[1], h->dV, h->dW, h->ddacc2[0], h->ddacc2[1], h->dscratch, h->dn, h->dflags, h->dso, h->dfac,
-                  h->d_ring, h->d_stream, h->dF, h->dQ, h->dTmp, h->dtagmap, h->dneff, h->d_det, h->d_assoc_step, h->dfloor, h->dqueue, h->dready,
+                  h->d_ring, h->d_stream, h->dF, h->dQ, h->dTmp, h->dtagmap, h->dneff, h->d_det, h->d_assoc_step, h->dfloor, h->dqueue, h->dready, h->dmbox,
                   h->d_assoc_out};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (h->h_ring) (void)hipHostFree(h->h_ring);
@@ -239,6 +243,8 @@ extern "C" int ekf_create(int device, int n_max, int batch, const ekf_config* cf
   CREATE_TRY(hipMalloc(&h->dfloor, sizeof(int) * batch));
   CREATE_TRY(hipMalloc(&h->dqueue, sizeof(unsigned) * flush_rs_queue_words()));
   CREATE_TRY(hipMalloc(&h->dready, sizeof(unsigned) * batch));
+  CREATE_TRY(hipMalloc(&h->dmbox, sizeof(SolveOut) * batch));
+  CREATE_TRY(hipMemsetAsync(h->dmbox, 0, sizeof(SolveOut) * batch, h->stream));
   CREATE_TRY(hipMemsetAsync(h->dready, 0, sizeof(unsigned) * batch, h->stream));
   CREATE_TRY(hipMalloc(&h->dso, sizeof(SolveOut) * batch));
   CREATE_TRY(hipMalloc(&h->dfac, sizeof(double) * FACS * batch));
@@ -549,6 +555,13 @@ static int enqueue_pass(ekf_handle* h, const StepIn* d_in, int m_hi) {
                       h->dflags, h->dfac, h->dfloor, h->dqueue, h->dready, ++h->step_seq, h->opt_fused_step == 1, h->dcfg, h->ld,
                       h->pstride,
                       h->batch, n_hi, h->pending_k);
+  } else if (h->opt_fused_step && mcap <= 8 && (long)((n_hi + 63) / 64) * h->batch > 512 &&
+             (long)(1 + (n_hi + 255) / 256) * h->batch <= 2L * h->cu_count) {
+    // the throughput shape of the panels with room left on the chip for one more workgroup per trajectory: still one
+    // launch -- workgroup 0 of a trajectory solves, the others gather their panels meanwhile (k_panels<.., SPLIT>)
+    launch_step_split_tp(h->stream, mcap, h->dP, h->dV, h->dW, dacc_in, dacc_out, mu_in, mu_out, h->dn, d_in, h->dso,
+                         h->dflags, h->dfac, h->dfloor, h->dqueue, h->dmbox, h->dready, ++h->step_seq, h->opt_fused_step == 1,
+                         h->dcfg, h->ld, h->pstride, h->batch, n_hi, h->pending_k);
   } else {
     launch_solve(h->stream, h->dP, h->dV, h->dW, dacc_in, dacc_out, mu_in, mu_out, h->dn, d_in, h->dso, h->dflags,
                  h->dfac, h->dfloor, h->dqueue, h->dcfg, h->ld, h->pstride, h->batch, h->pending_k);

@@ -48,7 +48,7 @@ static_assert(sizeof(SolveIter) % 16 == 0, "SolveIter must stay 16-byte granular
 constexpr int FACS = 2 * CMAX * KTOT;
 
 // Output of the sequential compressed solve for one trajectory; read by the panel and pass kernels.
-struct alignas(16) SolveOut {
+struct alignas(16) SolveHead {
   double g[2];          // G[0,2], G[1,2] of the motion Jacobian (0 when prediction is off)
   double rd[3];         // motion noise added to the pose block (0 when prediction is off)
   double p22h;          // 0.5 * P[2,2] before the step
@@ -61,12 +61,15 @@ struct alignas(16) SolveOut {
   int neff;             // active bound of this step (rows/cols >= neff of P are untouched diagonal)
   int C[CMAX + 1];      // gathered state indices, padded with 0
   double prow[2][CMAX + 1];   // P(0, C[a]) and P(1, C[a]) before the step (what state indices 0,1 gather)
+};
+struct alignas(16) SolveOut : SolveHead {
   SolveIter it[MMAX];
 #ifdef EKF_STAMPS
   unsigned long long stamps[128];   // diagnostic build only (tools/solve_probe.hip)
 #endif
 };
-static_assert(offsetof(SolveOut, it) % 16 == 0, "SolveOut::it must be 16-byte aligned");
+static_assert(sizeof(SolveHead) % 16 == 0, "SolveHead must stay 16-byte granular");
+// (SolveOut = head, then the records: `it` starts at sizeof(SolveHead))
 
 // Device-side association: one window of raw AprilTag detections per trajectory.
 constexpr int DMAX = 64;                // detections per window

@@ -180,19 +180,37 @@ __device__ __forceinline__ void stage_issue(StageRegs& R, __amdgpu_buffer_rsrc_t
     }
   }
 }
+// Where solve_body keeps the factors at C in LDS: its own padded arrays (k_solve: conflict-free for the stage writes
+// and for the MFMA fragment reads), or the panel kernels' [part][a][k] array (k_panels<.., SPLIT>: the solve workgroup
+// goes on to its panel with the factors already in place).
+struct FacStd {
+  double (*Wc)[WCS];
+  double (*Vc)[PCS];
+  static constexpr int ROWS = CMAX;
+  __device__ __forceinline__ double& w(int a, int k) const { return Wc[a][k]; }
+  __device__ __forceinline__ double& v(int k, int a) const { return Vc[k][a]; }
+};
+template <int CC>
+struct FacPanel {
+  double (*sF)[CC][KTOT];
+  static constexpr int ROWS = CC;
+  __device__ __forceinline__ double& w(int a, int k) const { return sF[0][a][k]; }
+  __device__ __forceinline__ double& v(int k, int a) const { return sF[1][a][k]; }
+};
+template <class Fac>
 __device__ __forceinline__ void stage_commit(const StageRegs& R, int c, int kb, int kofs, int wave, int lane,
-                                             double (*Wc)[WCS], double (*Vc)[PCS], double* __restrict__ fac) {
+                                             const Fac& F, double* __restrict__ fac) {
   const int k = kofs + lane;
   const int k8 = (kb + 7) & ~7;
   if (k >= KTOT) return;
 #pragma unroll
   for (int q = 0; q < SQ; ++q) {
     const int a = wave + 3 * q;                        // (a < 3 SQ = 36 <= PCS: rows c.. and ranks kb.. are staged as zeros,
-    if (a < CMAX) {                                    //  so the product below needs no masks)
+    if (a < Fac::ROWS) {                               //  so the product below needs no masks)
       const bool in = a < c && k < kb;
       const double w = in ? R.wv[q] : 0.0, v = in ? R.vv[q] : 0.0;
-      Wc[a][k] = w;
-      Vc[k][a] = v;
+      F.w(a, k) = w;
+      F.v(k, a) = v;
       if (fac && a < c && k < k8) {
         fac[a * KTOT + k] = w;
         fac[CMAX * KTOT + a * KTOT + k] = v;
@@ -213,18 +231,22 @@ __device__ __forceinline__ void stage_commit(const StageRegs& R, int c, int kb, 
 // of a step reads an entry another workgroup of the same step writes).  `its` receives the
 // per-landmark records.
 // ---------------------------------------------------------------------------------------------
-struct SolveLds {
+struct SolveCore {
   double Pc[CPAD][PCS];
   double Ms[CPAD][PCS];                                // W[C,:] V[:,C], the pending ranks' share of the gathered block
   double2 hpS[CPAD], kcS[CPAD];
   int Cs[CPAD];
   double mot[6];                                       // motion model (wave 3): predicted x, y, theta, G[0,2], G[1,2]
-  double Wc[CMAX][WCS];
-  double Vc[KTOT][PCS];
   double2 hS[6];                                       // next linearisation: {h[0][k], h[1][k]} k<5
 };
+struct SolveLds : SolveCore {
+  double Wc[CMAX][WCS];
+  double Vc[KTOT][PCS];
+  __device__ __forceinline__ FacStd fac_view() { return FacStd{Wc, Vc}; }
+};
 
-__device__ __forceinline__ void solve_body(SolveLds& L, const double* __restrict__ Pb,
+template <class Fac>
+__device__ __forceinline__ void solve_body(SolveCore& L, const Fac& F, const double* __restrict__ Pb,
                                            const double* __restrict__ Vb, const double* __restrict__ Wb,
                                            const double* __restrict__ dacc_in, double* __restrict__ dacc_out,
                                            const double* __restrict__ mu_in_b, double* __restrict__ mu_out_b,
@@ -237,8 +259,6 @@ __device__ __forceinline__ void solve_body(SolveLds& L, const double* __restrict
   auto& hpS = L.hpS;
   auto& kcS = L.kcS;
   auto& Cs = L.Cs;
-  auto& Wc = L.Wc;
-  auto& Vc = L.Vc;
   auto& hS = L.hS;
 
   STAMP(o, 0);
@@ -325,10 +345,10 @@ __device__ __forceinline__ void solve_body(SolveLds& L, const double* __restrict
   STAMP(o, 112);
   if (kbase > 0) {
     if (gw < 3) {
-      stage_commit(SR, c, kbase, 0, gw, lane, Wc, Vc, writer ? fac_b : nullptr);
+      stage_commit(SR, c, kbase, 0, gw, lane, F, writer ? fac_b : nullptr);
       if (kbase > 64) {                                // (more than 64 pending ranks: second pass)
         stage_issue(SR, rsV, rsW, Cl, c, kbase, 64, ld, gw, lane);
-        stage_commit(SR, c, kbase, 64, gw, lane, Wc, Vc, writer ? fac_b : nullptr);
+        stage_commit(SR, c, kbase, 64, gw, lane, F, writer ? fac_b : nullptr);
       }
     }
     WG_LDS_BARRIER();
@@ -352,23 +372,22 @@ __device__ __forceinline__ void solve_body(SolveLds& L, const double* __restrict
       // the pending ones were staged as zeros.  Four k-tiles of fragments per round trip to LDS, the next four in
       // flight under the MFMAs; even and odd k-tiles accumulate separately (a dependent v_mfma_f64_16x16x4 waits
       // for its predecessor).
-      const double* wr = &Wc[min(ar, CMAX - 1)][lq];
-      const double* vc = &Vc[lq][min(bc, PCS - 1)];
+      const int ra = min(ar, Fac::ROWS - 1), cb = min(bc, Fac::ROWS - 1);
       const int nb = (nkt + 3) >> 2;                   // batches of 4 k-tiles (16 ranks); 16 nb <= KTOT
       double4_t acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
       double av[4], bv[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        av[u] = wr[4 * u];
-        bv[u] = vc[4 * u * PCS];
+        av[u] = F.w(ra, lq + 4 * u);
+        bv[u] = F.v(lq + 4 * u, cb);
       }
       for (int bt = 0; bt < nb; ++bt) {
         const int kn = min(16 * (bt + 1), KTOT - 16);  // (the fetch behind the last batch is not used)
         double an[4], bn[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-          an[u] = wr[kn + 4 * u];
-          bn[u] = vc[(kn + 4 * u) * PCS];
+          an[u] = F.w(ra, lq + kn + 4 * u);
+          bn[u] = F.v(lq + kn + 4 * u, cb);
         }
         __builtin_amdgcn_sched_barrier(0);
         acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[0], bv[0], acc0, 0, 0, 0);
@@ -647,7 +666,7 @@ __global__ __launch_bounds__(256) void k_solve(const double* __restrict__ P, con
   // active bound of this step: what the host baked into the record, raised to the handle's floor (the bound the
   // state had when the enqueueing call started: a stream uploaded earlier knows only its own observations)
   const int neff_eff = min(nact[b], max(in[b].neff, neff_floor[b]));
-  solve_body(L, P + (long)b * pstride, V + (long)b * KTOT * ld, W + (long)b * KTOT * ld, dacc_in + 4 * b,
+  solve_body(L, L.fac_view(), P + (long)b * pstride, V + (long)b * KTOT * ld, W + (long)b * KTOT * ld, dacc_in + 4 * b,
              dacc_out + 4 * b, mu_in + (long)b * ld, mu_out + (long)b * ld, in[b], out[b], out[b].it,
              flags + b, fac + (long)b * FACS, cfg, ld, kbase, true, neff_eff);
 }
@@ -814,7 +833,7 @@ __device__ __forceinline__ void panel_beyond_bound(const PanelIdx& t, int kb) {
 // From the gathered x[a] = P(C[a], i) on: prediction on the panel, the m sequential rank-2 updates, the new rank
 // entries, the mean.  `o`, `sIt` (per-landmark records) and `sC` may live in LDS or (o) in global memory.
 template <int MCAP>
-__device__ __forceinline__ void panels_finish(const PanelIdx& t, const SolveOut& o, const SolveIter* sIt, const int* sC,
+__device__ __forceinline__ void panels_finish(const PanelIdx& t, const SolveHead& o, const SolveIter* sIt, const int* sC,
                                               double (&X)[3 + 2 * MCAP]) {
   constexpr int CC = 3 + 2 * MCAP, KTP = ranks_for(MCAP);
   const int lane = t.lane, i0 = t.i0, i = t.i, ii = t.ii, ld = t.ld, ld16 = t.ld16;
@@ -924,24 +943,109 @@ __device__ __forceinline__ void panels_finish(const PanelIdx& t, const SolveOut&
   }
 }
 
+// ---- hand-over of a solve's results to the panel workgroups of the same launch ----
+// Workgroups of one launch run on different XCDs, whose L2s are not coherent with each other.  Publishing through
+// release/acquire fences works (buffer_wbl2 / buffer_inv), but each fence writes back or invalidates a whole L2: fine
+// with 64 workgroups, ruinous with 512 that are streaming their panels through those L2s (k_panels<.., SPLIT>: 80 us per
+// step instead of 35).  So the results travel through a mailbox instead: the solve workgroup copies header and records
+// (6.4 KB) with device-scope stores (sc1: written through), waits for them, then sets the trajectory's step counter the
+// same way; a panel wave polls the counter and reads the mailbox with device-scope loads (sc1: past its own L2).  No
+// fence, nothing else leaves or enters a cache.
+__device__ __forceinline__ void mailbox_publish(const SolveOut& src, SolveOut* mbox, int m, unsigned* ready, unsigned seq,
+                                                int publish) {
+  __syncthreads();                                     // every wave's own stores to src have been issued and waited for
+  const int words = (int)(sizeof(SolveHead) / 8) + m * (int)(sizeof(SolveIter) / 8);
+  const double* s = reinterpret_cast<const double*>(&src);
+  double* d = reinterpret_cast<double*>(mbox);
+  for (int w = threadIdx.x; w < words; w += blockDim.x)
+    __hip_atomic_store(d + w, s[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // written through ...
+  __syncthreads();                                     // ... by every wave ...
+  if (threadIdx.x == 0 && publish) __hip_atomic_store(ready, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ... then the word
+}
+// One wave: wait (bounded) for the counter, then fetch header and records into LDS.  Returns false on a timeout.
+__device__ __forceinline__ bool mailbox_fetch(const SolveOut* mbox, int m, const unsigned* ready, unsigned seq, int spin_limit,
+                                              SolveHead* head_lds, SolveIter* it_lds) {
+  const int lane = threadIdx.x & 63;
+  unsigned got = 0;
+  for (int spin = 0; spin < spin_limit; ++spin) {
+    got = __hip_atomic_load(ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (got == seq) break;
+    __builtin_amdgcn_s_sleep(4);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (the loads below are issued after the counter was seen)
+  const double* s = reinterpret_cast<const double*>(mbox);
+  constexpr int HW = (int)(sizeof(SolveHead) / 8), IW = (int)(sizeof(SolveIter) / 8);
+  double* dh = reinterpret_cast<double*>(head_lds);
+  double* di = reinterpret_cast<double*>(it_lds);
+  for (int w = lane; w < HW; w += 64) dh[w] = __hip_atomic_load(s + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  for (int w = lane; w < m * IW; w += 64) di[w] = __hip_atomic_load(s + HW + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  WAVE_LDS_SYNC();
+  return got == seq;
+}
+
+constexpr int SPLIT_SPIN_LIMIT = 1 << 18;              // bounded device-scope waits: x (s_sleep + one load from L2), tens of ms
+
 // (k_panels keeps its own copy of the gather and replay code below: routed through the shared helpers above, the
 //  same source compiles to a slower kernel at 32 trajectories -- 35.9 us against 33.7 us, same box)
-template <int MCAP, int NW, bool KSPLIT>
-__global__ __launch_bounds__(64 * NW) void k_panels(double* __restrict__ P, double* __restrict__ V,
-                                                    double* __restrict__ W, const double* __restrict__ mu_in,
-                                                    double* __restrict__ mu_out, const int* __restrict__ nact,
-                                                    const SolveOut* __restrict__ so,
-                                                    const double* __restrict__ fac, int ld, long pstride) {
+//
+// SPLIT (throughput shape only): the whole step in this one launch, as in k_step_split, for batches whose panel
+// workgroups leave room on the chip for one more workgroup per trajectory.  Workgroup 0 of a trajectory is the solve
+// (its factors at C live in sF) and publishes its results through the mailbox; workgroup x >= 1 takes block x - 1 of
+// 256 state indices, forms C from the step's inputs, stages the factors at C for itself, gathers its panel while the
+// solve runs, and waits for the trajectory's step counter before it fetches header and records and replays.  Every
+// write of a panel workgroup comes after its wait.  (Letting the solve workgroup take a block of panel work after its
+// solve -- so that a batch that fills the chip exactly, 32 trajectories at N=2000, could use this too -- was measured:
+// 53 us per step against 47 us with two launches; the solve runs slower beside the gathers and its own block then
+// starts late.)
+struct SplitArgs {
+  const double* dacc_in;
+  double* dacc_out;
+  const StepIn* in;
+  SolveOut* out;
+  unsigned* flags;
+  double* fac;
+  const int* neff_floor;
+  unsigned* queue;
+  SolveOut* mbox;       // per trajectory: header + records of this launch's solve, written through (see mailbox_publish)
+  unsigned* ready;
+  unsigned seq;
+  int publish, kbase;
+  DeviceConfig cfg;
+};
+struct Empty {};
+
+// (The body is a device function so that the SPLIT kernel can carry its own launch bounds: it needs the register cap of
+//  two waves per SIMD, and a second __launch_bounds__ argument -- which cannot be left out conditionally -- makes the
+//  compiler move a dynamically indexed private array of the rank-split shape into LDS: 8 KB more per workgroup and
+//  that kernel 2.4 x slower at 8 trajectories.)
+template <int MCAP, int NW, bool KSPLIT, bool SPLIT>
+__device__ __forceinline__ void panels_mono(double* __restrict__ P, double* __restrict__ V,
+                                            double* __restrict__ W, const double* __restrict__ mu_in,
+                                            double* __restrict__ mu_out, const int* __restrict__ nact,
+                                            const SolveOut* __restrict__ so,
+                                            const double* __restrict__ fac, int ld, long pstride,
+                                            const SplitArgs& sa) {
+  static_assert(!SPLIT || (!KSPLIT && NW == 4), "SPLIT is the throughput shape");
   constexpr int CC = 3 + 2 * MCAP, KTP = ranks_for(MCAP), NT = 64 * NW;
   __shared__ __attribute__((aligned(16))) double sF[2][CC][KTOT];   // [0]: W[C[a]][k], [1]: V[k][C[a]]
   __shared__ SolveIter sIt[MCAP];
   __shared__ int sC[CC + 1];
   __shared__ double sPart[KSPLIT ? NW - 1 : 1][KSPLIT ? CC : 1][64];   // KSPLIT: partial gathers of waves 1..
+  __shared__ std::conditional_t<SPLIT, SolveCore, Empty> sL;          // SPLIT: the solve's own LDS (factors: sF)
+  __shared__ std::conditional_t<SPLIT, SolveHead, Empty> sH;          // SPLIT: the header fetched from the mailbox
   const int b = blockIdx.y;
   const int n = nact[b];
-  const int w0 = blockIdx.x * (KSPLIT ? 64 : NT);
-  if (w0 >= n) return;
-  const SolveOut& o = so[b];
+  const bool solver = SPLIT && blockIdx.x == 0;
+  const bool early = SPLIT && !solver;                 // this workgroup gathers before the solve has finished
+  // (SPLIT: what the solve of THIS launch writes is read through sa.out, which carries no read-only promise)
+  const int w0 = (SPLIT ? (int)blockIdx.x - 1 : (int)blockIdx.x) * (KSPLIT ? 64 : NT);
+  if (!solver && w0 >= n) return;
+  // (SPLIT: a panel workgroup reads the header it fetched into LDS; the solve workgroup what it wrote itself)
+  const SolveHead& o = [&]() -> const SolveHead& {
+    if constexpr (SPLIT) return early ? static_cast<const SolveHead&>(sH) : static_cast<const SolveHead&>(sa.out[b]);
+    else return so[b];
+  }();
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int ld16 = ld >> 4;
@@ -950,8 +1054,38 @@ __global__ __launch_bounds__(64 * NW) void k_panels(double* __restrict__ P, doub
   double* Wb = W + (long)b * KTOT * ld;
   const double* mu_in_b = mu_in + (long)b * ld;
   double* mu_out_b = mu_out + (long)b * ld;
-  const int kb = o.kbase, neff = o.neff;
-  const int m = min(o.m, MCAP), c = o.c;
+  int kb, neff, m, c, cmaxv, Cl = 0;
+  if constexpr (SPLIT) {
+    const int neff_eff = min(n, max(sa.in[b].neff, sa.neff_floor[b]));
+    if (solver) {
+      if (b == 0 && tid < 8) sa.queue[tid * RS_QSTRIDE] = 0u;   // (see k_solve)
+      solve_body(sL, FacPanel<CC>{sF}, Pb, Vb, Wb, sa.dacc_in + 4 * b, sa.dacc_out + 4 * b, mu_in_b, mu_out_b, sa.in[b],
+                 sa.out[b], sa.out[b].it, sa.flags + b, sa.fac + (long)b * FACS, sa.cfg, ld, sa.kbase, true, neff_eff);
+      {
+        int ms = ((sa.in[b].flags & FLAG_UPDATE) && sa.cfg.enable_measurement_model) ? sa.in[b].m : 0;
+        mailbox_publish(sa.out[b], sa.mbox + b, min(ms, MMAX), sa.ready + b, sa.seq, sa.publish);
+      }
+      return;
+    }
+    const StepIn& st = sa.in[b];                       // the gathered indices, as the solve forms them
+    const int my_idx = (lane >= 3 && lane < CMAX) ? st.idx[(lane - 3) >> 1] : 0;
+    int mm = ((st.flags & FLAG_UPDATE) && sa.cfg.enable_measurement_model) ? st.m : 0;
+    mm = min(min(mm, MMAX), MCAP);
+    m = mm;
+    c = 3 + 2 * mm;
+    Cl = (lane < 3) ? lane : (lane < c ? 3 + 2 * my_idx + ((lane - 3) & 1) : 0);
+    cmaxv = Cl;
+#pragma unroll
+    for (int sh = 32; sh > 0; sh >>= 1) cmaxv = max(cmaxv, __shfl_xor(cmaxv, sh));
+    kb = sa.kbase;
+    neff = neff_eff;
+  } else {
+    kb = o.kbase;
+    neff = o.neff;
+    m = min(o.m, MCAP);
+    c = o.c;
+    cmaxv = o.cmax;
+  }
   const int i0 = KSPLIT ? w0 : w0 + wave * 64;
   const int i = i0 + lane;
   const bool act = i < n;
@@ -959,9 +1093,44 @@ __global__ __launch_bounds__(64 * NW) void k_panels(double* __restrict__ P, doub
   const int kw = KSPLIT ? wave : 0;                    // KSPLIT: this wave takes every NW-th group of 8 ranks
   constexpr int KSTEP = KSPLIT ? 8 * NW : 8;
 
-  if (w0 < neff) {                                     // (uniform) some wave of this workgroup replays the step
+  if (early) {
+    // the factors at C for this workgroup, straight from V and W: sF[0][a][k] = W[C[a]][k], sF[1][a][k] = V[k][C[a]]
+    // (zero up to a whole group of 8 ranks); wave w takes the rows w, w + 4, ..., lane = rank (see stage_issue)
+    if (tid < CC + 1) sC[tid] = Cl;
+    if (w0 < neff && kb > 0) {
+      const __amdgpu_buffer_rsrc_t rsV = rs_rsrc(Vb), rsW = rs_rsrc(Wb);
+      constexpr int Q = (CC + 3) / 4;
+      const int k8 = (kb + 7) & ~7;
+      for (int kofs = 0; kofs < kb; kofs += 64) {
+        const int k = kofs + lane, kc = min(k, kb - 1);
+        const unsigned kW = (unsigned)(((kc >> 2) * ld16) * 64 + (kc & 3) * 16) * 8u;
+        const unsigned kV = (unsigned)(kc * ld) * 8u;
+        double wv[Q], vv[Q];
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+          const int a = wave + 4 * q;
+          wv[q] = 0.0;
+          vv[q] = 0.0;
+          if (a < c) {                                 // (wave-uniform)
+            const int row = __builtin_amdgcn_readlane(Cl, a);
+            wv[q] = ldb8(rsW, kW, (unsigned)((row >> 4) * 64 + (row & 15)) * 8u);
+            vv[q] = ldb8(rsV, kV, (unsigned)row * 8u);
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+          const int a = wave + 4 * q;
+          if (a < CC && k < k8) {
+            const bool live = a < c && k < kb;
+            sF[0][a][k] = live ? wv[q] : 0.0;
+            sF[1][a][k] = live ? vv[q] : 0.0;
+          }
+        }
+      }
+    }
+  } else if (w0 < neff) {                              // (uniform) some wave of this workgroup replays the step
     if (kb > 0) {
-      const double2* src0 = reinterpret_cast<const double2*>(fac + (long)b * FACS);
+      const double2* src0 = reinterpret_cast<const double2*>((SPLIT ? sa.fac : fac) + (long)b * FACS);
       const double2* src1 = src0 + CMAX * KTOT / 2;
       double2* dst0 = reinterpret_cast<double2*>(&sF[0][0][0]);
       double2* dst1 = reinterpret_cast<double2*>(&sF[1][0][0]);
@@ -983,7 +1152,11 @@ __global__ __launch_bounds__(64 * NW) void k_panels(double* __restrict__ P, doub
       }
     }
     {
-      const double2* src = reinterpret_cast<const double2*>(o.it);
+      const SolveOut& og = [&]() -> const SolveOut& {
+        if constexpr (SPLIT) return sa.out[b];
+        else return so[b];
+      }();
+      const double2* src = reinterpret_cast<const double2*>(og.it);
       double2* dst = reinterpret_cast<double2*>(sIt);
       constexpr int PER = (int)(sizeof(SolveIter) / 16), CNT = MCAP * PER, Q = (CNT + NT - 1) / NT;
       const int count = m * PER;
@@ -1001,7 +1174,7 @@ __global__ __launch_bounds__(64 * NW) void k_panels(double* __restrict__ P, doub
   if (i0 < neff && i0 < n && kw == 0) {
 #pragma unroll
     for (int a = 0; a < CC; ++a) {
-      const int row = o.C[a];
+      const int row = early ? __builtin_amdgcn_readlane(Cl, a) : o.C[a];
 #ifdef PANELS_SKIP_COLG                                 /* diagnostic build: no column-direction gathers */
       X[a] = Pb[(long)min(row, i0) * ld + max(row, ii)];
 #else
@@ -1118,10 +1291,18 @@ __global__ __launch_bounds__(64 * NW) void k_panels(double* __restrict__ P, doub
   };
 #ifndef PANELS_SKIP_PEND                                  /* diagnostic build: no pending-rank gather */
   if (kb > 0) {                                        // (uniform) right after a covariance pass nothing is pending
-    if (o.cmax > i0) gather_pending(std::true_type{});
+    if (cmaxv > i0) gather_pending(std::true_type{});
     else gather_pending(std::false_type{});
   }
 #endif
+  if constexpr (SPLIT) {
+    if (early) {
+      // Wait for the solve of this trajectory (every wave for itself: some waves of the last block have left), then
+      // fetch its header and records from the mailbox -- every wave writes the same values into sH and sIt.
+      const bool ok = mailbox_fetch(sa.mbox + b, m, sa.ready + b, sa.seq, SPLIT_SPIN_LIMIT, &sH, sIt);
+      if (!ok && lane == 0) atomicOr(sa.flags + b, EKF_FLAG_INTERNAL);
+    }
+  }
   if (KSPLIT) {                                        // waves 1.. hand their partial sums to wave 0 and leave
     if (kw > 0) {
 #pragma unroll
@@ -1240,6 +1421,22 @@ __global__ __launch_bounds__(64 * NW) void k_panels(double* __restrict__ P, doub
   }
 }
 
+template <int MCAP, int NW, bool KSPLIT>
+__global__ __launch_bounds__(64 * NW) void k_panels(double* __restrict__ P, double* __restrict__ V,
+                                                    double* __restrict__ W, const double* __restrict__ mu_in,
+                                                    double* __restrict__ mu_out, const int* __restrict__ nact,
+                                                    const SolveOut* __restrict__ so,
+                                                    const double* __restrict__ fac, int ld, long pstride) {
+  panels_mono<MCAP, NW, KSPLIT, false>(P, V, W, mu_in, mu_out, nact, so, fac, ld, pstride, SplitArgs{});
+}
+template <int MCAP>
+__global__ __launch_bounds__(256, 2) void k_panels_split(double* __restrict__ P, double* __restrict__ V,
+                                                         double* __restrict__ W, const double* __restrict__ mu_in,
+                                                         double* __restrict__ mu_out, const int* __restrict__ nact,
+                                                         int ld, long pstride, SplitArgs sa) {
+  panels_mono<MCAP, 4, false, true>(P, V, W, mu_in, mu_out, nact, nullptr, nullptr, ld, pstride, sa);
+}
+
 // ---------------------------------------------------------------------------------------------
 // k_step_split: the whole step in ONE launch for launches of few workgroups (the latency regime: at most 512 waves
 // of state indices, where k_panels runs in its rank-split shape).  Workgroup 0 of a trajectory is the sequential solve
@@ -1248,18 +1445,18 @@ __global__ __launch_bounds__(64 * NW) void k_panels(double* __restrict__ P, doub
 // at C are staged by every panel workgroup for itself (scattered loads the idle CUs have time for) -- so base entries
 // and pending ranks are gathered while the chain runs.  Only then does a panel workgroup wait for its trajectory's
 // solve (release / acquire at device scope on a per-trajectory step counter: the solve's records travel through
-// global memory), replay the step on the gathered panel and write its ranks.  Every write of a panel workgroup
+// global memory; with this few workgroups the two L2 flushes are cheaper than the mailbox of k_panels_split: 19.0 us
+// per step against 21.1 us), replay the step on the gathered panel and write its ranks.  Every write of a panel workgroup
 // happens after that wait, so the solve never sees a half-written step.  A workgroup only ever waits for one with a
 // smaller linear index (dispatched before it), the wait is bounded, and a timeout raises EKF_FLAG_INTERNAL.
 // ---------------------------------------------------------------------------------------------
-constexpr int SPLIT_SPIN_LIMIT = 1 << 18;              // x (s_sleep + one load from L2): tens of milliseconds
 
 template <int MCAP>
 __global__ __launch_bounds__(256) void k_step_split(double* __restrict__ P, double* __restrict__ V,
                                                     double* __restrict__ W, const double* __restrict__ dacc_in,
                                                     double* __restrict__ dacc_out, const double* __restrict__ mu_in,
                                                     double* __restrict__ mu_out, const int* __restrict__ nact,
-                                                    const StepIn* __restrict__ in, SolveOut* __restrict__ out,
+                                                    const StepIn* __restrict__ in, SolveOut* out,
                                                     unsigned* __restrict__ flags, double* __restrict__ fac,
                                                     const int* __restrict__ neff_floor, unsigned* __restrict__ queue,
                                                     unsigned* __restrict__ ready, unsigned seq, int publish,
@@ -1280,7 +1477,7 @@ __global__ __launch_bounds__(256) void k_step_split(double* __restrict__ P, doub
   const int neff_eff = min(n, max(in[b].neff, neff_floor[b]));
   if (blockIdx.x == 0) {                               // ---- the solve of trajectory b ----
     if (b == 0 && tid < 8) queue[tid * RS_QSTRIDE] = 0u;   // (see k_solve)
-    solve_body(U.L, P + (long)b * pstride, V + (long)b * KTOT * ld, W + (long)b * KTOT * ld, dacc_in + 4 * b,
+    solve_body(U.L, U.L.fac_view(), P + (long)b * pstride, V + (long)b * KTOT * ld, W + (long)b * KTOT * ld, dacc_in + 4 * b,
                dacc_out + 4 * b, mu_in + (long)b * ld, mu_out + (long)b * ld, in[b], out[b], out[b].it, flags + b,
                fac + (long)b * FACS, cfg, ld, kbase, true, neff_eff);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); // this wave's stores are visible device-wide ...
@@ -2542,10 +2739,9 @@ static void launch_panels_t(hipStream_t st, double* P, double* V, double* W, con
     hipLaunchKernelGGL((k_panels<MCAP, 4, true>), dim3((n_hi + 63) / 64, batch), dim3(256), 0, st, P, V, W, mu_in,
                        mu_out, nact, so, fac, ld, pstride);
   else
-    hipLaunchKernelGGL((k_panels<MCAP, 4, false>), dim3((n_hi + 255) / 256, batch), dim3(256), 0, st, P, V, W, mu_in,
-                       mu_out, nact, so, fac, ld, pstride);
+    hipLaunchKernelGGL((k_panels<MCAP, 4, false>), dim3((n_hi + 255) / 256, batch), dim3(256), 0, st, P, V, W,
+                       mu_in, mu_out, nact, so, fac, ld, pstride);
 }
-
 void launch_panels(hipStream_t st, int mcap, double* P, double* V, double* W, const double* mu_in,
                    double* mu_out, const int* nact, const SolveOut* so, const double* fac, int ld, long pstride,
                    int batch, int n_hi) {
@@ -2556,6 +2752,26 @@ void launch_panels(hipStream_t st, int mcap, double* P, double* V, double* W, co
     case 8: launch_panels_t<8>(st, P, V, W, mu_in, mu_out, nact, so, fac, ld, pstride, batch, n_hi); break;
     default: launch_panels_t<16>(st, P, V, W, mu_in, mu_out, nact, so, fac, ld, pstride, batch, n_hi); break;
   }
+}
+
+// The throughput shape of the single-launch step: k_panels<.., SPLIT> (see there).
+void launch_step_split_tp(hipStream_t st, int mcap, double* P, double* V, double* W, const double* dacc_in,
+                          double* dacc_out, const double* mu_in, double* mu_out, const int* nact, const StepIn* in,
+                          SolveOut* out, unsigned* flags, double* fac, const int* neff_floor, unsigned* queue,
+                          SolveOut* mbox, unsigned* ready, unsigned seq, int publish, const DeviceConfig& cfg, int ld,
+                          long pstride, int batch, int n_hi, int kbase) {
+  const dim3 grid(1 + (n_hi + 255) / 256, batch);
+  SplitArgs sa{dacc_in, dacc_out, in, out, flags, fac, neff_floor, queue, mbox, ready, seq, publish, kbase, cfg};
+#define EKF_SPLIT_TP(M)                                                                                              \
+  hipLaunchKernelGGL((k_panels_split<M>), grid, dim3(256), 0, st, P, V, W, mu_in, mu_out, nact, ld, pstride, sa)
+  switch (mcap) {
+    case 1: EKF_SPLIT_TP(1); break;
+    case 2: EKF_SPLIT_TP(2); break;
+    case 4: EKF_SPLIT_TP(4); break;
+    case 8: EKF_SPLIT_TP(8); break;
+    default: break;                                    // (16 landmarks per pass: registers for one wave per SIMD only; the caller
+  }                                                    //  takes the two-launch path)
+#undef EKF_SPLIT_TP
 }
 
 // Whether a step of this shape is run as one launch (the latency regime, see k_step_split): while every panel

@@ -236,3 +236,14 @@ def test_single_launch_step_wait_is_bounded(sd):
         f.set_state_diag(mean0, diag0)             # (the step above left garbage)
         f.step(lin[0], ang[0], idx[0], zr[0], zb[0])
         assert np.isfinite(f.mean()).all()
+    # the same for the throughput shape (k_panels_split: the counter travels with the mailbox)
+    N, B = 1200, 16
+    streams = [orc.synthetic_stream(N, 2, 8, 80 + t) for t in range(B)]
+    with sd.EkfSlam(3 + 2 * N, batch=B) as f:
+        for b, s in enumerate(streams):
+            f.set_state_diag(s[0], s[1], b)
+        f.set_option("fused_step", 2)
+        f.step([s[2][0] for s in streams], [s[3][0] for s in streams], [s[4][0] for s in streams],
+               [s[5][0] for s in streams], [s[6][0] for s in streams])
+        f.sync()
+        assert all(f.flags(b) & 4 for b in range(B))

@@ -720,3 +720,39 @@ def test_single_launch_step_is_bit_identical(sd):
         assert np.array_equal(out[0, "mid"][b], out[1, "mid"][b])
         assert np.array_equal(out[0, "end"][b][0], out[1, "end"][b][0])
         assert np.array_equal(out[0, "end"][b][1], out[1, "end"][b][1])
+
+
+def test_single_launch_step_throughput_shape_is_bit_identical(sd):
+    """Mid-size batches (more than 512 waves of state indices, but room on the chip for one more workgroup per
+    trajectory) run a step as k_panels_split: workgroup 0 of a trajectory solves, the others gather their panels
+    meanwhile and fetch the solve's header and records from the mailbox.  Same results as the two-launch path bit for
+    bit (16 trajectories of different sizes, active bound on and off), and the reference's for one of them."""
+    N, B, m, steps = 1200, 16, 8, 8
+    streams = [orc.synthetic_stream(N, steps, m, 70 + t) for t in range(B)]
+    sizes = [3 + 2 * (N - 37 * (t % 5)) for t in range(B)]
+    out = {}
+    for bound in (0, 1):
+        for fused in (0, 1):
+            with sd.EkfSlam(3 + 2 * N, batch=B) as f:
+                f.set_option("fused_step", fused)
+                f.set_option("active_bound", bound)
+                for b, s in enumerate(streams):
+                    f.set_state_diag(s[0][:sizes[b]], s[1][:sizes[b]], b)
+                for k in range(steps):
+                    idx = [s[4][k] % ((sizes[b] - 3) // 2) for b, s in enumerate(streams)]
+                    f.step([s[2][k] for s in streams], [s[3][k] for s in streams], idx,
+                           [s[5][k] for s in streams], [s[6][k] for s in streams])
+                out[bound, fused] = [f.state(b) for b in (0, 3, 7, 15)] + [f.mean(b) for b in range(B)]
+                assert [f.flags(b) for b in range(B)] == [0] * B
+        for x, y in zip(out[bound, 0], out[bound, 1]):
+            if isinstance(x, tuple):
+                assert np.array_equal(x[0], y[0]) and np.array_equal(x[1], y[1])
+            else:
+                assert np.array_equal(x, y)
+    cfg = orc.EkfConfig()
+    s = streams[0]
+    om, oP = s[0].copy(), np.diag(s[1])
+    for k in range(steps):
+        om, oP = orc.ekf_step_structured(om, oP, s[2][k], s[3][k], s[4][k], s[5][k], s[6][k], cfg)
+    close(out[0, 1][0][0], om)
+    close(out[0, 1][0][1], oP)
