@@ -2127,7 +2127,7 @@ __global__ __launch_bounds__(512, 2) void k_flush_rs(double* __restrict__ P, con
                                                      const double* __restrict__ dacc,
                                                      const int* __restrict__ nact,
                                                      const SolveOut* __restrict__ so, int ld, long pstride,
-                                                     int nkt, int batch, int nrb, int nch, int cs_arg, int pair,
+                                                     int nkt, int batch, int nrb, int nch, int cs_arg, int mode,
                                                      unsigned* __restrict__ queue) {
   constexpr int RPW = NKT / 2;                         // ranks of a V strip each of the 8 waves stages
   __shared__ __attribute__((aligned(16))) double vbuf[2][NKT * 256];   // V strip as B fragments: [k-tile][col tile][lane]
@@ -2161,21 +2161,38 @@ __global__ __launch_bounds__(512, 2) void k_flush_rs(double* __restrict__ P, con
   int unit_no = -1;
 #endif
   bool own_empty = false;
-  // Queue g2 (one per XCD) holds the trajectories g2, g2 + 8, ...
-  //   pair form (batches of 8 and more, unless "pass_chunk" is set): one trajectory after the other, whole slabs longest
-  //     first -- the workgroup that got the longest slab of one trajectory gets the shortest of the next -- and if
-  //     their number is odd the last of them finds no partner: its slabs, only they, are cut into `nch` chunks;
-  //   uniform form: every slab of every trajectory in `nch` chunks, chunk-major.
-  //   (Dealing the slabs of the batch-modulo-8 last trajectories over all queues was measured too: no better.)
+  // The units of queue g2 (one queue per XCD), by `mode`:
+  //   0  uniform ("pass_chunk" set, or fewer than 8 trajectories): trajectories g2, g2 + 8, ..., every slab in `nch`
+  //      chunks, chunk-major;
+  //   1  pairs (batch a multiple of 8): trajectories g2, g2 + 8, ... one after the other, whole slabs longest
+  //      first -- the workgroup that got the longest slab of one trajectory gets the shortest of the next; the last of
+  //      an odd number (8 trajectories: the only one) has no partner and its slabs, only they, are cut into `nch` chunks;
+  //   2  dealt (any other batch): the queue's own trajectories among the first 8 * (batch / 8), plus the slabs
+  //      rb = (g2 - j) mod 8, + 8, ... of each of the batch-modulo-8 last trajectories j -- every queue carries the same
+  //      work -- whole slabs, longest first over ALL of them (slab index major): list scheduling in that order is
+  //      as good as the longest slab allows; the price is that an XCD walks the V strips of several trajectories at
+  //      once (1-3 % on the batches where mode 1 applies, hence not used there).  N=2000, 20 trajectories: 496 us
+  //      against 524 us with mode 1, 28: 662 against 700; 24 (mode 1): 560 against 584 with mode 2.
   // A unit comes back as (trajectory * nrb + slab) * 1024 + chunk, chunk = 1023 for a whole slab.
+  const int nfull = batch >> 3, nleft = batch & 7;
   auto pop = [&]() -> int {
     int found = -1;
     for (int a = 0; a < 8 && found < 0; ++a) {
       const int g2 = (grp + a) & 7;
-      const int tq = (g2 < batch) ? ((batch - g2 + 7) >> 3) : 0;
-      const int lone = (pair && (tq & 1)) ? 1 : 0;
-      const int whole = pair ? (tq - lone) * nrb : 0;
-      const int cnt = pair ? whole + lone * upt : tq * upt;
+      int cnt, tq = 0, whole = 0;
+      if (mode == 2) {
+        int dealt = 0;                                 // slabs rb < nrb with ((g2 - rb) & 7) < nleft
+        for (int j = 0; j < nleft; ++j) {
+          const int r0 = (g2 - j) & 7;
+          dealt += (r0 < nrb) ? ((nrb - r0 + 7) >> 3) : 0;
+        }
+        cnt = nfull * nrb + dealt;
+      } else {
+        tq = (g2 < batch) ? ((batch - g2 + 7) >> 3) : 0;
+        const int lone = (mode == 1 && (tq & 1)) ? 1 : 0;
+        whole = mode == 1 ? (tq - lone) * nrb : 0;
+        cnt = mode == 1 ? whole + lone * upt : tq * upt;
+      }
       if (cnt == 0) continue;
       unsigned* head = queue + g2 * RS_QSTRIDE;
       if (a > 0 || own_empty) {
@@ -2184,10 +2201,23 @@ __global__ __launch_bounds__(512, 2) void k_flush_rs(double* __restrict__ P, con
       const unsigned u = atomicAdd(head, 1u);
       if (u < (unsigned)cnt) {
         int r = (int)u;
-        if (!pair) {
+        if (mode == 0) {
           const int t = r / upt;
           r -= t * upt;
           found = ((g2 + 8 * t) * nrb + r % nrb) * 1024 + (nch > 1 ? r / nrb : 1023);
+        } else if (mode == 2) {
+          // slab-index major: a block of 8 consecutive slabs holds 8 * nfull own units and nleft dealt ones
+          const int per = 8 * nfull + nleft, blk = r / per;
+          r -= blk * per;
+          for (int i = 0; i < 8; ++i) {
+            const int rb = 8 * blk + i, j = (g2 - rb) & 7;
+            const int ci = nfull + (j < nleft ? 1 : 0);
+            if (r < ci) {
+              found = ((r < nfull ? g2 + 8 * r : 8 * nfull + j) * nrb + rb) * 1024 + 1023;
+              break;
+            }
+            r -= ci;
+          }
         } else if (r < whole) {
           found = ((g2 + 8 * (r / nrb)) * nrb + r % nrb) * 1024 + 1023;
         } else {
@@ -2856,24 +2886,27 @@ static void launch_flush_rs_t(hipStream_t st, double* P, const double* V, const 
                               const int* nact, const SolveOut* so, int ld, long pstride, int batch, int n_hi, int nkt,
                               int workgroups, unsigned* queue, int chunk) {
   const int nrb = (n_hi + RS_ROWS - 1) / RS_ROWS;
-  // Units.  The workgroups of an XCD take the slabs of their queue's trajectories in order (trajectory by trajectory,
-  // longest slab first): with an even number of trajectories per queue the workgroup that got the longest slab of one
-  // trajectory gets the shortest of the next, and whole slabs balance perfectly (16 trajectories: 366 us against
-  // 430 us in chunks of 22 strips); with an odd number (8 trajectories: one per queue; 17-24: three) the last
-  // trajectory of the queue finds no partner, and its slabs -- only its -- are cut in two (N=2000: 8 trajectories 203 us
-  // against 256 us with the former rule and 328 us whole; 24: 557 us against 668 us) -- profiles/r02_chunk_sweep.txt.
-  // Below 8 trajectories (the row-slab kernel then only runs for long ones, N=8000) every slab is cut so that there are
-  // about three units per CU.
+  // Units (see the three modes at k_flush_rs's `pop`).  With an even number of trajectories per queue whole slabs taken
+  // trajectory by trajectory balance perfectly (16 trajectories: 366 us against 430 us in chunks of 22 strips); the
+  // last trajectory of an odd number finds no partner and its slabs -- only they -- are cut in two (N=2000: 8
+  // trajectories 203 us against 256 us with the former rule and 328 us whole; 24: 557 us against 668 us); a batch that
+  // is no multiple of 8 would leave the queues with unequal work, so its last trajectories are dealt over all queues
+  // slab by slab -- profiles/r02_chunk_sweep.txt, profiles/r02_batch_sweep.txt.  Below 8 trajectories (the row-slab
+  // kernel then only runs for long ones, N=8000) every slab is cut so that there are about three units per CU.
   const int s_max = (n_hi + 63) / 64;                  // strips of the longest slab
-  int cs = s_max, nch = 1, pair = 0;
+  int cs = s_max, nch = 1, mode = 0;
   if (chunk > 0) {                                     // ("pass_chunk" option: every slab of every trajectory)
     cs = std::min(std::max(chunk, 1), s_max);
     nch = (s_max + cs - 1) / cs;
-  } else if (batch >= 8) {                             // the unpaired trajectory of a queue: slabs cut in two
-    if (s_max >= 4) {
-      cs = (s_max + 1) / 2;
-      nch = 2;
-      pair = 1;
+  } else if (batch >= 8) {
+    if (batch % 8 == 0) {                              // pairs; an unpaired trajectory (8: each queue's only one) cut in two
+      mode = 1;
+      if (s_max >= 4) {
+        cs = (s_max + 1) / 2;
+        nch = 2;
+      }
+    } else {
+      mode = 2;                                        // equal work per queue, longest slabs first
     }
   } else {                                             // a few long trajectories (N=8000): about three units per CU
     long steps = 0;
@@ -2884,9 +2917,9 @@ static void launch_flush_rs_t(hipStream_t st, double* P, const double* V, const 
       nch = (s_max + cs - 1) / cs;
     }
   }
-  const long units = (long)nrb * (pair ? 1 : nch) * batch;   // (pair: at least; only the grid size depends on it)
+  const long units = (long)nrb * (mode ? 1 : nch) * batch;   // (modes 1, 2: at least; only the grid size depends on it)
   hipLaunchKernelGGL((k_flush_rs<NKT, NT>), dim3((unsigned)std::min<long>(workgroups, units)), dim3(512), 0, st, P, V, W,
-                     dacc, nact, so, ld, pstride, nkt, batch, nrb, nch, cs, pair, queue);
+                     dacc, nact, so, ld, pstride, nkt, batch, nrb, nch, cs, mode, queue);
 }
 
 void launch_flush_rs(hipStream_t st, bool streaming, double* P, const double* V, const double* W, const double* dacc,
