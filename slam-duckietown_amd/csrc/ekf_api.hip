@@ -29,6 +29,7 @@ void launch_flush_pc(hipStream_t, bool, double*, const double*, const double*, c
 void launch_flush_rs(hipStream_t, bool, double*, const double*, const double*, const double*, const int*,
                      const SolveOut*, int, long, int, int, int, int, unsigned*, int);
 int flush_rs_queue_words();
+int debug_pass_units(int batch, int nrb, int nch, int mode, int* out, int cap);
 void launch_predict_rc(hipStream_t, double*, const double*, double*, const int*, const SolveOut*, int, long,
                        int, int);
 void launch_add_landmarks(hipStream_t, double*, double*, int, int, int, double, const double*);
@@ -1001,6 +1002,13 @@ extern "C" int ekf_debug_read(ekf_handle* h, void* dst, long bytes) {
   const long have = (long)sizeof(unsigned) * flush_rs_queue_words();
   HIP_TRY(h, hipMemcpy(dst, h->dqueue, (size_t)std::min(bytes, have), hipMemcpyDeviceToHost));
   return EKF_OK;
+}
+
+// (development aid, not declared in the header; no device needed) the units of the row-slab pass's work queues in
+// hand-out order for a batch of `batch` trajectories of `nrb` slabs: what tests/test_cpu_host.py checks for coverage
+extern "C" int ekf_debug_pass_units(int batch, int nrb, int nch, int mode, int* out, int cap) {
+  if (batch < 1 || nrb < 1 || nch < 1 || mode < 0 || mode > 2 || (cap > 0 && !out)) return -1;
+  return debug_pass_units(batch, nrb, nch, mode, out, cap);
 }
 
 extern "C" int ekf_last_pass(ekf_handle* h, int* kernel, int* k_tiles, int* streaming) {

