@@ -1007,7 +1007,7 @@ extern "C" int ekf_debug_read(ekf_handle* h, void* dst, long bytes) {
 // (development aid, not declared in the header; no device needed) the units of the row-slab pass's work queues in
 // hand-out order for a batch of `batch` trajectories of `nrb` slabs: what tests/test_cpu_host.py checks for coverage
 extern "C" int ekf_debug_pass_units(int batch, int nrb, int nch, int mode, int* out, int cap) {
-  if (batch < 1 || nrb < 1 || nch < 1 || mode < 0 || mode > 2 || (cap > 0 && !out)) return -1;
+  if (batch < 1 || nrb < 1 || nch < 1 || mode < 0 || mode > 3 || (cap > 0 && !out)) return -1;
   return debug_pass_units(batch, nrb, nch, mode, out, cap);
 }
 

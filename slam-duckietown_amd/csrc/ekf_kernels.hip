@@ -2134,11 +2134,15 @@ __device__ __forceinline__ void stb16(__amdgpu_buffer_rsrc_t rs, unsigned lane_b
 //      as good as the longest slab allows; the price is that an XCD walks the V strips of several trajectories at
 //      once (1-3 % on the batches where mode 1 applies, hence not used there).  N=2000, 20 trajectories: 496 us
 //      against 524 us with mode 1, 28: 662 against 700; 24 (mode 1): 560 against 584 with mode 2.
+//   3  dealt halves (8 < batch <= 12, where one trajectory per queue leaves a workgroup less than two slabs): as mode 2,
+//      but every slab in two chunks of cs = 2 h strips; chunk 1 of slab rb is as long as slab rb + h, so handing out
+//      "chunk 0 of slab v, chunk 1 of slab v - h" for v = 0, 1, ... is again longest first.  (`nch` carries h.)
 // A unit is (trajectory * nrb + slab) * 1024 + chunk, chunk = 1023 for a whole slab.  Plain integer functions, also
 // compiled for the host: tests/test_cpu_host.py enumerates them through ekf_debug_pass_units and checks that every
 // (trajectory, slab, chunk) comes exactly once.
 __host__ __device__ inline int rs_queue_count(int g2, int batch, int nrb, int nch, int mode) {
   const int upt = nrb * nch;
+  if (mode == 3) return 2 * rs_queue_count(g2, batch, nrb, 1, 2);
   if (mode == 2) {
     const int nfull = batch >> 3, nleft = batch & 7;
     int dealt = 0;                                     // slabs rb < nrb with ((g2 - rb) & 7) < nleft
@@ -2156,6 +2160,20 @@ __host__ __device__ inline int rs_queue_count(int g2, int batch, int nrb, int nc
 __host__ __device__ inline int rs_queue_unit(int g2, int u, int batch, int nrb, int nch, int mode) {
   const int upt = nrb * nch;
   int r = u;
+  if (mode == 3) {
+    const int nfull = batch >> 3, nleft = batch & 7, h = nch;
+    for (int v = 0; v < nrb + h; ++v) {                // (a few dozen iterations, once per unit, one thread)
+      for (int chunk = 0; chunk < 2; ++chunk) {
+        const int rb = v - chunk * h;
+        if (rb < 0 || rb >= nrb) continue;
+        const int j = (g2 - rb) & 7;
+        const int ci = nfull + (j < nleft ? 1 : 0);
+        if (r < ci) return ((r < nfull ? g2 + 8 * r : 8 * nfull + j) * nrb + rb) * 1024 + chunk;
+        r -= ci;
+      }
+    }
+    return -1;                                         // (not reached for u < rs_queue_count)
+  }
   if (mode == 0) {
     const int t = r / upt;
     r -= t * upt;
@@ -2923,6 +2941,11 @@ static void launch_flush_rs_t(hipStream_t st, double* P, const double* V, const 
         cs = (s_max + 1) / 2;
         nch = 2;
       }
+    } else if (batch <= 12 && s_max >= 8) {             // (N=2000: 9 trajectories 253 us against 329 us whole, 10: 284 / 333,
+                                                       //  12: 327 / 342; 14: 360 / 344 -- from 13 on whole slabs)
+      mode = 3;                                        // equal work per queue, half slabs, longest first
+      nch = (s_max + 3) / 4;                           // h: half a chunk; chunks of cs = 2 h strips
+      cs = 2 * nch;
     } else {
       mode = 2;                                        // equal work per queue, longest slabs first
     }
@@ -2935,7 +2958,7 @@ static void launch_flush_rs_t(hipStream_t st, double* P, const double* V, const 
       nch = (s_max + cs - 1) / cs;
     }
   }
-  const long units = (long)nrb * (mode ? 1 : nch) * batch;   // (modes 1, 2: at least; only the grid size depends on it)
+  const long units = (long)nrb * (mode == 0 ? nch : mode == 3 ? 2 : 1) * batch;   // (modes 1, 2: at least; only the grid size depends on it)
   hipLaunchKernelGGL((k_flush_rs<NKT, NT>), dim3((unsigned)std::min<long>(workgroups, units)), dim3(512), 0, st, P, V, W,
                      dacc, nact, so, ld, pstride, nkt, batch, nrb, nch, cs, mode, queue);
 }

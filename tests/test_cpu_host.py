@@ -230,7 +230,8 @@ def test_every_entry_point_selects_its_device():
 
 def test_row_slab_pass_hands_out_every_unit_exactly_once(sd):
     """The work queues of the row-slab covariance pass (k_flush_rs): whatever the batch, the number of 128-row slabs and
-    the mode (0 uniform chunks, 1 pairs with the unpaired trajectory cut, 2 last trajectories dealt over the queues),
+    the mode (0 uniform chunks, 1 pairs with the unpaired trajectory cut, 2 last trajectories dealt over the queues,
+    3 the same in half slabs),
     the eight queues together hand out every (trajectory, slab) exactly once -- as one whole slab or as all of its
     chunks.  The integer functions are the ones the kernel calls (`__host__ __device__`), reached here through an
     undeclared test hook of the library; no device needed."""
@@ -242,12 +243,14 @@ def test_row_slab_pass_hands_out_every_unit_exactly_once(sd):
     buf = (C.c_int * 70000)()
     for batch in list(range(1, 42)) + [64, 100]:
         for nrb in (1, 2, 5, 7, 8, 9, 15, 16, 17, 32, 126):
-            for nch, mode in ((1, 0), (2, 0), (3, 0), (2, 1), (1, 2)):
+            for nch, mode in ((1, 0), (2, 0), (3, 0), (2, 1), (1, 2), (1, 3), (3, 3), (8, 3), (16, 3)):
                 total = fn(batch, nrb, nch, mode, buf, len(buf))
                 assert 0 < total <= len(buf)
                 units = np.frombuffer(buf, dtype=np.int32, count=total)
                 assert (units >= 0).all()
                 code, slab = units & 1023, units >> 10
+                if mode == 3:
+                    nch = 2                                     # (mode 3: `nch` carried half the chunk length; two chunks)
                 traj, rb = slab // nrb, slab % nrb
                 assert traj.max() == batch - 1 and traj.min() == 0
                 whole = code == 1023
