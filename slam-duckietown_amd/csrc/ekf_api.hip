@@ -455,7 +455,17 @@ static int flush_workgroups(int n_hi, int rows_per_block) {
 static int flush_rows_per_block(const ekf_handle* h, bool streaming, int n_hi) {
   if (h->opt_rows_per_block > 0) return (h->opt_rows_per_block + 15) / 16 * 16;
   const long cus = h->cu_count;
-  if (streaming && (long)flush_workgroups(n_hi, 256) * h->batch >= 4 * cus) return 256;
+  if (streaming && (long)flush_workgroups(n_hi, 256) * h->batch >= 4 * cus) {
+    // 256 rows, or 512 where that fills its rounds of 2 x CUs workgroups better (N=8000, 1 trajectory: 1024 workgroups
+    // = two full rounds, 421 us against 454 us with 256 rows = 2016 workgroups; 2 trajectories 840 / 852 us)
+    const long slots = 2 * cus;
+    auto fill = [&](int r) {
+      const long w = (long)flush_workgroups(n_hi, r) * h->batch;
+      return (double)w / (double)((w + slots - 1) / slots * slots);
+    };
+    if ((long)flush_workgroups(n_hi, 512) * h->batch >= 2 * slots && fill(512) > fill(256) + 0.01) return 512;
+    return 256;
+  }
   if ((long)flush_workgroups(n_hi, 96) * h->batch > 5 * cus / 2) return 96;
   int best = 96;
   double best_cost = 0.0;
