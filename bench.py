@@ -255,6 +255,8 @@ def main():
                                  "(DESIGN.md section 4), see `mfma`"},
             "device_ms_per_step": dev_ms / args.steps,
         }
+        if os.environ.get("EKFSLAM_HIP_VARIANT"):      # a diagnostic build of the library was timed: not a product number
+            out["library_variant"] = os.environ["EKFSLAM_HIP_VARIANT"]
         out["roofline"].update(pmc_traffic(f"N{args.landmarks}_B{B}", args.option))
     if world == 1 and rank == 0:
         if not args.no_single:

@@ -26,10 +26,18 @@ extern "C" {
 #define EKF_ERR_STATE (-3)    /* call not valid in the current state */
 
 #define EKF_MMAX 16           /* max landmarks per single device update pass (longer lists are split) */
+#define EKF_N_MAX_LIMIT 23167 /* largest n_max = 3 + 2N ekf_create accepts (N = 11582): the kernels address one
+                                 covariance with unsigned 32-bit byte offsets, so its padded rows x ld x 8 bytes
+                                 must stay below 4 GiB; larger values fail with EKF_ERR_ARG */
 
 /* sticky per-trajectory flags, ekf_status_flags() */
 #define EKF_FLAG_NONFINITE 1u /* a non-finite mean entry was produced (q = 0 at :466-469, singular S at :473) */
-#define EKF_FLAG_INTERNAL 4u  /* a bounded wait inside the covariance pass timed out (must never happen) */
+#define EKF_FLAG_INTERNAL 4u  /* a bounded wait inside a single-launch step timed out (the GPU did not run the solve
+                                 workgroup of the launch beside its panel workgroups for tens of ms).  The timed-out
+                                 workgroups write nothing, so that step did not happen as a whole and the trajectory's
+                                 state is undefined from there on: ekf_sync and ekf_download_* return EKF_ERR_STATE while
+                                 the flag is set.  Recovery: upload the trajectory again (ekf_upload_state* clears the
+                                 flag); ekf_set_option("fused_step", 0) selects the two-launch step, which has no wait. */
 #define EKF_FLAG_ASSOC 2u     /* device-side association dropped a detection: tag id outside [0, 1024), state full,
                                  or more than EKF_MMAX distinct tags in one window */
 #define EKF_DMAX 64           /* detections per window for ekf_step_detections */
@@ -123,7 +131,9 @@ int ekf_predict_dense(ekf_handle *h, int b, const double *F, const double *Q);
  * applies what is pending now (asynchronous).  Every call that reads or rewrites the covariance flushes by
  * itself. */
 int ekf_flush(ekf_handle *h);
+/* Wait for everything enqueued.  EKF_ERR_STATE if any trajectory carries EKF_FLAG_INTERNAL (ekf_last_error names it). */
 int ekf_sync(ekf_handle *h);
+/* The sticky flags of trajectory b (always EKF_OK for a valid b: this is how a failed trajectory is identified). */
 int ekf_status_flags(ekf_handle *h, int b, unsigned *flags);
 
 /* Message of the last failure on this handle (h == NULL: last failure of ekf_create). */
@@ -138,9 +148,8 @@ int ekf_profile_read(ekf_handle *h, double *pass_ms_total, long long *pass_launc
 /* Tuning knobs: "flush_every" (steps per covariance pass, 0 = auto), "rank_limit" (auto cadence: pending
  * ranks that trigger the pass, 2..80), "pass_rows_per_block", "pass_streaming" (-1 auto / 0 resident /
  * 1 nontemporal), "active_bound" (0 = treat every state index as correlated), "pass_kernel" (-1 = auto:
- * the row-slab kernel for batches that stream through HBM and fill every CU, else k_flush; 0 = k_flush,
- * 1 = k_flush_pc, the producer/consumer form, 2 = k_flush_rs, the row-slab form; all give the same result
- * bit for bit), "pass_chunk" (row-slab pass: strips per work unit, 0 = auto), "pass_workgroups" (row-slab pass:
+ * the row-slab kernel where the launch streams through HBM and gives every CU work, else k_flush; 0 = k_flush, the
+ * column-strip form, 2 = k_flush_rs, the row-slab form; both give the same result bit for bit), "pass_chunk" (row-slab pass: strips per work unit, 0 = auto), "pass_workgroups" (row-slab pass:
  * persistent workgroups, 0 = one per CU; fewer leaves whole CUs to other streams), "fused_step" (1 = small launches
  * run a step as one kernel, the panels gathered beside the solve -- same results; 0 = always two kernels; 2 =
  * diagnostic: the solve never publishes its completion, every bounded wait times out with EKF_FLAG_INTERNAL);

@@ -9,7 +9,8 @@ lifted with ``ast`` -- FunctionDef nodes plus the upper-case module constants --
 and executed unmodified against NumPy:
 
   src/replay_no_ros.py : EKF_pose_estimation (:269-482), delta_phi (:250-266),
-                         displacement (:484-497), flags (:15-36), and the offline
+                         displacement (:484-497), flags (:15-36, incl. IGNORE_TAGS :36-37 and
+                         ENABLE_GOD_EKF / GOD_SECRET_KEY :23-26), and the offline
                          loop replay (:66-248) with its I/O boundary replaced
                          (frames looked up in a table instead of cv2 + dt_apriltags,
                          plot_path recording its arguments instead of drawing)
@@ -251,11 +252,20 @@ def make_events_csv(seed: int, duration: float, n_tags: int):
     return text, frames
 
 
-def run_reference_replay(slam, text, frames, tmpdir, fast_mode=False):
+def events_tag_ids(seed: int, n_tags: int):
+    """The tag ids make_events_csv(seed, ., n_tags) gives its landmarks, in landmark order (its first two draws)."""
+    rng = np.random.default_rng(seed)
+    rng.uniform(-1.0, 1.2, n_tags); rng.uniform(-0.9, 1.1, n_tags)
+    return [int(t) for t in rng.permutation(np.arange(10, 10 + 4 * n_tags))[:n_tags]]
+
+
+def run_reference_replay(slam, text, frames, tmpdir, fast_mode=False, god_key=None):
     """Execute the reference's own replay() (src/replay_no_ros.py:66-248) on the synthetic log.  Its I/O
     boundary is replaced: frames are looked up in `frames` instead of cv2.imread + dt_apriltags
     (:587-597), and plot_path (:499-580) records what it is handed instead of drawing.
-    fast_mode: the reference's ENABLE_FAST_MODE (:32, :122-123, :216-227)."""
+    fast_mode: the reference's ENABLE_FAST_MODE (:32, :122-123, :216-227).
+    god_key: ENABLE_GOD_EKF = True with GOD_SECRET_KEY = god_key (:23-26, :140-157): at the `landmarks` event the
+    state is pre-sized with the true positions at zero variance and TAG_INDEX maps god_key[i] -> i."""
     os.makedirs(tmpdir, exist_ok=True)
     with open(os.path.join(tmpdir, "events.csv"), "w") as fh:
         fh.write(text)
@@ -272,11 +282,14 @@ def run_reference_replay(slam, text, frames, tmpdir, fast_mode=False):
         rec["tag_index"] = dict(tag_index)
 
     saved = {k: slam.get(k) for k in ("load_grayscale", "detect_tags", "plot_path", "plt", "visualize_bounding_boxes",
-                                      "ENABLE_CAMERA_VISUALIZATION", "os", "image_list", "print", "ENABLE_FAST_MODE")}
+                                      "ENABLE_CAMERA_VISUALIZATION", "os", "image_list", "print", "ENABLE_FAST_MODE",
+                                      "ENABLE_GOD_EKF", "GOD_SECRET_KEY")}
     slam.update(load_grayscale=lambda path: path, detect_tags=fake_detect, plot_path=fake_plot,
                 plt=SimpleNamespace(pause=lambda *_a: None), visualize_bounding_boxes=lambda *_a: None,
                 ENABLE_CAMERA_VISUALIZATION=False, os=os, image_list=[], print=lambda *_a: None,
                 ENABLE_FAST_MODE=bool(fast_mode))
+    if god_key is not None:
+        slam.update(ENABLE_GOD_EKF=True, GOD_SECRET_KEY=list(god_key))
     try:
         slam["replay"](tmpdir)
     finally:
@@ -390,6 +403,17 @@ def main():
              flag_circular=np.bool_(flags["ENABLE_CIRCULAR_INTERPOLATION"]),
              flag_no_motion=np.bool_(flags["DISABLE_MOTION_MODEL"]), **out)
 
+    # 1b. IGNORE_TAGS (:36-37, :286): two of the scenario's tags are dropped before the gate, so they never get a
+    # landmark index.  The detections themselves (ignored ones included) are the fixture's inputs.
+    lin, ang, rec = replay_scenario(105, 40, 7, False)
+    seen_ids = list(dict.fromkeys(int(t) for t in rec["tag_id"]))
+    ignore = [seen_ids[1], seen_ids[4]]
+    out = run_replay(slam, lin, ang, rec, dict(base_flags, IGNORE_TAGS=list(ignore)))
+    assert not set(ignore) & {int(t) for t, _ in out["out_tag_index"]} and len(out["out_tag_index"]) == len(seen_ids) - 2
+    save("replay_ignore_tags", lin=lin, ang=ang, det_step=rec["step"], det_frame=rec["frame"], det_tag_id=rec["tag_id"],
+         det_pose_t=rec["pose_t"], det_err=rec["err"], flag_measurement=np.bool_(True), flag_circular=np.bool_(True),
+         flag_no_motion=np.bool_(False), ignore_tags=np.array(ignore, dtype=np.int64), **out)
+
     # 2. synthetic stream: config 1 (N=20, 500 steps), N=50, N=500 (rows + sums only)
     save("stream_n20_m8", **run_stream(slam, 20, 500, 8, keep_every=25))
     save("stream_n20_m1", **run_stream(slam, 20, 100, 1, keep_every=25))
@@ -426,6 +450,13 @@ def main():
     with tempfile.TemporaryDirectory() as tmp:
         rec_fast = run_reference_replay(slam, text, frames, tmp, fast_mode=True)
     save("replay_events_fast", **pack_replay(rec_fast))
+
+    # 2c'. the same log with ENABLE_GOD_EKF (:23-26, :140-157): GOD_SECRET_KEY = the log's tag ids in landmark order.
+    god_key = events_tag_ids(5, 9)
+    with tempfile.TemporaryDirectory() as tmp:
+        rec_god = run_reference_replay(slam, text, frames, tmp, god_key=god_key)
+    assert all(len(m) == 3 + 2 * 9 for m in rec_god["mean"]) and rec_god["tag_index"] == {t: i for i, t in enumerate(god_key)}
+    save("replay_events_god", god_key=np.array(god_key, dtype=np.int64), **pack_replay(rec_god))
 
     # 2d. Vicon ground-truth alignment on the recorded data
     if not only or "vicon_alignment" in only:

@@ -24,8 +24,6 @@ void launch_panels(hipStream_t, int, double*, double*, double*, const double*, d
                    const SolveOut*, const double*, int, long, int, int);
 void launch_flush(hipStream_t, bool, double*, const double*, const double*, const double*, const int*,
                   const SolveOut*, int, long, int, int, int, int);
-void launch_flush_pc(hipStream_t, bool, double*, const double*, const double*, const double*, const int*,
-                     const SolveOut*, int, long, int, int, int, int, unsigned*);
 void launch_flush_rs(hipStream_t, bool, double*, const double*, const double*, const double*, const int*,
                      const SolveOut*, int, long, int, int, int, int, unsigned*, int);
 int flush_rs_queue_words();
@@ -91,7 +89,7 @@ struct ekf_handle {
   size_t prof_used = 0;
   int opt_rank_limit = KTOT;      // automatic cadence: flush when the next step would exceed this many ranks
                                   // (20 MFMA k-tiles: 15 of the V strip in registers, 5 in LDS)
-  int opt_pass_kernel = -1;       // -1 = auto, 0 = k_flush, 1 = k_flush_pc (producer/consumer waves), 2 = k_flush_rs (row slabs)
+  int opt_pass_kernel = -1;       // -1 = auto, 0 = k_flush (column strips), 2 = k_flush_rs (row slabs)
   unsigned* dqueue = nullptr;     // work-queue heads of k_flush_rs (zeroed before every launch)
   unsigned* dready = nullptr;     // per trajectory: sequence number of the last solve that completed (k_step_split)
   SolveOut* dmbox = nullptr;      // per trajectory: that solve's header and records, written through (mailbox_publish)
@@ -104,6 +102,7 @@ struct ekf_handle {
   int last_kernel = -1, last_nkt = 0, last_streaming = 0;   // what the last covariance pass launched
   int opt_flush_every = 0;        // 0 = auto; k = flush the pending low-rank update after k steps
   int opt_streaming = -1;         // -1 = auto (by working-set size), 0 = resident kernel, 1 = nontemporal kernel
+  std::vector<unsigned> flags_host;
   std::string err;
 };
 
@@ -168,6 +167,16 @@ extern "C" int ekf_create(int device, int n_max, int batch, const ekf_config* cf
   *out = nullptr;
   if (n_max < 3 || (n_max & 1) == 0) return fail(nullptr, EKF_ERR_ARG, "ekf_create: n_max must be 3 + 2*N");
   if (batch < 1) return fail(nullptr, EKF_ERR_ARG, "ekf_create: batch must be >= 1");
+  // The kernels address one trajectory's covariance with unsigned 32-bit byte offsets (buffer instructions: k_flush_rs,
+  // k_solve's staging, k_gemm_f64's resources): rows x ld x 8 bytes must stay below 4 GiB.  Checked before the device is
+  // looked for, so that the limit can be tested without one.
+  {
+    const unsigned long long rows = ((unsigned long long)n_max + 63) / 64 * 64;
+    if (rows * rows * 8ull >= (1ull << 32))
+      return fail(nullptr, EKF_ERR_ARG,
+                  "ekf_create: n_max = " + std::to_string(n_max) + " exceeds EKF_N_MAX_LIMIT = " +
+                      std::to_string(EKF_N_MAX_LIMIT) + " (one covariance must stay below 4 GiB: 32-bit byte offsets)");
+  }
   int count = 0;
   hipError_t e = hipGetDeviceCount(&count);
   if (e != hipSuccess || count <= 0)
@@ -305,6 +314,35 @@ static int check_b(ekf_handle* h, int b, const char* fn) {
   return EKF_OK;
 }
 
+// A bounded wait of a single-launch step that ran into its limit leaves EKF_FLAG_INTERNAL on the trajectory: the
+// timed-out workgroups wrote nothing, so that step (and whatever was enqueued behind it) did not happen as a whole and
+// the trajectory's state is undefined until it is uploaded again (ekf_upload_state* clears the flag).  Every call that
+// hands results to the host reports it: EKF_ERR_STATE.  b < 0: any trajectory.  Synchronises the stream.
+static int check_internal(ekf_handle* h, int b, const char* fn) {
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  h->flags_host.resize(h->batch);
+  HIP_TRY(h, hipMemcpy(h->flags_host.data(), h->dflags, sizeof(unsigned) * h->batch, hipMemcpyDeviceToHost));
+  for (int t = (b < 0 ? 0 : b); t < (b < 0 ? h->batch : b + 1); ++t)
+    if (h->flags_host[t] & EKF_FLAG_INTERNAL)
+      return fail(h, EKF_ERR_STATE,
+                  std::string(fn) + ": trajectory " + std::to_string(t) +
+                      " carries EKF_FLAG_INTERNAL (a bounded wait inside a single-launch step timed out; the step wrote "
+                      "nothing, the state is undefined): upload the state again (ekf_upload_state / ekf_upload_state_diag) "
+                      "and consider ekf_set_option(\"fused_step\", 0)");
+  return EKF_OK;
+}
+// (an upload replaces mean and covariance of trajectory b entirely: the trajectory is good again)
+static int clear_internal(ekf_handle* h, int b) {
+  unsigned f = 0;
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  HIP_TRY(h, hipMemcpy(&f, h->dflags + b, sizeof(unsigned), hipMemcpyDeviceToHost));
+  if (f & EKF_FLAG_INTERNAL) {
+    f &= ~EKF_FLAG_INTERNAL;
+    HIP_TRY(h, hipMemcpy(h->dflags + b, &f, sizeof(unsigned), hipMemcpyHostToDevice));
+  }
+  return EKF_OK;
+}
+
 static int set_size(ekf_handle* h, int b, int n) {
   h->n[b] = n;
   HIP_TRY(h, hipMemcpyAsync(h->dn + b, &h->n[b], sizeof(int), hipMemcpyHostToDevice, h->stream));
@@ -336,6 +374,7 @@ extern "C" int ekf_upload_state(ekf_handle* h, int b, const double* mu, const do
   if (n < 3 || (n & 1) == 0 || n > h->n_max) return fail(h, EKF_ERR_ARG, "ekf_upload_state: n must be 3+2N and <= n_max");
   HIP_TRY(h, hipSetDevice(h->device));
   if (int rc = flush_pending(h)) return rc;
+  if (int rc = clear_internal(h, b)) return rc;
   HIP_TRY(h, hipMemcpy2DAsync(h->dP + (size_t)b * h->pstride, sizeof(double) * h->ld, P, sizeof(double) * n,
                               sizeof(double) * n, n, hipMemcpyHostToDevice, h->stream));
   HIP_TRY(h, hipMemcpyAsync(h->dmu2[h->cur] + (size_t)b * h->ld, mu, sizeof(double) * n, hipMemcpyHostToDevice, h->stream));
@@ -351,6 +390,7 @@ extern "C" int ekf_upload_state_diag(ekf_handle* h, int b, const double* mu, con
   if (n < 3 || (n & 1) == 0 || n > h->n_max) return fail(h, EKF_ERR_ARG, "ekf_upload_state_diag: n must be 3+2N and <= n_max");
   HIP_TRY(h, hipSetDevice(h->device));
   if (int rc = flush_pending(h)) return rc;
+  if (int rc = clear_internal(h, b)) return rc;
   HIP_TRY(h, hipMemcpyAsync(h->dscratch, diagP, sizeof(double) * n, hipMemcpyHostToDevice, h->stream));
   launch_fill_diag(h->stream, h->dP + (size_t)b * h->pstride, h->ld, n, h->dscratch);
   HIP_TRY(h, hipGetLastError());
@@ -376,6 +416,7 @@ extern "C" int ekf_download_state(ekf_handle* h, int b, double* mu, double* P, i
   if (int rc = check_b(h, b, "ekf_download_state")) return rc;
   if (n != h->n[b]) return fail(h, EKF_ERR_ARG, "ekf_download_state: n does not match the state size");
   HIP_TRY(h, hipSetDevice(h->device));
+  if (int rc = check_internal(h, b, "ekf_download_state")) return rc;
   if (P) {
     if (int rc = materialize(h, b)) return rc;     // the covariance is P_base + pending ranks, upper triangle
   }
@@ -394,6 +435,7 @@ extern "C" int ekf_download_block(ekf_handle* h, int b, int r0, int c0, int rows
   if (!out || rows <= 0 || cols <= 0 || r0 < 0 || c0 < 0 || r0 + rows > n || c0 + cols > n)
     return fail(h, EKF_ERR_ARG, "ekf_download_block: block outside the state");
   HIP_TRY(h, hipSetDevice(h->device));
+  if (int rc = check_internal(h, b, "ekf_download_block")) return rc;
   if (int rc = materialize(h, b)) return rc;
   HIP_TRY(h, hipMemcpy2DAsync(out, sizeof(double) * cols, h->dP + (size_t)b * h->pstride + (size_t)r0 * h->ld + c0,
                               sizeof(double) * h->ld, sizeof(double) * cols, rows, hipMemcpyDeviceToHost, h->stream));
@@ -523,9 +565,6 @@ static int flush_pending(ekf_handle* h) {
     launch_flush_rs(h->stream, streaming, h->dP, h->dV, h->dW, h->ddacc2[h->dcur], h->dn, h->dso, h->ld, h->pstride,
                     h->batch, e_hi, nkt, h->opt_pass_workgroups > 0 ? std::min(h->opt_pass_workgroups, h->cu_count) : h->cu_count,
                     h->dqueue, h->opt_pass_chunk);
-  } else if (kernel == 1) {
-    launch_flush_pc(h->stream, streaming, h->dP, h->dV, h->dW, h->ddacc2[h->dcur], h->dn, h->dso, h->ld, h->pstride,
-                    h->batch, e_hi, nkt, flush_rows_per_block(h, streaming, e_hi), h->dflags);
   } else {
     launch_flush(h->stream, streaming, h->dP, h->dV, h->dW, h->ddacc2[h->dcur], h->dn, h->dso, h->ld, h->pstride, h->batch,
                  e_hi, nkt, flush_rows_per_block(h, streaming, e_hi));
@@ -947,8 +986,7 @@ extern "C" int ekf_flush(ekf_handle* h) {
 extern "C" int ekf_sync(ekf_handle* h) {
   if (!h) return EKF_ERR_ARG;
   HIP_TRY(h, hipSetDevice(h->device));
-  HIP_TRY(h, hipStreamSynchronize(h->stream));
-  return EKF_OK;
+  return check_internal(h, -1, "ekf_sync");          // (synchronises)
 }
 
 extern "C" int ekf_status_flags(ekf_handle* h, int b, unsigned* flags) {
@@ -1014,6 +1052,27 @@ extern "C" int ekf_debug_read(ekf_handle* h, void* dst, long bytes) {
   return EKF_OK;
 }
 
+// (development aid, not declared in the header) raw device buffers of trajectory b, exactly as they stand -- no flush,
+// no mirror, no status check: which = 0 P_base (rows x ld), 1 V (80 x ld), 2 W (80 x ld, MFMA-tiled), 3 the mean buffer
+// the NEXT step reads, 4 the other mean buffer.  Returns the number of doubles the buffer holds (copies min(count, that)).
+extern "C" long ekf_debug_snapshot(ekf_handle* h, int b, int which, double* dst, long count) {
+  if (!h || b < 0 || b >= h->batch || which < 0 || which > 4) return -1;
+  if (hipSetDevice(h->device) != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess) return -1;
+  const double* src = nullptr;
+  long have = 0;
+  switch (which) {
+    case 0: src = h->dP + (size_t)b * h->pstride; have = h->pstride; break;
+    case 1: src = h->dV + (size_t)b * KTOT * h->ld; have = (long)KTOT * h->ld; break;
+    case 2: src = h->dW + (size_t)b * KTOT * h->ld; have = (long)KTOT * h->ld; break;
+    case 3: src = h->dmu2[h->cur] + (size_t)b * h->ld; have = h->ld; break;
+    default: src = h->dmu2[h->cur ^ 1] + (size_t)b * h->ld; have = h->ld; break;
+  }
+  if (dst && count > 0 &&
+      hipMemcpy(dst, src, sizeof(double) * (size_t)std::min(count, have), hipMemcpyDeviceToHost) != hipSuccess)
+    return -1;
+  return have;
+}
+
 // (development aid, not declared in the header; no device needed) the units of the row-slab pass's work queues in
 // hand-out order for a batch of `batch` trajectories of `nrb` slabs: what tests/test_cpu_host.py checks for coverage
 extern "C" int ekf_debug_pass_units(int batch, int nrb, int nch, int mode, int* out, int cap) {
@@ -1032,7 +1091,8 @@ extern "C" int ekf_last_pass(ekf_handle* h, int* kernel, int* k_tiles, int* stre
 extern "C" int ekf_set_option(ekf_handle* h, const char* name, int value) {
   if (!h || !name) return EKF_ERR_ARG;
   if (std::strcmp(name, "pass_kernel") == 0) {
-    if (value < -1 || value > 2) return fail(h, EKF_ERR_ARG, "pass_kernel: -1 (auto), 0, 1 or 2");
+    if (value != -1 && value != 0 && value != 2)         // (1 was the producer/consumer form, removed in round 3: never faster)
+      return fail(h, EKF_ERR_ARG, "pass_kernel: -1 (auto), 0 (column strips) or 2 (row slabs)");
     h->opt_pass_kernel = value;
     return EKF_OK;
   }

@@ -1300,7 +1300,10 @@ __device__ __forceinline__ void panels_mono(double* __restrict__ P, double* __re
       // Wait for the solve of this trajectory (every wave for itself: some waves of the last block have left), then
       // fetch its header and records from the mailbox -- every wave writes the same values into sH and sIt.
       const bool ok = mailbox_fetch(sa.mbox + b, m, sa.ready + b, sa.seq, SPLIT_SPIN_LIMIT, &sH, sIt);
-      if (!ok && lane == 0) atomicOr(sa.flags + b, EKF_FLAG_INTERNAL);
+      if (!ok) {                                       // (wave-uniform) the solve never reported: this wave has written
+        if (lane == 0) atomicOr(sa.flags + b, EKF_FLAG_INTERNAL);   // nothing yet and writes nothing -- P_base, V, W and the
+        return;                                        // mean stay as they were; the host turns the flag into EKF_ERR_STATE
+      }
     }
   }
   if (KSPLIT) {                                        // waves 1.. hand their partial sums to wave 0 and leave
@@ -1596,8 +1599,11 @@ __global__ __launch_bounds__(256) void k_step_split(double* __restrict__ P, doub
       if (got == seq) break;
       __builtin_amdgcn_s_sleep(4);
     }
+    if (got != seq) {                                  // (wave-uniform) the solve never reported: nothing has been written by
+      if (lane == 0) atomicOr(flags + b, EKF_FLAG_INTERNAL);   // this workgroup and nothing will be -- P_base, V, W and the
+      return;                                          // mean stay as they were; the host turns the flag into EKF_ERR_STATE
+    }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    if (got != seq && lane == 0) atomicOr(flags + b, EKF_FLAG_INTERNAL);
   }
   const SolveOut& o = out[b];
   {
@@ -1809,248 +1815,6 @@ __global__ __launch_bounds__(256, 2) void k_flush(double* __restrict__ P, const 
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_flush_pc: the same update with the two sides of the pass in different waves of an 8-wave workgroup
-// (one workgroup per CU).  Strip s (64 columns) is served by
-//   wave s      "matrix" wave: V strip in registers (+ LDS), W fragments from L2, accumulators read from and
-//               written back to a ring slot in LDS; never touches P in global memory
-//   wave 4 + s  "memory" wave: streams the strip's P tiles global -> registers -> ring slot (two tiles in
-//               flight besides the one being filled) and ring slot -> global once the matrix wave is done
-// through a ring of three 16 x 64 tile images per strip.  A slot's word goes EMPTY -> FULL (memory wave)
-// -> DONE (matrix wave) -> EMPTY (memory wave); one writer per transition, the data of a transition is
-// complete (s_waitcnt lgkmcnt(0)) before the word changes.  The memory wave fills tile t, then drains tile
-// t-2: three slots never overflow, and the matrix wave finds the next tile waiting when it finishes one.
-// Every wait is bounded: on a timeout the wave raises EKF_FLAG_INTERNAL and the workgroup's abort word, and
-// all eight waves leave (the result is then wrong, the kernel still terminates).
-// ---------------------------------------------------------------------------------------------
-constexpr int PC_SLOTS = 3;
-constexpr int PC_SPIN_LIMIT = 1 << 14;                 // x (s_sleep 1 + poll) ~ 1.5 M cycles
-
-template <int NKTM, int NKL, bool NT>
-__global__ __launch_bounds__(512, 1) void k_flush_pc(double* __restrict__ P, const double* __restrict__ V,
-                                                     const double* __restrict__ W,
-                                                     const double* __restrict__ dacc,
-                                                     const int* __restrict__ nact,
-                                                     const SolveOut* __restrict__ so, int ld, long pstride,
-                                                     int nkt, int rows_per_block, int gx,
-                                                     unsigned* __restrict__ status) {
-  __shared__ double ring[4][PC_SLOTS][16 * FTS];
-  __shared__ double vlds[NKL > 0 ? 4 : 1][NKL > 0 ? NKL * 4 * 64 : 1];
-  // slot words and the abort word: relaxed workgroup-scope atomics on the __shared__ objects themselves, so that the
-  // polls are ds_read_b32 (a volatile or generic access becomes a flat load, which waits for vmcnt(0) as well)
-  __shared__ int state[4][PC_SLOTS + 1];               // [..][PC_SLOTS] unused padding
-  __shared__ int abort_word;
-#define PC_LOAD(x) __hip_atomic_load(&(x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
-#define PC_STORE(x, v) __hip_atomic_store(&(x), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
-  const int b = blockIdx.z;
-  const int n = min(nact[b], so[b].neff);
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int strip = wave & 3;
-  const bool memory_wave = wave >= 4;
-  const int lane = threadIdx.x & 63;
-  int bx, by = 0;                                      // same enumeration of the triangle as k_flush
-  {
-    const int total = gridDim.x;
-    const int lin = blockIdx.x;
-    const int q = total >> 3, r = total & 7, xcd = lin & 7, slot = lin >> 3;
-    int rem = ((xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
-    for (;; ++by) {
-      const int cnt = gx - (by * rows_per_block) / 256;
-      if (rem < cnt || cnt <= 0) break;
-      rem -= cnt;
-    }
-    bx = (by * rows_per_block) / 256 + rem;
-  }
-  const int j0 = (bx * 4 + strip) * 64;
-  const int i_begin = by * rows_per_block;
-  const int i_lim = min(n, j0 + 64);
-  const bool valid = j0 < n && i_begin < i_lim;
-  const int i_end = min(i_lim, i_begin + rows_per_block);
-  const int ntiles = valid ? (i_end - i_begin + 15) >> 4 : 0;
-  if (threadIdx.x < 4 * (PC_SLOTS + 1)) state[threadIdx.x / (PC_SLOTS + 1)][threadIdx.x % (PC_SLOTS + 1)] = 0;
-  if (threadIdx.x == 0) abort_word = 0;
-  __syncthreads();                                     // the only workgroup barrier; everyone reaches it
-  if (ntiles == 0) return;
-
-  double (*R)[16 * FTS] = ring[strip];
-  const int ld16 = ld >> 4;
-  double* Pb = P + (long)b * pstride;
-  const double* Vb = V + (long)b * KTOT * ld;
-  const double* Wb = W + (long)b * KTOT * ld;
-  // wait until slot word == want; false = timed out or the workgroup is aborting
-  auto wait_for = [&](int slot, int want) -> bool {
-    for (int spin = 0; spin < PC_SPIN_LIMIT; ++spin) {
-      if (PC_LOAD(state[strip][slot]) == want) return true;
-      if (PC_LOAD(abort_word)) return false;
-      __builtin_amdgcn_s_sleep(1);
-    }
-    if (lane == 0) {
-      atomicOr(status + b, EKF_FLAG_INTERNAL);
-      PC_STORE(abort_word, 1);
-    }
-    return false;
-  };
-
-  if (!memory_wave) {
-    // ------------------------------------------------------------------ matrix wave
-    const int li = lane & 15, lq = lane >> 4;
-    int nct = (n - j0 + 15) >> 4;
-    if (nct > 4) nct = 4;
-    double vf[NKTM][4];
-#pragma unroll
-    for (int t = 0; t < NKTM; ++t)
-#pragma unroll
-      for (int ct = 0; ct < 4; ++ct)
-        vf[t][ct] = (t < nkt && ct < nct) ? Vb[(long)(4 * t + lq) * ld + j0 + ct * 16 + li] : 0.0;
-    double* VL = vlds[NKL > 0 ? strip : 0];
-    if (NKL > 0) {
-      double tmp[NKL > 0 ? NKL * 4 : 1];               // all loads first: a store to LDS after each load serialises them
-#pragma unroll
-      for (int t = 0; t < NKL; ++t)
-#pragma unroll
-        for (int ct = 0; ct < 4; ++ct)
-          tmp[t * 4 + ct] = Vb[(long)(4 * min(NKTM + t, nkt - 1) + lq) * ld + j0 + ct * 16 + li];
-#pragma unroll
-      for (int t = 0; t < NKL; ++t)
-#pragma unroll
-        for (int ct = 0; ct < 4; ++ct) VL[(t * 4 + ct) * 64 + lane] = (NKTM + t < nkt && ct < nct) ? tmp[t * 4 + ct] : 0.0;
-      LDS_SYNC();
-    }
-    // W fragments: this wave issues no other global load, so the fragments of the NEXT row tile can take over
-    // each half of the register set as soon as that half's MFMAs have issued (loads complete in order, and
-    // here nothing else is queued between them): no MFMA ever waits for an L2 round trip.
-    constexpr int NKT_ALL = NKTM + NKL, HA = NKT_ALL / 2, HB = NKT_ALL - HA;
-    double wa[HA], wb[HB];
-    auto wload_a = [&](int t) {
-      const double* wsrc = Wb + (long)((i_begin + 16 * t) >> 4) * 64 + lane;
-#pragma unroll
-      for (int k = 0; k < HA; ++k) wa[k] = wsrc[(long)min(k, nkt - 1) * ld16 * 64];
-    };
-    auto wload_b = [&](int t) {
-      const double* wsrc = Wb + (long)((i_begin + 16 * t) >> 4) * 64 + lane;
-#pragma unroll
-      for (int k = 0; k < HB; ++k) wb[k] = wsrc[(long)min(HA + k, nkt - 1) * ld16 * 64];
-    };
-    auto bfrag = [&](int k, int ct) -> double {        // B fragment of k-tile k: registers, or LDS beyond NKTM
-      return (k < NKTM) ? vf[k < NKTM ? k : 0][ct] : VL[((k - NKTM) * 4 + ct) * 64 + lane];
-    };
-    wload_a(0);
-    wload_b(0);
-    int slot = 0;
-    for (int t = 0; t < ntiles; ++t) {
-      const int i0 = i_begin + 16 * t;
-      const int tn = min(t + 1, ntiles - 1);           // (the last tile re-reads its own fragments)
-      if (!wait_for(slot, 1)) return;
-      LDS_SYNC();
-      const double* T = R[slot];
-      double4_t acc[4];
-#pragma unroll
-      for (int ct = 0; ct < 4; ++ct)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) acc[ct][r] = T[(lq + 4 * r) * FTS + ct * 16 + li];
-#pragma unroll
-      for (int k = 0; k < HA; ++k)
-        if (k < nkt) {
-#pragma unroll
-          for (int ct = 0; ct < 4; ++ct)
-            acc[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(wa[k], bfrag(k, ct), acc[ct], 0, 0, 0);
-        }
-      wload_a(tn);
-#pragma unroll
-      for (int k = 0; k < HB; ++k)
-        if (HA + k < nkt) {
-#pragma unroll
-          for (int ct = 0; ct < 4; ++ct)
-            acc[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(wb[k], bfrag(HA + k, ct), acc[ct], 0, 0, 0);
-        }
-      wload_b(tn);
-      if (i0 == 0 && j0 == 0) {                        // pose-block noise accumulated since the last flush
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = lq + 4 * r;
-          if (row < 3 && li == row) acc[0][r] += dacc[4 * b + row];
-        }
-      }
-      double* Tw = R[slot];
-#pragma unroll
-      for (int ct = 0; ct < 4; ++ct)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) Tw[(lq + 4 * r) * FTS + ct * 16 + li] = acc[ct][r];
-      LDS_SYNC();
-      if (lane == 0) PC_STORE(state[strip][slot], 2);
-      slot = (slot + 1 == PC_SLOTS) ? 0 : slot + 1;
-    }
-  } else {
-    // ------------------------------------------------------------------ memory wave
-    const int rr = lane >> 5, rc = (lane & 31) * 2;    // row-major image: 2 rows per instruction
-    const int jc = j0 + rc;                            // ld is a multiple of 64: the strip lies inside the row
-    double ga[16], gb[16];
-    auto gload = [&](int t, double* g) {
-      const int i0 = i_begin + 16 * t;
-#pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const double2 x = ld2<NT>(Pb + (long)(i0 + 2 * q + rr) * ld + jc);
-        g[2 * q] = x.x;
-        g[2 * q + 1] = x.y;
-      }
-    };
-    auto fill = [&](int t, const double* g) {          // tile t: registers -> ring slot, publish
-      double* T = R[t % PC_SLOTS];
-#pragma unroll
-      for (int q = 0; q < 8; ++q)
-        *reinterpret_cast<double2*>(&T[(2 * q + rr) * FTS + rc]) = make_double2(g[2 * q], g[2 * q + 1]);
-      LDS_SYNC();
-      if (lane == 0) PC_STORE(state[strip][t % PC_SLOTS], 1);
-    };
-    auto drain = [&](int t) -> bool {                  // tile t: ring slot -> global once the matrix wave is done
-      const int slot = t % PC_SLOTS;
-      if (!wait_for(slot, 2)) return false;
-      LDS_SYNC();
-      const double* T = R[slot];
-      const int i0 = i_begin + 16 * t;
-#pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const double2 o = *reinterpret_cast<const double2*>(&T[(2 * q + rr) * FTS + rc]);
-        st2<NT>(Pb + (long)(i0 + 2 * q + rr) * ld + jc, o);
-      }
-      LDS_SYNC();
-      if (lane == 0) PC_STORE(state[strip][slot], 0);
-      return true;
-    };
-    gload(0, ga);
-    if (ntiles > 1) gload(1, gb);
-    fill(0, ga);
-    if (2 < ntiles) gload(2, ga);
-    if (ntiles > 1) {
-      fill(1, gb);
-      if (3 < ntiles) gload(3, gb);
-    }
-    int t = 2;
-    for (; t + 3 < ntiles; t += 2) {                   // steady state: no access under a branch
-      fill(t, ga);                                     // (its slot was drained a step ago: the matrix wave always
-      gload(t + 2, ga);                                //  has the next tile waiting when it finishes one)
-      if (!drain(t - 2)) return;
-      fill(t + 1, gb);
-      gload(t + 3, gb);
-      if (!drain(t - 1)) return;
-    }
-    for (; t < ntiles; ++t) {                          // last (up to three) tiles
-      if ((t & 1) == 0) {
-        fill(t, ga);
-        if (t + 2 < ntiles) gload(t + 2, ga);
-      } else {
-        fill(t, gb);
-        if (t + 2 < ntiles) gload(t + 2, gb);
-      }
-      if (!drain(t - 2)) return;
-    }
-    for (int u = max(ntiles - 2, 0); u < ntiles; ++u)
-      if (!drain(u)) return;
-  }
-}
-#undef PC_LOAD
-#undef PC_STORE
-
-// ---------------------------------------------------------------------------------------------
 // k_flush_rs: the same update, "row slab" form (the default for batches that stream through HBM).
 // The roles of the two operands are swapped with respect to k_flush: a wave keeps the W fragments of ITS 16 rows
 // in registers (A operands: 2 VGPRs per k-tile instead of the 8 a 64-column V strip costs) and walks along those
@@ -2088,21 +1852,43 @@ __device__ __forceinline__ double2 ldb16(__amdgpu_buffer_rsrc_t rs, unsigned lan
   r.y = __builtin_bit_cast(double, uint2v_t{v.z, v.w});
   return r;
 }
+// The 16-byte store of k_flush_rs.  A 16-byte store reads its data registers in two passes; a VALU instruction issued
+// right behind it that writes one of them can overtake the second pass (dwords 2-3 of the last lanes).  The compiler's
+// hazard recogniser adds the wait states for global/flat stores and for buffer stores WITHOUT an SGPR offset only (it
+// assumes the SGPR read covers it); on gfx950 the form used here (offen + SGPR soffset) was caught corrupting the low
+// mantissa bits of the odd columns of a tile's last row pair (`buffer_store_dwordx4 v[76:79]` followed by
+// `v_add_u32 v78`).  Store and wait states therefore come out of ONE inline-asm block: nothing can be scheduled
+// between them (tests/test_cpu_host.py scans the ISA for it).  The resource goes in as four plain words (an opaque
+// __amdgpu_buffer_rsrc_t cannot be an asm operand): base, base_hi | stride 0, num_records = 2^32 - 1 (no range check:
+// ekf_create bounds the size of a covariance), DST_SEL/format word 0x00020000 as rs_rsrc makes it.
+__device__ __forceinline__ uint4v_t rs_words(const void* base) {
+  const unsigned long long p = reinterpret_cast<unsigned long long>(base);
+  return uint4v_t{(unsigned)p, (unsigned)(p >> 32) & 0xffffu, 0xffffffffu, 0x00020000u};
+}
 template <bool NT>
-__device__ __forceinline__ void stb16(__amdgpu_buffer_rsrc_t rs, unsigned lane_bytes, unsigned tile_bytes, double2 v) {
+__device__ __forceinline__ void stb16(uint4v_t rs, unsigned lane_bytes, unsigned tile_bytes, double2 v) {
 #ifdef RS_SKIP_PMEM
   if (v.x == 1.2345e-300) /* never: keeps the value alive, drops the traffic */
 #endif
   {
   const uint2v_t a = __builtin_bit_cast(uint2v_t, v.x), b = __builtin_bit_cast(uint2v_t, v.y);
-  __builtin_amdgcn_raw_buffer_store_b128(uint4v_t{a.x, a.y, b.x, b.y}, rs, (int)lane_bytes, (int)tile_bytes, NT ? 2 : 0);
-  // A 16-byte store reads its data registers in two passes; a VALU instruction issued right behind it that writes
-  // one of them can overtake the second pass (dwords 2-3 of the last lanes).  The compiler's hazard recogniser adds
-  // the wait state for global/flat stores and for buffer stores WITHOUT an SGPR offset only (it assumes the SGPR read
-  // covers it); on gfx950 the form used here (offen + SGPR soffset) was caught corrupting the low mantissa bits of the
-  // odd columns of a tile's last row pair (`buffer_store_dwordx4 v[76:79]` followed by `v_add_u32 v78`): keep two
-  // wait states behind every such store.
+  const uint4v_t d{a.x, a.y, b.x, b.y};
+#if defined(RS_STORE_TIED)
+  // (measured alternative: the compiler's own store -- which it counts in vmcnt -- followed by wait states that READ the
+  //  data registers, so that no write to them can be scheduled in front of the wait states)
+  __builtin_amdgcn_raw_buffer_store_b128(d, __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)(rs.y & 0xffffu) << 32) | rs.x), 0, -1, 0x00020000),
+                                         (int)lane_bytes, (int)tile_bytes, NT ? 2 : 0);
+  asm volatile("s_nop 1" ::"v"(d) : "memory");
+#elif defined(RS_STORE_OLD)
+  __builtin_amdgcn_raw_buffer_store_b128(d, __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)(rs.y & 0xffffu) << 32) | rs.x), 0, -1, 0x00020000),
+                                         (int)lane_bytes, (int)tile_bytes, NT ? 2 : 0);
   asm volatile("s_nop 1" ::: "memory");
+#else
+  if (NT)
+    asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen nt\n\ts_nop 1" ::"v"(d), "v"(lane_bytes), "s"(rs), "s"(tile_bytes) : "memory");
+  else
+    asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen\n\ts_nop 1" ::"v"(d), "v"(lane_bytes), "s"(rs), "s"(tile_bytes) : "memory");
+#endif
   }
 }
 #define RS_CBAR() asm volatile("" ::: "memory")
@@ -2416,7 +2202,7 @@ __global__ __launch_bounds__(512, 2) void k_flush_rs(double* __restrict__ P, con
       constexpr int NE = FIRST ? 0 : 4, NV = STAGE ? 1 : 0;
       constexpr int OVA = 0, OW0 = OVA + NV, OE1A = OW0 + NE, OE2A = OE1A + NE, OE1B = OE2A + NE, OE2B = OE1B + NE,
                     OVB = OE2B + NE, ON1 = OVB + NV, ON2 = ON1 + 8, OWB = ON2 + 16, ON3 = OWB + NV, NSIDE = ON3 + 8;
-      const __amdgpu_buffer_rsrc_t rsP = rs_rsrc(Pb);
+      const uint4v_t rsP = rs_words(Pb);
       const unsigned off_prev = tile_off(t - 1);       // tile t-1 (FIRST: unused)
 #ifdef RS_SKIP_PMEM
       const bool ok2 = false;
@@ -2506,7 +2292,7 @@ __global__ __launch_bounds__(512, 2) void k_flush_rs(double* __restrict__ P, con
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg) T[cd_index(ct, rg)] = acc[ct][rg];
       RS_CBAR();
-      const __amdgpu_buffer_rsrc_t rsP = rs_rsrc(Pb);
+      const uint4v_t rsP = rs_words(Pb);
       const unsigned off_last = tile_off(Sw - 1);
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
@@ -2871,32 +2657,6 @@ static void launch_flush_t(hipStream_t st, double* P, const double* V, const dou
   for (int by = 0; by < gy; ++by) total += std::max(0, gx - (by * rows_per_block) / 256);
   hipLaunchKernelGGL((k_flush<NKTM, NKL, NT>), dim3(total, 1, batch), dim3(256), 0, st, P, V, W, dacc, nact, so, ld,
                      pstride, nkt, rows_per_block, gx);
-}
-
-template <int NKTM, int NKL, bool NT>
-static void launch_flush_pc_t(hipStream_t st, double* P, const double* V, const double* W, const double* dacc,
-                              const int* nact, const SolveOut* so, int ld, long pstride, int batch, int n_hi,
-                              int nkt, int rows_per_block, unsigned* status) {
-  const int gx = (n_hi + 255) / 256, gy = (n_hi + rows_per_block - 1) / rows_per_block;
-  int total = 0;
-  for (int by = 0; by < gy; ++by) total += std::max(0, gx - (by * rows_per_block) / 256);
-  hipLaunchKernelGGL((k_flush_pc<NKTM, NKL, NT>), dim3(total, 1, batch), dim3(512), 0, st, P, V, W, dacc, nact, so,
-                     ld, pstride, nkt, rows_per_block, gx, status);
-}
-
-// the producer/consumer form of the pass (k_flush_pc), same arguments plus the status words
-void launch_flush_pc(hipStream_t st, bool streaming, double* P, const double* V, const double* W,
-                     const double* dacc, const int* nact, const SolveOut* so, int ld, long pstride, int batch,
-                     int n_hi, int nkt, int rows_per_block, unsigned* status) {
-#define EKF_FLUSH_PC(N, L)                                                                                \
-  do {                                                                                                    \
-    if (streaming) launch_flush_pc_t<N, L, true>(st, P, V, W, dacc, nact, so, ld, pstride, batch, n_hi, nkt, rows_per_block, status); \
-    else launch_flush_pc_t<N, L, false>(st, P, V, W, dacc, nact, so, ld, pstride, batch, n_hi, nkt, rows_per_block, status);          \
-  } while (0)
-  if (nkt <= 8) EKF_FLUSH_PC(8, 0);
-  else if (nkt <= 16) EKF_FLUSH_PC(16, 0);
-  else EKF_FLUSH_PC(16, 4);
-#undef EKF_FLUSH_PC
 }
 
 // streaming = the batch's covariances do not fit the Infinity Cache: nontemporal accesses

@@ -32,6 +32,8 @@ _LIB_NAME = "libekfslam_hip.so"
 EKF_MMAX = 16
 EKF_FLAG_NONFINITE = 1
 EKF_FLAG_ASSOC = 2
+EKF_FLAG_INTERNAL = 4             # a bounded wait of a single-launch step timed out: sync()/state()/mean() raise EkfError
+EKF_N_MAX_LIMIT = 23167           # largest n_max (one covariance stays below 4 GiB: 32-bit byte offsets in the kernels)
 EKF_DMAX = 64
 EKF_TAGMAX = 1024
 
@@ -70,6 +72,10 @@ def library_path() -> str:
     """The in-tree library.  EKFSLAM_HIP_VARIANT=<tag> selects a diagnostic build libekfslam_hip_<tag>.so made with
     `make -C csrc variant TAG=<tag> EXTRA=...` (kernel experiments; never set in production)."""
     tag = os.environ.get("EKFSLAM_HIP_VARIANT")
+    if tag:
+        warnings.warn(f"EKFSLAM_HIP_VARIANT={tag}: loading the diagnostic build libekfslam_hip_{tag}.so instead of the "
+                      "product library -- such builds may knowingly compute wrong covariances (timing experiments only)",
+                      RuntimeWarning, stacklevel=2)
     return os.path.join(_HERE, f"libekfslam_hip_{tag}.so" if tag else _LIB_NAME)
 
 
@@ -443,9 +449,6 @@ class EkfSlam:
         if k.value == 2:
             return f"ekf::k_flush_rs<{tiles}, {nt}>"
         regs = {4: (4, 0), 8: (8, 0), 12: (12, 0), 16: (16, 0), 20: (15, 5)}[tiles]
-        if k.value == 1:
-            regs = (8, 0) if tiles <= 8 else ((16, 0) if tiles <= 16 else (16, 4))
-            return f"ekf::k_flush_pc<{regs[0]}, {regs[1]}, {nt}>"
         return f"ekf::k_flush<{regs[0]}, {regs[1]}, {nt}>"
 
     def set_option(self, name: str, value: int):

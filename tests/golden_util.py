@@ -33,4 +33,9 @@ def tags_from_obs(idx, zr, zb):
 
 
 REPLAY_CASES = ["replay_default", "replay_bigturns", "replay_no_measurement", "replay_no_motion",
-                "replay_linear_interp"]
+                "replay_linear_interp", "replay_ignore_tags"]
+
+
+def ignore_tags(g):
+    """IGNORE_TAGS the fixture was generated with (src/replay_no_ros.py:36-37, :286); () for the default list."""
+    return tuple(int(t) for t in g["ignore_tags"]) if "ignore_tags" in g else ()

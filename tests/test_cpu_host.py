@@ -79,14 +79,16 @@ def test_frontend_association_matches_reference_order(sd, case):
         det = gu.detections_for_step(g, k)
         n = int(g["out_size"][k - 1]) if k else 3
         pose = g["out_mean"][k - 1, :3] if k else np.zeros(3)
-        tp = sd.associate(det, tag_index, pose)
-        op = orc.associate(det, o_index, pose, orc.EkfConfig())
+        tp = sd.associate(det, tag_index, pose, ignore_tags=gu.ignore_tags(g))
+        op = orc.associate(det, o_index, pose, orc.EkfConfig(ignore_tags=gu.ignore_tags(g)))
         assert list(tp.keys()) == [i for i in g["out_obs_order"][k] if i >= 0]
         assert list(tp.keys()) == list(op.keys())
         for key in tp:
             assert tp[key][3] == op[key][3]
             assert np.array_equal(np.array(tp[key], dtype=float), np.array(op[key], dtype=float))
     assert sorted(tag_index.items(), key=lambda kv: kv[1]) == [tuple(r) for r in g["out_tag_index"]]
+    if case == "replay_ignore_tags":                 # the ignored tags were detected, and got no landmark index
+        assert set(gu.ignore_tags(g)) <= {int(t) for t in g["det_tag_id"]} and not set(gu.ignore_tags(g)) & set(tag_index)
 
 
 def test_frontend_gate_and_ignore(sd):
@@ -265,3 +267,47 @@ def test_row_slab_pass_hands_out_every_unit_exactly_once(sd):
                 if mode == 2:                                   # equal work: queue sizes differ by at most the dealt remainder
                     sizes = [fn(batch, nrb, nch, mode, None, 0)]   # (total only; per-queue balance is implied by coverage)
                     assert sizes[0] == batch * nrb
+
+
+def test_store_hazard_guard_is_in_the_shipped_machine_code(sd):
+    """The 16-byte buffer stores of the row-slab pass (offen + SGPR soffset: the form LLVM's hazard recogniser does not
+    cover) must each be followed immediately by their wait states in the library that ships --
+    checked on the disassembly of the gfx950 code objects inside libekfslam_hip.so, not on the source."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import isa_lint
+    stores, gaps, bad = isa_lint.lint(sd.library_path())
+    assert stores >= 500, f"only {stores} guarded stores found: did the pass kernel change its store form?"
+    assert not bad, "\n".join(bad)
+    assert gaps == 0, f"{gaps} stores with instructions scheduled between them and their s_nop"
+    # the scanner itself: a VALU write of a data register between store and nop is what it exists to catch
+    assert isa_lint.writes_vgpr("v_add_u32_e32 v78, v1, v2", 76, 79)
+    assert isa_lint.writes_vgpr("ds_read_b128 v[76:79], v248 offset:4096", 64, 76)
+    assert not isa_lint.writes_vgpr("s_add_i32 s37, s60, s79", 76, 79)
+    assert not isa_lint.writes_vgpr("v_add_u32_e32 v80, v78, v2", 76, 79)
+    assert not isa_lint.writes_vgpr("buffer_store_dwordx4 v[76:79], v251, s[48:51], s39 offen nt", 76, 79)
+
+
+def test_create_rejects_sizes_beyond_the_32_bit_offsets(sd):
+    """The kernels address one covariance with unsigned 32-bit byte offsets: ekf_create refuses an n_max whose padded
+    rows x ld x 8 bytes reach 4 GiB, before it looks for a device (so this runs without one)."""
+    import ctypes
+    from slam_duckietown_amd import ekf_bindings as eb
+    lib = sd.load_library()
+    text = open(os.path.join(ROOT, "include", "ekfslam_hip.h")).read()
+    limit = int(re.search(r"#define EKF_N_MAX_LIMIT (\d+)", text).group(1))
+    assert limit == eb.EKF_N_MAX_LIMIT and limit % 2 == 1
+    rows = (limit + 63) // 64 * 64
+    assert rows * rows * 8 < 2 ** 32 <= (rows + 64) ** 2 * 8
+    h = ctypes.c_void_p()
+    for n_max in (limit + 2, 3 + 2 * 12000, 3 + 2 * 50000):
+        assert lib.ekf_create(0, n_max, 1, None, ctypes.byref(h)) == -1          # EKF_ERR_ARG
+        msg = lib.ekf_last_error(None).decode()
+        assert "EKF_N_MAX_LIMIT" in msg and str(limit) in msg and not h.value
+        with pytest.raises(sd.EkfError, match="EKF_N_MAX_LIMIT"):
+            sd.EkfSlam(n_max)
+    # at the limit the size check passes (what fails here, without a GPU, is the device probe)
+    rc = lib.ekf_create(0, limit, 1, None, ctypes.byref(h))
+    if rc == 0:
+        lib.ekf_destroy(h)
+    else:
+        assert rc == -2 and "EKF_N_MAX_LIMIT" not in lib.ekf_last_error(None).decode()

@@ -220,30 +220,84 @@ def test_gpu_backend_device_association_beyond_the_device_limits(sd):
     close(res[0][1], oP)
 
 
+def _snapshot(sd, f, b=0):
+    """P_base, V, W and the mean the next step reads, raw (development hook ekf_debug_snapshot: no flush, no check)."""
+    import ctypes as C
+    lib = sd.load_library()
+    lib.ekf_debug_snapshot.restype = C.c_long
+    lib.ekf_debug_snapshot.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double), C.c_long]
+    out = []
+    for which in (0, 1, 2, 3):
+        count = lib.ekf_debug_snapshot(f._h, b, which, None, 0)
+        assert count > 0
+        a = np.empty(count)
+        assert lib.ekf_debug_snapshot(f._h, b, which, a.ctypes.data_as(C.POINTER(C.c_double)), count) == count
+        out.append(a)
+    return out
+
+
 def test_single_launch_step_wait_is_bounded(sd):
     """The panel workgroups of the single-launch step wait for their trajectory's solve on a device-scope word.  With
-    the diagnostic setting `fused_step=2` the solve never publishes it: every wait must run into its bound, raise
-    EKF_FLAG_INTERNAL and let the launch finish (no hang); the handle stays usable."""
+    the diagnostic setting `fused_step=2` the solve never publishes it: every wait must run into its bound and let the
+    launch finish (no hang) WITHOUT writing anything -- P_base, V, W and the mean stay bit for bit what they were --
+    and raise EKF_FLAG_INTERNAL, which every call that hands results to the host reports as an error (EKF_ERR_STATE)
+    until the trajectory is uploaded again."""
+    from slam_duckietown_amd import ekf_bindings as eb
     N = 40
-    mean0, diag0, lin, ang, idx, zr, zb = orc.synthetic_stream(N, 3, 4, 3)
+    mean0, diag0, lin, ang, idx, zr, zb = orc.synthetic_stream(N, 4, 4, 3)
     with sd.EkfSlam(len(mean0)) as f:
+        f.set_option("active_bound", 0)            # every panel workgroup takes part (none is "beyond the bound")
         f.set_state_diag(mean0, diag0)
-        f.set_option("fused_step", 2)
-        f.step(lin[0], ang[0], idx[0], zr[0], zb[0])
+        for k in range(2):                         # two good steps: ranks are pending, V and W hold data
+            f.step(lin[k], ang[k], idx[k], zr[k], zb[k])
         f.sync()
-        assert f.flags(0) & 4                      # EKF_FLAG_INTERNAL
+        before = _snapshot(sd, f)
+        f.set_option("fused_step", 2)
+        f.step(lin[2], ang[2], idx[2], zr[2], zb[2])
+        with pytest.raises(sd.EkfError, match="EKF_FLAG_INTERNAL"):
+            f.sync()
+        assert f.flags(0) & eb.EKF_FLAG_INTERNAL   # (reading the flags stays possible: that is how the trajectory is found)
+        for name, a, b in zip(("P_base", "V", "W"), before, _snapshot(sd, f)):
+            assert np.array_equal(a, b, equal_nan=True), f"{name} changed although the step timed out"
+        # the mean the failed step READ is untouched (the handle has moved on to the other buffer, where the solve
+        # workgroup -- which ran -- left its entries at C)
+        import ctypes as C
+        lib = sd.load_library()
+        mu_read = np.empty(len(before[3]))
+        assert lib.ekf_debug_snapshot(f._h, 0, 4, mu_read.ctypes.data_as(C.POINTER(C.c_double)), len(mu_read)) == len(mu_read)
+        assert np.array_equal(mu_read, before[3])
+        for call in (f.state, f.mean, f.covariance, lambda: f.covariance_block(0, 0, 3, 3)):
+            with pytest.raises(sd.EkfError, match="EKF_FLAG_INTERNAL"):
+                call()
+        # recovery as documented: upload the trajectory again, two-launch (or healthy single-launch) steps from there
         f.set_option("fused_step", 1)
-        f.set_state_diag(mean0, diag0)             # (the step above left garbage)
-        f.step(lin[0], ang[0], idx[0], zr[0], zb[0])
-        assert np.isfinite(f.mean()).all()
+        f.set_state_diag(mean0, diag0)
+        assert not f.flags(0) & eb.EKF_FLAG_INTERNAL
+        om, oP = mean0.copy(), np.diag(diag0)
+        cfg = orc.EkfConfig()
+        for k in range(3):
+            f.step(lin[k], ang[k], idx[k], zr[k], zb[k])
+            om, oP = orc.ekf_step_dense(om, oP, lin[k], ang[k], idx[k], zr[k], zb[k], cfg)
+        mu, P = f.state()
+        assert orc.rel_fro(mu, om) < 1e-9 and orc.rel_fro(P, oP) < 1e-9
     # the same for the throughput shape (k_panels_split: the counter travels with the mailbox)
     N, B = 1200, 16
     streams = [orc.synthetic_stream(N, 2, 8, 80 + t) for t in range(B)]
     with sd.EkfSlam(3 + 2 * N, batch=B) as f:
+        f.set_option("active_bound", 0)
         for b, s in enumerate(streams):
             f.set_state_diag(s[0], s[1], b)
-        f.set_option("fused_step", 2)
-        f.step([s[2][0] for s in streams], [s[3][0] for s in streams], [s[4][0] for s in streams],
-               [s[5][0] for s in streams], [s[6][0] for s in streams])
+        args = lambda k: ([s[2][k] for s in streams], [s[3][k] for s in streams], [s[4][k] for s in streams],
+                          [s[5][k] for s in streams], [s[6][k] for s in streams])
+        f.step(*args(0))
         f.sync()
-        assert all(f.flags(b) & 4 for b in range(B))
+        before = _snapshot(sd, f, 5)
+        f.set_option("fused_step", 2)
+        f.step(*args(1))
+        with pytest.raises(sd.EkfError, match="EKF_FLAG_INTERNAL"):
+            f.sync()
+        assert all(f.flags(b) & eb.EKF_FLAG_INTERNAL for b in range(B))
+        for name, a, b in zip(("P_base", "V", "W"), before, _snapshot(sd, f, 5)):
+            assert np.array_equal(a, b, equal_nan=True), f"{name} changed although the step timed out"
+        with pytest.raises(sd.EkfError, match="trajectory 5"):
+            f.mean(5)

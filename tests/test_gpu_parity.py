@@ -73,7 +73,7 @@ def test_drop_in_function_golden(sd, case):
     g = gu.load(case)
     eb.DROP_IN_CONFIG = sd.EkfConfig(enable_measurement_model=bool(g["flag_measurement"]),
                                      enable_circular_interpolation=bool(g["flag_circular"]),
-                                     disable_motion_model=bool(g["flag_no_motion"]))
+                                     disable_motion_model=bool(g["flag_no_motion"]), ignore_tags=gu.ignore_tags(g))
     try:
         mean = np.array([0.0, 0.0, 0.0])
         cov = np.eye(3) * 0.1
@@ -474,6 +474,8 @@ def test_device_side_association_golden(sd, case):
                        enable_circular_interpolation=bool(g["flag_circular"]),
                        disable_motion_model=bool(g["flag_no_motion"]))
     with sd.EkfSlam(3 + 2 * 12, config=cfg) as f:
+        if gu.ignore_tags(g):                      # IGNORE_TAGS (:36-37, :286) in the device's ignore table
+            f.set_association(1.5, gu.ignore_tags(g))
         for k in range(len(g["lin"])):
             det = gu.detections_for_step(g, k)
             f.step_detections(g["lin"][k], g["ang"][k], det)
@@ -557,31 +559,6 @@ def test_scattered_landmarks_varying_m(sd):
         assert f.flags(0) == 0 and f.flags(1) == 0
 
 
-def test_producer_consumer_pass_is_bit_identical(sd):
-    """`pass_kernel=1` (k_flush_pc: matrix waves and memory waves hand tiles over through an LDS ring) applies the
-    same update as k_flush, bit for bit, over several cadences, and raises no internal flag."""
-    N, B, steps, m = 300, 2, 13, 8
-    n = 3 + 2 * N
-    streams = [orc.synthetic_stream(N, steps, m, t) for t in range(B)]
-    out = {}
-    for kernel in (0, 1):
-        for limit in (16, 64, 80):
-            with sd.EkfSlam(n, batch=B) as f:
-                f.set_option("pass_kernel", kernel)
-                f.set_option("rank_limit", limit)
-                for b, s in enumerate(streams):
-                    f.set_state_diag(s[0], s[1], b)
-                for k in range(steps):
-                    f.step([s[2][k] for s in streams], [s[3][k] for s in streams], [s[4][k] for s in streams],
-                           [s[5][k] for s in streams], [s[6][k] for s in streams])
-                out[kernel, limit] = [f.state(b) for b in range(B)]
-                assert [f.flags(b) for b in range(B)] == [0] * B
-    for limit in (16, 64, 80):
-        for b in range(B):
-            assert np.array_equal(out[0, limit][b][0], out[1, limit][b][0])
-            assert np.array_equal(out[0, limit][b][1], out[1, limit][b][1])
-
-
 @pytest.mark.parametrize("N,B,m", [(300, 2, 8), (531, 3, 5), (64, 9, 8), (1100, 2, 3)])
 def test_row_slab_pass_is_bit_identical(sd, N, B, m):
     """`pass_kernel=2` (k_flush_rs: W fragments in registers, the V strip shared through LDS, software-pipelined
@@ -622,6 +599,47 @@ def test_row_slab_pass_is_bit_identical(sd, N, B, m):
         om, oP = orc.ekf_step_dense(om, oP, s[2][k], s[3][k], s[4][k], s[5][k], s[6][k], cfg)
     close(out[2, 80, 1][0][0], om)
     close(out[2, 80, 1][0][1], oP)
+
+
+@pytest.mark.parametrize("B", [8, 10, 13, 16, 24])
+def test_row_slab_queue_modes_on_the_device(sd, B):
+    """The hand-out orders of the row-slab pass that the automatic rule picks by batch size (launch_flush_rs_t), checked
+    for VALUES on the device, not only as host enumerations: 8 trajectories (mode 1, every queue's only trajectory cut
+    into chunks), 10 (mode 3: dealt half slabs), 13 (mode 2: dealt whole slabs), 16 (mode 1, pairs), 24 (mode 1: a pair
+    plus a chunked lone trajectory per queue) -- each bit for bit the column-strip kernel's result."""
+    N, m, steps = 300, 8, 6                        # n = 603: 5 slabs of up to 10 strips (mode 3 needs >= 8 strips)
+    n = 3 + 2 * N
+    streams = [orc.synthetic_stream(N, steps, m, 130 + t) for t in range(B)]
+    starts = []
+    for t in range(B):
+        rng = np.random.default_rng(290 + t)
+        A = rng.normal(size=(n, 4)) * 0.3
+        starts.append(A @ A.T + np.diag(rng.uniform(0.5, 2.0, n)))
+    out = {}
+    for kernel in (0, 2):
+        with sd.EkfSlam(n, batch=B) as f:
+            f.set_option("pass_kernel", kernel)        # (2 with pass_chunk = 0: the automatic hand-out order)
+            f.set_option("pass_streaming", 1)
+            f.set_option("active_bound", 0)
+            for b, s in enumerate(streams):
+                f.set_state(s[0], starts[b], b)
+            for k in range(steps):
+                f.step([s[2][k] for s in streams], [s[3][k] for s in streams], [s[4][k] for s in streams],
+                       [s[5][k] for s in streams], [s[6][k] for s in streams])
+            f.flush()
+            assert f.last_pass().startswith("ekf::k_flush_rs" if kernel == 2 else "ekf::k_flush<")
+            out[kernel] = [f.state(b) for b in range(B)]
+            assert [f.flags(b) for b in range(B)] == [0] * B
+    for b in range(B):
+        assert np.array_equal(out[0][b][0], out[2][b][0]), b
+        assert np.array_equal(out[0][b][1], out[2][b][1]), b
+    cfg = orc.EkfConfig()
+    s = streams[B - 1]
+    om, oP = s[0].copy(), starts[B - 1].copy()
+    for k in range(steps):
+        om, oP = orc.ekf_step_dense(om, oP, s[2][k], s[3][k], s[4][k], s[5][k], s[6][k], cfg)
+    close(out[2][B - 1][0], om)
+    close(out[2][B - 1][1], oP)
 
 
 def test_row_slab_pass_with_active_bound_and_growing_state(sd):

@@ -15,7 +15,7 @@ TOL_S = 1e-9     # structured O(n^2) formulation vs reference (bar for the produ
 def cfg_of(g):
     return orc.EkfConfig(enable_measurement_model=bool(g["flag_measurement"]),
                          enable_circular_interpolation=bool(g["flag_circular"]),
-                         disable_motion_model=bool(g["flag_no_motion"]))
+                         disable_motion_model=bool(g["flag_no_motion"]), ignore_tags=gu.ignore_tags(g))
 
 
 @pytest.mark.parametrize("case", gu.REPLAY_CASES)

@@ -127,6 +127,43 @@ def test_god_mode_presizes_the_state():
     assert np.array_equal(res.mean[3:], [1.0, 2.0, 3.0, -1.0]) and np.array_equal(res.covariance[3:, 3:], np.zeros((4, 4)))
 
 
+def god_fixture():
+    g, gg = gu.load("replay_events"), gu.load("replay_events_god")
+    merged = dict(g)
+    merged.update(gg)
+    return g, merged, [int(t) for t in gg["god_key"]]
+
+
+def test_god_mode_matches_reference_cpu():
+    """ENABLE_GOD_EKF with GOD_SECRET_KEY = the log's tag ids (src/replay_no_ros.py:23-26, :140-157): the reference's
+    own replay() with the flag set, on the same log (tests/golden/replay_events_god.npz)."""
+    import slam_duckietown_amd.replay as rp
+    g, merged, key = god_fixture()
+    detect, seen = fixture_detector(g)
+    sizes = []
+    res = rp.replay(str(g["events_csv"]).splitlines(), backend=OracleBackend(), detector=detect, god_key=key,
+                    on_window=lambda d: sizes.append(len(d["tag_index"])))
+    check_against_reference_loop(res, merged, seen, 1e-11)
+    assert sizes == list(merged["out_ntags"]) and set(merged["out_size"]) == {3 + 2 * len(key)}
+    assert not np.array_equal(merged["out_mean"][-1][:3], g["out_mean"][-1][:3])     # the flag changes the result
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("device_association", [False, True])
+def test_god_mode_matches_reference_gpu(device_association):
+    """The god-mode log through the shipped GpuBackend: host association, and the whole front end on the GPU (the
+    pre-filled TAG_INDEX goes to the device table)."""
+    import slam_duckietown_amd.replay as rp
+    g, merged, key = god_fixture()
+    detect, seen = fixture_detector(g)
+    be = rp.GpuBackend(capacity=3 + 2 * 16, device_association=device_association)
+    try:
+        res = rp.replay(str(g["events_csv"]).splitlines(), backend=be, detector=detect, god_key=key)
+    finally:
+        be.close()
+    check_against_reference_loop(res, merged, seen, 1e-9)
+
+
 @pytest.mark.gpu
 def test_replay_loop_matches_reference_gpu():
     import slam_duckietown_amd.replay as rp
