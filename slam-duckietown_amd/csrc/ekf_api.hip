@@ -36,6 +36,11 @@ void launch_associate(hipStream_t, const DetIn*, int*, int*, int*, double*, doub
                       AssocOut*, unsigned*, const AssocConfig&, int, long, int, int, int);
 void launch_fill_diag(hipStream_t, double*, int, int, const double*);
 int dense_propagate(hipStream_t, double* P, double* tmp, const double* F, const double* Q, int n, int ld);
+int cadence_steps_max(int mcap);
+void launch_solve_cad(hipStream_t, int, double*, double*, double*, const double*, double*, double*, const int*, const StepIn*,
+                      int, int, SolveOut*, CadOut*, unsigned*, const int*, unsigned*, const DeviceConfig&, int, long);
+void launch_panels_cad(hipStream_t, int, double*, double*, double*, const double*, double*, const int*, const CadOut*, int,
+                       long, int, int);
 }  // namespace ekf
 
 using namespace ekf;
@@ -95,6 +100,9 @@ struct ekf_handle {
   SolveOut* dmbox = nullptr;      // per trajectory: that solve's header and records, written through (mailbox_publish)
   unsigned step_seq = 0;          // sequence number of the last single-launch step
   int opt_fused_step = 1;         // 1 = one launch per step where the launch is small (k_step_split), 0 = always two
+  int opt_fused_cadence = 1;      // 1 = uploaded streams run whole cadences as one solve + one panel launch (ekf_cadence.hip)
+  CadOut* dcad = nullptr;         // per trajectory: head + per-landmark records of the cadence in flight (allocated on first use)
+  long cadences = 0, cadence_steps = 0;   // statistics: fused cadences launched, steps they covered
   int cu_count = 0;
   int opt_rows_per_block = 0;     // 0 = auto (flush kernel: rows per workgroup, multiple of 16)
   int opt_pass_chunk = 0;         // 0 = auto (k_flush_rs: strips per unit)
@@ -150,7 +158,7 @@ static void free_all(ekf_handle* h) {
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   void* ptrs[] = {h->dP, h->dmu2[0], h->dmu2[1], h->dV, h->dW, h->ddacc2[0], h->ddacc2[1], h->dscratch, h->dn, h->dflags, h->dso, h->dfac,
                   h->d_ring, h->d_stream, h->dF, h->dQ, h->dTmp, h->dtagmap, h->dneff, h->d_det, h->d_assoc_step, h->dfloor, h->dqueue, h->dready, h->dmbox,
-                  h->d_assoc_out};
+                  h->d_assoc_out, h->dcad};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (h->h_ring) (void)hipHostFree(h->h_ring);
   if (h->h_det) (void)hipHostFree(h->h_det);
@@ -631,6 +639,46 @@ static int enqueue_pass(ekf_handle* h, const StepIn* d_in, int m_hi) {
   return EKF_OK;
 }
 
+// How many steps of the uploaded stream, starting at step k, can run as one fused cadence (0 = none).
+static int cadence_length(const ekf_handle* h, int k, int end) {
+  if (!h->opt_fused_cadence || h->pending_k != 0 || h->sizes_dirty || k >= end) return 0;
+  const int m0 = h->stream_mhi[k];
+  if (m0 < 1) return 0;
+  const int mcap = cap_for(m0), ktp = ranks_for(mcap);
+  int g = std::min(end - k, cadence_steps_max(mcap));
+  g = std::min(g, h->opt_flush_every > 0 ? h->opt_flush_every : h->opt_rank_limit / ktp);   // the pass cadence
+  for (int t = 1; t < g; ++t)
+    if (h->stream_mhi[k + t] < 1 || cap_for(h->stream_mhi[k + t]) != mcap) g = t;
+  return g;
+}
+
+// Steps [k, k + g) of the uploaded stream as one cadence; the covariance pass follows when it is due.
+static int enqueue_cadence(ekf_handle* h, int k, int g) {
+  const int n_hi = *std::max_element(h->n.begin(), h->n.end());
+  const int mcap = cap_for(h->stream_mhi[k]), ktp = ranks_for(mcap);
+  if (!h->dcad) HIP_TRY(h, hipMalloc(&h->dcad, sizeof(CadOut) * h->batch));
+  for (int b = 0; b < h->batch; ++b)                   // the cadence's active bound is its last step's
+    h->neff_enq[b] = std::min(h->n[b], std::max(h->floor_host[b], h->stream_own[(size_t)(k + g - 1) * h->batch + b]));
+  const double* mu_in = h->dmu2[h->cur];
+  double* mu_out = h->dmu2[h->cur ^ 1];
+  launch_solve_cad(h->stream, mcap, h->dP, h->dV, h->dW, mu_in, mu_out, h->ddacc2[h->dcur ^ 1], h->dn,
+                   h->d_stream + (size_t)k * h->batch, h->batch, g, h->dso, h->dcad, h->dflags, h->dfloor, h->dqueue,
+                   h->dcfg, h->ld, h->pstride);
+  launch_panels_cad(h->stream, mcap, h->dP, h->dV, h->dW, mu_in, mu_out, h->dn, h->dcad, h->ld, h->pstride, h->batch,
+                    n_hi);
+  HIP_TRY(h, hipGetLastError());
+  h->dcur ^= 1;
+  h->cur ^= 1;
+  h->pending_k += g * ktp;
+  h->pending_steps += g;
+  h->cadences += 1;
+  h->cadence_steps += g;
+  const bool due = h->opt_flush_every > 0 ? h->pending_steps >= h->opt_flush_every : h->pending_k + ktp > h->opt_rank_limit;
+  if (due || h->pending_k + 2 > KTOT)
+    if (int rc = flush_pending(h)) return rc;
+  return EKF_OK;
+}
+
 // Validate one trajectory's whole observation list (all device passes of it) before any handle state changes:
 // indices inside the current state, no index twice (the reference keys observations by landmark index,
 // replay_no_ros.py:312-313).
@@ -926,10 +974,20 @@ extern "C" int ekf_stream_run(ekf_handle* h, int first, int count) {
       return fail(h, EKF_ERR_STATE, "ekf_stream_run: the uploaded stream observes landmarks the current state does not have");
   HIP_TRY(h, hipSetDevice(h->device));
   if (int rc = push_floor(h, true)) return rc;
-  for (int k = first; k < first + count; ++k) {
+  for (int k = first; k < first + count;) {
+    // A whole cadence at once where nothing is pending: the steps up to the next covariance pass as one solve launch
+    // and one panel launch (ekf_cadence.hip).  It takes steps of one rank-slot size (1, 2, 4, 8 or 16 landmarks), all
+    // with something observed, as many as the pass cadence allows -- at least two, or the per-step path is as good.
+    const int g = cadence_length(h, k, first + count);
+    if (g >= 2) {
+      if (int rc = enqueue_cadence(h, k, g)) return rc;
+      k += g;
+      continue;
+    }
     for (int b = 0; b < h->batch; ++b)
       h->neff_enq[b] = std::min(h->n[b], std::max(h->floor_host[b], h->stream_own[(size_t)k * h->batch + b]));
     if (int rc = enqueue_pass(h, h->d_stream + (size_t)k * h->batch, h->stream_mhi[k])) return rc;
+    ++k;
   }
   if (count > 0)
     for (int b = 0; b < h->batch; ++b)
@@ -1052,6 +1110,15 @@ extern "C" int ekf_debug_read(ekf_handle* h, void* dst, long bytes) {
   return EKF_OK;
 }
 
+// (development aid, not declared in the header) how many fused cadences ekf_stream_run has launched and how many steps
+// they covered: tests assert that the path they mean to check is the one that ran
+extern "C" int ekf_debug_cadences(ekf_handle* h, long* cadences, long* steps) {
+  if (!h) return EKF_ERR_ARG;
+  if (cadences) *cadences = h->cadences;
+  if (steps) *steps = h->cadence_steps;
+  return EKF_OK;
+}
+
 // (development aid, not declared in the header) raw device buffers of trajectory b, exactly as they stand -- no flush,
 // no mirror, no status check: which = 0 P_base (rows x ld), 1 V (80 x ld), 2 W (80 x ld, MFMA-tiled), 3 the mean buffer
 // the NEXT step reads, 4 the other mean buffer.  Returns the number of doubles the buffer holds (copies min(count, that)).
@@ -1116,6 +1183,11 @@ extern "C" int ekf_set_option(ekf_handle* h, const char* name, int value) {
     //  time out and raise EKF_FLAG_INTERNAL -- the results of such a step are garbage)
     if (value < 0 || value > 2) return fail(h, EKF_ERR_ARG, "fused_step must be 0, 1 or 2 (diagnostic)");
     h->opt_fused_step = value;
+    return EKF_OK;
+  }
+  if (std::strcmp(name, "fused_cadence") == 0) {
+    if (value != 0 && value != 1) return fail(h, EKF_ERR_ARG, "fused_cadence must be 0 or 1");
+    h->opt_fused_cadence = value;
     return EKF_OK;
   }
   if (std::strcmp(name, "pass_workgroups") == 0) {

@@ -1,0 +1,607 @@
+// Fused cadence for uploaded streams (gfx950, wave64): all steps between two covariance passes as ONE solve launch and
+// ONE panel launch.
+//
+// Per step the two-kernel path (ekf_kernels.hip: k_solve + k_panels) re-gathers what it needs of the CURRENT covariance:
+// the base entries P_base(C, i) of that step's observed indices plus every pending rank at every state index (V and W
+// re-read by every step of a cadence: 14 of k_panels' 34 us at N = 2000 x 32), and pays a launch pair and a scattered
+// gather per step.  Right after a covariance pass nothing is pending, and an uploaded stream knows the landmark indices
+// of its next steps.  So the union panel
+//     X[a][i] = P(C_u[a], i),   C_u = {0, 1, 2} + the landmark indices of ALL steps up to the next pass (<= 83 rows)
+// is gathered from P_base ONCE, and the predictions (src/replay_no_ros.py:368-430) and sequential landmark updates
+// (:436-480) of all those steps are replayed on it in registers -- the same recurrences as k_panels, with every pending
+// rank's effect carried in X instead of re-read from memory -- and the 80 ranks are appended once:
+//   k_solve_cad   one 8-wave workgroup per trajectory: the sequential chain on the c_u x c_u block in LDS (motion
+//                 models, predictions, per landmark: Jacobian at the current mean, S, K, down-date), emitting one record
+//                 per landmark {H (2x5), S^-1, y, K[C_u[a], :] for the positions a later landmark still reads}
+//   k_panels_cad  thread per state index i >= 3: gathers X[:, i] (83 loads in flight at once), replays, writes
+//                 V[k][i], W[i][k] for all ranks, its share of the in-place prediction (rows 0, 1 of P_base) and mu[i]
+// State indices 0..2 (the pose) are the solve's: it has the whole pose block, so it writes their V / W entries, the pose
+// block of P_base's rows 0, 1 and the pose mean itself -- the panel kernel has no special case for the first lanes.
+// Slot layout of C_u (CadGeom, ekf_device.h): later landmarks at LOWER positions, so what is still needed is always a
+// prefix of the positions: compile-time bounds for the panel's register array X, a shrinking prefix of lanes here.
+// Same algebra as the per-step path in a different summation order: results agree to rounding (<= 1e-12 relative,
+// tests/test_gpu_cadence.py), not bit for bit.
+#include <type_traits>
+
+#include "ekf_devfn.h"
+
+namespace ekf {
+
+constexpr int CAD_CS = 88;              // LDS row stride of the block (doubles): 83 columns, rows 16-byte aligned
+constexpr int CAD_ROWS = 84;
+constexpr int CAD_NW = 8;               // waves of the solve workgroup (512 threads: the register budget of 2 waves per SIMD;
+                                        // with 16 waves the chain's constants spilled, and the fp64 rate of the four SIMDs,
+                                        // not the number of waves, bounds the down-date)
+constexpr int CAD_DW = CAD_NW - 1;      // waves that share a down-date by rows (every wave but the mean wave)
+constexpr int CAD_DQ = (CAD_CU - 2 + 3 * CAD_DW - 1) / (3 * CAD_DW) * 3;   // rows per down-date wave, in batches of 3
+
+template <int MCAP>
+__global__ __launch_bounds__(64 * CAD_NW) void k_solve_cad(double* __restrict__ P, double* __restrict__ V, double* __restrict__ W,
+                                                    const double* __restrict__ mu_in, double* __restrict__ mu_out,
+                                                    double* __restrict__ dacc_out, const int* __restrict__ nact,
+                                                    const StepIn* __restrict__ in, int batch, int nsteps,
+                                                    SolveOut* __restrict__ so, CadOut* __restrict__ out,
+                                                    unsigned* __restrict__ flags, const int* __restrict__ neff_floor,
+                                                    unsigned* __restrict__ queue, DeviceConfig cfg, int ld, long pstride) {
+  using G = CadGeom<MCAP>;
+  constexpr int GM = G::GM, CU = G::CU;
+  __shared__ __attribute__((aligned(16))) double Pc[CAD_ROWS][CAD_CS];
+  __shared__ double2 hpS[128], kcS[128];
+  __shared__ int Cs[128];
+  __shared__ double2 zS[CAD_SLOTS];                    // (range, bearing) of slot s
+  __shared__ double2 laS[CAD_SLOTS];                   // (lin, ang) of step t
+  __shared__ int mS[CAD_SLOTS], fS[CAD_SLOTS];
+  __shared__ double mot[4];                            // G[0,2], G[1,2] of the step being predicted
+  __shared__ double2 hS[6];                            // next linearisation: {h[0][k], h[1][k]}, k < 5
+  const int b = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  double* Pb = P + (long)b * pstride;
+  double* Vb = V + (long)b * KTOT * ld;
+  double* Wb = W + (long)b * KTOT * ld;
+  const double* mu_in_b = mu_in + (long)b * ld;
+  CadOut& o = out[b];
+  const int ld16 = ld >> 4;
+  // the work-queue heads of the row-slab covariance pass start every pass at zero (see k_solve)
+  if (b == 0 && tid < 8) queue[tid * RS_QSTRIDE] = 0u;
+
+  // ---- inputs: slot s = t * MCAP + j of the cadence (thread s), its two positions, the steps' scalars ----
+  if (tid < 128) Cs[tid] = tid < 3 ? tid : 0;
+  __syncthreads();
+  if (tid < GM) {
+    const int s = tid, t = s / MCAP, j = s - t * MCAP;
+    int m = 0, idx = 0;
+    double zr = 0.0, zb = 0.0;
+    if (t < nsteps) {
+      const StepIn& st = in[(long)t * batch + b];
+      m = ((st.flags & FLAG_UPDATE) && cfg.enable_measurement_model) ? min(st.m, MCAP) : 0;
+      if (j < m) {
+        idx = st.idx[j];
+        zr = st.range[j];
+        zb = st.bearing[j];
+      }
+      if (j == 0) {
+        mS[t] = m;
+        fS[t] = st.flags;
+        laS[t] = make_double2(st.lin, st.ang);
+      }
+    }
+    const int p = G::pa(s);
+    const bool valid = t < nsteps && j < m;
+    Cs[p] = valid ? 3 + 2 * idx : 0;
+    Cs[p + 1] = valid ? 4 + 2 * idx : 0;
+    zS[s] = make_double2(zr, zb);
+  }
+  const int neff_eff = min(nact[b], max(in[(long)(nsteps - 1) * batch + b].neff, neff_floor[b]));
+  __syncthreads();
+  const int Cl0 = Cs[lane], Cl1 = Cs[64 + lane];       // positions lane and 64 + lane
+  if (tid <= CU) o.C[tid] = tid < CU ? Cs[tid] : 0;
+  if (tid < CAD_SLOTS) o.m[tid] = tid < nsteps ? mS[tid] : 0;
+  if (tid == 0) {
+    o.nsteps = nsteps;
+    o.neff = neff_eff;
+    o.nranks = 2 * MCAP * nsteps;
+    o.pad0 = 0;
+    so[b].neff = neff_eff;                             // what the covariance pass reads as this trajectory's bound
+  }
+
+  // ---- the mean wave (wave 1): lane l holds the mean at positions l and 64 + l ----
+  double mu0 = 0.0, mu1 = 0.0, y0 = 0.0, y1 = 0.0;
+  double rdsum0 = 0.0, rdsum1 = 0.0, rdsum2 = 0.0;     // (wave 1) pose-block noise of the whole cadence
+  LinGeom lg{};
+  auto mean_at = [&](int p) -> double {                // p wave-uniform
+    return p < 64 ? read_lane(mu0, p) : read_lane(mu1, p - 64);
+  };
+  // motion model of step t (src/replay_no_ros.py:368-417) at the current pose mean; publishes G[0,2], G[1,2]
+  auto motion = [&](int t) {
+    const double2 la = laS[t];
+    const bool do_pred = (fS[t] & FLAG_PREDICT) != 0;
+    const double th = read_lane(mu0, 2);
+    double g0 = 0.0, g1 = 0.0, nx = read_lane(mu0, 0), ny = read_lane(mu0, 1), nth = th;
+    if (do_pred && !cfg.disable_motion_model) {
+      const double lin = la.x, ang = la.y;
+      double s0, c0;
+      sincos(th, &s0, &c0);
+      if (cfg.enable_circular_interpolation && fabs(ang) > cfg.arc_threshold) {   // :390 arc
+        double s1, c1;
+        sincos(th + ang, &s1, &c1);
+        const double r = lin / ang;
+        nx += -r * s0 + r * s1;
+        ny += r * c0 - r * c1;
+        nth = wrap_pi(th + ang);                       // :397
+        g0 = -r * c0 + r * c1;                         // :401
+        g1 = -r * s0 + r * s1;                         // :402
+      } else {                                         // :376 straight / :405-417 linear mode
+        nx += lin * c0;
+        ny += lin * s0;
+        if (!cfg.enable_circular_interpolation) nth = th + ang;   // no wrap (:409); :381 keeps theta
+        g0 = -lin * s0;
+        g1 = lin * c0;
+      }
+    }
+    if (lane < 3) mu0 = lane == 0 ? nx : (lane == 1 ? ny : nth);
+    if (do_pred) {
+      rdsum0 += cfg.rd[0];
+      rdsum1 += cfg.rd[1];
+      rdsum2 += cfg.rd[2];
+    }
+    if (lane == 0) {
+      mot[0] = g0;
+      mot[1] = g1;
+      *reinterpret_cast<double2*>(o.g[t]) = make_double2(g0, g1);
+    }
+  };
+  auto jacobian_at_mean = [&](int p) {                 // landmark at positions p, p + 1: publishes hS, keeps the geometry
+    double hn[2][5];
+    lg = linearize_h(read_lane(mu0, 0), read_lane(mu0, 1), read_lane(mu0, 2), mean_at(p), mean_at(p + 1), hn);
+    if (lane == 0) {
+#pragma unroll
+      for (int k = 0; k < 5; ++k) hS[k] = make_double2(hn[0][k], hn[1][k]);
+    }
+  };
+
+  // ---- gather the block P_base[C_u, C_u] (nothing is pending: P = P_base); wave 1 starts on its means meanwhile ----
+  {
+    constexpr int RQ = (CU + CAD_NW - 1) / CAD_NW;     // rows per wave
+    double gv0[RQ], gv1[RQ];
+#pragma unroll
+    for (int q = 0; q < RQ; ++q) {
+      const int r = wave + CAD_NW * q;
+      gv0[q] = 0.0;
+      gv1[q] = 0.0;
+      if (r < CU) {                                    // (wave-uniform)
+        const int Cr = Cs[r];
+        gv0[q] = Pb[(long)min(Cr, Cl0) * ld + max(Cr, Cl0)];      // the upper triangle is authoritative
+        if (CU > 64) gv1[q] = Pb[(long)min(Cr, Cl1) * ld + max(Cr, Cl1)];
+      }
+    }
+    if (wave == 1) {
+      mu0 = mu_in_b[Cl0];
+      mu1 = mu_in_b[Cl1];
+    }
+#pragma unroll
+    for (int q = 0; q < RQ; ++q) {
+      const int r = wave + CAD_NW * q;
+      if (r < CU) {
+        Pc[r][lane] = gv0[q];
+        if (64 + lane < CAD_CS) Pc[r][64 + lane] = gv1[q];
+      }
+    }
+  }
+  if (wave == 1) motion(0);
+  WG_LDS_BARRIER();
+  if (wave == 0) {                                     // (diagnostic record) rows 0, 1 of the block before the cadence
+    if (lane < CU) {
+      o.prow[0][lane] = Pc[0][lane];
+      o.prow[1][lane] = Pc[1][lane];
+    }
+    if (64 + lane <= CU) {
+      o.prow[0][64 + lane] = 64 + lane < CU ? Pc[0][64 + lane] : 0.0;
+      o.prow[1][64 + lane] = 64 + lane < CU ? Pc[1][64 + lane] : 0.0;
+    }
+  }
+
+  double dd0 = 0.0, dd1 = 0.0;                         // (wave 0, lanes 0..2) in-place change of P_base(0, l), P_base(1, l)
+  const int ds = wave == 0 ? 0 : wave - 1;             // down-date slot of this wave (wave 1 has none)
+  for (int t = 0; t < nsteps; ++t) {
+    const int m = __builtin_amdgcn_readfirstlane(mS[t]);
+    const int s_first = t * MCAP;
+    const int ca = G::pa(s_first) + 2;                 // positions in use during this step: [0, ca)
+    const bool two = ca > 64;                          // (uniform) the second half of the columns is live
+    // ---- prediction of step t on the block: P' = G P G^T + R restricted to C_u (:428-430).  Only rows / columns 0, 1
+    // change, and the block is exactly symmetric: lane r holds P[0..2][r] = P[r][0..2] and produces P'[r][0], P'[r][1],
+    // which for r >= 2 are also P'[0][r], P'[1][r].  Wave 1 linearises the step's first landmark meanwhile.
+    if (wave == 0) {
+      const bool do_pred = (fS[t] & FLAG_PREDICT) != 0;
+      const double g0 = mot[0], g1 = mot[1];
+      const double rd0 = do_pred ? cfg.rd[0] : 0.0, rd1 = do_pred ? cfg.rd[1] : 0.0, rd2 = do_pred ? cfg.rd[2] : 0.0;
+      const double s20 = Pc[2][0], s21 = Pc[2][1], p22 = Pc[2][2];
+      const int r0 = min(lane, ca - 1), r1 = min(64 + lane, CAD_CS - 1);
+      const double p0 = Pc[0][r0], p1 = Pc[1][r0], p2 = Pc[2][r0];
+      const double q0 = Pc[0][r1], q1 = Pc[1][r1], q2 = Pc[2][r1];
+      const double gr = lane == 0 ? g0 : (lane == 1 ? g1 : 0.0);
+      double x0 = p0, x1 = p1, x2 = p2;                // row r of G P, columns 0..2 (rows 0, 1 take g_r x row 2)
+      if (lane < 2) {
+        x0 = fma(gr, s20, p0);
+        x1 = fma(gr, s21, p1);
+        x2 = fma(gr, p22, p2);
+      }
+      double c0n = fma(g0, x2, x0), c1n = fma(g1, x2, x1);
+      dd0 += fma(g0, x2, lane < 2 ? gr * s20 : 0.0);   // P'(0, l) - P(0, l) and P'(1, l) - P(1, l) without the noise
+      dd1 += fma(g1, x2, lane < 2 ? gr * s21 : 0.0);
+      if (lane == 0) c0n += rd0;
+      if (lane == 1) c1n += rd1;
+      const double e0n = fma(g0, q2, q0), e1n = fma(g1, q2, q1);
+      if (lane < ca) {
+        Pc[lane][0] = c0n;
+        Pc[lane][1] = c1n;
+        if (lane >= 2) {
+          Pc[0][lane] = c0n;
+          Pc[1][lane] = c1n;
+        }
+        if (lane == 2) Pc[2][2] = p2 + rd2;
+      }
+      if (two && 64 + lane < ca) {
+        Pc[64 + lane][0] = e0n;
+        Pc[64 + lane][1] = e1n;
+        Pc[0][64 + lane] = e0n;
+        Pc[1][64 + lane] = e1n;
+      }
+    } else if (wave == 1) {
+      if (m > 0) jacobian_at_mean(G::pa(s_first));
+    }
+    WG_LDS_BARRIER();                                  // S0(t): predicted block and hS published
+    if (wave == 1 && m > 0) {
+      const double2 z = zS[s_first];
+      innovation(lg, z.x, z.y, y0, y1);
+    }
+    double h[2][5];
+    if (wave == 0 && m > 0) {
+#pragma unroll
+      for (int k = 0; k < 5; ++k) {
+        const double2 tt = hS[k];
+        h[0][k] = tt.x;
+        h[1][k] = tt.y;
+      }
+    }
+    // ---- the step's landmarks, sequentially (:436-480) ----
+    for (int j = 0; j < m; ++j) {
+      const int s = s_first + j, pa = G::pa(s);        // this landmark sits at positions pa, pa + 1; [0, pa) lives on
+      const bool two_j = pa + 2 > 64;                  // columns 64.. still in use
+      const bool last = j + 1 == m && t + 1 == nsteps; // nothing reads the block after this landmark
+      double* rec = o.rec + G::rec_off(s);
+      double2 hpa = make_double2(0.0, 0.0), hpb = make_double2(0.0, 0.0);   // (H P)[:, l] of this wave's columns
+      if (wave == 0) {
+        // phase A: rows sel = {0, 1, 2, pa, pa + 1} of P at column l give (H P)[:, l]; P is symmetric, so P H^T is the
+        // transpose and the gain needs no second product
+        const int la = min(lane, pa + 1), lb = min(64 + lane, CAD_CS - 1);
+        double pra[5], prb[5];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+          const int r = k < 3 ? k : pa + (k - 3);
+          pra[k] = Pc[r][la];
+          prb[k] = two_j ? Pc[r][lb] : 0.0;
+        }
+        hpa = make_double2(h[0][0] * pra[0], h[1][0] * pra[0]);
+        hpb = make_double2(h[0][0] * prb[0], h[1][0] * prb[0]);
+#pragma unroll
+        for (int k = 1; k < 5; ++k) {
+          hpa.x = fma(h[0][k], pra[k], hpa.x);
+          hpa.y = fma(h[1][k], pra[k], hpa.y);
+          hpb.x = fma(h[0][k], prb[k], hpb.x);
+          hpb.y = fma(h[1][k], prb[k], hpb.y);
+        }
+        hpS[lane] = hpa;
+        hpS[64 + lane] = hpb;
+        WAVE_LDS_SYNC();
+        // phase B: S = H P H^T + Q (:473) from the five pairs at sel, every lane redundantly
+        double2 hv[5];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) hv[k] = hpS[k < 3 ? k : pa + (k - 3)];
+        double S00 = cfg.qd[0], S01 = 0.0, S10 = 0.0, S11 = cfg.qd[1];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+          S00 = fma(hv[k].x, h[0][k], S00);
+          S01 = fma(hv[k].x, h[1][k], S01);
+          S10 = fma(hv[k].y, h[0][k], S10);
+          S11 = fma(hv[k].y, h[1][k], S11);
+        }
+        const double rdet = 1.0 / (S00 * S11 - S01 * S10);
+        const double i00 = S11 * rdet, i01 = -S01 * rdet, i10 = -S10 * rdet, i11 = S00 * rdet;
+        const double2 ka = make_double2(hpa.x * i00 + hpa.y * i10, hpa.x * i01 + hpa.y * i11);   // K[C_u[l], :]
+        const double2 kb = make_double2(hpb.x * i00 + hpb.y * i10, hpb.x * i01 + hpb.y * i11);
+        kcS[lane] = ka;
+        kcS[64 + lane] = kb;
+        // the record of this landmark for the panel kernel; the pose's own entries of the new ranks
+        if (lane < pa) *reinterpret_cast<double2*>(rec + 16 + 2 * lane) = ka;
+        if (two_j && 64 + lane < pa) *reinterpret_cast<double2*>(rec + 16 + 2 * (64 + lane)) = kb;
+        if (lane == 0) {
+#pragma unroll
+          for (int k = 0; k < 5; ++k) *reinterpret_cast<double2*>(rec + 2 * k) = make_double2(h[0][k], h[1][k]);
+          *reinterpret_cast<double2*>(rec + 10) = make_double2(i00, i01);
+          *reinterpret_cast<double2*>(rec + 12) = make_double2(i10, i11);
+        }
+        if (lane < 3) {
+          Vb[(long)(2 * s) * ld + lane] = hpa.x;
+          Vb[(long)(2 * s + 1) * ld + lane] = hpa.y;
+          Wb[wm_index(ld16, 2 * s, lane)] = -ka.x;
+          Wb[wm_index(ld16, 2 * s + 1, lane)] = -ka.y;
+        }
+      }
+      WG_LDS_BARRIER();                                // b1: K and (H P) of this landmark are in LDS
+      if (wave == 1) {
+        // the mean (:476); then the next landmark's Jacobian at the new mean, or the next step's motion model
+        const double2 k0 = kcS[lane], k1 = kcS[64 + lane];
+        if (lane < pa + 2) mu0 += k0.x * y0 + k0.y * y1;
+        if (64 + lane < pa + 2) mu1 += k1.x * y0 + k1.y * y1;
+        if (lane == 0) *reinterpret_cast<double2*>(rec + 14) = make_double2(y0, y1);
+        if (j + 1 < m) jacobian_at_mean(pa - 2);
+        else if (t + 1 < nsteps) motion(t + 1);
+      } else if (!last) {
+        // down-date (:480) of what lives on: P[r][l] -= K[r, :] . (H P)[:, l] for r, l < pa, rows dealt to the other waves
+        if (wave != 0) {
+          hpa = hpS[lane];
+          if (two_j) hpb = hpS[64 + lane];
+        }
+        const int lb = min(64 + lane, CAD_CS - 1);
+#pragma unroll
+        for (int q0 = 0; q0 < CAD_DQ; q0 += 3) {
+          if (ds + CAD_DW * q0 < pa) {                 // (uniform)
+            double2 kr[3];
+            double pv[3], pw[3];
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+              const int r = min(ds + CAD_DW * (q0 + u), CAD_ROWS - 1);
+              kr[u] = kcS[r];
+              pv[u] = Pc[r][lane];
+              pw[u] = two_j ? Pc[r][lb] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+              pv[u] = fma(-kr[u].x, hpa.x, pv[u]);
+              pw[u] = fma(-kr[u].x, hpb.x, pw[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+              pv[u] = fma(-kr[u].y, hpa.y, pv[u]);
+              pw[u] = fma(-kr[u].y, hpb.y, pw[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+              const int r = ds + CAD_DW * (q0 + u);
+              if (r < pa && lane < pa) Pc[r][lane] = pv[u];
+              if (two_j && r < pa && 64 + lane < pa) Pc[r][64 + lane] = pw[u];
+            }
+          }
+        }
+      }
+      WG_LDS_BARRIER();                                // b2: block down-dated; hS (or the next step's G) published
+      if (wave == 1 && j + 1 < m) {
+        const double2 z = zS[s + 1];
+        innovation(lg, z.x, z.y, y0, y1);
+      }
+      if (wave == 0 && j + 1 < m) {
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+          const double2 tt = hS[k];
+          h[0][k] = tt.x;
+          h[1][k] = tt.y;
+        }
+      }
+    }
+    if (m == 0) {                                      // (uniform) no landmark whose tail could carry the next motion model
+      if (wave == 1 && t + 1 < nsteps) motion(t + 1);
+      WG_LDS_BARRIER();
+    }
+    // slots this step leaves empty: zero ranks at the pose's state indices (the panel kernel writes the others)
+    if (wave == 0 && lane < 3) {
+      for (int k = 2 * (s_first + m); k < 2 * (s_first + MCAP); ++k) {
+        Vb[(long)k * ld + lane] = 0.0;
+        Wb[wm_index(ld16, k, lane)] = 0.0;
+      }
+    }
+  }
+
+  // ---- results the solve owns: the pose mean, the pose block of P_base's rows 0, 1, the pending pose noise ----
+  if (wave == 1) {
+    double* mu_out_b = mu_out + (long)b * ld;
+    bool bad = false;
+    if (lane < 3) mu_out_b[lane] = mu0;
+    bad = !(fabs(mu0) <= 1.79769313486231570815e308) || (64 + lane < CU && !(fabs(mu1) <= 1.79769313486231570815e308));
+    if (__any(bad) && lane == 0) atomicOr(flags + b, EKF_FLAG_NONFINITE);
+    if (lane == 0) {
+      dacc_out[4 * b + 0] = rdsum0;
+      dacc_out[4 * b + 1] = rdsum1;
+      dacc_out[4 * b + 2] = rdsum2;
+    }
+  }
+  if (wave == 0 && lane < 3) {
+    Pb[lane] += dd0;                                   // entry (0, l)
+    if (lane >= 1) Pb[ld + lane] += dd1;               // entry (1, l); (1, 0) lies below the diagonal
+    for (int k = 2 * MCAP * nsteps; k < ((2 * MCAP * nsteps + 3) & ~3); ++k) {   // k-tile pad
+      Vb[(long)k * ld + lane] = 0.0;
+      Wb[wm_index(ld16, k, lane)] = 0.0;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_panels_cad: thread i (a state index >= 3) replays the whole cadence on its column X[a] = P(C_u[a], i).
+// NW waves of 64 state indices per workgroup share one staging of the records (LDS, 16-byte broadcast reads at
+// compile-time offsets); after the single barrier the waves never synchronise again.
+// ---------------------------------------------------------------------------------------------
+template <int MCAP, int NW>
+__global__ __launch_bounds__(64 * NW) void k_panels_cad(double* __restrict__ P, double* __restrict__ V,
+                                                        double* __restrict__ W, const double* __restrict__ mu_in,
+                                                        double* __restrict__ mu_out, const int* __restrict__ nact,
+                                                        const CadOut* __restrict__ co, int ld, long pstride) {
+  using G = CadGeom<MCAP>;
+  constexpr int CU = G::CU, GMAX = G::GMAX, NT = 64 * NW;
+  __shared__ __attribute__((aligned(16))) double sRec[G::REC];
+  __shared__ double2 sG[CAD_SLOTS];
+  __shared__ int sM[CAD_SLOTS];
+  const int b = blockIdx.y;
+  const int n = nact[b];
+  const int w0 = blockIdx.x * NT;
+  if (w0 >= n) return;
+  const CadOut& o = co[b];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nsteps = o.nsteps, neff = o.neff, nranks = o.nranks;
+  const int ld16 = ld >> 4;
+  double* Pb = P + (long)b * pstride;
+  double* Vb = V + (long)b * KTOT * ld;
+  double* Wb = W + (long)b * KTOT * ld;
+  const int i0 = w0 + wave * 64, i = i0 + lane;
+  const bool act = i < n;
+  const int ii = act ? i : n - 1;                      // idle lanes shadow the last state index (no stores)
+  const bool actw = act && i >= 3;                     // the pose's state indices are the solve's
+  const bool live = i0 < neff && i0 < n;               // (uniform) this wave replays
+  // the gather does not depend on the staged records: all of it is issued before the barrier
+  double X[CU];
+  if (live) {
+#pragma unroll
+    for (int a = 0; a < CU; ++a) {
+      const int row = o.C[a];
+      X[a] = Pb[(long)min(row, ii) * ld + max(row, ii)];
+    }
+  } else {
+#pragma unroll
+    for (int a = 0; a < CU; ++a) X[a] = 0.0;
+  }
+  if (w0 < neff) {                                     // (uniform) some wave of this workgroup replays: stage the records
+    const int cnt = G::rec_off(nsteps * MCAP) / 2;     // double2 units
+    const double2* src = reinterpret_cast<const double2*>(o.rec);
+    double2* dst = reinterpret_cast<double2*>(sRec);
+    for (int e = tid; e < cnt; e += NT) dst[e] = src[e];
+    if (tid < CAD_SLOTS) {
+      sM[tid] = o.m[tid];
+      sG[tid] = *reinterpret_cast<const double2*>(o.g[tid]);
+    }
+  }
+  __syncthreads();
+  if (i0 >= n) return;
+  const int nrp = (nranks + 3) & ~3;                   // ranks written: whole k-tiles
+  if (i0 >= neff) {
+    // beyond the active bound the rows and columns of P are exactly zero off the diagonal: the cadence's ranks are
+    // zero there and the mean is carried over
+    if (actw) {
+      for (int k = 0; k < nrp; ++k) {
+        Vb[(long)k * ld + i] = 0.0;
+        Wb[wm_index(ld16, k, i)] = 0.0;
+      }
+      mu_out[(long)b * ld + i] = mu_in[(long)b * ld + i];
+    }
+    return;
+  }
+  double d0 = 0.0, d1 = 0.0, dm = 0.0;
+#pragma unroll
+  for (int t = 0; t < GMAX; ++t) {
+    if (t < nsteps) {                                  // (uniform)
+      // prediction (:430): of the stored triangle it changes rows 0, 1 only; thread i adds its two entries to P_base at
+      // the end (the ranks are unaffected), the pose diagonal's noise never meets a state index >= 3
+      const double2 g = sG[t];
+      const double t0 = g.x * X[2], t1 = g.y * X[2];
+      X[0] += t0;
+      X[1] += t1;
+      d0 += t0;
+      d1 += t1;
+      const int mt = sM[t];
+#pragma unroll
+      for (int j = 0; j < MCAP; ++j) {
+        const int s = t * MCAP + j;                    // (compile-time after unrolling)
+        const int pa = G::pa(s), kr = 2 * s, off = G::rec_off(s);
+        if (j < mt) {                                  // (uniform)
+          const double2* R = reinterpret_cast<const double2*>(__builtin_assume_aligned(sRec + off, 16));
+          double2 hk[5];
+#pragma unroll
+          for (int k = 0; k < 5; ++k) hk[k] = R[k];
+          const double2 s01 = R[5], s23 = R[6], yy = R[7];
+          double e0 = hk[0].x * X[0], e1 = hk[0].y * X[0];      // (H_s P_s)[:, i] = h5 . x[sel]
+#pragma unroll
+          for (int k = 1; k < 5; ++k) {
+            const double xv = (k < 3) ? X[k] : X[pa + (k - 3)];
+            e0 = fma(hk[k].x, xv, e0);
+            e1 = fma(hk[k].y, xv, e1);
+          }
+          const double f0 = e0 * s01.x + e1 * s23.x;   // K_s[i, :] = (H_s P_s)[:, i]^T S^-1  (P symmetric)
+          const double f1 = e0 * s01.y + e1 * s23.y;
+          dm += f0 * yy.x + f1 * yy.y;                 // :476
+          if (actw) {
+            Vb[(long)kr * ld + i] = e0;
+            Vb[(long)(kr + 1) * ld + i] = e1;
+            Wb[wm_index(ld16, kr, i)] = -f0;
+            Wb[wm_index(ld16, kr + 1, i)] = -f1;
+          }
+          if (!(t + 1 == nsteps && j + 1 == mt)) {     // (uniform) x[a] -= K_s[C_u[a], :] . (H_s P_s)[:, i], what lives on
+#pragma unroll
+            for (int a = 0; a < pa; ++a) {
+              const double2 kc = R[8 + a];
+              X[a] = fma(-kc.x, e0, X[a]);
+              X[a] = fma(-kc.y, e1, X[a]);
+            }
+          }
+        } else if (actw) {
+          Vb[(long)kr * ld + i] = 0.0;
+          Vb[(long)(kr + 1) * ld + i] = 0.0;
+          Wb[wm_index(ld16, kr, i)] = 0.0;
+          Wb[wm_index(ld16, kr + 1, i)] = 0.0;
+        }
+      }
+    }
+  }
+  if (actw) {
+    for (int k = nranks; k < nrp; ++k) {               // k-tile pad
+      Vb[(long)k * ld + i] = 0.0;
+      Wb[wm_index(ld16, k, i)] = 0.0;
+    }
+    Pb[i] += d0;                                       // entry (0, i)
+    Pb[ld + i] += d1;                                  // entry (1, i)
+    mu_out[(long)b * ld + i] = mu_in[(long)b * ld + i] + dm;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// launchers (called from ekf_api.hip)
+// ---------------------------------------------------------------------------------------------
+int cadence_steps_max(int mcap) { return CAD_SLOTS / mcap; }
+
+void launch_solve_cad(hipStream_t st, int mcap, double* P, double* V, double* W, const double* mu_in, double* mu_out,
+                      double* dacc_out, const int* nact, const StepIn* in, int batch, int nsteps, SolveOut* so, CadOut* out,
+                      unsigned* flags, const int* neff_floor, unsigned* queue, const DeviceConfig& cfg, int ld, long pstride) {
+#define EKF_SOLVE_CAD(M)                                                                                              \
+  hipLaunchKernelGGL((k_solve_cad<M>), dim3(batch), dim3(64 * CAD_NW), 0, st, P, V, W, mu_in, mu_out, dacc_out, nact, in, batch, \
+                     nsteps, so, out, flags, neff_floor, queue, cfg, ld, pstride)
+  switch (mcap) {
+    case 1: EKF_SOLVE_CAD(1); break;
+    case 2: EKF_SOLVE_CAD(2); break;
+    case 4: EKF_SOLVE_CAD(4); break;
+    case 8: EKF_SOLVE_CAD(8); break;
+    default: EKF_SOLVE_CAD(16); break;
+  }
+#undef EKF_SOLVE_CAD
+}
+
+template <int MCAP>
+static void launch_panels_cad_t(hipStream_t st, double* P, double* V, double* W, const double* mu_in, double* mu_out,
+                                const int* nact, const CadOut* co, int ld, long pstride, int batch, int n_hi) {
+  // few waves (the latency regime): one wave per workgroup, so that every wave gets a CU to itself
+  if ((long)((n_hi + 63) / 64) * batch <= 1024)
+    hipLaunchKernelGGL((k_panels_cad<MCAP, 1>), dim3((n_hi + 63) / 64, batch), dim3(64), 0, st, P, V, W, mu_in, mu_out,
+                       nact, co, ld, pstride);
+  else
+    hipLaunchKernelGGL((k_panels_cad<MCAP, 4>), dim3((n_hi + 255) / 256, batch), dim3(256), 0, st, P, V, W, mu_in,
+                       mu_out, nact, co, ld, pstride);
+}
+void launch_panels_cad(hipStream_t st, int mcap, double* P, double* V, double* W, const double* mu_in, double* mu_out,
+                       const int* nact, const CadOut* co, int ld, long pstride, int batch, int n_hi) {
+  switch (mcap) {
+    case 1: launch_panels_cad_t<1>(st, P, V, W, mu_in, mu_out, nact, co, ld, pstride, batch, n_hi); break;
+    case 2: launch_panels_cad_t<2>(st, P, V, W, mu_in, mu_out, nact, co, ld, pstride, batch, n_hi); break;
+    case 4: launch_panels_cad_t<4>(st, P, V, W, mu_in, mu_out, nact, co, ld, pstride, batch, n_hi); break;
+    case 8: launch_panels_cad_t<8>(st, P, V, W, mu_in, mu_out, nact, co, ld, pstride, batch, n_hi); break;
+    default: launch_panels_cad_t<16>(st, P, V, W, mu_in, mu_out, nact, co, ld, pstride, batch, n_hi); break;
+  }
+}
+
+}  // namespace ekf

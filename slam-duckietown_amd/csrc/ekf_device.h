@@ -71,6 +71,46 @@ struct alignas(16) SolveOut : SolveHead {
 static_assert(sizeof(SolveHead) % 16 == 0, "SolveHead must stay 16-byte granular");
 // (SolveOut = head, then the records: `it` starts at sizeof(SolveHead))
 
+// ---- fused cadence (ekf_cadence.hip): the steps between two covariance passes of an uploaded stream as ONE solve launch
+// and ONE panel launch.  Right after a pass nothing is pending and the stream knows the next steps' landmark indices: the
+// union panel P(C_u, i), C_u = {0,1,2} + the landmark indices of all steps of the cadence, is gathered from P_base once,
+// the predictions and the sequential landmark updates of src/replay_no_ros.py:368-480 are replayed on it, and all ranks
+// are appended at once.  Landmark slot s = t * MCAP + j (step t of the cadence, j-th observation, in processing order)
+// sits at positions pa(s), pa(s) + 1 of C_u with pa(s) = 3 + 2 (GM - 1 - s): later slots at LOWER positions, so that
+// "everything a later update still needs" is always the prefix [0, pa(s)) of the positions -- compile-time bounds for the
+// panel's register array, a shrinking prefix of lanes for the solve.  A landmark observed in two steps simply has two
+// slots (duplicate positions carry identical values); unused slots (m_t < MCAP, fewer steps than GMAX) gather index 0.
+constexpr int CAD_SLOTS = KTOT / 2;                  // landmark slots of a cadence (2 ranks each)
+constexpr int CAD_CU = 3 + 2 * CAD_SLOTS;            // gathered positions at most (83)
+template <int MCAP>
+struct CadGeom {
+  static constexpr int GMAX = CAD_SLOTS / MCAP;      // steps of a full cadence (40, 20, 10, 5, 2)
+  static constexpr int GM = GMAX * MCAP;             // landmark slots (40; 32 at MCAP = 16)
+  static constexpr int CU = 3 + 2 * GM;              // gathered positions
+  __host__ __device__ static constexpr int pa(int s) { return 3 + 2 * (GM - 1 - s); }
+  // record of slot s (doubles): h5t[5][2], si[4], y[2], then K_s[C_u[a], :] for the positions a < pa(s) a later slot or
+  // step still reads; records are packed back to back
+  __host__ __device__ static constexpr int rec_off(int s) { return 16 * s + 2 * (s * (3 + 2 * (GM - 1)) - s * (s - 1)); }
+  static constexpr int REC = rec_off(GM);
+};
+constexpr int CAD_REC_MAX = CadGeom<8>::REC;         // 4000 doubles (the same for MCAP = 1, 2, 4, 8; less at 16)
+static_assert(CadGeom<1>::REC == CAD_REC_MAX && CadGeom<2>::REC == CAD_REC_MAX && CadGeom<4>::REC == CAD_REC_MAX &&
+              CadGeom<16>::REC <= CAD_REC_MAX, "record area");
+struct alignas(16) CadHead {
+  int nsteps;                 // steps of this cadence (<= GMAX)
+  int neff;                   // active bound of the cadence (its last step's)
+  int nranks;                 // ranks appended: 2 * MCAP * nsteps
+  int pad0;
+  int m[CAD_SLOTS];           // observations of step t (0 when the measurement model is off)
+  int C[CAD_CU + 1];          // gathered state indices by position
+  double g[CAD_SLOTS][2];     // G[0,2], G[1,2] of step t's motion Jacobian
+  double prow[2][CAD_CU + 1]; // (diagnostic) P(0, C_u[a]), P(1, C_u[a]) before the cadence
+};
+struct alignas(16) CadOut : CadHead {
+  double rec[CAD_REC_MAX];
+};
+static_assert(sizeof(CadHead) % 16 == 0, "CadHead must stay 16-byte granular");
+
 // Device-side association: one window of raw AprilTag detections per trajectory.
 constexpr int DMAX = 64;                // detections per window
 constexpr int TAGMAX = 1024;            // tag ids [0, TAGMAX) (tag36h11 has 587)

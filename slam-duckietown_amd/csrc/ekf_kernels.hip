@@ -36,115 +36,10 @@
 #define STAMP(o, i) do { } while (0)
 #endif
 
-// LDS hand-off between lanes of ONE wave (the other waves of the workgroup have exited): LDS
-// operations of a wave execute in issue order, so only the compiler must be kept from reordering.
-#define WAVE_SYNC()                                              \
-  do {                                                           \
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");       \
-    __builtin_amdgcn_wave_barrier();                             \
-  } while (0)
-
-// LDS hand-off between two waves of a workgroup: the writer's LDS stores have landed (lgkmcnt(0)) before it
-// flips the slot word, the reader issues its LDS loads after it saw the word; the "memory" clobber keeps the
-// compiler from moving LDS accesses across.  Unlike a workgroup fence this leaves the wave's global loads
-// and stores in flight (a fence drains vmcnt too).
-#define LDS_SYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
-
-// Workgroup barrier for data handed over through LDS only: the wave's LDS operations have completed, its global
-// loads and stores stay in flight (`__syncthreads()` and workgroup fences drain vmcnt as well: a store
-// acknowledgement is ~500 cycles away).  WAVE_LDS_SYNC: the same between lanes of one wave, where LDS operations
-// execute in issue order and only the compiler must be kept from reordering them.
-#define WG_LDS_BARRIER()                                         \
-  do {                                                           \
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           \
-    __builtin_amdgcn_s_barrier();                                \
-    asm volatile("" ::: "memory");                               \
-  } while (0)
-#define WAVE_LDS_SYNC()                                          \
-  do {                                                           \
-    asm volatile("" ::: "memory");                               \
-    __builtin_amdgcn_wave_barrier();                             \
-    asm volatile("" ::: "memory");                               \
-  } while (0)
+#include "ekf_devfn.h"
 
 namespace ekf {
 
-typedef double double4_t __attribute__((ext_vector_type(4)));
-
-// W is stored in MFMA A-operand tiles: k-tile (4 ranks) major, then 16-row groups, then [k&3][row&15],
-// so that one 8-byte-per-lane load of 64 consecutive doubles is exactly one 16x4 A fragment.
-__host__ __device__ __forceinline__ long wm_index(int ld16, int k, int i) {
-  return ((long)(k >> 2) * ld16 + (i >> 4)) * 64 + (k & 3) * 16 + (i & 15);
-}
-
-__device__ __forceinline__ double wrap_pi(double a) {
-  // (a + pi) % (2 pi) - pi with NumPy remainder semantics, result in [-pi, pi)
-  // (src/replay_no_ros.py:397, :458).  fma(-k, 2pi, x) is the exact remainder when k is the right
-  // quotient (the remainder is representable); the two fix-ups cover a quotient that is off by one.
-  const double two_pi = 2.0 * M_PI;
-  const double x = a + M_PI;
-  const double k = floor(x * (1.0 / two_pi));
-  double r = fma(-k, two_pi, x);
-  if (r < 0.0) r += two_pi;
-  else if (r >= two_pi) r -= two_pi;
-  return r - M_PI;
-}
-
-// Innovation and 2x5 Jacobian of one range/bearing observation (src/replay_no_ros.py:443-469), in two parts: the
-// Jacobian (needed first, by the covariance chain) and the innovation (atan2: twice as long, needed only by the mean).
-// h[r][k] = row r, column k on {x, y, theta, lx, ly}.  q == 0 gives NaN rows like NumPy's 0/0.
-struct LinGeom {
-  double dx, dy, th, sq;
-};
-__device__ __forceinline__ LinGeom linearize_h(double mx, double my, double mth, double lx, double ly, double (&h)[2][5]) {
-  LinGeom g;
-  g.dx = lx - mx;                                                 // :443
-  g.dy = ly - my;
-  g.th = mth;
-  const double dx = g.dx, dy = g.dy;
-  const double q = dx * dx + dy * dy;                             // :446
-  // 1/sqrt(q) once (hardware estimate + two Newton steps, <= 1 ulp); sqrt(q) = q * rs, 1/q = rs * rs.
-  // q == 0 -> rs = inf -> NaN rows below, like NumPy's 0/0 at :466-469.
-  double rs = __builtin_amdgcn_rsq(q);
-  rs = rs * fma(-0.5 * q * rs, rs, 1.5);
-  rs = rs * fma(-0.5 * q * rs, rs, 1.5);
-  g.sq = q * rs;
-  const double rq = rs * rs;
-  const double nanv = __builtin_nan("");
-  h[0][0] = -rs * dx;                                             // (-sqrt(q) dx) / q
-  h[0][1] = -rs * dy;
-  h[0][2] = (q > 0.0) ? 0.0 : nanv;                               // .0 / q
-  h[0][3] = rs * dx;
-  h[0][4] = rs * dy;
-  h[1][0] = dy * rq;
-  h[1][1] = -dx * rq;
-  h[1][2] = (q > 0.0 && q < __builtin_inf()) ? -1.0 : nanv;       // -q / q
-  h[1][3] = -dy * rq;
-  h[1][4] = dx * rq;
-  return g;
-}
-typedef unsigned int uint2v_t __attribute__((ext_vector_type(2)));
-typedef unsigned int uint4v_t __attribute__((ext_vector_type(4)));
-// buffer access with a 32-bit byte offset per lane (one instruction, no 64-bit address arithmetic)
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t rs_rsrc(const void* base) {
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, -1, 0x00020000);
-}
-__device__ __forceinline__ double ldb8(__amdgpu_buffer_rsrc_t rs, unsigned lane_bytes, unsigned row_bytes) {
-  return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs, (int)lane_bytes, (int)row_bytes, 0));
-}
-
-// lane `src` (wave-uniform) of a double, through the scalar registers
-__device__ __forceinline__ double read_lane(double v, int src) {
-  const uint2v_t u = __builtin_bit_cast(uint2v_t, v);
-  const unsigned lo = __builtin_amdgcn_readlane(u.x, src), hi = __builtin_amdgcn_readlane(u.y, src);
-  return __builtin_bit_cast(double, uint2v_t{lo, hi});
-}
-__device__ __forceinline__ void innovation(const LinGeom& g, double z_range, double z_bearing, double& y0, double& y1) {
-  y0 = z_range - g.sq;                                            // :455
-  y1 = wrap_pi(z_bearing - (atan2(g.dy, g.dx) - g.th));           // :453-458
-}
-
-constexpr int RS_QSTRIDE = 32;          // k_flush_rs: words between the per-XCD queue heads (one cache line each)
 constexpr int PCS = CMAX + 2;   // LDS row stride 37 doubles: column reads by 32 lanes are conflict-free
 constexpr int RCH = 8;          // rows per batch of the down-date
 constexpr int CPAD = (CMAX + RCH - 1) / RCH * RCH;   // 40
@@ -1858,7 +1753,10 @@ __device__ __forceinline__ double2 ldb16(__amdgpu_buffer_rsrc_t rs, unsigned lan
 // assumes the SGPR read covers it); on gfx950 the form used here (offen + SGPR soffset) was caught corrupting the low
 // mantissa bits of the odd columns of a tile's last row pair (`buffer_store_dwordx4 v[76:79]` followed by
 // `v_add_u32 v78`).  Store and wait states therefore come out of ONE inline-asm block: nothing can be scheduled
-// between them (tests/test_cpu_host.py scans the ISA for it).  The resource goes in as four plain words (an opaque
+// between them (tests/test_cpu_host.py scans the shipped machine code for it).  The compiler does not count an
+// inline-asm store in vmcnt, so its waits for later loads also cover these stores; measured against the builtin store
+// followed by a separate `s_nop` and against wait states tied to the data registers by an asm input: 715-720 us,
+// 713-723 us, 721 us for the 80-rank pass at N=2000 x 32 -- no difference (profiles/r03_store_forms.txt).  The resource goes in as four plain words (an opaque
 // __amdgpu_buffer_rsrc_t cannot be an asm operand): base, base_hi | stride 0, num_records = 2^32 - 1 (no range check:
 // ekf_create bounds the size of a covariance), DST_SEL/format word 0x00020000 as rs_rsrc makes it.
 __device__ __forceinline__ uint4v_t rs_words(const void* base) {
@@ -1873,22 +1771,10 @@ __device__ __forceinline__ void stb16(uint4v_t rs, unsigned lane_bytes, unsigned
   {
   const uint2v_t a = __builtin_bit_cast(uint2v_t, v.x), b = __builtin_bit_cast(uint2v_t, v.y);
   const uint4v_t d{a.x, a.y, b.x, b.y};
-#if defined(RS_STORE_TIED)
-  // (measured alternative: the compiler's own store -- which it counts in vmcnt -- followed by wait states that READ the
-  //  data registers, so that no write to them can be scheduled in front of the wait states)
-  __builtin_amdgcn_raw_buffer_store_b128(d, __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)(rs.y & 0xffffu) << 32) | rs.x), 0, -1, 0x00020000),
-                                         (int)lane_bytes, (int)tile_bytes, NT ? 2 : 0);
-  asm volatile("s_nop 1" ::"v"(d) : "memory");
-#elif defined(RS_STORE_OLD)
-  __builtin_amdgcn_raw_buffer_store_b128(d, __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)(rs.y & 0xffffu) << 32) | rs.x), 0, -1, 0x00020000),
-                                         (int)lane_bytes, (int)tile_bytes, NT ? 2 : 0);
-  asm volatile("s_nop 1" ::: "memory");
-#else
   if (NT)
     asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen nt\n\ts_nop 1" ::"v"(d), "v"(lane_bytes), "s"(rs), "s"(tile_bytes) : "memory");
   else
     asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen\n\ts_nop 1" ::"v"(d), "v"(lane_bytes), "s"(rs), "s"(tile_bytes) : "memory");
-#endif
   }
 }
 #define RS_CBAR() asm volatile("" ::: "memory")

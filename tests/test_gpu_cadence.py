@@ -1,0 +1,264 @@
+"""GPU parity of the fused cadence (slam-duckietown_amd/csrc/ekf_cadence.hip): uploaded streams run the steps between
+two covariance passes as one solve launch + one panel launch.
+
+The recurrences are those of the per-step kernels (src/replay_no_ros.py:368-480: motion model, P <- G P G^T + R, per
+landmark H, S, K, mean and covariance update) in a different summation order -- the effect of the cadence's earlier
+ranks is carried in registers instead of re-read from V and W -- so the two paths agree to rounding, not bit for bit.
+Stated tolerance: 1e-12 relative Frobenius between the paths (measured: 1e-15 .. 1e-13), and the usual 1e-9 / 1e-6
+against the oracle (the reference-shaped dense NumPy path, pinned to the reference's golden vectors).
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from oracle import ekf_oracle as orc
+from tests import golden_util as gu
+
+pytestmark = pytest.mark.gpu
+
+PATH_TOL = 1e-12
+TIGHT = 1e-9
+
+
+@pytest.fixture(scope="module")
+def sd():
+    import slam_duckietown_amd as sd
+    sd.load_library()
+    return sd
+
+
+def cadences(sd, f):
+    lib = sd.load_library()
+    lib.ekf_debug_cadences.argtypes = [C.c_void_p, C.POINTER(C.c_long), C.POINTER(C.c_long)]
+    a, b = C.c_long(), C.c_long()
+    assert lib.ekf_debug_cadences(f._h, C.byref(a), C.byref(b)) == 0
+    return a.value, b.value
+
+
+def dense_start(n, seed, rank=6):
+    rng = np.random.default_rng(seed)
+    A = rng.normal(size=(n, rank)) * 0.3
+    P = A @ A.T
+    P[np.arange(n), np.arange(n)] += rng.uniform(0.5, 2.0, n)
+    return P
+
+
+def run_stream(sd, n, B, starts, means, lin, ang, idx, zr, zb, m=None, options=(), diag=False, cfg=None):
+    """One handle, the whole stream; returns ([(mean, cov)] per trajectory, fused cadences, steps they covered)."""
+    with sd.EkfSlam(n, batch=B, config=cfg) as f:
+        for name, value in options:
+            f.set_option(name, value)
+        for b in range(B):
+            if diag:
+                f.set_state_diag(means[b], starts[b], b)
+            else:
+                f.set_state(means[b], starts[b], b)
+        f.run_stream(lin, ang, idx, zr, zb, m)
+        out = [f.state(b) for b in range(B)]
+        assert [f.flags(b) for b in range(B)] == [0] * B
+        c = cadences(sd, f)
+    return out, c
+
+
+def stack(streams, i):
+    return np.stack([s[i] for s in streams], axis=1)
+
+
+@pytest.mark.parametrize("N,B,m,steps", [(60, 1, 8, 12), (300, 3, 8, 11), (300, 2, 1, 85), (200, 2, 2, 43),
+                                         (257, 2, 4, 23), (120, 2, 16, 5), (700, 9, 8, 10)])
+def test_fused_cadence_equals_the_per_step_path_and_the_oracle(sd, N, B, m, steps):
+    """Every rank-slot size (1, 2, 4, 8, 16 landmarks per step), whole cadences plus a tail, dense starting
+    covariances, latency and throughput shapes of the panel launch: fused == per-step to 1e-12, == oracle to 1e-9."""
+    n = 3 + 2 * N
+    streams = [orc.synthetic_stream(N, steps, m, 300 + t) for t in range(B)]
+    starts = [dense_start(n, 400 + t) for t in range(B)]
+    means = [s[0] for s in streams]
+    args = (stack(streams, 2), stack(streams, 3), stack(streams, 4), stack(streams, 5), stack(streams, 6))
+    fused, (nc, ns) = run_stream(sd, n, B, starts, means, *args, options=[("active_bound", 0)])
+    plain, (pc, _) = run_stream(sd, n, B, starts, means, *args, options=[("active_bound", 0), ("fused_cadence", 0)])
+    g = 40 // {1: 1, 2: 2, 4: 4, 8: 8, 16: 16}[m]
+    assert pc == 0 and nc == steps // g + (1 if steps % g >= 2 else 0) and ns >= steps - 1
+    for b in range(B):
+        assert orc.rel_fro(fused[b][0], plain[b][0]) < PATH_TOL
+        assert orc.rel_fro(fused[b][1], plain[b][1]) < PATH_TOL
+        assert np.array_equal(fused[b][1], fused[b][1].T)
+    cfg = orc.EkfConfig()
+    s = streams[B - 1]
+    om, oP = s[0].copy(), starts[B - 1].copy()
+    step = orc.ekf_step_dense if n < 1000 else orc.ekf_step_structured    # (the O(n^2) form where dense takes seconds per step)
+    for k in range(steps):
+        om, oP = step(om, oP, s[2][k], s[3][k], s[4][k], s[5][k], s[6][k], cfg)
+    assert orc.rel_fro(fused[B - 1][0], om) < TIGHT and orc.rel_fro(fused[B - 1][1], oP) < TIGHT
+
+
+def test_ragged_observations_repeated_landmarks_and_empty_steps(sd):
+    """What real windows look like: per trajectory and step 0..8 observations (an empty step inside a cadence, a
+    trajectory that sees nothing at all in one cadence), and the SAME landmarks observed in consecutive steps (two
+    slots of the cadence then hold one state index).  Against the per-step path and the oracle."""
+    N, B, steps, M = 90, 3, 17, 8
+    n = 3 + 2 * N
+    rng = np.random.default_rng(5)
+    world = [orc.synthetic_world(N, 20 + t) for t in range(B)]
+    cfg = orc.EkfConfig()
+    lin = np.full((steps, B), 0.004)
+    ang = np.where(np.arange(steps)[:, None] % 4 == 3, 0.005, 0.02) * np.ones((1, B))
+    idx = np.zeros((steps, B, M), dtype=np.int32)
+    zr = np.zeros((steps, B, M))
+    zb = np.zeros((steps, B, M))
+    m = np.zeros((steps, B), dtype=np.int32)
+    pose = [np.zeros(3) for _ in range(B)]
+    for k in range(steps):
+        for b in range(B):
+            pose[b], _ = orc.motion_model(pose[b], lin[k, b], ang[k, b], cfg)
+            if b == 2 and 5 <= k < 10:
+                mb = 0                                    # trajectory 2 sees nothing during the whole second cadence
+            elif k % 6 == 2:
+                mb = 0                                    # an empty step inside a cadence
+            else:
+                mb = int(rng.integers(1, M + 1))
+            # landmarks come from a small pool: repeats across the steps of a cadence are the rule
+            vis = rng.choice(12, size=mb, replace=False) + (0 if k < 9 else 30)
+            d = world[b][1][vis] - pose[b][0:2]
+            cth, sth = np.cos(pose[b][2]), np.sin(pose[b][2])
+            xr = cth * d[:, 0] + sth * d[:, 1] + rng.normal(0, 0.01, mb)
+            yr = -sth * d[:, 0] + cth * d[:, 1] + rng.normal(0, 0.01, mb)
+            m[k, b] = mb
+            idx[k, b, :mb] = vis
+            zr[k, b, :mb] = np.sqrt(xr ** 2 + yr ** 2)
+            zb[k, b, :mb] = np.arctan2(yr, xr)
+    # every step has some trajectory with 5..8 observations, so that all steps take the 8-landmark slot size
+    m[:, 0] = np.maximum(m[:, 0], 5)
+    for k in range(steps):
+        if not zr[k, 0, :m[k, 0]].all():                  # (rows whose count was raised: fill them in)
+            vis = rng.choice(12, size=m[k, 0], replace=False) + 50
+            idx[k, 0, :m[k, 0]] = vis
+            zr[k, 0, :m[k, 0]] = 0.3 + 0.05 * np.arange(m[k, 0])
+            zb[k, 0, :m[k, 0]] = 0.1 * np.arange(m[k, 0]) - 0.3
+    means = [w[2] for w in world]
+    starts = [dense_start(n, 500 + t) for t in range(B)]
+    fused, (nc, ns) = run_stream(sd, n, B, starts, means, lin, ang, idx, zr, zb, m, options=[("active_bound", 0)])
+    plain, _ = run_stream(sd, n, B, starts, means, lin, ang, idx, zr, zb, m,
+                          options=[("active_bound", 0), ("fused_cadence", 0)])
+    assert nc == 4 and ns == 17                           # 5 + 5 + 5 + 2
+    for b in range(B):
+        assert orc.rel_fro(fused[b][0], plain[b][0]) < PATH_TOL and orc.rel_fro(fused[b][1], plain[b][1]) < PATH_TOL
+        om, oP = means[b].copy(), starts[b].copy()
+        for k in range(steps):
+            mb = m[k, b]
+            om, oP = orc.ekf_step_dense(om, oP, lin[k, b], ang[k, b], idx[k, b, :mb], zr[k, b, :mb], zb[k, b, :mb], cfg)
+        assert orc.rel_fro(fused[b][0], om) < TIGHT and orc.rel_fro(fused[b][1], oP) < TIGHT
+
+
+def test_block_diagonal_start_with_the_active_bound(sd):
+    """The benchmark's god-mode style start (P0 block diagonal) with the active bound ON: state indices
+    beyond the highest landmark seen so far are skipped by the cadence's panel launch and by the pass; trajectories of
+    different sizes in one batch."""
+    N, B, steps, m = 260, 3, 13, 8
+    streams = [orc.synthetic_stream(N, steps, m, 600 + t) for t in range(B)]
+    sizes = [3 + 2 * N, 3 + 2 * 100, 3 + 2 * 201]
+    means = [s[0][:sizes[b]] for b, s in enumerate(streams)]
+    diags = [s[1][:sizes[b]] for b, s in enumerate(streams)]
+    idx = np.stack([(s[4] * 3 + 1) % ((sizes[b] - 3) // 2 // 2) for b, s in enumerate(streams)], axis=1)
+    # (the remapped indices may repeat inside a step: keep the first of each)
+    mm = np.zeros((steps, B), dtype=np.int32)
+    for k in range(steps):
+        for b in range(B):
+            _, first = np.unique(idx[k, b], return_index=True)
+            keep = np.sort(first)
+            mm[k, b] = len(keep)
+            idx[k, b, :len(keep)] = idx[k, b, keep]
+    args = (stack(streams, 2), stack(streams, 3), idx, stack(streams, 5), stack(streams, 6), mm)
+    fused, (nc, _) = run_stream(sd, 3 + 2 * N, B, diags, means, *args, diag=True)
+    plain, _ = run_stream(sd, 3 + 2 * N, B, diags, means, *args, diag=True, options=[("fused_cadence", 0)])
+    dense, _ = run_stream(sd, 3 + 2 * N, B, diags, means, *args, diag=True, options=[("active_bound", 0)])
+    assert nc >= 2
+    for b in range(B):
+        assert fused[b][0].shape == (sizes[b],)
+        for other in (plain, dense):
+            assert orc.rel_fro(fused[b][0], other[b][0]) < PATH_TOL and orc.rel_fro(fused[b][1], other[b][1]) < PATH_TOL
+    cfg = orc.EkfConfig()
+    om, oP = means[1].copy(), np.diag(diags[1])
+    for k in range(steps):
+        om, oP = orc.ekf_step_dense(om, oP, streams[1][2][k], streams[1][3][k], idx[k, 1, :mm[k, 1]],
+                                    streams[1][5][k][:mm[k, 1]], streams[1][6][k][:mm[k, 1]], cfg)
+    assert orc.rel_fro(fused[1][0], om) < TIGHT and orc.rel_fro(fused[1][1], oP) < TIGHT
+
+
+@pytest.mark.parametrize("options,expect", [([("rank_limit", 48)], (4, 12)), ([("flush_every", 2)], (6, 12)),
+                                            ([("flush_every", 1)], (0, 0)), ([("rank_limit", 16)], (0, 0))])
+def test_cadence_follows_the_pass_cadence_options(sd, options, expect):
+    """`rank_limit` / `flush_every` shorten the cadence (3 and 2 steps here; a one-step cadence is the per-step path);
+    the result does not depend on it beyond rounding."""
+    N, B, steps, m = 150, 2, 13, 8
+    n = 3 + 2 * N
+    streams = [orc.synthetic_stream(N, steps, m, 700 + t) for t in range(B)]
+    starts = [dense_start(n, 800 + t) for t in range(B)]
+    means = [s[0] for s in streams]
+    args = (stack(streams, 2), stack(streams, 3), stack(streams, 4), stack(streams, 5), stack(streams, 6))
+    ref, _ = run_stream(sd, n, B, starts, means, *args, options=[("active_bound", 0), ("fused_cadence", 0)])
+    got, c = run_stream(sd, n, B, starts, means, *args, options=[("active_bound", 0)] + options)
+    assert c == expect
+    for b in range(B):
+        assert orc.rel_fro(got[b][0], ref[b][0]) < PATH_TOL and orc.rel_fro(got[b][1], ref[b][1]) < PATH_TOL
+
+
+@pytest.mark.parametrize("flags", [dict(disable_motion_model=True), dict(enable_circular_interpolation=False),
+                                   dict(enable_measurement_model=False)])
+def test_config_flags_through_the_cadence(sd, flags):
+    """The reference's module flags (src/replay_no_ros.py:18-19, :28) through the fused path; with the measurement
+    model off a step observes nothing and no cadence forms (prediction-only steps touch O(n) entries anyway)."""
+    N, B, steps, m = 80, 2, 11, 8
+    n = 3 + 2 * N
+    streams = [orc.synthetic_stream(N, steps, m, 900 + t) for t in range(B)]
+    starts = [dense_start(n, 950 + t) for t in range(B)]
+    means = [s[0] for s in streams]
+    args = (stack(streams, 2), stack(streams, 3), stack(streams, 4), stack(streams, 5), stack(streams, 6))
+    got, (nc, _) = run_stream(sd, n, B, starts, means, *args, options=[("active_bound", 0)], cfg=sd.EkfConfig(**flags))
+    assert nc == (0 if "enable_measurement_model" in flags else 2)
+    ocfg = orc.EkfConfig(**flags)
+    for b in range(B):
+        s = streams[b]
+        om, oP = s[0].copy(), starts[b].copy()
+        for k in range(steps):
+            om, oP = orc.ekf_step_dense(om, oP, s[2][k], s[3][k], s[4][k], s[5][k], s[6][k], ocfg)
+        assert orc.rel_fro(got[b][0], om) < TIGHT and orc.rel_fro(got[b][1], oP) < TIGHT
+
+
+def test_golden_stream_through_the_cadence(sd):
+    """BASELINE config 1 (N = 20, 500 steps, the reference's own outputs in tests/golden/stream_n20_m8.npz) as ONE
+    uploaded stream: 100 fused cadences back to back, final mean and covariance against the reference."""
+    g = gu.load("stream_n20_m8")
+    steps = len(g["lin"])
+    with sd.EkfSlam(len(g["mean0"])) as f:
+        f.set_state_diag(g["mean0"], g["diag0"])
+        f.run_stream(g["lin"], g["ang"], g["idx"], g["zr"], g["zb"])
+        mu, P = f.state()
+        assert cadences(sd, f) == (steps // 5, steps) and f.flags() == 0
+    assert orc.rel_fro(mu, g["out_mean"][-1]) < TIGHT
+    assert orc.rel_fro(P, g["out_cov"][-1]) < TIGHT
+
+
+def test_config4_shape_n2000_x32_fused_against_per_step(sd):
+    """The benchmarked shape (N = 2000, m = 8, 32 trajectories: the throughput form of the panel launch, the row-slab
+    pass behind every cadence): two cadences + a tail against the per-step path."""
+    N, B, steps, m, K = 2000, 32, 11, 8, 2
+    n = 3 + 2 * N
+    streams = [orc.synthetic_stream(N, steps, m, 40 + t) for t in range(K)]
+    starts = [dense_start(n, 7 + t, rank=8) for t in range(K)]
+    pick = [streams[b % K] for b in range(B)]
+    args = (stack(pick, 2), stack(pick, 3), stack(pick, 4), stack(pick, 5), stack(pick, 6))
+    res = {}
+    for fused in (1, 0):
+        with sd.EkfSlam(n, batch=B) as f:
+            f.set_option("active_bound", 0)
+            f.set_option("fused_cadence", fused)
+            for b in range(B):
+                f.set_state(pick[b][0], starts[b % K], b)
+            f.run_stream(*args)
+            res[fused] = [f.state(b) for b in (0, 1, 30, 31)]
+            assert [f.flags(b) for b in range(B)] == [0] * B
+            assert cadences(sd, f) == ((2, 10) if fused else (0, 0))
+    for a, b in zip(res[1], res[0]):
+        assert orc.rel_fro(a[0], b[0]) < PATH_TOL and orc.rel_fro(a[1], b[1]) < PATH_TOL
+    assert np.array_equal(res[1][0][1], res[1][2][1]) and np.array_equal(res[1][1][0], res[1][3][0])   # replicas agree bit for bit
