@@ -1119,6 +1119,15 @@ extern "C" int ekf_debug_cadences(ekf_handle* h, long* cadences, long* steps) {
   return EKF_OK;
 }
 
+// (development aid, not declared in the header) the fused cadence's record of trajectory b (head + per-landmark records)
+extern "C" long ekf_debug_cad(ekf_handle* h, int b, void* dst, long bytes) {
+  if (!h || b < 0 || b >= h->batch || !h->dcad) return -1;
+  if (hipSetDevice(h->device) != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess) return -1;
+  const long have = (long)sizeof(CadOut);
+  if (dst && bytes > 0 && hipMemcpy(dst, h->dcad + b, (size_t)std::min(bytes, have), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  return have;
+}
+
 // (development aid, not declared in the header) raw device buffers of trajectory b, exactly as they stand -- no flush,
 // no mirror, no status check: which = 0 P_base (rows x ld), 1 V (80 x ld), 2 W (80 x ld, MFMA-tiled), 3 the mean buffer
 // the NEXT step reads, 4 the other mean buffer.  Returns the number of doubles the buffer holds (copies min(count, that)).

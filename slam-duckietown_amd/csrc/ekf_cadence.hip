@@ -27,13 +27,33 @@
 
 namespace ekf {
 
+// Diagnostic build (-DCAD_STAMPS): s_memtime stamps of the solve's phases for landmark slots CAD_STAMP_S0.. (3 slots x 16
+// stamps) into the record's `prow` area; tools/cad_stamps.py reads them through ekf_debug_cad.
+#ifdef CAD_STAMPS
+#ifndef CAD_STAMP_S0
+#define CAD_STAMP_S0 16
+#endif
+#define CSTAMP(w, s, k)                                                                          \
+  do {                                                                                           \
+    if (wave == (w) && (s) >= CAD_STAMP_S0 && (s) < CAD_STAMP_S0 + 3) {                          \
+      __builtin_amdgcn_sched_barrier(0);                                                         \
+      unsigned long long t_;                                                                     \
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                \
+      __builtin_amdgcn_sched_barrier(0);                                                         \
+      if (lane == 0) reinterpret_cast<unsigned long long*>(&o.prow[0][0])[((s) - CAD_STAMP_S0) * 16 + (k)] = t_;   \
+    }                                                                                            \
+  } while (0)
+#else
+#define CSTAMP(w, s, k) do { } while (0)
+#endif
+
 constexpr int CAD_CS = 88;              // LDS row stride of the block (doubles): 83 columns, rows 16-byte aligned
 constexpr int CAD_ROWS = 84;
 constexpr int CAD_NW = 8;               // waves of the solve workgroup (512 threads: the register budget of 2 waves per SIMD;
-                                        // with 16 waves the chain's constants spilled, and the fp64 rate of the four SIMDs,
-                                        // not the number of waves, bounds the down-date)
-constexpr int CAD_DW = CAD_NW - 1;      // waves that share a down-date by rows (every wave but the mean wave)
-constexpr int CAD_DQ = (CAD_CU - 2 + 3 * CAD_DW - 1) / (3 * CAD_DW) * 3;   // rows per down-date wave, in batches of 3
+                                        // with 16 waves the chain's constants spilled)
+constexpr int CAD_DW = CAD_NW - 2;      // waves that share a down-date by rows (all but the mean wave and the record wave)
+constexpr int CAD_DCH = 7;              // rows of a down-date chunk (all reads of a chunk in flight together)
+constexpr int CAD_DQ = (CAD_CU - 2 + CAD_DCH * CAD_DW - 1) / (CAD_DCH * CAD_DW) * CAD_DCH;   // rows per down-date wave
 
 template <int MCAP>
 __global__ __launch_bounds__(64 * CAD_NW) void k_solve_cad(double* __restrict__ P, double* __restrict__ V, double* __restrict__ W,
@@ -52,7 +72,8 @@ __global__ __launch_bounds__(64 * CAD_NW) void k_solve_cad(double* __restrict__ 
   __shared__ double2 laS[CAD_SLOTS];                   // (lin, ang) of step t
   __shared__ int mS[CAD_SLOTS], fS[CAD_SLOTS];
   __shared__ double mot[4];                            // G[0,2], G[1,2] of the step being predicted
-  __shared__ double2 hS[6];                            // next linearisation: {h[0][k], h[1][k]}, k < 5
+  __shared__ double2 hS[2][6];                         // linearisation of slot s in hS[s & 1]: {h[0][k], h[1][k]}, k < 5
+  __shared__ double2 siS[2];                           // S^-1 of the slot in flight
   const int b = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -151,12 +172,12 @@ __global__ __launch_bounds__(64 * CAD_NW) void k_solve_cad(double* __restrict__ 
       *reinterpret_cast<double2*>(o.g[t]) = make_double2(g0, g1);
     }
   };
-  auto jacobian_at_mean = [&](int p) {                 // landmark at positions p, p + 1: publishes hS, keeps the geometry
+  auto jacobian_at_mean = [&](int p, int par) {        // landmark at positions p, p + 1: publishes hS[par], keeps the geometry
     double hn[2][5];
     lg = linearize_h(read_lane(mu0, 0), read_lane(mu0, 1), read_lane(mu0, 2), mean_at(p), mean_at(p + 1), hn);
     if (lane == 0) {
 #pragma unroll
-      for (int k = 0; k < 5; ++k) hS[k] = make_double2(hn[0][k], hn[1][k]);
+      for (int k = 0; k < 5; ++k) hS[par][k] = make_double2(hn[0][k], hn[1][k]);
     }
   };
 
@@ -190,6 +211,7 @@ __global__ __launch_bounds__(64 * CAD_NW) void k_solve_cad(double* __restrict__ 
   }
   if (wave == 1) motion(0);
   WG_LDS_BARRIER();
+#ifndef CAD_STAMPS
   if (wave == 0) {                                     // (diagnostic record) rows 0, 1 of the block before the cadence
     if (lane < CU) {
       o.prow[0][lane] = Pc[0][lane];
@@ -200,9 +222,13 @@ __global__ __launch_bounds__(64 * CAD_NW) void k_solve_cad(double* __restrict__ 
       o.prow[1][64 + lane] = 64 + lane < CU ? Pc[1][64 + lane] : 0.0;
     }
   }
+#endif
 
   double dd0 = 0.0, dd1 = 0.0;                         // (wave 0, lanes 0..2) in-place change of P_base(0, l), P_base(1, l)
-  const int ds = wave == 0 ? 0 : wave - 1;             // down-date slot of this wave (wave 1 has none)
+  // wave roles: 0 = the covariance chain (+ a down-date share), 1 = the mean, CAD_NW - 1 = the records (everything the
+  // panel kernel gets goes to memory from there, off the chain), the others: down-date
+  const bool rec_wave = wave == CAD_NW - 1;
+  const int ds = wave == 0 ? 0 : wave - 1;             // down-date slot of this wave (waves 0, 2 .. CAD_NW - 2)
   for (int t = 0; t < nsteps; ++t) {
     const int m = __builtin_amdgcn_readfirstlane(mS[t]);
     const int s_first = t * MCAP;
@@ -248,9 +274,9 @@ __global__ __launch_bounds__(64 * CAD_NW) void k_solve_cad(double* __restrict__ 
         Pc[1][64 + lane] = e1n;
       }
     } else if (wave == 1) {
-      if (m > 0) jacobian_at_mean(G::pa(s_first));
+      if (m > 0) jacobian_at_mean(G::pa(s_first), s_first & 1);
     }
-    WG_LDS_BARRIER();                                  // S0(t): predicted block and hS published
+    WG_LDS_BARRIER();                                  // S0(t): predicted block and the first Jacobian published
     if (wave == 1 && m > 0) {
       const double2 z = zS[s_first];
       innovation(lg, z.x, z.y, y0, y1);
@@ -259,7 +285,7 @@ __global__ __launch_bounds__(64 * CAD_NW) void k_solve_cad(double* __restrict__ 
     if (wave == 0 && m > 0) {
 #pragma unroll
       for (int k = 0; k < 5; ++k) {
-        const double2 tt = hS[k];
+        const double2 tt = hS[s_first & 1][k];
         h[0][k] = tt.x;
         h[1][k] = tt.y;
       }
@@ -269,8 +295,9 @@ __global__ __launch_bounds__(64 * CAD_NW) void k_solve_cad(double* __restrict__ 
       const int s = s_first + j, pa = G::pa(s);        // this landmark sits at positions pa, pa + 1; [0, pa) lives on
       const bool two_j = pa + 2 > 64;                  // columns 64.. still in use
       const bool last = j + 1 == m && t + 1 == nsteps; // nothing reads the block after this landmark
-      double* rec = o.rec + G::rec_off(s);
       double2 hpa = make_double2(0.0, 0.0), hpb = make_double2(0.0, 0.0);   // (H P)[:, l] of this wave's columns
+      CSTAMP(0, s, 0);
+      CSTAMP(1, s, 8);
       if (wave == 0) {
         // phase A: rows sel = {0, 1, 2, pa, pa + 1} of P at column l give (H P)[:, l]; P is symmetric, so P H^T is the
         // transpose and the gain needs no second product
@@ -280,20 +307,30 @@ __global__ __launch_bounds__(64 * CAD_NW) void k_solve_cad(double* __restrict__ 
         for (int k = 0; k < 5; ++k) {
           const int r = k < 3 ? k : pa + (k - 3);
           pra[k] = Pc[r][la];
-          prb[k] = two_j ? Pc[r][lb] : 0.0;
+          prb[k] = 0.0;
+        }
+        if (two_j) {                                   // (uniform)
+#pragma unroll
+          for (int k = 0; k < 5; ++k) prb[k] = Pc[k < 3 ? k : pa + (k - 3)][lb];
         }
         hpa = make_double2(h[0][0] * pra[0], h[1][0] * pra[0]);
-        hpb = make_double2(h[0][0] * prb[0], h[1][0] * prb[0]);
 #pragma unroll
         for (int k = 1; k < 5; ++k) {
           hpa.x = fma(h[0][k], pra[k], hpa.x);
           hpa.y = fma(h[1][k], pra[k], hpa.y);
-          hpb.x = fma(h[0][k], prb[k], hpb.x);
-          hpb.y = fma(h[1][k], prb[k], hpb.y);
         }
         hpS[lane] = hpa;
-        hpS[64 + lane] = hpb;
+        if (two_j) {
+          hpb = make_double2(h[0][0] * prb[0], h[1][0] * prb[0]);
+#pragma unroll
+          for (int k = 1; k < 5; ++k) {
+            hpb.x = fma(h[0][k], prb[k], hpb.x);
+            hpb.y = fma(h[1][k], prb[k], hpb.y);
+          }
+          hpS[64 + lane] = hpb;
+        }
         WAVE_LDS_SYNC();
+        CSTAMP(0, s, 1);
         // phase B: S = H P H^T + Q (:473) from the five pairs at sel, every lane redundantly
         double2 hv[5];
 #pragma unroll
@@ -309,92 +346,115 @@ __global__ __launch_bounds__(64 * CAD_NW) void k_solve_cad(double* __restrict__ 
         const double rdet = 1.0 / (S00 * S11 - S01 * S10);
         const double i00 = S11 * rdet, i01 = -S01 * rdet, i10 = -S10 * rdet, i11 = S00 * rdet;
         const double2 ka = make_double2(hpa.x * i00 + hpa.y * i10, hpa.x * i01 + hpa.y * i11);   // K[C_u[l], :]
-        const double2 kb = make_double2(hpb.x * i00 + hpb.y * i10, hpb.x * i01 + hpb.y * i11);
         kcS[lane] = ka;
-        kcS[64 + lane] = kb;
-        // the record of this landmark for the panel kernel; the pose's own entries of the new ranks
-        if (lane < pa) *reinterpret_cast<double2*>(rec + 16 + 2 * lane) = ka;
-        if (two_j && 64 + lane < pa) *reinterpret_cast<double2*>(rec + 16 + 2 * (64 + lane)) = kb;
+        if (two_j) kcS[64 + lane] = make_double2(hpb.x * i00 + hpb.y * i10, hpb.x * i01 + hpb.y * i11);
         if (lane == 0) {
-#pragma unroll
-          for (int k = 0; k < 5; ++k) *reinterpret_cast<double2*>(rec + 2 * k) = make_double2(h[0][k], h[1][k]);
-          *reinterpret_cast<double2*>(rec + 10) = make_double2(i00, i01);
-          *reinterpret_cast<double2*>(rec + 12) = make_double2(i10, i11);
+          siS[0] = make_double2(i00, i01);
+          siS[1] = make_double2(i10, i11);
         }
-        if (lane < 3) {
-          Vb[(long)(2 * s) * ld + lane] = hpa.x;
-          Vb[(long)(2 * s + 1) * ld + lane] = hpa.y;
-          Wb[wm_index(ld16, 2 * s, lane)] = -ka.x;
-          Wb[wm_index(ld16, 2 * s + 1, lane)] = -ka.y;
-        }
+        CSTAMP(0, s, 2);
       }
-      WG_LDS_BARRIER();                                // b1: K and (H P) of this landmark are in LDS
+      CSTAMP(0, s, 3);
+      CSTAMP(1, s, 9);
+      WG_LDS_BARRIER();                                // b1: K, (H P) and S^-1 of this landmark are in LDS
+      CSTAMP(0, s, 4);
+      CSTAMP(1, s, 10);
       if (wave == 1) {
         // the mean (:476); then the next landmark's Jacobian at the new mean, or the next step's motion model
         const double2 k0 = kcS[lane], k1 = kcS[64 + lane];
         if (lane < pa + 2) mu0 += k0.x * y0 + k0.y * y1;
         if (64 + lane < pa + 2) mu1 += k1.x * y0 + k1.y * y1;
-        if (lane == 0) *reinterpret_cast<double2*>(rec + 14) = make_double2(y0, y1);
-        if (j + 1 < m) jacobian_at_mean(pa - 2);
+        CSTAMP(1, s, 13);
+        if (lane == 0) *reinterpret_cast<double2*>(o.rec + G::rec_off(s) + 14) = make_double2(y0, y1);
+        CSTAMP(1, s, 14);
+        if (j + 1 < m) jacobian_at_mean(pa - 2, (s + 1) & 1);
         else if (t + 1 < nsteps) motion(t + 1);
+      } else if (rec_wave) {
+        // the record of this landmark for the panel kernel, and the pose's own entries of the new ranks
+        double2* rec2 = reinterpret_cast<double2*>(o.rec + G::rec_off(s));
+        const double2 ka = kcS[lane], kb = kcS[64 + lane];
+        if (lane < pa) rec2[8 + lane] = ka;
+        if (two_j && 64 + lane < pa) rec2[8 + 64 + lane] = kb;
+        if (lane < 5) rec2[lane] = hS[s & 1][lane];
+        if (lane == 5 || lane == 6) rec2[lane] = siS[lane - 5];
+        if (lane < 3) {
+          const double2 hp = hpS[lane];
+          Vb[(long)(2 * s) * ld + lane] = hp.x;
+          Vb[(long)(2 * s + 1) * ld + lane] = hp.y;
+          Wb[wm_index(ld16, 2 * s, lane)] = -ka.x;
+          Wb[wm_index(ld16, 2 * s + 1, lane)] = -ka.y;
+        }
       } else if (!last) {
-        // down-date (:480) of what lives on: P[r][l] -= K[r, :] . (H P)[:, l] for r, l < pa, rows dealt to the other waves
+        // down-date (:480) of what lives on: P[r][l] -= K[r, :] . (H P)[:, l] for r, l < pa; rows ds, ds + CAD_DW, ... are
+        // this wave's.  Every access is unconditional and every address one base plus a compile-time offset: a row or a
+        // column >= pa is dead (nothing reads it again), so what lands there does not matter, and rows up to
+        // ds + CAD_DW (CAD_DQ - 1) <= 83 exist; all reads of a chunk are in flight before its first FMA.
+        static_assert(CAD_DW - 1 + CAD_DW * (CAD_DQ - 1) < CAD_ROWS, "down-date rows stay inside the block");
         if (wave != 0) {
           hpa = hpS[lane];
           if (two_j) hpb = hpS[64 + lane];
         }
-        const int lb = min(64 + lane, CAD_CS - 1);
+        const bool lane_b = 64 + lane < CAD_CS;        // second column half: columns 64 .. CAD_CS - 1 exist
+        const int lb = lane_b ? 64 + lane : 64;
 #pragma unroll
-        for (int q0 = 0; q0 < CAD_DQ; q0 += 3) {
+        for (int q0 = 0; q0 < CAD_DQ; q0 += CAD_DCH) {
           if (ds + CAD_DW * q0 < pa) {                 // (uniform)
-            double2 kr[3];
-            double pv[3], pw[3];
+            double2 kr[CAD_DCH];
+            double pv[CAD_DCH], pw[CAD_DCH];
 #pragma unroll
-            for (int u = 0; u < 3; ++u) {
-              const int r = min(ds + CAD_DW * (q0 + u), CAD_ROWS - 1);
-              kr[u] = kcS[r];
-              pv[u] = Pc[r][lane];
-              pw[u] = two_j ? Pc[r][lb] : 0.0;
+            for (int u = 0; u < CAD_DCH; ++u) {
+              kr[u] = kcS[ds + CAD_DW * (q0 + u)];
+              pv[u] = Pc[ds + CAD_DW * (q0 + u)][lane];
+              pw[u] = 0.0;
+            }
+            if (two_j) {                               // (uniform)
+#pragma unroll
+              for (int u = 0; u < CAD_DCH; ++u) pw[u] = Pc[ds + CAD_DW * (q0 + u)][lb];
             }
 #pragma unroll
-            for (int u = 0; u < 3; ++u) {
-              pv[u] = fma(-kr[u].x, hpa.x, pv[u]);
-              pw[u] = fma(-kr[u].x, hpb.x, pw[u]);
-            }
+            for (int u = 0; u < CAD_DCH; ++u) pv[u] = fma(-kr[u].x, hpa.x, pv[u]);
 #pragma unroll
-            for (int u = 0; u < 3; ++u) {
-              pv[u] = fma(-kr[u].y, hpa.y, pv[u]);
-              pw[u] = fma(-kr[u].y, hpb.y, pw[u]);
-            }
+            for (int u = 0; u < CAD_DCH; ++u) pv[u] = fma(-kr[u].y, hpa.y, pv[u]);
 #pragma unroll
-            for (int u = 0; u < 3; ++u) {
-              const int r = ds + CAD_DW * (q0 + u);
-              if (r < pa && lane < pa) Pc[r][lane] = pv[u];
-              if (two_j && r < pa && 64 + lane < pa) Pc[r][64 + lane] = pw[u];
+            for (int u = 0; u < CAD_DCH; ++u) Pc[ds + CAD_DW * (q0 + u)][lane] = pv[u];
+            if (two_j) {
+#pragma unroll
+              for (int u = 0; u < CAD_DCH; ++u) pw[u] = fma(-kr[u].x, hpb.x, pw[u]);
+#pragma unroll
+              for (int u = 0; u < CAD_DCH; ++u) pw[u] = fma(-kr[u].y, hpb.y, pw[u]);
+              if (lane_b) {
+#pragma unroll
+                for (int u = 0; u < CAD_DCH; ++u) Pc[ds + CAD_DW * (q0 + u)][64 + lane] = pw[u];
+              }
             }
           }
         }
       }
-      WG_LDS_BARRIER();                                // b2: block down-dated; hS (or the next step's G) published
+      CSTAMP(0, s, 5);
+      CSTAMP(1, s, 11);
+      WG_LDS_BARRIER();                                // b2: block down-dated; next Jacobian (or the next step's G) published
+      CSTAMP(0, s, 6);
       if (wave == 1 && j + 1 < m) {
         const double2 z = zS[s + 1];
         innovation(lg, z.x, z.y, y0, y1);
       }
+      CSTAMP(1, s, 12);
       if (wave == 0 && j + 1 < m) {
 #pragma unroll
         for (int k = 0; k < 5; ++k) {
-          const double2 tt = hS[k];
+          const double2 tt = hS[(s + 1) & 1][k];
           h[0][k] = tt.x;
           h[1][k] = tt.y;
         }
       }
+      CSTAMP(0, s, 7);
     }
     if (m == 0) {                                      // (uniform) no landmark whose tail could carry the next motion model
       if (wave == 1 && t + 1 < nsteps) motion(t + 1);
       WG_LDS_BARRIER();
     }
     // slots this step leaves empty: zero ranks at the pose's state indices (the panel kernel writes the others)
-    if (wave == 0 && lane < 3) {
+    if (rec_wave && lane < 3) {
       for (int k = 2 * (s_first + m); k < 2 * (s_first + MCAP); ++k) {
         Vb[(long)k * ld + lane] = 0.0;
         Wb[wm_index(ld16, k, lane)] = 0.0;
@@ -418,6 +478,8 @@ __global__ __launch_bounds__(64 * CAD_NW) void k_solve_cad(double* __restrict__ 
   if (wave == 0 && lane < 3) {
     Pb[lane] += dd0;                                   // entry (0, l)
     if (lane >= 1) Pb[ld + lane] += dd1;               // entry (1, l); (1, 0) lies below the diagonal
+  }
+  if (rec_wave && lane < 3) {
     for (int k = 2 * MCAP * nsteps; k < ((2 * MCAP * nsteps + 3) & ~3); ++k) {   // k-tile pad
       Vb[(long)k * ld + lane] = 0.0;
       Wb[wm_index(ld16, k, lane)] = 0.0;
