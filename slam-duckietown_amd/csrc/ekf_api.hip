@@ -25,7 +25,9 @@ void launch_panels(hipStream_t, int, double*, double*, double*, const double*, d
 void launch_flush(hipStream_t, bool, double*, const double*, const double*, const double*, const int*,
                   const SolveOut*, int, long, int, int, int, int);
 void launch_flush_rs(hipStream_t, bool, double*, const double*, const double*, const double*, const int*,
-                     const SolveOut*, int, long, int, int, int, int, unsigned*, int);
+                     const SolveOut*, int, long, int, int, int, int, unsigned*, int, const int*);
+int build_pass_shares(int batch, int n_hi, int workgroups, int* out);
+int pass_share_pieces();
 int flush_rs_queue_words();
 int debug_pass_units(int batch, int nrb, int nch, int mode, int* out, int cap);
 void launch_predict_rc(hipStream_t, double*, const double*, double*, const int*, const SolveOut*, int, long,
@@ -96,6 +98,9 @@ struct ekf_handle {
                                   // (20 MFMA k-tiles: 15 of the V strip in registers, 5 in LDS)
   int opt_pass_kernel = -1;       // -1 = auto, 0 = k_flush (column strips), 2 = k_flush_rs (row slabs)
   unsigned* dqueue = nullptr;     // work-queue heads of k_flush_rs (zeroed before every launch)
+  int* dshares = nullptr;         // k_flush_rs, equal static shares (a few long trajectories): the piece table on the device
+  int shares_key[3] = {0, 0, 0};  // (batch, e_hi, workgroups) the table was built for
+  int shares_ok = 0;              // pieces of its longest share (0: no table for this key -- the queue modes are used)
   unsigned* dready = nullptr;     // per trajectory: sequence number of the last solve that completed (k_step_split)
   SolveOut* dmbox = nullptr;      // per trajectory: that solve's header and records, written through (mailbox_publish)
   unsigned step_seq = 0;          // sequence number of the last single-launch step
@@ -108,6 +113,7 @@ struct ekf_handle {
   int opt_pass_chunk = 0;         // 0 = auto (k_flush_rs: strips per unit)
   int opt_pass_workgroups = 0;    // 0 = one per CU (k_flush_rs: persistent workgroups; fewer leaves CUs to other streams)
   int last_kernel = -1, last_nkt = 0, last_streaming = 0;   // what the last covariance pass launched
+  int last_shares = 0;            // ... and whether it ran on equal static shares (k_flush_rs, a few long trajectories)
   int opt_flush_every = 0;        // 0 = auto; k = flush the pending low-rank update after k steps
   int opt_streaming = -1;         // -1 = auto (by working-set size), 0 = resident kernel, 1 = nontemporal kernel
   std::vector<unsigned> flags_host;
@@ -158,7 +164,7 @@ static void free_all(ekf_handle* h) {
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   void* ptrs[] = {h->dP, h->dmu2[0], h->dmu2[1], h->dV, h->dW, h->ddacc2[0], h->ddacc2[1], h->dscratch, h->dn, h->dflags, h->dso, h->dfac,
                   h->d_ring, h->d_stream, h->dF, h->dQ, h->dTmp, h->dtagmap, h->dneff, h->d_det, h->d_assoc_step, h->dfloor, h->dqueue, h->dready, h->dmbox,
-                  h->d_assoc_out, h->dcad};
+                  h->d_assoc_out, h->dcad, h->dshares};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (h->h_ring) (void)hipHostFree(h->h_ring);
   if (h->h_det) (void)hipHostFree(h->h_det);
@@ -550,29 +556,53 @@ static int prof_event(ekf_handle* h, hipEvent_t* ev) {
 static int flush_pending(ekf_handle* h) {
   if (h->pending_k == 0) return EKF_OK;
   const int n_hi = h->sizes_dirty ? h->n_max : *std::max_element(h->n.begin(), h->n.end());
-  hipEvent_t e0 = nullptr, e1 = nullptr;
-  if (h->profile) {
-    if (int rc = prof_event(h, &e0)) return rc;
-    if (int rc = prof_event(h, &e1)) return rc;
-    HIP_TRY(h, hipEventRecord(e0, h->stream));
-  }
   int e_hi = 3;                                        // grid covers the largest active bound of the batch
   for (int b = 0; b < h->batch; ++b) e_hi = std::max(e_hi, std::min(h->n[b], h->neff_enq[b]));
   if (h->sizes_dirty) e_hi = h->n_max;
   const bool streaming = streaming_pass(h, n_hi);
   const int nkt = (h->pending_k + 3) / 4;
   int kernel = h->opt_pass_kernel;
+  const int rs_workgroups = h->opt_pass_workgroups > 0 ? std::min(h->opt_pass_workgroups, h->cu_count) : h->cu_count;
+  // A few LONG trajectories (N = 8000 x 1: 126 slabs of up to 251 strips for 256 CUs): the row-slab pass with one equal
+  // static share of the strips per workgroup (build_pass_shares) -- where a share is long enough (>= 40 strips) for
+  // the pipeline fills at its piece boundaries not to matter.
+  const long slabs = (e_hi + 127) / 128, s_last = (e_hi - 1) >> 6;
+  const long strips = (long)h->batch * (slabs * (s_last + 1) - slabs * (slabs - 1));
+  const bool long_few = h->batch < 8 && h->opt_pass_chunk == 0 && strips >= 40L * rs_workgroups;
   // auto: the row-slab form where the batch streams through HBM and has at least one 128-row slab per CU (below
-  // three per CU the slabs are cut into chunks of strips); measured at N=2000: 8 trajectories 256 us against 266 us
-  // with k_flush, 4 trajectories 166 / 164 us, 1 trajectory 97 / 52 us (pipeline fills dominate)
-  if (kernel < 0) kernel = (streaming && (long)h->batch * ((e_hi + 127) / 128) >= (long)h->cu_count) ? 2 : 0;
+  // three per CU the slabs are cut into chunks of strips) or is a few long trajectories; measured at N=2000: 8
+  // trajectories 256 us against 266 us with k_flush, 4 trajectories 166 / 164 us, 1 trajectory 97 / 52 us (pipeline
+  // fills dominate)
+  if (kernel < 0) kernel = (streaming && ((long)h->batch * slabs >= (long)h->cu_count || long_few)) ? 2 : 0;
+  const int* shares = nullptr;
+  if (kernel == 2 && long_few) {
+    if (h->shares_key[0] != h->batch || h->shares_key[1] != e_hi || h->shares_key[2] != rs_workgroups) {
+      const size_t words = (size_t)h->cu_count * pass_share_pieces() * 4;
+      std::vector<int> table(words, 0);
+      h->shares_ok = build_pass_shares(h->batch, e_hi, rs_workgroups, table.data());
+      if (!h->dshares) HIP_TRY(h, hipMalloc(&h->dshares, sizeof(int) * words));
+      // (rare: once per (batch, size); the table must be on the device before the launch below reads it)
+      HIP_TRY(h, hipMemcpyAsync(h->dshares, table.data(), sizeof(int) * words, hipMemcpyHostToDevice, h->stream));
+      HIP_TRY(h, hipStreamSynchronize(h->stream));
+      h->shares_key[0] = h->batch;
+      h->shares_key[1] = e_hi;
+      h->shares_key[2] = rs_workgroups;
+    }
+    if (h->shares_ok > 0) shares = h->dshares;
+  }
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (h->profile) {
+    if (int rc = prof_event(h, &e0)) return rc;
+    if (int rc = prof_event(h, &e1)) return rc;
+    HIP_TRY(h, hipEventRecord(e0, h->stream));
+  }
   h->last_kernel = kernel;
   h->last_nkt = nkt;
   h->last_streaming = streaming ? 1 : 0;
+  h->last_shares = shares ? h->shares_ok : 0;
   if (kernel == 2) {                                   // (k_solve of the last step left the queue heads at zero)
     launch_flush_rs(h->stream, streaming, h->dP, h->dV, h->dW, h->ddacc2[h->dcur], h->dn, h->dso, h->ld, h->pstride,
-                    h->batch, e_hi, nkt, h->opt_pass_workgroups > 0 ? std::min(h->opt_pass_workgroups, h->cu_count) : h->cu_count,
-                    h->dqueue, h->opt_pass_chunk);
+                    h->batch, e_hi, nkt, rs_workgroups, h->dqueue, h->opt_pass_chunk, shares);
   } else {
     launch_flush(h->stream, streaming, h->dP, h->dV, h->dW, h->ddacc2[h->dcur], h->dn, h->dso, h->ld, h->pstride, h->batch,
                  e_hi, nkt, flush_rows_per_block(h, streaming, e_hi));
@@ -1109,6 +1139,18 @@ extern "C" int ekf_debug_read(ekf_handle* h, void* dst, long bytes) {
   HIP_TRY(h, hipMemcpy(dst, h->dqueue, (size_t)std::min(bytes, have), hipMemcpyDeviceToHost));
   return EKF_OK;
 }
+
+// (development aid, not declared in the header; no device needed) the equal static shares of the row-slab pass for a
+// few long trajectories: out = workgroups x 16 pieces x (trajectory, slab, first strip, strips); returns the pieces of
+// the longest share (0: no table) -- tests/test_cpu_host.py checks that every strip of every slab is covered exactly once
+extern "C" int ekf_debug_pass_shares(int batch, int n_hi, int workgroups, int* out) {
+  if (batch < 1 || n_hi < 3 || workgroups < 1 || !out) return -1;
+  return build_pass_shares(batch, n_hi, workgroups, out);
+}
+
+// (development aid, not declared in the header) pieces of the longest share if the last covariance pass ran on equal
+// static shares, else 0
+extern "C" int ekf_debug_last_pass_shares(ekf_handle* h) { return h ? h->last_shares : -1; }
 
 // (development aid, not declared in the header) how many fused cadences ekf_stream_run has launched and how many steps
 // they covered: tests assert that the path they mean to check is the one that ran

@@ -1870,6 +1870,72 @@ __host__ __device__ inline int rs_queue_unit(int g2, int u, int batch, int nrb, 
   r -= whole;
   return ((g2 + 8 * (tq - 1)) * nrb + r % nrb) * 1024 + r / nrb;
 }
+// ---- mode 4: equal static shares (a few LONG trajectories, e.g. N = 8000 x 1: 126 slabs for 256 CUs) ----
+// Whole slabs cannot balance 256 workgroups there, and dynamically handed-out chunks end in a tail as long as a chunk
+// while every unit boundary costs about two strips' worth (pipeline fill and drain).  So the batch's strips -- trajectory
+// by trajectory, slab by slab, each slab from its right end to the diagonal -- are cut into one contiguous share per
+// workgroup of equal COST (strips + RS_PIECE_COST per piece): a share is a handful of pieces (trajectory, slab, first
+// strip, strips), at most RS_PIECES.  No queue, no atomics; the table depends on (batch, n_hi, workgroups) only and is
+// cached on the device.  Returns the pieces of the longest share, 0 if some share would need more than RS_PIECES.
+// (Groups of 2 / 4 / 8 workgroups walking ADJACENT strips of the same rows in step -- longer contiguous row segments in
+//  flight at any time -- were measured at N = 8000 x 1: 401 / 439 / 471 us against 391 us: not adopted.)
+constexpr int RS_PIECES = 16;
+constexpr int RS_PIECE_COST = 2;
+int build_pass_shares(int batch, int n_hi, int workgroups, int* out /* workgroups x RS_PIECES x 4 */) {
+  const int nrb = (n_hi + RS_ROWS - 1) / RS_ROWS, s_last = (n_hi - 1) >> 6;
+  long rem_strips = 0;
+  for (int rb = 0; rb < nrb; ++rb) rem_strips += s_last - 2 * rb + 1;
+  rem_strips *= batch;
+  long rem_slabs = (long)batch * nrb;                  // slabs not yet started
+  for (int i = 0; i < workgroups * RS_PIECES * 4; ++i) out[i] = 0;
+  int w = 0, k = 0, longest = 0;
+  // what a share may cost: what is left (strips + a piece per slab still to start + a piece per share still to open,
+  // the continuation of a slab cut by a share boundary) over the shares left -- recomputed whenever a share is opened
+  auto budget_now = [&](int slab_left) {
+    const long left = rem_strips + RS_PIECE_COST * (rem_slabs + (slab_left > 0 ? 1 : 0) + (workgroups - w - 1));
+    return (double)left / (double)(workgroups - w);
+  };
+  double budget = budget_now(0), used = 0.0;
+  for (int b = 0; b < batch; ++b)
+    for (int v = 0; v < nrb; ++v) {
+      // slabs of a trajectory alternately from both ends (longest, shortest, second longest, ...): the many short slabs
+      // near the diagonal's end do not pile up in one share
+      const int rb = (v & 1) ? nrb - 1 - (v >> 1) : (v >> 1);
+      int S = s_last - 2 * rb + 1, start = 0;
+      --rem_slabs;
+      while (S > 0) {
+        if (k > 0 && used + RS_PIECE_COST + 1 > budget && w + 1 < workgroups) {   // no room for even one strip: next share
+          ++w;
+          k = 0;
+          used = 0.0;
+          budget = budget_now(S);
+        }
+        const int room = w + 1 < workgroups ? (int)(budget - used - RS_PIECE_COST + 0.5) : S;
+        const int cnt = room < 1 ? 1 : (room < S ? room : S);
+        if (k >= RS_PIECES) return 0;
+        int* pc = out + ((long)w * RS_PIECES + k) * 4;
+        pc[0] = b;
+        pc[1] = rb;
+        pc[2] = start;
+        pc[3] = cnt;
+        ++k;
+        longest = k > longest ? k : longest;
+        used += cnt + RS_PIECE_COST;
+        start += cnt;
+        S -= cnt;
+        rem_strips -= cnt;
+        if (S > 0 && w + 1 < workgroups) {             // the slab goes on in the next share
+          ++w;
+          k = 0;
+          used = 0.0;
+          budget = budget_now(S);
+        }
+      }
+    }
+  return longest;
+}
+int pass_share_pieces() { return RS_PIECES; }
+
 // (test hook) all units of all queues in hand-out order; returns their number (may exceed cap)
 int debug_pass_units(int batch, int nrb, int nch, int mode, int* out, int cap) {
   int total = 0;
@@ -1888,7 +1954,7 @@ __global__ __launch_bounds__(512, 2) void k_flush_rs(double* __restrict__ P, con
                                                      const int* __restrict__ nact,
                                                      const SolveOut* __restrict__ so, int ld, long pstride,
                                                      int nkt, int batch, int nrb, int nch, int cs_arg, int mode,
-                                                     unsigned* __restrict__ queue) {
+                                                     unsigned* __restrict__ queue, const int* __restrict__ shares) {
   constexpr int RPW = NKT / 2;                         // ranks of a V strip each of the 8 waves stages
   __shared__ __attribute__((aligned(16))) double vbuf[2][NKT * 256];   // V strip as B fragments: [k-tile][col tile][lane]
   __shared__ __attribute__((aligned(16))) double img[8][16 * 64];      // per wave: 16 x 64 tile image (swizzled)
@@ -1937,6 +2003,7 @@ __global__ __launch_bounds__(512, 2) void k_flush_rs(double* __restrict__ P, con
     }
     return found;
   };
+  int piece = 0;                                       // (mode 4) next piece of this workgroup's share
   for (;;) {
 #ifdef RS_STAMPS
     ++unit_no;
@@ -1944,14 +2011,28 @@ __global__ __launch_bounds__(512, 2) void k_flush_rs(double* __restrict__ P, con
     RS_STAMP(0);
     __syncthreads();                                   // every wave is done with the LDS of the previous unit
     RS_STAMP(1);
-    if (threadIdx.x == 0) s_unit = pop();
-    __syncthreads();
+    int b, rb, u_start, u_count;                       // the unit: strips [u_start, u_start + u_count) of slab rb of trajectory b
+    if (mode == 4) {                                   // equal static shares: this workgroup's own list, no queue
+      if (piece >= RS_PIECES) return;
+      const int* pc = shares + ((long)blockIdx.x * RS_PIECES + piece) * 4;
+      ++piece;
+      b = pc[0];
+      rb = pc[1];
+      u_start = pc[2];
+      u_count = pc[3];
+      if (u_count <= 0) return;                        // end of the share: all eight waves leave together
+    } else {
+      if (threadIdx.x == 0) s_unit = pop();
+      __syncthreads();
+      const int unit = __builtin_amdgcn_readfirstlane(s_unit);   // (an LDS load is a vector value to the compiler)
+      if (unit < 0) return;                            // every queue is empty: all eight waves leave together
+      const int code = unit & 1023;
+      b = (unit >> 10) / nrb;
+      rb = (unit >> 10) - b * nrb;
+      u_count = code == 1023 ? (1 << 20) : cs_arg;     // strips per unit: the whole slab, or a chunk of it
+      u_start = code == 1023 ? 0 : code * cs_arg;
+    }
     RS_STAMP(2);
-    const int unit = __builtin_amdgcn_readfirstlane(s_unit);   // (an LDS load is a vector value to the compiler)
-    if (unit < 0) return;                              // every queue is empty: all eight waves leave together
-    const int code = unit & 1023, b = (unit >> 10) / nrb, rb = (unit >> 10) - b * nrb;
-    const int chunk = code == 1023 ? 0 : code;
-    const int cs = code == 1023 ? (1 << 20) : cs_arg;   // strips per unit: the whole slab, or a chunk of it
     const int n = min(nact[b], so[b].neff);            // rows/cols beyond the active bound are untouched
     const int i0 = rb * RS_ROWS;
     if (i0 >= n) continue;
@@ -1960,10 +2041,10 @@ __global__ __launch_bounds__(512, 2) void k_flush_rs(double* __restrict__ P, con
     // chip: nch = 1).  Below, j_last / S / Sw describe THIS UNIT's strips.
     const int j_right = ((n - 1) >> 6) << 6;
     const int S_slab = ((j_right - i0) >> 6) + 1;
-    if (chunk * cs >= S_slab) continue;
-    const int j_last = j_right - 64 * chunk * cs;      // first (rightmost) strip of the unit
-    const int S = min(cs, S_slab - chunk * cs);
-    const bool has_diag = chunk * cs + S == S_slab;    // the unit ends on the strip that holds the diagonal
+    if (u_start >= S_slab) continue;
+    const int j_last = j_right - 64 * u_start;         // first (rightmost) strip of the unit
+    const int S = min(u_count, S_slab - u_start);
+    const bool has_diag = u_start + S == S_slab;       // the unit ends on the strip that holds the diagonal
     const int i0w = i0 + 16 * wave;
     // tiles of this wave: none if its rows lie beyond n; in the strip that holds the diagonal (columns i0..i0+63)
     // the rows of waves 4-7 lie strictly below it
@@ -2566,8 +2647,13 @@ void launch_flush(hipStream_t st, bool streaming, double* P, const double* V, co
 template <int NKT, bool NT>
 static void launch_flush_rs_t(hipStream_t st, double* P, const double* V, const double* W, const double* dacc,
                               const int* nact, const SolveOut* so, int ld, long pstride, int batch, int n_hi, int nkt,
-                              int workgroups, unsigned* queue, int chunk) {
+                              int workgroups, unsigned* queue, int chunk, const int* shares) {
   const int nrb = (n_hi + RS_ROWS - 1) / RS_ROWS;
+  if (shares) {                                        // equal static shares (mode 4): one per workgroup
+    hipLaunchKernelGGL((k_flush_rs<NKT, NT>), dim3((unsigned)workgroups), dim3(512), 0, st, P, V, W, dacc, nact, so, ld,
+                       pstride, nkt, batch, nrb, 1, 0, 4, queue, shares);
+    return;
+  }
   // Units (see the three modes at k_flush_rs's `pop`).  With an even number of trajectories per queue whole slabs taken
   // trajectory by trajectory balance perfectly (16 trajectories: 366 us against 430 us in chunks of 22 strips); the
   // last trajectory of an odd number finds no partner and its slabs -- only they -- are cut in two (N=2000: 8
@@ -2606,16 +2692,16 @@ static void launch_flush_rs_t(hipStream_t st, double* P, const double* V, const 
   }
   const long units = (long)nrb * (mode == 0 ? nch : mode == 3 ? 2 : 1) * batch;   // (modes 1, 2: at least; only the grid size depends on it)
   hipLaunchKernelGGL((k_flush_rs<NKT, NT>), dim3((unsigned)std::min<long>(workgroups, units)), dim3(512), 0, st, P, V, W,
-                     dacc, nact, so, ld, pstride, nkt, batch, nrb, nch, cs, mode, queue);
+                     dacc, nact, so, ld, pstride, nkt, batch, nrb, nch, cs, mode, queue, nullptr);
 }
 
 void launch_flush_rs(hipStream_t st, bool streaming, double* P, const double* V, const double* W, const double* dacc,
                      const int* nact, const SolveOut* so, int ld, long pstride, int batch, int n_hi, int nkt,
-                     int workgroups, unsigned* queue, int chunk) {
+                     int workgroups, unsigned* queue, int chunk, const int* shares) {
 #define EKF_FLUSH_RS(N)                                                                                   \
   do {                                                                                                    \
-    if (streaming) launch_flush_rs_t<N, true>(st, P, V, W, dacc, nact, so, ld, pstride, batch, n_hi, nkt, workgroups, queue, chunk); \
-    else launch_flush_rs_t<N, false>(st, P, V, W, dacc, nact, so, ld, pstride, batch, n_hi, nkt, workgroups, queue, chunk);          \
+    if (streaming) launch_flush_rs_t<N, true>(st, P, V, W, dacc, nact, so, ld, pstride, batch, n_hi, nkt, workgroups, queue, chunk, shares); \
+    else launch_flush_rs_t<N, false>(st, P, V, W, dacc, nact, so, ld, pstride, batch, n_hi, nkt, workgroups, queue, chunk, shares);          \
   } while (0)
   if (nkt <= 4) EKF_FLUSH_RS(4);
   else if (nkt <= 8) EKF_FLUSH_RS(8);

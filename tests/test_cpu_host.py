@@ -311,3 +311,34 @@ def test_create_rejects_sizes_beyond_the_32_bit_offsets(sd):
         lib.ekf_destroy(h)
     else:
         assert rc == -2 and "EKF_N_MAX_LIMIT" not in lib.ekf_last_error(None).decode()
+
+
+def test_row_slab_pass_equal_shares_cover_every_strip_once(sd):
+    """The static partition the row-slab pass uses for a few long trajectories (N = 8000 x 1: 126 slabs for 256
+    workgroups): every strip of every slab of every trajectory in exactly one piece, at most 16 pieces per share, and
+    shares of equal cost (strips + 2 per piece) to within a few strips."""
+    import ctypes
+    lib = sd.load_library()
+    lib.ekf_debug_pass_shares.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_int)]
+    for batch, n, wgs in [(1, 16003, 256), (2, 16003, 256), (1, 16003, 240), (3, 12003, 256), (7, 16003, 256),
+                          (1, 23167, 256), (3, 1403, 8), (3, 1403, 5), (1, 4003, 8)]:
+        out = np.zeros(wgs * 16 * 4, dtype=np.int32)
+        longest = lib.ekf_debug_pass_shares(batch, n, wgs, out.ctypes.data_as(ctypes.POINTER(ctypes.c_int)))
+        assert 1 <= longest <= 16, (batch, n, wgs, longest)
+        nrb, s_last = (n + 127) // 128, (n - 1) >> 6
+        seen = np.zeros((batch, nrb, s_last + 1), dtype=np.int32)
+        costs = []
+        for share in out.reshape(wgs, 16, 4):
+            cost, ended = 0, False
+            for b, rb, start, cnt in share:
+                if cnt <= 0:
+                    ended = True
+                    continue
+                assert not ended and 0 <= b < batch and 0 <= rb < nrb and start >= 0
+                assert start + cnt <= s_last - 2 * rb + 1
+                seen[b, rb, start:start + cnt] += 1
+                cost += cnt + 2
+            costs.append(cost)
+        for rb in range(nrb):
+            assert (seen[:, rb, :s_last - 2 * rb + 1] == 1).all() and (seen[:, rb, s_last - 2 * rb + 1:] == 0).all()
+        assert max(costs) - min(costs) <= 4, (batch, n, wgs, min(costs), max(costs))

@@ -703,6 +703,64 @@ def test_pass_scheduling_knobs_do_not_change_the_result(sd):
             assert np.array_equal(got[b][1], ref[b][1]), opts
 
 
+def test_row_slab_pass_on_equal_static_shares_is_bit_identical(sd):
+    """The row-slab pass for a few long trajectories: one equal static share of the strips per workgroup, pieces that
+    start and end inside slabs (launch_flush_rs with a share table; automatic at N = 8000 x 1, forced here at a size the
+    oracle handles through `pass_workgroups`).  Trajectories of different sizes, dense and block-diagonal starts, 80 and
+    16 ranks -- bit for bit the column-strip kernel's result, and the reference's."""
+    import ctypes as C
+    lib = sd.load_library()
+    N, B, m, steps = 700, 3, 8, 6
+    n = 3 + 2 * N
+    sizes = [n, 3 + 2 * 450, n]
+    streams = [orc.synthetic_stream(N, steps, m, 160 + t) for t in range(B)]
+    starts = []
+    for t in range(B):
+        rng = np.random.default_rng(390 + t)
+        A = rng.normal(size=(sizes[t], 4)) * 0.3
+        starts.append(A @ A.T + np.diag(rng.uniform(0.5, 2.0, sizes[t])))
+    idx = [np.stack([s[4][k] % ((sizes[b] - 3) // 2) for k in range(steps)]) for b, s in enumerate(streams)]
+
+    def run(options, dense):
+        with sd.EkfSlam(n, batch=B) as f:
+            f.set_option("pass_streaming", 1)
+            f.set_option("active_bound", 0 if dense else 1)
+            for name, value in options:
+                f.set_option(name, value)
+            for b, s in enumerate(streams):
+                if dense:
+                    f.set_state(s[0][:sizes[b]], starts[b], b)
+                else:
+                    f.set_state_diag(s[0][:sizes[b]], s[1][:sizes[b]], b)
+            used = []
+            for k in range(steps):
+                f.step([s[2][k] for s in streams], [s[3][k] for s in streams], [idx[b][k] for b in range(B)],
+                       [s[5][k] for s in streams], [s[6][k] for s in streams])
+                if k in (4, 5):
+                    f.flush()
+                    used.append(lib.ekf_debug_last_pass_shares(C.c_void_p(f._h.value)))
+            assert [f.flags(b) for b in range(B)] == [0] * B
+            return [f.state(b) for b in range(B)], used
+
+    for dense in (True, False):
+        ref, used0 = run([("pass_kernel", 0)], dense)
+        assert used0 == [0, 0]
+        for wgs in (8, 5):
+            got, used = run([("pass_kernel", 2), ("pass_workgroups", wgs)], dense)
+            if dense:                                          # (block-diagonal start: the active bound is still small,
+                assert all(u >= 1 for u in used), used         #  the queue modes apply) both passes ran on share tables
+            for b in range(B):
+                assert np.array_equal(got[b][0], ref[b][0]) and np.array_equal(got[b][1], ref[b][1]), (dense, wgs, b)
+    cfg = orc.EkfConfig()
+    s = streams[1]
+    om, oP = s[0][:sizes[1]].copy(), starts[1].copy()
+    for k in range(steps):
+        om, oP = orc.ekf_step_dense(om, oP, s[2][k], s[3][k], idx[1][k], s[5][k], s[6][k], cfg)
+    got, _ = run([("pass_kernel", 2), ("pass_workgroups", 8)], True)
+    close(got[1][0], om)
+    close(got[1][1], oP)
+
+
 def test_single_launch_step_is_bit_identical(sd):
     """`fused_step=1` (k_step_split: solve and panel workgroups in one launch, the panels gathered beside the solve and
     released by a per-trajectory step counter) gives the results of the two-launch path bit for bit: ragged observation
