@@ -47,6 +47,7 @@ namespace ekf {
 #define CSTAMP(w, s, k) do { } while (0)
 #endif
 
+constexpr int CAD_KS_WAVES = 512;        // panel launches of up to this many waves of state indices take the row-split form
 constexpr int CAD_CS = 88;              // LDS row stride of the block (doubles): 83 columns, rows 16-byte aligned
 constexpr int CAD_ROWS = 84;
 constexpr int CAD_NW = 8;               // waves of the solve workgroup (512 threads: the register budget of 2 waves per SIMD;
@@ -624,6 +625,167 @@ __global__ __launch_bounds__(64 * NW) void k_panels_cad(double* __restrict__ P, 
 }
 
 // ---------------------------------------------------------------------------------------------
+// k_panels_cad_ks: the latency form of the panel launch (few state indices: one trajectory at N = 2000 is 63 waves on
+// 256 CUs, and one wave's replay is a serial chain of 40 landmarks x up to 83 rows).  The four waves of a workgroup
+// share 64 state indices and split the ROWS of X: every wave keeps the pose rows, landmark position-slot q (positions
+// 3 + 2q, 4 + 2q) belongs to wave q & 3.  Per landmark the owner of its two rows finishes e = (H P)[:, i] -- the same
+// chain of five FMAs as k_panels_cad, so the two forms agree bit for bit -- and hands it to the others through LDS
+// (double-buffered by landmark parity: one barrier per landmark); each wave then down-dates its own rows (<= 23 instead
+// of 83).  Rows of a wave sit at position 3 + 8p + 2 wave + e: one base address per wave, compile-time offsets.
+// ---------------------------------------------------------------------------------------------
+template <int MCAP>
+__global__ __launch_bounds__(256) void k_panels_cad_ks(double* __restrict__ P, double* __restrict__ V,
+                                                       double* __restrict__ W, const double* __restrict__ mu_in,
+                                                       double* __restrict__ mu_out, const int* __restrict__ nact,
+                                                       const CadOut* __restrict__ co, int ld, long pstride) {
+  using G = CadGeom<MCAP>;
+  constexpr int GM = G::GM, CU = G::CU, GMAX = G::GMAX;
+  constexpr int LP = (GM + 3) / 4;                     // landmark position-slots per wave
+  __shared__ __attribute__((aligned(16))) double sRec[G::REC + 32];   // (+ what the last record's K reads may overshoot)
+  __shared__ double2 sG[CAD_SLOTS];
+  __shared__ int sM[CAD_SLOTS];
+  __shared__ double2 sE[2][64];
+  const int b = blockIdx.y;
+  const int n = nact[b];
+  const int i0 = blockIdx.x * 64;
+  if (i0 >= n) return;
+  const CadOut& o = co[b];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nsteps = o.nsteps, neff = o.neff, nranks = o.nranks;
+  const int ld16 = ld >> 4;
+  double* Pb = P + (long)b * pstride;
+  double* Vb = V + (long)b * KTOT * ld;
+  double* Wb = W + (long)b * KTOT * ld;
+  const int i = i0 + lane;
+  const bool act = i < n;
+  const int ii = act ? i : n - 1;                      // idle lanes shadow the last state index (no stores)
+  const bool actw = act && i >= 3;                     // the pose's state indices are the solve's
+  const bool live = i0 < neff;                         // (uniform) this workgroup replays
+  double XP[3], XL[2 * LP];
+  if (live) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) XP[k] = Pb[(long)min(k, ii) * ld + max(k, ii)];
+#pragma unroll
+    for (int r = 0; r < 2 * LP; ++r) {
+      const int a = 3 + 8 * (r >> 1) + 2 * wave + (r & 1);
+      const int row = o.C[min(a, CU)];                 // (C[CU] = 0: a position beyond the cadence's)
+      XL[r] = Pb[(long)min(row, ii) * ld + max(row, ii)];
+    }
+    const int cnt = G::rec_off(nsteps * MCAP) / 2;     // double2 units
+    const double2* src = reinterpret_cast<const double2*>(o.rec);
+    double2* dst = reinterpret_cast<double2*>(sRec);
+    for (int e = tid; e < cnt; e += 256) dst[e] = src[e];
+    if (tid < 16) dst[cnt + tid] = make_double2(0.0, 0.0);
+    if (tid < CAD_SLOTS) {
+      sM[tid] = o.m[tid];
+      sG[tid] = *reinterpret_cast<const double2*>(o.g[tid]);
+    }
+  }
+  __syncthreads();
+  const int nrp = (nranks + 3) & ~3;                   // ranks written: whole k-tiles
+  if (!live) {
+    // beyond the active bound the rows and columns of P are exactly zero off the diagonal: the cadence's ranks are
+    // zero there and the mean is carried over
+    if (actw && wave == 0) {
+      for (int k = 0; k < nrp; ++k) {
+        Vb[(long)k * ld + i] = 0.0;
+        Wb[wm_index(ld16, k, i)] = 0.0;
+      }
+      mu_out[(long)b * ld + i] = mu_in[(long)b * ld + i];
+    }
+    return;
+  }
+  const double* recw = sRec + 4 * wave;                // K of this wave's rows: + compile-time offsets
+  double d0 = 0.0, d1 = 0.0, dm = 0.0;
+  int par = 0;                                         // (uniform) hand-over buffer: alternates with every landmark processed
+#pragma unroll
+  for (int t = 0; t < GMAX; ++t) {
+    if (t < nsteps) {                                  // (uniform)
+      const double2 g = sG[t];
+      const double t0 = g.x * XP[2], t1 = g.y * XP[2]; // prediction (:430): rows 0, 1 (see k_panels_cad)
+      XP[0] += t0;
+      XP[1] += t1;
+      d0 += t0;
+      d1 += t1;
+      const int mt = sM[t];
+#pragma unroll
+      for (int j = 0; j < MCAP; ++j) {
+        const int s = t * MCAP + j;                    // (compile-time after unrolling)
+        const int pa = G::pa(s), kr = 2 * s, off = G::rec_off(s);
+        const int q = GM - 1 - s, OW = q & 3, PL = q >> 2;   // the landmark's position-slot: owner wave, its local pair
+        if (j < mt) {                                  // (uniform)
+          const double2* R = reinterpret_cast<const double2*>(__builtin_assume_aligned(sRec + off, 16));
+          if (wave == OW) {                            // (uniform) e = (H_s P_s)[:, i] = h5 . x[sel], finished by the rows' owner
+            double2 hk[5];
+#pragma unroll
+            for (int k = 0; k < 5; ++k) hk[k] = R[k];
+            double e0 = hk[0].x * XP[0], e1 = hk[0].y * XP[0];
+#pragma unroll
+            for (int k = 1; k < 5; ++k) {
+              const double xv = (k < 3) ? XP[k] : XL[2 * PL + (k - 3)];
+              e0 = fma(hk[k].x, xv, e0);
+              e1 = fma(hk[k].y, xv, e1);
+            }
+            sE[par][lane] = make_double2(e0, e1);
+          }
+          WG_LDS_BARRIER();
+          const double2 ee = sE[par][lane];
+          par ^= 1;
+          const double e0 = ee.x, e1 = ee.y;
+          const double2 s01 = R[5], s23 = R[6], yy = R[7];
+          const double f0 = e0 * s01.x + e1 * s23.x;   // K_s[i, :] = (H_s P_s)[:, i]^T S^-1  (P symmetric)
+          const double f1 = e0 * s01.y + e1 * s23.y;
+          dm += f0 * yy.x + f1 * yy.y;                 // :476
+          if (actw && wave == (s & 3)) {               // (the ranks' stores dealt over the waves)
+            Vb[(long)kr * ld + i] = e0;
+            Vb[(long)(kr + 1) * ld + i] = e1;
+            Wb[wm_index(ld16, kr, i)] = -f0;
+            Wb[wm_index(ld16, kr + 1, i)] = -f1;
+          }
+          if (!(t + 1 == nsteps && j + 1 == mt)) {     // (uniform) x[a] -= K_s[C_u[a], :] . (H_s P_s)[:, i], what lives on
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+              const double2 kc = R[8 + k];
+              XP[k] = fma(-kc.x, e0, XP[k]);
+              XP[k] = fma(-kc.y, e1, XP[k]);
+            }
+            // own landmark rows at positions 3 + 8p + 2 wave + e < pa; the pair at the boundary may already be dead for
+            // this wave: what lands in a dead row does not matter
+            const double2* Rw = reinterpret_cast<const double2*>(__builtin_assume_aligned(recw + off + 16, 16));
+#pragma unroll
+            for (int pp = 0; pp < LP; ++pp) {
+              if (3 + 8 * pp < pa) {                   // (compile-time) some wave's rows of this pair are live
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                  const double2 kc = Rw[3 + 8 * pp + e];
+                  XL[2 * pp + e] = fma(-kc.x, e0, XL[2 * pp + e]);
+                  XL[2 * pp + e] = fma(-kc.y, e1, XL[2 * pp + e]);
+                }
+              }
+            }
+          }
+        } else if (actw && wave == (s & 3)) {
+          Vb[(long)kr * ld + i] = 0.0;
+          Vb[(long)(kr + 1) * ld + i] = 0.0;
+          Wb[wm_index(ld16, kr, i)] = 0.0;
+          Wb[wm_index(ld16, kr + 1, i)] = 0.0;
+        }
+      }
+    }
+  }
+  if (actw && wave == 0) {
+    for (int k = nranks; k < nrp; ++k) {               // k-tile pad
+      Vb[(long)k * ld + i] = 0.0;
+      Wb[wm_index(ld16, k, i)] = 0.0;
+    }
+    Pb[i] += d0;                                       // entry (0, i)
+    Pb[ld + i] += d1;                                  // entry (1, i)
+    mu_out[(long)b * ld + i] = mu_in[(long)b * ld + i] + dm;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // launchers (called from ekf_api.hip)
 // ---------------------------------------------------------------------------------------------
 int cadence_steps_max(int mcap) { return CAD_SLOTS / mcap; }
@@ -647,8 +809,12 @@ void launch_solve_cad(hipStream_t st, int mcap, double* P, double* V, double* W,
 template <int MCAP>
 static void launch_panels_cad_t(hipStream_t st, double* P, double* V, double* W, const double* mu_in, double* mu_out,
                                 const int* nact, const CadOut* co, int ld, long pstride, int batch, int n_hi) {
-  // few waves (the latency regime): one wave per workgroup, so that every wave gets a CU to itself
-  if ((long)((n_hi + 63) / 64) * batch <= 1024)
+  // few state indices (the latency regime): four waves split the rows of the panel of 64 state indices (k_panels_cad_ks);
+  // up to one wave per SIMD: one wave per workgroup
+  if ((long)((n_hi + 63) / 64) * batch <= CAD_KS_WAVES)
+    hipLaunchKernelGGL((k_panels_cad_ks<MCAP>), dim3((n_hi + 63) / 64, batch), dim3(256), 0, st, P, V, W, mu_in, mu_out,
+                       nact, co, ld, pstride);
+  else if ((long)((n_hi + 63) / 64) * batch <= 1024)
     hipLaunchKernelGGL((k_panels_cad<MCAP, 1>), dim3((n_hi + 63) / 64, batch), dim3(64), 0, st, P, V, W, mu_in, mu_out,
                        nact, co, ld, pstride);
   else

@@ -225,6 +225,33 @@ def test_config_flags_through_the_cadence(sd, flags):
         assert orc.rel_fro(got[b][0], om) < TIGHT and orc.rel_fro(got[b][1], oP) < TIGHT
 
 
+def test_all_three_shapes_of_the_panel_launch_agree(sd):
+    """The panel launch of a cadence has three shapes by the number of state indices in the launch: rows of the panel
+    split over the four waves of a workgroup (k_panels_cad_ks: up to 512 waves of state indices), one wave per workgroup
+    (up to 1024), four independent waves per workgroup (beyond).  N = 1300 with 3, 16 and 30 trajectories walks through
+    all three; trajectory b of every batch runs the same stream from the same block-diagonal start, so the three must
+    return the same state for it -- bit for bit: the forms perform the same operations in the same order."""
+    N, steps, m = 1300, 7, 8
+    n = 3 + 2 * N
+    streams = [orc.synthetic_stream(N, steps, m, 1100 + t) for t in range(3)]
+    res = {}
+    for B in (3, 16, 30):
+        pick = [streams[b % 3] for b in range(B)]
+        args = (stack(pick, 2), stack(pick, 3), stack(pick, 4), stack(pick, 5), stack(pick, 6))
+        out, (nc, ns) = run_stream(sd, n, B, [s[1] for s in pick], [s[0] for s in pick], *args, diag=True,
+                                   options=[("active_bound", 0)])
+        assert (nc, ns) == (2, 7)
+        res[B] = out
+    for b in range(3):
+        for B in (16, 30):
+            assert np.array_equal(res[3][b][0], res[B][b][0]) and np.array_equal(res[3][b][1], res[B][b][1]), (B, b)
+    plain, _ = run_stream(sd, n, 3, [s[1] for s in streams], [s[0] for s in streams], stack(streams, 2), stack(streams, 3),
+                          stack(streams, 4), stack(streams, 5), stack(streams, 6), diag=True,
+                          options=[("active_bound", 0), ("fused_cadence", 0)])
+    for b in range(3):
+        assert orc.rel_fro(res[3][b][0], plain[b][0]) < PATH_TOL and orc.rel_fro(res[3][b][1], plain[b][1]) < PATH_TOL
+
+
 def test_golden_stream_through_the_cadence(sd):
     """BASELINE config 1 (N = 20, 500 steps, the reference's own outputs in tests/golden/stream_n20_m8.npz) as ONE
     uploaded stream: 100 fused cadences back to back, final mean and covariance against the reference."""
