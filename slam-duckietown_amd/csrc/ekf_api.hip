@@ -39,10 +39,10 @@ void launch_associate(hipStream_t, const DetIn*, int*, int*, int*, double*, doub
 void launch_fill_diag(hipStream_t, double*, int, int, const double*);
 int dense_propagate(hipStream_t, double* P, double* tmp, const double* F, const double* Q, int n, int ld);
 int cadence_steps_max(int mcap);
-void launch_solve_cad(hipStream_t, int, double*, double*, double*, const double*, double*, double*, const int*, const StepIn*,
-                      int, int, SolveOut*, CadOut*, unsigned*, const int*, unsigned*, const DeviceConfig&, int, long);
-void launch_panels_cad(hipStream_t, int, double*, double*, double*, const double*, double*, const int*, const CadOut*, int,
-                       long, int, int);
+void launch_solve_cad(hipStream_t, int, const double*, const double*, double*, double*, const int*, const StepIn*, int, int,
+                      CadOut*, unsigned*, const int*, const DeviceConfig&, int, long);
+void launch_panels_cad(hipStream_t, int, double*, double*, double*, const double*, double*, const int*, const CadOut*,
+                       SolveOut*, unsigned*, int, long, int, int);
 }  // namespace ekf
 
 using namespace ekf;
@@ -691,11 +691,11 @@ static int enqueue_cadence(ekf_handle* h, int k, int g) {
     h->neff_enq[b] = std::min(h->n[b], std::max(h->floor_host[b], h->stream_own[(size_t)(k + g - 1) * h->batch + b]));
   const double* mu_in = h->dmu2[h->cur];
   double* mu_out = h->dmu2[h->cur ^ 1];
-  launch_solve_cad(h->stream, mcap, h->dP, h->dV, h->dW, mu_in, mu_out, h->ddacc2[h->dcur ^ 1], h->dn,
-                   h->d_stream + (size_t)k * h->batch, h->batch, g, h->dso, h->dcad, h->dflags, h->dfloor, h->dqueue,
-                   h->dcfg, h->ld, h->pstride);
-  launch_panels_cad(h->stream, mcap, h->dP, h->dV, h->dW, mu_in, mu_out, h->dn, h->dcad, h->ld, h->pstride, h->batch,
-                    n_hi);
+  launch_solve_cad(h->stream, mcap, h->dP, mu_in, mu_out, h->ddacc2[h->dcur ^ 1], h->dn,
+                   h->d_stream + (size_t)k * h->batch, h->batch, g, h->dcad, h->dflags, h->dfloor, h->dcfg, h->ld,
+                   h->pstride);
+  launch_panels_cad(h->stream, mcap, h->dP, h->dV, h->dW, mu_in, mu_out, h->dn, h->dcad, h->dso, h->dqueue, h->ld,
+                    h->pstride, h->batch, n_hi);
   HIP_TRY(h, hipGetLastError());
   h->dcur ^= 1;
   h->cur ^= 1;

@@ -15,8 +15,11 @@
 //                 per landmark {H (2x5), S^-1, y, K[C_u[a], :] for the positions a later landmark still reads}
 //   k_panels_cad  thread per state index i >= 3: gathers X[:, i] (83 loads in flight at once), replays, writes
 //                 V[k][i], W[i][k] for all ranks, its share of the in-place prediction (rows 0, 1 of P_base) and mu[i]
-// State indices 0..2 (the pose) are the solve's: it has the whole pose block, so it writes their V / W entries, the pose
-// block of P_base's rows 0, 1 and the pose mean itself -- the panel kernel has no special case for the first lanes.
+// State indices 0..2 (the pose) are the solve's: it has the whole pose block, so it computes their V / W entries, the pose
+// block's share of P_base's rows 0, 1 and the pose mean itself -- the panel kernel's replay has no special case for the
+// first lanes.  Of these only the mean is written by the solve: the rest travels in the record and is stored by the panel
+// launch (pose_epilogue), so that the solve touches neither V, W, P_base nor anything else a covariance pass uses -- which
+// lets the solve of the NEXT cadence run beside the pass of this one (ekf_api.hip: look-ahead).
 // Slot layout of C_u (CadGeom, ekf_device.h): later landmarks at LOWER positions, so what is still needed is always a
 // prefix of the positions: compile-time bounds for the panel's register array X, a shrinking prefix of lanes here.
 // Same algebra as the per-step path in a different summation order: results agree to rounding (<= 1e-12 relative,
@@ -57,13 +60,13 @@ constexpr int CAD_DCH = 7;              // rows of a down-date chunk (all reads 
 constexpr int CAD_DQ = (CAD_CU - 2 + CAD_DCH * CAD_DW - 1) / (CAD_DCH * CAD_DW) * CAD_DCH;   // rows per down-date wave
 
 template <int MCAP>
-__global__ __launch_bounds__(64 * CAD_NW) void k_solve_cad(double* __restrict__ P, double* __restrict__ V, double* __restrict__ W,
+__global__ __launch_bounds__(64 * CAD_NW) void k_solve_cad(const double* __restrict__ P,
                                                     const double* __restrict__ mu_in, double* __restrict__ mu_out,
                                                     double* __restrict__ dacc_out, const int* __restrict__ nact,
                                                     const StepIn* __restrict__ in, int batch, int nsteps,
-                                                    SolveOut* __restrict__ so, CadOut* __restrict__ out,
-                                                    unsigned* __restrict__ flags, const int* __restrict__ neff_floor,
-                                                    unsigned* __restrict__ queue, DeviceConfig cfg, int ld, long pstride) {
+                                                    CadOut* __restrict__ out, unsigned* __restrict__ flags,
+                                                    const int* __restrict__ neff_floor, DeviceConfig cfg, int ld,
+                                                    long pstride) {
   using G = CadGeom<MCAP>;
   constexpr int GM = G::GM, CU = G::CU;
   __shared__ __attribute__((aligned(16))) double Pc[CAD_ROWS][CAD_CS];
@@ -78,14 +81,9 @@ __global__ __launch_bounds__(64 * CAD_NW) void k_solve_cad(double* __restrict__ 
   const int b = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  double* Pb = P + (long)b * pstride;
-  double* Vb = V + (long)b * KTOT * ld;
-  double* Wb = W + (long)b * KTOT * ld;
+  const double* Pb = P + (long)b * pstride;
   const double* mu_in_b = mu_in + (long)b * ld;
   CadOut& o = out[b];
-  const int ld16 = ld >> 4;
-  // the work-queue heads of the row-slab covariance pass start every pass at zero (see k_solve)
-  if (b == 0 && tid < 8) queue[tid * RS_QSTRIDE] = 0u;
 
   // ---- inputs: slot s = t * MCAP + j of the cadence (thread s), its two positions, the steps' scalars ----
   if (tid < 128) Cs[tid] = tid < 3 ? tid : 0;
@@ -124,7 +122,6 @@ __global__ __launch_bounds__(64 * CAD_NW) void k_solve_cad(double* __restrict__ 
     o.neff = neff_eff;
     o.nranks = 2 * MCAP * nsteps;
     o.pad0 = 0;
-    so[b].neff = neff_eff;                             // what the covariance pass reads as this trajectory's bound
   }
 
   // ---- the mean wave (wave 1): lane l holds the mean at positions l and 64 + l ----
@@ -380,10 +377,9 @@ __global__ __launch_bounds__(64 * CAD_NW) void k_solve_cad(double* __restrict__ 
         if (lane == 5 || lane == 6) rec2[lane] = siS[lane - 5];
         if (lane < 3) {
           const double2 hp = hpS[lane];
-          Vb[(long)(2 * s) * ld + lane] = hp.x;
-          Vb[(long)(2 * s + 1) * ld + lane] = hp.y;
-          Wb[wm_index(ld16, 2 * s, lane)] = -ka.x;
-          Wb[wm_index(ld16, 2 * s + 1, lane)] = -ka.y;
+          double2* vw = reinterpret_cast<double2*>(o.posevw[s][lane]);
+          vw[0] = hp;
+          vw[1] = make_double2(-ka.x, -ka.y);
         }
       } else if (!last) {
         // down-date (:480) of what lives on: P[r][l] -= K[r, :] . (H P)[:, l] for r, l < pa; rows ds, ds + CAD_DW, ... are
@@ -454,13 +450,6 @@ __global__ __launch_bounds__(64 * CAD_NW) void k_solve_cad(double* __restrict__ 
       if (wave == 1 && t + 1 < nsteps) motion(t + 1);
       WG_LDS_BARRIER();
     }
-    // slots this step leaves empty: zero ranks at the pose's state indices (the panel kernel writes the others)
-    if (rec_wave && lane < 3) {
-      for (int k = 2 * (s_first + m); k < 2 * (s_first + MCAP); ++k) {
-        Vb[(long)k * ld + lane] = 0.0;
-        Wb[wm_index(ld16, k, lane)] = 0.0;
-      }
-    }
   }
 
   // ---- results the solve owns: the pose mean, the pose block of P_base's rows 0, 1, the pending pose noise ----
@@ -477,15 +466,39 @@ __global__ __launch_bounds__(64 * CAD_NW) void k_solve_cad(double* __restrict__ 
     }
   }
   if (wave == 0 && lane < 3) {
-    Pb[lane] += dd0;                                   // entry (0, l)
-    if (lane >= 1) Pb[ld + lane] += dd1;               // entry (1, l); (1, 0) lies below the diagonal
+    o.ddpose[0][lane] = dd0;                           // entry (0, l)
+    o.ddpose[1][lane] = dd1;                           // entry (1, l)
   }
-  if (rec_wave && lane < 3) {
-    for (int k = 2 * MCAP * nsteps; k < ((2 * MCAP * nsteps + 3) & ~3); ++k) {   // k-tile pad
+}
+
+// What the solve leaves to the panel launch (its workgroup 0 of every trajectory, lanes 0..2 of wave 0): the new ranks'
+// entries at the pose's state indices, zero ranks for the slots a step leaves empty, the k-tile pad, the pose block's
+// share of the in-place prediction, the active bound the next covariance pass reads, and (trajectory 0) the work-queue
+// heads of the row-slab pass, which start every pass at zero.
+template <int MCAP>
+__device__ __forceinline__ void pose_epilogue(const CadOut& o, double* Pb, double* Vb, double* Wb, SolveOut* so, unsigned* queue,
+                                              int b, int ld, int lane) {
+  const int ld16 = ld >> 4;
+  if (lane < 3) {
+    for (int t = 0; t < o.nsteps; ++t)
+      for (int j = 0; j < MCAP; ++j) {
+        const int s = t * MCAP + j;
+        double4_t vw = {0.0, 0.0, 0.0, 0.0};
+        if (j < o.m[t]) vw = *reinterpret_cast<const double4_t*>(o.posevw[s][lane]);
+        Vb[(long)(2 * s) * ld + lane] = vw[0];
+        Vb[(long)(2 * s + 1) * ld + lane] = vw[1];
+        Wb[wm_index(ld16, 2 * s, lane)] = vw[2];
+        Wb[wm_index(ld16, 2 * s + 1, lane)] = vw[3];
+      }
+    for (int k = o.nranks; k < ((o.nranks + 3) & ~3); ++k) {   // k-tile pad
       Vb[(long)k * ld + lane] = 0.0;
       Wb[wm_index(ld16, k, lane)] = 0.0;
     }
+    Pb[lane] += o.ddpose[0][lane];                     // entry (0, l)
+    if (lane >= 1) Pb[ld + lane] += o.ddpose[1][lane]; // entry (1, l); (1, 0) lies below the diagonal
   }
+  if (lane == 0) so[b].neff = o.neff;                  // what the covariance pass reads as this trajectory's bound
+  if (b == 0 && lane < 8) queue[lane * RS_QSTRIDE] = 0u;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -497,7 +510,8 @@ template <int MCAP, int NW>
 __global__ __launch_bounds__(64 * NW) void k_panels_cad(double* __restrict__ P, double* __restrict__ V,
                                                         double* __restrict__ W, const double* __restrict__ mu_in,
                                                         double* __restrict__ mu_out, const int* __restrict__ nact,
-                                                        const CadOut* __restrict__ co, int ld, long pstride) {
+                                                        const CadOut* __restrict__ co, SolveOut* __restrict__ so,
+                                                        unsigned* __restrict__ queue, int ld, long pstride) {
   using G = CadGeom<MCAP>;
   constexpr int CU = G::CU, GMAX = G::GMAX, NT = 64 * NW;
   __shared__ __attribute__((aligned(16))) double sRec[G::REC];
@@ -622,6 +636,7 @@ __global__ __launch_bounds__(64 * NW) void k_panels_cad(double* __restrict__ P, 
     Pb[ld + i] += d1;                                  // entry (1, i)
     mu_out[(long)b * ld + i] = mu_in[(long)b * ld + i] + dm;
   }
+  if (blockIdx.x == 0 && wave == 0) pose_epilogue<MCAP>(o, Pb, Vb, Wb, so, queue, b, ld, lane);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -637,7 +652,8 @@ template <int MCAP>
 __global__ __launch_bounds__(256) void k_panels_cad_ks(double* __restrict__ P, double* __restrict__ V,
                                                        double* __restrict__ W, const double* __restrict__ mu_in,
                                                        double* __restrict__ mu_out, const int* __restrict__ nact,
-                                                       const CadOut* __restrict__ co, int ld, long pstride) {
+                                                       const CadOut* __restrict__ co, SolveOut* __restrict__ so,
+                                                       unsigned* __restrict__ queue, int ld, long pstride) {
   using G = CadGeom<MCAP>;
   constexpr int GM = G::GM, CU = G::CU, GMAX = G::GMAX;
   constexpr int LP = (GM + 3) / 4;                     // landmark position-slots per wave
@@ -783,6 +799,7 @@ __global__ __launch_bounds__(256) void k_panels_cad_ks(double* __restrict__ P, d
     Pb[ld + i] += d1;                                  // entry (1, i)
     mu_out[(long)b * ld + i] = mu_in[(long)b * ld + i] + dm;
   }
+  if (blockIdx.x == 0 && wave == 0) pose_epilogue<MCAP>(o, Pb, Vb, Wb, so, queue, b, ld, lane);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -790,12 +807,12 @@ __global__ __launch_bounds__(256) void k_panels_cad_ks(double* __restrict__ P, d
 // ---------------------------------------------------------------------------------------------
 int cadence_steps_max(int mcap) { return CAD_SLOTS / mcap; }
 
-void launch_solve_cad(hipStream_t st, int mcap, double* P, double* V, double* W, const double* mu_in, double* mu_out,
-                      double* dacc_out, const int* nact, const StepIn* in, int batch, int nsteps, SolveOut* so, CadOut* out,
-                      unsigned* flags, const int* neff_floor, unsigned* queue, const DeviceConfig& cfg, int ld, long pstride) {
+void launch_solve_cad(hipStream_t st, int mcap, const double* P, const double* mu_in, double* mu_out, double* dacc_out,
+                      const int* nact, const StepIn* in, int batch, int nsteps, CadOut* out, unsigned* flags,
+                      const int* neff_floor, const DeviceConfig& cfg, int ld, long pstride) {
 #define EKF_SOLVE_CAD(M)                                                                                              \
-  hipLaunchKernelGGL((k_solve_cad<M>), dim3(batch), dim3(64 * CAD_NW), 0, st, P, V, W, mu_in, mu_out, dacc_out, nact, in, batch, \
-                     nsteps, so, out, flags, neff_floor, queue, cfg, ld, pstride)
+  hipLaunchKernelGGL((k_solve_cad<M>), dim3(batch), dim3(64 * CAD_NW), 0, st, P, mu_in, mu_out, dacc_out, nact, in, batch, \
+                     nsteps, out, flags, neff_floor, cfg, ld, pstride)
   switch (mcap) {
     case 1: EKF_SOLVE_CAD(1); break;
     case 2: EKF_SOLVE_CAD(2); break;
@@ -808,27 +825,29 @@ void launch_solve_cad(hipStream_t st, int mcap, double* P, double* V, double* W,
 
 template <int MCAP>
 static void launch_panels_cad_t(hipStream_t st, double* P, double* V, double* W, const double* mu_in, double* mu_out,
-                                const int* nact, const CadOut* co, int ld, long pstride, int batch, int n_hi) {
+                                const int* nact, const CadOut* co, SolveOut* so, unsigned* queue, int ld, long pstride,
+                                int batch, int n_hi) {
   // few state indices (the latency regime): four waves split the rows of the panel of 64 state indices (k_panels_cad_ks);
   // up to one wave per SIMD: one wave per workgroup
   if ((long)((n_hi + 63) / 64) * batch <= CAD_KS_WAVES)
     hipLaunchKernelGGL((k_panels_cad_ks<MCAP>), dim3((n_hi + 63) / 64, batch), dim3(256), 0, st, P, V, W, mu_in, mu_out,
-                       nact, co, ld, pstride);
+                       nact, co, so, queue, ld, pstride);
   else if ((long)((n_hi + 63) / 64) * batch <= 1024)
     hipLaunchKernelGGL((k_panels_cad<MCAP, 1>), dim3((n_hi + 63) / 64, batch), dim3(64), 0, st, P, V, W, mu_in, mu_out,
-                       nact, co, ld, pstride);
+                       nact, co, so, queue, ld, pstride);
   else
     hipLaunchKernelGGL((k_panels_cad<MCAP, 4>), dim3((n_hi + 255) / 256, batch), dim3(256), 0, st, P, V, W, mu_in,
-                       mu_out, nact, co, ld, pstride);
+                       mu_out, nact, co, so, queue, ld, pstride);
 }
 void launch_panels_cad(hipStream_t st, int mcap, double* P, double* V, double* W, const double* mu_in, double* mu_out,
-                       const int* nact, const CadOut* co, int ld, long pstride, int batch, int n_hi) {
+                       const int* nact, const CadOut* co, SolveOut* so, unsigned* queue, int ld, long pstride, int batch,
+                       int n_hi) {
   switch (mcap) {
-    case 1: launch_panels_cad_t<1>(st, P, V, W, mu_in, mu_out, nact, co, ld, pstride, batch, n_hi); break;
-    case 2: launch_panels_cad_t<2>(st, P, V, W, mu_in, mu_out, nact, co, ld, pstride, batch, n_hi); break;
-    case 4: launch_panels_cad_t<4>(st, P, V, W, mu_in, mu_out, nact, co, ld, pstride, batch, n_hi); break;
-    case 8: launch_panels_cad_t<8>(st, P, V, W, mu_in, mu_out, nact, co, ld, pstride, batch, n_hi); break;
-    default: launch_panels_cad_t<16>(st, P, V, W, mu_in, mu_out, nact, co, ld, pstride, batch, n_hi); break;
+    case 1: launch_panels_cad_t<1>(st, P, V, W, mu_in, mu_out, nact, co, so, queue, ld, pstride, batch, n_hi); break;
+    case 2: launch_panels_cad_t<2>(st, P, V, W, mu_in, mu_out, nact, co, so, queue, ld, pstride, batch, n_hi); break;
+    case 4: launch_panels_cad_t<4>(st, P, V, W, mu_in, mu_out, nact, co, so, queue, ld, pstride, batch, n_hi); break;
+    case 8: launch_panels_cad_t<8>(st, P, V, W, mu_in, mu_out, nact, co, so, queue, ld, pstride, batch, n_hi); break;
+    default: launch_panels_cad_t<16>(st, P, V, W, mu_in, mu_out, nact, co, so, queue, ld, pstride, batch, n_hi); break;
   }
 }
 

@@ -105,9 +105,11 @@ struct alignas(16) CadHead {
   int C[CAD_CU + 1];          // gathered state indices by position
   double g[CAD_SLOTS][2];     // G[0,2], G[1,2] of step t's motion Jacobian
   double prow[2][CAD_CU + 1]; // (diagnostic) P(0, C_u[a]), P(1, C_u[a]) before the cadence
+  double ddpose[2][4];        // what the cadence's predictions add to P_base(0, l), P_base(1, l), l < 3 (the pose block)
 };
 struct alignas(16) CadOut : CadHead {
   double rec[CAD_REC_MAX];
+  double posevw[CAD_SLOTS][3][4];   // the new ranks' entries at the pose's state indices l < 3: V[2s][l], V[2s+1][l], W[l][2s], W[l][2s+1]
 };
 static_assert(sizeof(CadHead) % 16 == 0, "CadHead must stay 16-byte granular");
 
