@@ -40,7 +40,10 @@ void launch_fill_diag(hipStream_t, double*, int, int, const double*);
 int dense_propagate(hipStream_t, double* P, double* tmp, const double* F, const double* Q, int n, int ld);
 int cadence_steps_max(int mcap);
 void launch_solve_cad(hipStream_t, int, const double*, const double*, double*, double*, const int*, const StepIn*, int, int,
-                      CadOut*, unsigned*, const int*, const DeviceConfig&, int, long);
+                      CadOut*, unsigned*, const int*, const DeviceConfig&, int, long, const double*, int);
+void launch_gather_cad(hipStream_t, int, const double*, const double*, const double*, const double*, const StepIn*, int, int,
+                       int, const DeviceConfig&, int, long, double*);
+long cadence_gbuf_doubles();
 void launch_panels_cad(hipStream_t, int, double*, double*, double*, const double*, double*, const int*, const CadOut*,
                        SolveOut*, unsigned*, int, long, int, int);
 }  // namespace ekf
@@ -108,6 +111,13 @@ struct ekf_handle {
   int opt_fused_cadence = 1;      // 1 = uploaded streams run whole cadences as one solve + one panel launch (ekf_cadence.hip)
   CadOut* dcad = nullptr;         // per trajectory: head + per-landmark records of the cadence in flight (allocated on first use)
   long cadences = 0, cadence_steps = 0;   // statistics: fused cadences launched, steps they covered
+  // look-ahead (small launches): the solve of the next cadence runs on the handle's stream beside the covariance pass of
+  // this one, which goes to a second stream between two events; see ekf_stream_run
+  int opt_lookahead = 1;
+  hipStream_t aux = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  double* dgbuf = nullptr;        // per trajectory: the next cadence's block, gathered while this one's ranks are pending
+  long lookaheads = 0;
   int cu_count = 0;
   int opt_rows_per_block = 0;     // 0 = auto (flush kernel: rows per workgroup, multiple of 16)
   int opt_pass_chunk = 0;         // 0 = auto (k_flush_rs: strips per unit)
@@ -126,6 +136,7 @@ static int fail(ekf_handle* h, int code, const std::string& msg) {
 }
 
 static int flush_pending(ekf_handle* h);
+static int flush_pending(ekf_handle* h, hipStream_t st);
 static int materialize(ekf_handle* h, int b);
 
 #define HIP_TRY(h, expr)                                                                   \
@@ -164,7 +175,7 @@ static void free_all(ekf_handle* h) {
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   void* ptrs[] = {h->dP, h->dmu2[0], h->dmu2[1], h->dV, h->dW, h->ddacc2[0], h->ddacc2[1], h->dscratch, h->dn, h->dflags, h->dso, h->dfac,
                   h->d_ring, h->d_stream, h->dF, h->dQ, h->dTmp, h->dtagmap, h->dneff, h->d_det, h->d_assoc_step, h->dfloor, h->dqueue, h->dready, h->dmbox,
-                  h->d_assoc_out, h->dcad, h->dshares};
+                  h->d_assoc_out, h->dcad, h->dshares, h->dgbuf};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (h->h_ring) (void)hipHostFree(h->h_ring);
   if (h->h_det) (void)hipHostFree(h->h_det);
@@ -172,6 +183,12 @@ static void free_all(ekf_handle* h) {
   for (auto& e : h->prof_pool) (void)hipEventDestroy(e);
   if (h->t0) (void)hipEventDestroy(h->t0);
   if (h->t1) (void)hipEventDestroy(h->t1);
+  if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+  if (h->ev_join) (void)hipEventDestroy(h->ev_join);
+  if (h->aux) {
+    (void)hipStreamSynchronize(h->aux);
+    (void)hipStreamDestroy(h->aux);
+  }
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
 }
@@ -252,6 +269,9 @@ extern "C" int ekf_create(int device, int n_max, int batch, const ekf_config* cf
   } while (0)
   CREATE_TRY(hipSetDevice(device));
   CREATE_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+  CREATE_TRY(hipStreamCreateWithFlags(&h->aux, hipStreamNonBlocking));
+  CREATE_TRY(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+  CREATE_TRY(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
   const size_t ldz = (size_t)h->ld;
   const size_t rowz = (size_t)h->rows;
   CREATE_TRY(hipMalloc(&h->dP, sizeof(double) * rowz * ldz * batch));
@@ -552,41 +572,55 @@ static int prof_event(ekf_handle* h, hipEvent_t* ev) {
   return EKF_OK;
 }
 
-// Apply the pending low-rank update to P_base:  P_base += W V + diag(dacc)  (one pass over P).
-static int flush_pending(ekf_handle* h) {
-  if (h->pending_k == 0) return EKF_OK;
-  const int n_hi = h->sizes_dirty ? h->n_max : *std::max_element(h->n.begin(), h->n.end());
-  int e_hi = 3;                                        // grid covers the largest active bound of the batch
-  for (int b = 0; b < h->batch; ++b) e_hi = std::max(e_hi, std::min(h->n[b], h->neff_enq[b]));
-  if (h->sizes_dirty) e_hi = h->n_max;
-  const bool streaming = streaming_pass(h, n_hi);
-  const int nkt = (h->pending_k + 3) / 4;
-  int kernel = h->opt_pass_kernel;
-  const int rs_workgroups = h->opt_pass_workgroups > 0 ? std::min(h->opt_pass_workgroups, h->cu_count) : h->cu_count;
+// What the next covariance pass will launch (decided from the handle's state alone, so that the caller can ask before
+// it launches).
+struct PassPlan {
+  int n_hi, e_hi, nkt, kernel, rs_workgroups;
+  bool streaming, long_few;
+};
+static PassPlan plan_pass(const ekf_handle* h) {
+  PassPlan p;
+  p.n_hi = h->sizes_dirty ? h->n_max : *std::max_element(h->n.begin(), h->n.end());
+  p.e_hi = 3;                                          // the grid covers the largest active bound of the batch
+  for (int b = 0; b < h->batch; ++b) p.e_hi = std::max(p.e_hi, std::min(h->n[b], h->neff_enq[b]));
+  if (h->sizes_dirty) p.e_hi = h->n_max;
+  p.streaming = streaming_pass(h, p.n_hi);
+  p.nkt = (h->pending_k + 3) / 4;
+  p.kernel = h->opt_pass_kernel;
+  p.rs_workgroups = h->opt_pass_workgroups > 0 ? std::min(h->opt_pass_workgroups, h->cu_count) : h->cu_count;
   // A few LONG trajectories (N = 8000 x 1: 126 slabs of up to 251 strips for 256 CUs): the row-slab pass with one equal
   // static share of the strips per workgroup (build_pass_shares) -- where a share is long enough (>= 40 strips) for
   // the pipeline fills at its piece boundaries not to matter.
-  const long slabs = (e_hi + 127) / 128, s_last = (e_hi - 1) >> 6;
+  const long slabs = (p.e_hi + 127) / 128, s_last = (p.e_hi - 1) >> 6;
   const long strips = (long)h->batch * (slabs * (s_last + 1) - slabs * (slabs - 1));
-  const bool long_few = h->batch < 8 && h->opt_pass_chunk == 0 && strips >= 40L * rs_workgroups;
+  p.long_few = h->batch < 8 && h->opt_pass_chunk == 0 && strips >= 40L * p.rs_workgroups;
   // auto: the row-slab form where the batch streams through HBM and has at least one 128-row slab per CU (below
   // three per CU the slabs are cut into chunks of strips) or is a few long trajectories; measured at N=2000: 8
   // trajectories 256 us against 266 us with k_flush, 4 trajectories 166 / 164 us, 1 trajectory 97 / 52 us (pipeline
   // fills dominate)
-  if (kernel < 0) kernel = (streaming && ((long)h->batch * slabs >= (long)h->cu_count || long_few)) ? 2 : 0;
+  if (p.kernel < 0) p.kernel = (p.streaming && ((long)h->batch * slabs >= (long)h->cu_count || p.long_few)) ? 2 : 0;
+  return p;
+}
+
+// Apply the pending low-rank update to P_base:  P_base += W V + diag(dacc)  (one pass over P), on stream `st` (the
+// handle's own unless the look-ahead of ekf_stream_run sends it to the second one).
+static int flush_pending(ekf_handle* h, hipStream_t st) {
+  if (h->pending_k == 0) return EKF_OK;
+  if (!st) st = h->stream;
+  const PassPlan p = plan_pass(h);
   const int* shares = nullptr;
-  if (kernel == 2 && long_few) {
-    if (h->shares_key[0] != h->batch || h->shares_key[1] != e_hi || h->shares_key[2] != rs_workgroups) {
+  if (p.kernel == 2 && p.long_few) {
+    if (h->shares_key[0] != h->batch || h->shares_key[1] != p.e_hi || h->shares_key[2] != p.rs_workgroups) {
       const size_t words = (size_t)h->cu_count * pass_share_pieces() * 4;
       std::vector<int> table(words, 0);
-      h->shares_ok = build_pass_shares(h->batch, e_hi, rs_workgroups, table.data());
+      h->shares_ok = build_pass_shares(h->batch, p.e_hi, p.rs_workgroups, table.data());
       if (!h->dshares) HIP_TRY(h, hipMalloc(&h->dshares, sizeof(int) * words));
       // (rare: once per (batch, size); the table must be on the device before the launch below reads it)
-      HIP_TRY(h, hipMemcpyAsync(h->dshares, table.data(), sizeof(int) * words, hipMemcpyHostToDevice, h->stream));
-      HIP_TRY(h, hipStreamSynchronize(h->stream));
+      HIP_TRY(h, hipMemcpyAsync(h->dshares, table.data(), sizeof(int) * words, hipMemcpyHostToDevice, st));
+      HIP_TRY(h, hipStreamSynchronize(st));
       h->shares_key[0] = h->batch;
-      h->shares_key[1] = e_hi;
-      h->shares_key[2] = rs_workgroups;
+      h->shares_key[1] = p.e_hi;
+      h->shares_key[2] = p.rs_workgroups;
     }
     if (h->shares_ok > 0) shares = h->dshares;
   }
@@ -594,25 +628,26 @@ static int flush_pending(ekf_handle* h) {
   if (h->profile) {
     if (int rc = prof_event(h, &e0)) return rc;
     if (int rc = prof_event(h, &e1)) return rc;
-    HIP_TRY(h, hipEventRecord(e0, h->stream));
+    HIP_TRY(h, hipEventRecord(e0, st));
   }
-  h->last_kernel = kernel;
-  h->last_nkt = nkt;
-  h->last_streaming = streaming ? 1 : 0;
+  h->last_kernel = p.kernel;
+  h->last_nkt = p.nkt;
+  h->last_streaming = p.streaming ? 1 : 0;
   h->last_shares = shares ? h->shares_ok : 0;
-  if (kernel == 2) {                                   // (k_solve of the last step left the queue heads at zero)
-    launch_flush_rs(h->stream, streaming, h->dP, h->dV, h->dW, h->ddacc2[h->dcur], h->dn, h->dso, h->ld, h->pstride,
-                    h->batch, e_hi, nkt, rs_workgroups, h->dqueue, h->opt_pass_chunk, shares);
+  if (p.kernel == 2) {                                 // (the step before left the queue heads at zero)
+    launch_flush_rs(st, p.streaming, h->dP, h->dV, h->dW, h->ddacc2[h->dcur], h->dn, h->dso, h->ld, h->pstride,
+                    h->batch, p.e_hi, p.nkt, p.rs_workgroups, h->dqueue, h->opt_pass_chunk, shares);
   } else {
-    launch_flush(h->stream, streaming, h->dP, h->dV, h->dW, h->ddacc2[h->dcur], h->dn, h->dso, h->ld, h->pstride, h->batch,
-                 e_hi, nkt, flush_rows_per_block(h, streaming, e_hi));
+    launch_flush(st, p.streaming, h->dP, h->dV, h->dW, h->ddacc2[h->dcur], h->dn, h->dso, h->ld, h->pstride, h->batch,
+                 p.e_hi, p.nkt, flush_rows_per_block(h, p.streaming, p.e_hi));
   }
-  if (h->profile) HIP_TRY(h, hipEventRecord(e1, h->stream));
+  if (h->profile) HIP_TRY(h, hipEventRecord(e1, st));
   HIP_TRY(h, hipGetLastError());
   h->pending_k = 0;                                    // (with no rank pending k_solve takes the pending noise as zero: no clearing)
   h->pending_steps = 0;
   return EKF_OK;
 }
+static int flush_pending(ekf_handle* h) { return flush_pending(h, nullptr); }
 
 // Enqueue one device pass with inputs already at d_in (StepIn[batch]); m_hi = max m over the batch.
 static int enqueue_pass(ekf_handle* h, const StepIn* d_in, int m_hi) {
@@ -670,8 +705,8 @@ static int enqueue_pass(ekf_handle* h, const StepIn* d_in, int m_hi) {
 }
 
 // How many steps of the uploaded stream, starting at step k, can run as one fused cadence (0 = none).
-static int cadence_length(const ekf_handle* h, int k, int end) {
-  if (!h->opt_fused_cadence || h->pending_k != 0 || h->sizes_dirty || k >= end) return 0;
+static int cadence_length(const ekf_handle* h, int k, int end, bool after_pass = false) {
+  if (!h->opt_fused_cadence || (h->pending_k != 0 && !after_pass) || h->sizes_dirty || k >= end) return 0;
   const int m0 = h->stream_mhi[k];
   if (m0 < 1) return 0;
   const int mcap = cap_for(m0), ktp = ranks_for(mcap);
@@ -683,7 +718,14 @@ static int cadence_length(const ekf_handle* h, int k, int end) {
 }
 
 // Steps [k, k + g) of the uploaded stream as one cadence; the covariance pass follows when it is due.
-static int enqueue_cadence(ekf_handle* h, int k, int g) {
+// Look-ahead (small launches, where the covariance pass -- the column-strip kernel -- leaves CUs free): when the pass is
+// due and the steps behind it form a cadence too, that cadence's solve does not wait for the pass.  Its block
+// P[C_u, C_u] is gathered while this cadence's ranks are still pending (k_gather_cad: base entries + the ranks' product
+// at C_u), the pass goes to the handle's second stream between two events, and the solve -- which touches nothing the
+// pass uses -- runs on the handle's own stream beside it; the next cadence's panel launch waits for both.  `presolved`
+// says that this cadence's solve has already been enqueued that way; *next_presolved that the next one's now is.
+static int enqueue_cadence(ekf_handle* h, int k, int g, int end, bool presolved, bool* next_presolved) {
+  *next_presolved = false;
   const int n_hi = *std::max_element(h->n.begin(), h->n.end());
   const int mcap = cap_for(h->stream_mhi[k]), ktp = ranks_for(mcap);
   if (!h->dcad) HIP_TRY(h, hipMalloc(&h->dcad, sizeof(CadOut) * h->batch));
@@ -691,9 +733,10 @@ static int enqueue_cadence(ekf_handle* h, int k, int g) {
     h->neff_enq[b] = std::min(h->n[b], std::max(h->floor_host[b], h->stream_own[(size_t)(k + g - 1) * h->batch + b]));
   const double* mu_in = h->dmu2[h->cur];
   double* mu_out = h->dmu2[h->cur ^ 1];
-  launch_solve_cad(h->stream, mcap, h->dP, mu_in, mu_out, h->ddacc2[h->dcur ^ 1], h->dn,
-                   h->d_stream + (size_t)k * h->batch, h->batch, g, h->dcad, h->dflags, h->dfloor, h->dcfg, h->ld,
-                   h->pstride);
+  if (!presolved)
+    launch_solve_cad(h->stream, mcap, h->dP, mu_in, mu_out, h->ddacc2[h->dcur ^ 1], h->dn,
+                     h->d_stream + (size_t)k * h->batch, h->batch, g, h->dcad, h->dflags, h->dfloor, h->dcfg, h->ld,
+                     h->pstride, nullptr, 0);
   launch_panels_cad(h->stream, mcap, h->dP, h->dV, h->dW, mu_in, mu_out, h->dn, h->dcad, h->dso, h->dqueue, h->ld,
                     h->pstride, h->batch, n_hi);
   HIP_TRY(h, hipGetLastError());
@@ -704,8 +747,32 @@ static int enqueue_cadence(ekf_handle* h, int k, int g) {
   h->cadences += 1;
   h->cadence_steps += g;
   const bool due = h->opt_flush_every > 0 ? h->pending_steps >= h->opt_flush_every : h->pending_k + ktp > h->opt_rank_limit;
-  if (due || h->pending_k + 2 > KTOT)
-    if (int rc = flush_pending(h)) return rc;
+  if (!(due || h->pending_k + 2 > KTOT)) return EKF_OK;
+  // (worth it where the pass is the column-strip kernel -- the row-slab pass fills every CU by itself -- and long enough
+  //  to pay for the gather and the two cross-stream hand-overs, ~25 us together: from ~48 MB of covariance.  N = 2000 x 1:
+  //  38.7 k -> 45.1 k steps/s, x 2: 57.6 k -> 61.9 k, x 4: 89.5 k -> 92.1 k; N = 500 x 1 and N = 20 x 1 lose 4 - 9 %)
+  const int k2 = k + g, g2 = h->opt_lookahead ? cadence_length(h, k2, end, true) : 0;
+  const PassPlan plan = plan_pass(h);
+  if (g2 < 2 || plan.kernel != 0 || (double)h->batch * 8.0 * plan.e_hi * plan.e_hi < 48.0e6) return flush_pending(h);
+  // ---- look-ahead: gather (stream) -> { pass (second stream) | solve of the next cadence (stream) } -> join ----
+  const int mcap2 = cap_for(h->stream_mhi[k2]);
+  if (!h->dgbuf) HIP_TRY(h, hipMalloc(&h->dgbuf, sizeof(double) * cadence_gbuf_doubles() * h->batch));
+  launch_gather_cad(h->stream, mcap2, h->dP, h->dV, h->dW, h->ddacc2[h->dcur], h->d_stream + (size_t)k2 * h->batch, h->batch,
+                    g2, (h->pending_k + 3) & ~3, h->dcfg, h->ld, h->pstride, h->dgbuf);
+  HIP_TRY(h, hipGetLastError());
+  HIP_TRY(h, hipEventRecord(h->ev_fork, h->stream));
+  HIP_TRY(h, hipStreamWaitEvent(h->aux, h->ev_fork, 0));
+  // (the solve first: it is ready to go the moment the gather ends, the pass has an event to wait for -- the one
+  //  workgroup per trajectory finds its CU before the pass fills the chip)
+  launch_solve_cad(h->stream, mcap2, h->dP, h->dmu2[h->cur], h->dmu2[h->cur ^ 1], h->ddacc2[h->dcur ^ 1], h->dn,
+                   h->d_stream + (size_t)k2 * h->batch, h->batch, g2, h->dcad, h->dflags, h->dfloor, h->dcfg, h->ld,
+                   h->pstride, h->dgbuf, (((h->pending_k + 3) & ~3) + 7) / 8);
+  HIP_TRY(h, hipGetLastError());
+  if (int rc = flush_pending(h, h->aux)) return rc;
+  HIP_TRY(h, hipEventRecord(h->ev_join, h->aux));
+  HIP_TRY(h, hipStreamWaitEvent(h->stream, h->ev_join, 0));   // whatever follows on the handle's stream follows the pass
+  h->lookaheads += 1;
+  *next_presolved = true;
   return EKF_OK;
 }
 
@@ -1004,13 +1071,14 @@ extern "C" int ekf_stream_run(ekf_handle* h, int first, int count) {
       return fail(h, EKF_ERR_STATE, "ekf_stream_run: the uploaded stream observes landmarks the current state does not have");
   HIP_TRY(h, hipSetDevice(h->device));
   if (int rc = push_floor(h, true)) return rc;
+  bool presolved = false;                              // the cadence that starts at k has its solve enqueued already (look-ahead)
   for (int k = first; k < first + count;) {
     // A whole cadence at once where nothing is pending: the steps up to the next covariance pass as one solve launch
     // and one panel launch (ekf_cadence.hip).  It takes steps of one rank-slot size (1, 2, 4, 8 or 16 landmarks), all
     // with something observed, as many as the pass cadence allows -- at least two, or the per-step path is as good.
     const int g = cadence_length(h, k, first + count);
     if (g >= 2) {
-      if (int rc = enqueue_cadence(h, k, g)) return rc;
+      if (int rc = enqueue_cadence(h, k, g, first + count, presolved, &presolved)) return rc;
       k += g;
       continue;
     }
@@ -1160,6 +1228,8 @@ extern "C" int ekf_debug_cadences(ekf_handle* h, long* cadences, long* steps) {
   if (steps) *steps = h->cadence_steps;
   return EKF_OK;
 }
+// (development aid, not declared in the header) how many of them had their solve run beside the previous covariance pass
+extern "C" long ekf_debug_lookaheads(ekf_handle* h) { return h ? h->lookaheads : -1; }
 
 // (development aid, not declared in the header) the fused cadence's record of trajectory b (head + per-landmark records)
 extern "C" long ekf_debug_cad(ekf_handle* h, int b, void* dst, long bytes) {
@@ -1234,6 +1304,11 @@ extern "C" int ekf_set_option(ekf_handle* h, const char* name, int value) {
     //  time out and raise EKF_FLAG_INTERNAL -- the results of such a step are garbage)
     if (value < 0 || value > 2) return fail(h, EKF_ERR_ARG, "fused_step must be 0, 1 or 2 (diagnostic)");
     h->opt_fused_step = value;
+    return EKF_OK;
+  }
+  if (std::strcmp(name, "lookahead") == 0) {
+    if (value != 0 && value != 1) return fail(h, EKF_ERR_ARG, "lookahead must be 0 or 1");
+    h->opt_lookahead = value;
     return EKF_OK;
   }
   if (std::strcmp(name, "fused_cadence") == 0) {

@@ -66,7 +66,7 @@ __global__ __launch_bounds__(64 * CAD_NW) void k_solve_cad(const double* __restr
                                                     const StepIn* __restrict__ in, int batch, int nsteps,
                                                     CadOut* __restrict__ out, unsigned* __restrict__ flags,
                                                     const int* __restrict__ neff_floor, DeviceConfig cfg, int ld,
-                                                    long pstride) {
+                                                    long pstride, const double* __restrict__ gbuf, int gparts) {
   using G = CadGeom<MCAP>;
   constexpr int GM = G::GM, CU = G::CU;
   __shared__ __attribute__((aligned(16))) double Pc[CAD_ROWS][CAD_CS];
@@ -179,19 +179,47 @@ __global__ __launch_bounds__(64 * CAD_NW) void k_solve_cad(const double* __restr
     }
   };
 
-  // ---- gather the block P_base[C_u, C_u] (nothing is pending: P = P_base); wave 1 starts on its means meanwhile ----
+  // ---- gather the block P[C_u, C_u] (nothing is pending: P = P_base -- or the look-ahead gather's copy); wave 1 starts on
+  // its means meanwhile ----
   {
     constexpr int RQ = (CU + CAD_NW - 1) / CAD_NW;     // rows per wave
+    const int lane_b = min(64 + lane, CAD_CS - 1);
     double gv0[RQ], gv1[RQ];
 #pragma unroll
     for (int q = 0; q < RQ; ++q) {
-      const int r = wave + CAD_NW * q;
       gv0[q] = 0.0;
       gv1[q] = 0.0;
-      if (r < CU) {                                    // (wave-uniform)
-        const int Cr = Cs[r];
-        gv0[q] = Pb[(long)min(Cr, Cl0) * ld + max(Cr, Cl0)];      // the upper triangle is authoritative
-        if (CU > 64) gv1[q] = Pb[(long)min(Cr, Cl1) * ld + max(Cr, Cl1)];
+    }
+    if (gbuf) {
+      // (uniform) look-ahead: the block was gathered (base + the ranks still pending then) by k_gather_cad, in `gparts`
+      // parts, added here in a fixed order; all loads of a part are in flight together
+#pragma unroll
+      for (int gp = 0; gp < KTOT / 8; ++gp) {
+        if (gp < gparts) {                             // (uniform)
+          double t0[RQ], t1[RQ];
+#pragma unroll
+          for (int q = 0; q < RQ; ++q) {
+            const int r = min(wave + CAD_NW * q, CU - 1);
+            const double* gb = gbuf + (((long)gp * batch + b) * CAD_ROWS + r) * CAD_CS;
+            t0[q] = gb[lane];
+            t1[q] = gb[lane_b];
+          }
+#pragma unroll
+          for (int q = 0; q < RQ; ++q) {
+            gv0[q] += t0[q];
+            gv1[q] += t1[q];
+          }
+        }
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < RQ; ++q) {
+        const int r = wave + CAD_NW * q;
+        if (r < CU) {                                  // (wave-uniform)
+          const int Cr = Cs[r];
+          gv0[q] = Pb[(long)min(Cr, Cl0) * ld + max(Cr, Cl0)];      // the upper triangle is authoritative
+          if (CU > 64) gv1[q] = Pb[(long)min(Cr, Cl1) * ld + max(Cr, Cl1)];
+        }
       }
     }
     if (wave == 1) {
@@ -479,17 +507,18 @@ template <int MCAP>
 __device__ __forceinline__ void pose_epilogue(const CadOut& o, double* Pb, double* Vb, double* Wb, SolveOut* so, unsigned* queue,
                                               int b, int ld, int lane) {
   const int ld16 = ld >> 4;
+  // one (slot, pose index) pair per lane and round: the loads of a round are in flight together
+  const int pairs = 3 * MCAP * o.nsteps;
+  for (int e = lane; e < pairs; e += 64) {
+    const int s = e / 3, l = e - 3 * s, t = s / MCAP, j = s - t * MCAP;
+    double4_t vw = {0.0, 0.0, 0.0, 0.0};
+    if (j < o.m[t]) vw = *reinterpret_cast<const double4_t*>(o.posevw[s][l]);
+    Vb[(long)(2 * s) * ld + l] = vw[0];
+    Vb[(long)(2 * s + 1) * ld + l] = vw[1];
+    Wb[wm_index(ld16, 2 * s, l)] = vw[2];
+    Wb[wm_index(ld16, 2 * s + 1, l)] = vw[3];
+  }
   if (lane < 3) {
-    for (int t = 0; t < o.nsteps; ++t)
-      for (int j = 0; j < MCAP; ++j) {
-        const int s = t * MCAP + j;
-        double4_t vw = {0.0, 0.0, 0.0, 0.0};
-        if (j < o.m[t]) vw = *reinterpret_cast<const double4_t*>(o.posevw[s][lane]);
-        Vb[(long)(2 * s) * ld + lane] = vw[0];
-        Vb[(long)(2 * s + 1) * ld + lane] = vw[1];
-        Wb[wm_index(ld16, 2 * s, lane)] = vw[2];
-        Wb[wm_index(ld16, 2 * s + 1, lane)] = vw[3];
-      }
     for (int k = o.nranks; k < ((o.nranks + 3) & ~3); ++k) {   // k-tile pad
       Vb[(long)k * ld + lane] = 0.0;
       Wb[wm_index(ld16, k, lane)] = 0.0;
@@ -499,6 +528,136 @@ __device__ __forceinline__ void pose_epilogue(const CadOut& o, double* Pb, doubl
   }
   if (lane == 0) so[b].neff = o.neff;                  // what the covariance pass reads as this trajectory's bound
   if (b == 0 && lane < 8) queue[lane * RS_QSTRIDE] = 0u;
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_gather_cad (look-ahead): the block P[C_u, C_u] of the NEXT cadence while the ranks of this one are still pending --
+//     P(a, b) = P_base[a][b] + sum_k W[a][k] V[k][b] + [a == b < 3] dacc[a]      (a <= b;  P(b, a) := P(a, b))
+// -- written to gbuf, so that that cadence's solve no longer depends on the covariance pass in between and can run
+// beside it (small launches: the pass leaves CUs free).  The factors at C_u are 83 x 80 scattered entries of W and as
+// many of V, and a CU takes about a cycle per cache line it touches: one workgroup per trajectory spent 22 us on them.
+// So the ranks are dealt over CAD_GP workgroups per trajectory, 8 ranks (two MFMA k-tiles) each: a workgroup stages
+// Wc[a][k] = W[C_u[a]][k], Vc[k][a] = V[k][C_u[a]] for its ranks, forms its share of M = Wc Vc on the matrix cores,
+// and writes G_p[r][l] = M[r][l] where P(C_u[r], C_u[l]) is stored that way round, M[l][r] where it is stored mirrored
+// (part 0 adds the base entries and the pending pose noise); the solve adds the parts in a fixed order.  The positions
+// C_u are formed exactly as k_solve_cad forms them.
+// ---------------------------------------------------------------------------------------------
+constexpr int CAD_GP = KTOT / 8;        // parts (workgroups per trajectory): 8 ranks each
+constexpr int CAD_GW = 8;               // waves of a gather workgroup
+constexpr int CAD_VS = 96 + 1;          // row stride of Vc and of M
+
+template <int MCAP>
+__global__ __launch_bounds__(64 * CAD_GW) void k_gather_cad(const double* __restrict__ P, const double* __restrict__ V,
+                                                            const double* __restrict__ W, const double* __restrict__ dacc,
+                                                            const StepIn* __restrict__ in, int batch, int nsteps, int kb,
+                                                            DeviceConfig cfg, int ld, long pstride,
+                                                            double* __restrict__ gbuf) {
+  using G = CadGeom<MCAP>;
+  constexpr int GM = G::GM, CU = G::CU;
+  __shared__ __attribute__((aligned(16))) double Wc[96][9];          // [a][k], 8 ranks (stride 9: rows on different banks)
+  __shared__ __attribute__((aligned(16))) double Vc[8][CAD_VS];      // [k][a]
+  __shared__ __attribute__((aligned(16))) double Ms[96][CAD_VS];     // this part's share of M
+  __shared__ int Cs[128];
+  const int part = blockIdx.x, b = blockIdx.y;
+  const int k0 = 8 * part;                             // this workgroup's ranks: k0 .. k0 + 7
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const double* Pb = P + (long)b * pstride;
+  const double* Vb = V + (long)b * KTOT * ld;
+  const double* Wb = W + (long)b * KTOT * ld;
+  const int ld16 = ld >> 4;
+  if (tid < 128) Cs[tid] = tid < 3 ? tid : 0;
+  __syncthreads();
+  if (tid < GM) {                                      // (as in k_solve_cad)
+    const int s = tid, t = s / MCAP, j = s - t * MCAP;
+    int m = 0, idx = 0;
+    if (t < nsteps) {
+      const StepIn& st = in[(long)t * batch + b];
+      m = ((st.flags & FLAG_UPDATE) && cfg.enable_measurement_model) ? min(st.m, MCAP) : 0;
+      if (j < m) idx = st.idx[j];
+    }
+    const int p = G::pa(s);
+    const bool valid = t < nsteps && j < m;
+    Cs[p] = valid ? 3 + 2 * idx : 0;
+    Cs[p + 1] = valid ? 4 + 2 * idx : 0;
+  }
+  __syncthreads();
+  const int Cl0 = Cs[lane], Cl1 = Cs[64 + lane];
+  // (part 0) the base entries first: their latency hides under the staging and the product
+  constexpr int RQ = (CU + CAD_GW - 1) / CAD_GW;       // rows per wave
+  double gv0[RQ], gv1[RQ];
+#pragma unroll
+  for (int q = 0; q < RQ; ++q) {
+    const int r = wave + CAD_GW * q;
+    gv0[q] = 0.0;
+    gv1[q] = 0.0;
+    if (part == 0 && r < CU) {                         // (wave-uniform)
+      const int Cr = Cs[r];
+      gv0[q] = Pb[(long)min(Cr, Cl0) * ld + max(Cr, Cl0)];
+      if (CU > 64) gv1[q] = Pb[(long)min(Cr, Cl1) * ld + max(Cr, Cl1)];
+    }
+  }
+  // the factors at C_u for this part's ranks: lane = (position within a group of 8, rank); both loads of both groups of a
+  // thread are in flight before the first LDS store
+  {
+    const int kk = lane & 7, k = k0 + kk;
+    const int kc = min(k, max(kb - 1, 0));             // (ranks beyond the pending ones: the last one again, masked below)
+    double wv[2], vv[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int a = 8 * (wave + CAD_GW * u) + (lane >> 3);   // (a < 128)
+      const int row = a < CU ? Cs[a] : 0;
+      wv[u] = Wb[wm_index(ld16, kc, row)];
+      vv[u] = Vb[(long)kc * ld + row];
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int a = 8 * (wave + CAD_GW * u) + (lane >> 3);
+      if (a < 96) {
+        const bool in_k = a < CU && k < kb;
+        Wc[a][kk] = in_k ? wv[u] : 0.0;
+        Vc[kk][a] = in_k ? vv[u] : 0.0;
+      }
+    }
+  }
+  __syncthreads();
+  // M = Wc Vc: 6 x 6 tiles of 16 x 16 dealt to the 8 waves, two k-tiles each: A[i = li][k = lq] = Wc[16 rt + li][4 kt + lq],
+  // B[k = lq][j = li] = Vc[4 kt + lq][16 ct + li]
+  const int li = lane & 15, lq = lane >> 4;
+#pragma unroll
+  for (int u = 0; u < 5; ++u) {
+    const int t = wave + CAD_GW * u;
+    if (t < 36) {                                      // (wave-uniform)
+      const int rt = t / 6, ct = t - 6 * rt;
+      double4_t acc = {0.0, 0.0, 0.0, 0.0};
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Wc[16 * rt + li][lq], Vc[lq][16 * ct + li], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Wc[16 * rt + li][4 + lq], Vc[4 + lq][16 * ct + li], acc, 0, 0, 0);
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) Ms[16 * rt + lq + 4 * reg][16 * ct + li] = acc[reg];
+    }
+  }
+  __syncthreads();
+  const double d0 = part == 0 ? dacc[4 * b] : 0.0, d1 = part == 0 ? dacc[4 * b + 1] : 0.0, d2 = part == 0 ? dacc[4 * b + 2] : 0.0;
+  double* gb = gbuf + ((long)part * batch + b) * CAD_ROWS * CAD_CS;
+#pragma unroll
+  for (int q = 0; q < RQ; ++q) {
+    const int r = wave + CAD_GW * q;
+    if (r < CU) {
+      const int Cr = Cs[r];
+      {
+        const int l = min(lane, CU - 1);
+        double v = gv0[q] + ((Cr <= Cl0) ? Ms[r][l] : Ms[l][r]);
+        if (Cr == Cl0 && Cr < 3) v += Cr == 0 ? d0 : (Cr == 1 ? d1 : d2);
+        gb[(long)r * CAD_CS + lane] = v;
+      }
+      if (64 + lane < CAD_CS) {
+        const int l = min(64 + lane, CU - 1);
+        double v = gv1[q] + ((Cr <= Cl1) ? Ms[r][l] : Ms[l][r]);
+        if (Cr == Cl1 && Cr < 3) v += Cr == 0 ? d0 : (Cr == 1 ? d1 : d2);
+        gb[(long)r * CAD_CS + 64 + lane] = v;
+      }
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -807,12 +966,31 @@ __global__ __launch_bounds__(256) void k_panels_cad_ks(double* __restrict__ P, d
 // ---------------------------------------------------------------------------------------------
 int cadence_steps_max(int mcap) { return CAD_SLOTS / mcap; }
 
+long cadence_gbuf_doubles() { return (long)CAD_GP * CAD_ROWS * CAD_CS; }   // per trajectory: CAD_GP parts
+
+// (look-ahead) the next cadence's block while `kb` ranks are pending -> gbuf
+void launch_gather_cad(hipStream_t st, int mcap, const double* P, const double* V, const double* W, const double* dacc,
+                       const StepIn* in, int batch, int nsteps, int kb, const DeviceConfig& cfg, int ld, long pstride,
+                       double* gbuf) {
+#define EKF_GATHER_CAD(M)                                                                                             \
+  hipLaunchKernelGGL((k_gather_cad<M>), dim3((kb + 7) / 8, batch), dim3(64 * CAD_GW), 0, st, P, V, W, dacc, in, batch, nsteps, \
+                     kb, cfg, ld, pstride, gbuf)
+  switch (mcap) {
+    case 1: EKF_GATHER_CAD(1); break;
+    case 2: EKF_GATHER_CAD(2); break;
+    case 4: EKF_GATHER_CAD(4); break;
+    case 8: EKF_GATHER_CAD(8); break;
+    default: EKF_GATHER_CAD(16); break;
+  }
+#undef EKF_GATHER_CAD
+}
+
 void launch_solve_cad(hipStream_t st, int mcap, const double* P, const double* mu_in, double* mu_out, double* dacc_out,
                       const int* nact, const StepIn* in, int batch, int nsteps, CadOut* out, unsigned* flags,
-                      const int* neff_floor, const DeviceConfig& cfg, int ld, long pstride) {
+                      const int* neff_floor, const DeviceConfig& cfg, int ld, long pstride, const double* gbuf, int gparts) {
 #define EKF_SOLVE_CAD(M)                                                                                              \
   hipLaunchKernelGGL((k_solve_cad<M>), dim3(batch), dim3(64 * CAD_NW), 0, st, P, mu_in, mu_out, dacc_out, nact, in, batch, \
-                     nsteps, out, flags, neff_floor, cfg, ld, pstride)
+                     nsteps, out, flags, neff_floor, cfg, ld, pstride, gbuf, gparts)
   switch (mcap) {
     case 1: EKF_SOLVE_CAD(1); break;
     case 2: EKF_SOLVE_CAD(2); break;

@@ -140,6 +140,10 @@ def test_config5_n8000_active_bound_bit_identical(sd):
     for bound in (1, 0):
         with sd.EkfSlam(n) as f:
             f.set_option("active_bound", bound)
+            # (with the bound on, the pass covers 6003 state indices and is the column-strip kernel, and such a launch
+            #  would take the look-ahead -- whose gathered block sums the pending ranks in another order than the pass:
+            #  equal to rounding, tests/test_gpu_cadence.py, but this test is about the bound being EXACT)
+            f.set_option("lookahead", 0)
             f.set_state_diag(mean0, diag0)
             f.run_stream(lin, ang, idx, zr, zb)
             mu, P = f.state()
