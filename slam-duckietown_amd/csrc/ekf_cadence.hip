@@ -50,7 +50,12 @@ namespace ekf {
 #define CSTAMP(w, s, k) do { } while (0)
 #endif
 
-constexpr int CAD_KS_WAVES = 512;        // panel launches of up to this many waves of state indices take the row-split form
+#ifndef CAD_KS_WAVES_OVERRIDE
+constexpr int CAD_KS_WAVES = 512;       // panel launches of up to this many waves of state indices take the row-split form
+#else
+constexpr int CAD_KS_WAVES = CAD_KS_WAVES_OVERRIDE;   // (diagnostic builds: the row-split form everywhere / nowhere)
+#endif
+typedef double v2d_u __attribute__((ext_vector_type(2), aligned(8)));   // two adjacent doubles, 8-byte aligned: one 16-byte load
 constexpr int CAD_CS = 88;              // LDS row stride of the block (doubles): 83 columns, rows 16-byte aligned
 constexpr int CAD_ROWS = 84;
 constexpr int CAD_NW = 8;               // waves of the solve workgroup (512 threads: the register budget of 2 waves per SIMD;
@@ -697,9 +702,28 @@ __global__ __launch_bounds__(64 * NW) void k_panels_cad(double* __restrict__ P, 
   double X[CU];
   if (live) {
 #pragma unroll
-    for (int a = 0; a < CU; ++a) {
-      const int row = o.C[a];
-      X[a] = Pb[(long)min(row, ii) * ld + max(row, ii)];
+    for (int a = 0; a < 3; ++a) X[a] = Pb[(long)min(a, ii) * ld + max(a, ii)];
+    // A landmark's two positions are two ADJACENT state indices c, c + 1.  For the state indices i <= c the entries
+    // P(c, i), P(c + 1, i) are stored mirrored, as P_base(i, c), P_base(i, c + 1): side by side in row i.  Those column-
+    // direction gathers touch a different cache line per lane (a CU takes about a cycle per line: 42 of this kernel's 92 us
+    // at N = 2000 x 32 when every entry was its own 8-byte load), so a wave that lies entirely at or above the pair takes
+    // both with ONE 16-byte load per lane (8-byte aligned: column 3 + 2 idx is odd).
+#pragma unroll
+    for (int a = 3; a < CU; a += 2) {
+      const int c0 = o.C[a], c1 = o.C[a + 1];
+#ifdef CADP_SKIP_GATHER                                 /* diagnostic build: every gather reads the row direction */
+      X[a] = Pb[(long)min(c0, 2) * ld + ii];
+      X[a + 1] = Pb[(long)min(c1, 2) * ld + ii];
+#else
+      if (c1 == c0 + 1 && i0 + 63 <= c0) {             // (uniform)
+        const v2d_u v = *reinterpret_cast<const v2d_u*>(Pb + (long)ii * ld + c0);
+        X[a] = v.x;
+        X[a + 1] = v.y;
+      } else {
+        X[a] = Pb[(long)min(c0, ii) * ld + max(c0, ii)];
+        X[a + 1] = Pb[(long)min(c1, ii) * ld + max(c1, ii)];
+      }
+#endif
     }
   } else {
 #pragma unroll
@@ -763,7 +787,11 @@ __global__ __launch_bounds__(64 * NW) void k_panels_cad(double* __restrict__ P, 
           const double f0 = e0 * s01.x + e1 * s23.x;   // K_s[i, :] = (H_s P_s)[:, i]^T S^-1  (P symmetric)
           const double f1 = e0 * s01.y + e1 * s23.y;
           dm += f0 * yy.x + f1 * yy.y;                 // :476
+#ifdef CADP_SKIP_STORE                                  /* diagnostic build: no rank stores (a value that is never -7 keeps e, f alive) */
+          if (actw && e0 == -7.0 && f0 == -7.0) {
+#else
           if (actw) {
+#endif
             Vb[(long)kr * ld + i] = e0;
             Vb[(long)(kr + 1) * ld + i] = e1;
             Wb[wm_index(ld16, kr, i)] = -f0;
@@ -771,7 +799,11 @@ __global__ __launch_bounds__(64 * NW) void k_panels_cad(double* __restrict__ P, 
           }
           if (!(t + 1 == nsteps && j + 1 == mt)) {     // (uniform) x[a] -= K_s[C_u[a], :] . (H_s P_s)[:, i], what lives on
 #pragma unroll
+#ifdef CADP_SKIP_DD                                     /* diagnostic build: only the rows the next landmark reads are down-dated */
+            for (int a = 0; a < (pa < 5 ? pa : 5); ++a) {
+#else
             for (int a = 0; a < pa; ++a) {
+#endif
               const double2 kc = R[8 + a];
               X[a] = fma(-kc.x, e0, X[a]);
               X[a] = fma(-kc.y, e1, X[a]);
@@ -842,10 +874,17 @@ __global__ __launch_bounds__(256) void k_panels_cad_ks(double* __restrict__ P, d
 #pragma unroll
     for (int k = 0; k < 3; ++k) XP[k] = Pb[(long)min(k, ii) * ld + max(k, ii)];
 #pragma unroll
-    for (int r = 0; r < 2 * LP; ++r) {
-      const int a = 3 + 8 * (r >> 1) + 2 * wave + (r & 1);
-      const int row = o.C[min(a, CU)];                 // (C[CU] = 0: a position beyond the cadence's)
-      XL[r] = Pb[(long)min(row, ii) * ld + max(row, ii)];
+    for (int pp = 0; pp < LP; ++pp) {
+      const int a = 3 + 8 * pp + 2 * wave;
+      const int c0 = o.C[min(a, CU)], c1 = o.C[min(a + 1, CU)];   // (C[CU] = 0: a position beyond the cadence's)
+      if (c1 == c0 + 1 && i0 + 63 <= c0) {             // (uniform) both mirrored: side by side in row i (see k_panels_cad)
+        const v2d_u v = *reinterpret_cast<const v2d_u*>(Pb + (long)ii * ld + c0);
+        XL[2 * pp] = v.x;
+        XL[2 * pp + 1] = v.y;
+      } else {
+        XL[2 * pp] = Pb[(long)min(c0, ii) * ld + max(c0, ii)];
+        XL[2 * pp + 1] = Pb[(long)min(c1, ii) * ld + max(c1, ii)];
+      }
     }
     const int cnt = G::rec_off(nsteps * MCAP) / 2;     // double2 units
     const double2* src = reinterpret_cast<const double2*>(o.rec);

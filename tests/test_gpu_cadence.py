@@ -296,6 +296,38 @@ def test_lookahead_solve_beside_the_pass(sd, N, B, m, steps):
     assert orc.rel_fro(res[1][0][0], om) < TIGHT and orc.rel_fro(res[1][0][1], oP) < TIGHT
 
 
+def test_stream_run_in_pieces_with_flushes_and_downloads_in_between(sd):
+    """`stream_run(first, count)` called in pieces that cut cadences (and look-ahead chains) anywhere, with `flush()`,
+    `mean()` and `covariance_block()` between them: every piece starts from whatever is pending (a cadence only forms
+    where nothing is), and the result is the whole stream's to rounding.  At N = 1250 x 1 the look-ahead applies, so the
+    second stream is exercised across API calls too."""
+    N, B, m, steps = 1250, 1, 8, 41
+    n = 3 + 2 * N
+    s = orc.synthetic_stream(N, steps, m, 1500)
+    start = dense_start(n, 1501)
+    args = (s[2][:, None], s[3][:, None], s[4][:, None], s[5][:, None], s[6][:, None])
+    whole, (nc, _) = run_stream(sd, n, B, [start], [s[0]], *args, options=[("active_bound", 0)])
+    assert nc == 8
+    with sd.EkfSlam(n) as f:
+        f.set_option("active_bound", 0)
+        f.set_state(s[0], start)
+        f.stream_upload(*args)
+        k = 0
+        for i, count in enumerate((7, 1, 12, 3, 10, 8)):
+            f.stream_run(k, count)
+            k += count
+            if i == 1:
+                f.flush()
+            elif i == 2:
+                assert np.isfinite(f.mean()).all()
+            elif i == 3:
+                assert np.isfinite(f.covariance_block(0, 0, 3, 3)).all()
+        assert k == steps
+        mu, P = f.state()
+        assert f.flags() == 0 and lookaheads(sd, f) >= 2
+    assert orc.rel_fro(mu, whole[0][0]) < PATH_TOL and orc.rel_fro(P, whole[0][1]) < PATH_TOL
+
+
 def test_golden_stream_through_the_cadence(sd):
     """BASELINE config 1 (N = 20, 500 steps, the reference's own outputs in tests/golden/stream_n20_m8.npz) as ONE
     uploaded stream: 100 fused cadences back to back, final mean and covariance against the reference."""
