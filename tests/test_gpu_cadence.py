@@ -328,6 +328,53 @@ def test_stream_run_in_pieces_with_flushes_and_downloads_in_between(sd):
     assert orc.rel_fro(mu, whole[0][0]) < PATH_TOL and orc.rel_fro(P, whole[0][1]) < PATH_TOL
 
 
+def test_slot_size_changes_along_the_stream(sd):
+    """The number of observations per step wanders between the rank-slot sizes (1, 2, 4, 8, 16 landmarks): a cadence only
+    takes steps of one size, so fused cadences, per-step kernels on top of pending ranks and passes at odd ranks
+    alternate along the stream.  Against the per-step path and the oracle."""
+    N, B, steps = 200, 2, 46
+    n = 3 + 2 * N
+    rng = np.random.default_rng(77)
+    sizes = [8] * 7 + [3] * 6 + [1] * 9 + [16] * 5 + [8] * 2 + [2] * 11 + [5] * 6     # runs of a size, of odd lengths
+    assert len(sizes) == steps
+    world = [orc.synthetic_world(N, 40 + t) for t in range(B)]
+    cfg = orc.EkfConfig()
+    M = 16
+    lin = np.full((steps, B), 0.004)
+    ang = np.full((steps, B), 0.02)
+    idx = np.zeros((steps, B, M), dtype=np.int32)
+    zr = np.zeros((steps, B, M))
+    zb = np.zeros((steps, B, M))
+    m = np.zeros((steps, B), dtype=np.int32)
+    pose = [np.zeros(3) for _ in range(B)]
+    for k in range(steps):
+        for b in range(B):
+            pose[b], _ = orc.motion_model(pose[b], lin[k, b], ang[k, b], cfg)
+            mb = sizes[k] if b == 0 else int(rng.integers(0, sizes[k] + 1))   # trajectory 0 sets the step's slot size
+            vis = rng.choice(N, size=mb, replace=False)
+            d = world[b][1][vis] - pose[b][0:2]
+            cth, sth = np.cos(pose[b][2]), np.sin(pose[b][2])
+            xr = cth * d[:, 0] + sth * d[:, 1] + rng.normal(0, 0.01, mb)
+            yr = -sth * d[:, 0] + cth * d[:, 1] + rng.normal(0, 0.01, mb)
+            m[k, b] = mb
+            idx[k, b, :mb] = vis
+            zr[k, b, :mb] = np.sqrt(xr ** 2 + yr ** 2)
+            zb[k, b, :mb] = np.arctan2(yr, xr)
+    means = [w[2] for w in world]
+    starts = [dense_start(n, 1600 + t) for t in range(B)]
+    fused, (nc, ns) = run_stream(sd, n, B, starts, means, lin, ang, idx, zr, zb, m, options=[("active_bound", 0)])
+    plain, _ = run_stream(sd, n, B, starts, means, lin, ang, idx, zr, zb, m,
+                          options=[("active_bound", 0), ("fused_cadence", 0)])
+    assert nc >= 5 and 10 <= ns < steps                   # cadences formed, and not everywhere
+    for b in range(B):
+        assert orc.rel_fro(fused[b][0], plain[b][0]) < PATH_TOL and orc.rel_fro(fused[b][1], plain[b][1]) < PATH_TOL
+        om, oP = means[b].copy(), starts[b].copy()
+        for k in range(steps):
+            mb = m[k, b]
+            om, oP = orc.ekf_step_dense(om, oP, lin[k, b], ang[k, b], idx[k, b, :mb], zr[k, b, :mb], zb[k, b, :mb], cfg)
+        assert orc.rel_fro(fused[b][0], om) < TIGHT and orc.rel_fro(fused[b][1], oP) < TIGHT
+
+
 def test_golden_stream_through_the_cadence(sd):
     """BASELINE config 1 (N = 20, 500 steps, the reference's own outputs in tests/golden/stream_n20_m8.npz) as ONE
     uploaded stream: 100 fused cadences back to back, final mean and covariance against the reference."""
