@@ -398,8 +398,10 @@ __global__ __launch_bounds__(64 * CAD_NW) void k_solve_cad(const double* __restr
         CSTAMP(1, s, 13);
         if (lane == 0) *reinterpret_cast<double2*>(o.rec + G::rec_off(s) + 14) = make_double2(y0, y1);
         CSTAMP(1, s, 14);
+#ifndef CADS_SKIP_JAC                                    /* diagnostic build: no re-linearisation (wrong results) */
         if (j + 1 < m) jacobian_at_mean(pa - 2, (s + 1) & 1);
         else if (t + 1 < nsteps) motion(t + 1);
+#endif
       } else if (rec_wave) {
         // the record of this landmark for the panel kernel, and the pose's own entries of the new ranks
         double2* rec2 = reinterpret_cast<double2*>(o.rec + G::rec_off(s));
@@ -414,7 +416,11 @@ __global__ __launch_bounds__(64 * CAD_NW) void k_solve_cad(const double* __restr
           vw[0] = hp;
           vw[1] = make_double2(-ka.x, -ka.y);
         }
+#ifdef CADS_SKIP_DD                                     /* diagnostic build: the block is never down-dated (wrong results) */
+      } else if (false) {
+#else
       } else if (!last) {
+#endif
         // down-date (:480) of what lives on: P[r][l] -= K[r, :] . (H P)[:, l] for r, l < pa; rows ds, ds + CAD_DW, ... are
         // this wave's.  Every access is unconditional and every address one base plus a compile-time offset: a row or a
         // column >= pa is dead (nothing reads it again), so what lands there does not matter, and rows up to
