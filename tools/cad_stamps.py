@@ -11,8 +11,6 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
-NAMES5 = {0: "w0 start (next rows' reads issued)", 1: "w0 Jacobian + innovation done", 2: "w0 (H P) published", 3: "w0 S, K, records' inputs published",
-          4: "w0 mean + own five rows down-dated", 5: "w0 at B(s)", 6: "w0 past B(s)", 8: "w1 (bulk) at B(s)"}
 NAMES = {0: "w0 start", 1: "w0 (H P) published", 2: "w0 S, K published", 3: "w0 records issued / at b1", 4: "w0 past b1",
          5: "w0 down-date done / at b2", 6: "w0 past b2", 7: "w0 next H read", 8: "w1 start", 9: "w1 at b1", 10: "w1 past b1",
          11: "w1 mean + next Jacobian done / at b2", 12: "w1 innovation done", 13: "w1 mean updated", 14: "w1 y record issued",
@@ -45,7 +43,7 @@ def main():
     off = (4 + 40 + 84) * 4 // 8 + 80
     st = buf[off:off + 48].astype(np.int64).reshape(3, 16)
     t0 = st[0, 0]
-    names = NAMES5 if os.environ.get("CAD_FORM", "5") == "5" else NAMES
+    names = NAMES
     for s in range(3):
         print(f"-- slot {s} (relative to slot 0's start, cycles)")
         for k in np.argsort(st[s]):
