@@ -132,6 +132,21 @@ def test_shard_partition_properties(sd):
     assert [len(shard_trajectories(256, 8, r)) for r in range(8)] == [32] * 8
 
 
+def test_banks_of_a_rank(sd):
+    from slam_duckietown_amd.sharding import split_banks
+    for count, size in [(32, 32), (64, 32), (48, 32), (33, 32), (5, 2), (0, 32), (100, 32)]:
+        ids = list(range(7, 7 + count))
+        banks = split_banks(ids, size)
+        assert [t for b in banks for t in b] == ids
+        assert all(1 <= len(b) <= size for b in banks)
+        assert len(banks) == -(-count // size)
+        if banks:
+            assert max(map(len, banks)) - min(map(len, banks)) <= 1
+    assert [len(b) for b in split_banks(range(64))] == [32, 32]
+    with pytest.raises(ValueError):
+        split_banks([1, 2], 0)
+
+
 RANK_SCRIPT = textwrap.dedent("""
     import json, os, sys, time
     sys.path.insert(0, {root!r})
