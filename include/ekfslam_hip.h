@@ -152,7 +152,11 @@ int ekf_profile_read(ekf_handle *h, double *pass_ms_total, long long *pass_launc
  * column-strip form, 2 = k_flush_rs, the row-slab form; both give the same result bit for bit), "pass_chunk" (row-slab pass: strips per work unit, 0 = auto), "pass_workgroups" (row-slab pass:
  * persistent workgroups, 0 = one per CU; fewer leaves whole CUs to other streams), "fused_step" (1 = small launches
  * run a step as one kernel, the panels gathered beside the solve -- same results; 0 = always two kernels; 2 =
- * diagnostic: the solve never publishes its completion, every bounded wait times out with EKF_FLAG_INTERNAL);
+ * diagnostic: the solve never publishes its completion, every bounded wait times out with EKF_FLAG_INTERNAL),
+ * "fused_cadence" (1 = ekf_stream_run replays all steps between two covariance passes -- up to 40 landmark updates,
+ * src/replay_no_ros.py:368-480 for each -- with one solve launch and one panel launch; equal to the per-step kernels to
+ * rounding (<= 1e-10 relative, tested), not bit for bit; 0 = one step at a time), "lookahead" (1 = where the pass is a
+ * small launch, the next cadence's solve runs beside it on the handle's second stream; 0 = strictly in sequence);
  * unknown names fail. */
 int ekf_set_option(ekf_handle *h, const char *name, int value);
 /* Which form of the covariance pass the last launch used (-1 = none yet; values as for "pass_kernel"), how many
