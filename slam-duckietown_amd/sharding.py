@@ -42,6 +42,18 @@ def split_banks(trajectory_ids: List[int], bank_size: int = 32) -> List[List[int
     return out
 
 
+def run_banks(banks, first: int, count: int, slice_steps: int = 50) -> None:
+    """Enqueue steps [first, first + count) of the uploaded streams of several EkfSlam handles ("banks", see
+    split_banks) from ONE host thread, `slice_steps` at a time and bank after bank, so that every bank's stream is fed
+    from the start: the launches of a bank are asynchronous, and the solve / panel launches of one bank run under the
+    covariance pass of another (tools/two_banks.py).  Nothing is synchronised here -- call sync() on the banks."""
+    if slice_steps < 1:
+        raise ValueError("slice_steps must be positive")
+    for k in range(first, first + count, slice_steps):
+        for f in banks:
+            f.stream_run(k, min(slice_steps, first + count - k))
+
+
 class RankGroup:
     """Rank bookkeeping from the torchrun environment (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*)."""
 

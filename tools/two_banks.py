@@ -31,11 +31,8 @@ for g in range(G):
 for f in banks:
     f.sync()
 t0 = time.perf_counter()
-# enqueue in slices so that both queues are fed from the start
-CH = 50
-for k in range(warm, warm + steps, CH):
-    for f in banks:
-        f.stream_run(k, min(CH, warm + steps - k))
+from slam_duckietown_amd.sharding import run_banks
+run_banks(banks, warm, steps)                 # slices of 50 steps, bank after bank: both queues are fed from the start
 for f in banks:
     f.flush()
 for f in banks:
