@@ -412,3 +412,36 @@ def test_config4_shape_n2000_x32_fused_against_per_step(sd):
     for a, b in zip(res[1], res[0]):
         assert orc.rel_fro(a[0], b[0]) < PATH_TOL and orc.rel_fro(a[1], b[1]) < PATH_TOL
     assert np.array_equal(res[1][0][1], res[1][2][1]) and np.array_equal(res[1][1][0], res[1][3][0])   # replicas agree bit for bit
+
+
+def test_trajectories_of_different_size_in_one_bank(sd):
+    """A bank whose trajectories hold different numbers of landmarks (n = 3 + 2 N_b each, one capacity): the cadence
+    kernels take every trajectory's own size (its rows beyond are never touched).  Each trajectory against its own
+    single-trajectory handle of the same capacity -- bit for bit (same launches shapes apart from the batch) -- and one of
+    them against the oracle."""
+    sizes, steps, m = [400, 250, 120], 23, 8
+    n_max = 3 + 2 * max(sizes)
+    streams = [orc.synthetic_stream(N, steps, m, 1700 + t) for t, N in enumerate(sizes)]
+    starts = [dense_start(3 + 2 * N, 1800 + t) for t, N in enumerate(sizes)]
+    args = [np.stack([s[i] for s in streams], axis=1) for i in (2, 3, 4, 5, 6)]
+    with sd.EkfSlam(n_max, batch=len(sizes)) as f:
+        for b, s in enumerate(streams):
+            f.set_state(s[0], starts[b], b)
+        f.run_stream(*args)
+        together = [f.state(b) for b in range(len(sizes))]
+        assert [f.flags(b) for b in range(len(sizes))] == [0] * len(sizes)
+        assert cadences(sd, f)[0] >= 4
+        assert [f.size(b) for b in range(len(sizes))] == [3 + 2 * N for N in sizes]
+    for b, s in enumerate(streams):
+        with sd.EkfSlam(n_max, batch=1) as f:
+            f.set_state(s[0], starts[b], 0)
+            f.run_stream(*[a[:, b:b + 1] for a in args])
+            mu, P = f.state(0)
+        assert mu.shape == (3 + 2 * sizes[b],)
+        assert np.array_equal(mu, together[b][0]) and np.array_equal(P, together[b][1]), b
+    cfg = orc.EkfConfig()
+    s = streams[2]
+    om, oP = s[0].copy(), starts[2].copy()
+    for k in range(steps):
+        om, oP = orc.ekf_step_dense(om, oP, s[2][k], s[3][k], s[4][k], s[5][k], s[6][k], cfg)
+    assert orc.rel_fro(together[2][0], om) < TIGHT and orc.rel_fro(together[2][1], oP) < TIGHT
