@@ -445,3 +445,35 @@ def test_trajectories_of_different_size_in_one_bank(sd):
     for k in range(steps):
         om, oP = orc.ekf_step_dense(om, oP, s[2][k], s[3][k], s[4][k], s[5][k], s[6][k], cfg)
     assert orc.rel_fro(together[2][0], om) < TIGHT and orc.rel_fro(together[2][1], oP) < TIGHT
+
+
+def test_q_zero_inside_a_cadence_sets_the_flag_and_stays_in_its_trajectory(sd):
+    """A landmark exactly at the robot (q = 0, src/replay_no_ros.py:446, :466-469) at the head of a fused cadence (everything after it in the cadence replays NaN): NaN
+    like NumPy's 0/0, the sticky EKF_FLAG_NONFINITE on that trajectory -- and the other trajectory of the batch, replayed
+    by the same launches, is untouched by it (against the oracle)."""
+    N, steps, m = 40, 12, 4
+    n = 3 + 2 * N
+    cfg = dict(disable_motion_model=True)              # the pose mean stays where the update leaves it: (0, 0) at step 0
+    streams = [orc.synthetic_stream(N, steps, m, 1900 + t) for t in range(2)]
+    means = [s[0].copy() for s in streams]
+    means[0][0:3] = 0.0
+    means[0][3 + 2 * int(streams[0][4][0, 0])] = 0.0     # the first landmark observed sits exactly at the robot
+    means[0][4 + 2 * int(streams[0][4][0, 0])] = 0.0
+    means[1][0:3] = 0.0
+    starts = [dense_start(n, 1950 + t) for t in range(2)]
+    args = (stack(streams, 2), stack(streams, 3), stack(streams, 4), stack(streams, 5), stack(streams, 6))
+    with sd.EkfSlam(n, batch=2, config=sd.EkfConfig(**cfg)) as f:
+        f.set_option("active_bound", 0)
+        for b in range(2):
+            f.set_state(means[b], starts[b], b)
+        f.run_stream(*args)
+        assert cadences(sd, f)[0] >= 1
+        assert f.flags(0) & 1 and f.flags(1) == 0         # EKF_FLAG_NONFINITE
+        assert not np.isfinite(f.mean(0)).all()
+        mu1, P1 = f.state(1)
+    ocfg = orc.EkfConfig(**cfg)
+    s = streams[1]
+    om, oP = means[1].copy(), starts[1].copy()
+    for k in range(steps):
+        om, oP = orc.ekf_step_dense(om, oP, s[2][k], s[3][k], s[4][k], s[5][k], s[6][k], ocfg)
+    assert orc.rel_fro(mu1, om) < TIGHT and orc.rel_fro(P1, oP) < TIGHT
