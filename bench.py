@@ -182,15 +182,19 @@ def cpu_baseline(n_landmarks, m, budget_s=25.0):
         times.append(time.perf_counter() - t0)
         if time.perf_counter() - t_all > budget_s and len(times) >= 2:
             break
+    blas = "BLAS unknown"
     try:
         from threadpoolctl import threadpool_info
-        cores = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+        pools = threadpool_info()
+        cores = max([p.get("num_threads", 1) for p in pools] or [1])
+        blas = ", ".join(sorted({f"{p.get('internal_api', '?')} {p.get('version', '?')}" for p in pools})) or blas
     except Exception:
         cores = os.cpu_count() or 1
     med = float(np.median(times))
     return {"value": 1.0 / med, "unit": "steps/s", "cores": int(cores), "kind": "port",
             "sample": f"{len(times)} steps of N={n_landmarks}, m={m}, 1 trajectory, dense NumPy "
-                      f"(oracle.ekf_step_dense), median {med * 1e3:.0f} ms/step"}
+                      f"(oracle.ekf_step_dense), median {med * 1e3:.0f} ms/step; NumPy {np.__version__}, {blas}, "
+                      f"os.cpu_count() = {os.cpu_count()}"}
 
 
 def main():
