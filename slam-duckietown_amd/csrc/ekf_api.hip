@@ -590,10 +590,14 @@ static PassPlan plan_pass(const ekf_handle* h) {
   p.rs_workgroups = h->opt_pass_workgroups > 0 ? std::min(h->opt_pass_workgroups, h->cu_count) : h->cu_count;
   // A few LONG trajectories (N = 8000 x 1: 126 slabs of up to 251 strips for 256 CUs): the row-slab pass with one equal
   // static share of the strips per workgroup (build_pass_shares) -- where a share is long enough (>= 40 strips) for
-  // the pipeline fills at its piece boundaries not to matter.
+  // the pipeline fills at its piece boundaries not to matter.  The same for 10 .. 14 trajectories, where the queues
+  // hold one to two whole slabs per workgroup and cannot balance them (N = 2000, 80 ranks, queues -> shares: x 10
+  // 290 -> 261 us, x 11 321 -> 289, x 12 334 -> 303, x 13 350 -> 335, x 14 352 -> 346; N = 3000 x 12 753 -> 706;
+  // 8, 9, 15 - 17 and from 23 on the queues are as good or better, 18 - 22 gain 2 - 5 % at N = 2000 but lose at N = 3000:
+  // profiles/r03_pass_vs_batch.txt).
   const long slabs = (p.e_hi + 127) / 128, s_last = (p.e_hi - 1) >> 6;
   const long strips = (long)h->batch * (slabs * (s_last + 1) - slabs * (slabs - 1));
-  p.long_few = h->batch < 8 && h->opt_pass_chunk == 0 && strips >= 40L * p.rs_workgroups;
+  p.long_few = (h->batch < 8 || (h->batch >= 10 && h->batch <= 14)) && h->opt_pass_chunk == 0 && strips >= 40L * p.rs_workgroups;
   // auto: the row-slab form where the batch streams through HBM and has at least one 128-row slab per CU (below
   // three per CU the slabs are cut into chunks of strips) or is a few long trajectories; measured at N=2000: 8
   // trajectories 256 us against 266 us with k_flush, 4 trajectories 166 / 164 us, 1 trajectory 97 / 52 us (pipeline

@@ -761,6 +761,36 @@ def test_row_slab_pass_on_equal_static_shares_is_bit_identical(sd):
     close(got[1][1], oP)
 
 
+def test_static_shares_for_ten_to_fourteen_trajectories(sd):
+    """10 .. 14 trajectories take the row-slab pass on equal static shares as well (the queue modes cannot balance one
+    to two slabs per workgroup): bit for bit the column-strip kernel's result.  `pass_workgroups` = 6 makes the shares
+    long enough at a size the test can download (automatic from N ~ 1700 on the full chip)."""
+    import ctypes as C
+    lib = sd.load_library()
+    N, B, m, steps = 300, 12, 8, 11
+    n = 3 + 2 * N
+    streams = [orc.synthetic_stream(N, steps, m, 260 + t) for t in range(B)]
+    args = [np.stack([s[i] for s in streams], axis=1) for i in (2, 3, 4, 5, 6)]
+    res = {}
+    for kernel, wgs in ((0, 0), (2, 6)):
+        with sd.EkfSlam(n, batch=B) as f:
+            f.set_option("pass_streaming", 1)
+            f.set_option("active_bound", 0)
+            f.set_option("pass_kernel", kernel)
+            if wgs:
+                f.set_option("pass_workgroups", wgs)
+            for b, s in enumerate(streams):
+                f.set_state_diag(s[0], s[1], b)
+            f.run_stream(*args)
+            f.flush()
+            res[kernel] = [f.state(b) for b in range(B)]
+            assert [f.flags(b) for b in range(B)] == [0] * B
+            shares = lib.ekf_debug_last_pass_shares(C.c_void_p(f._h.value))
+            assert (shares >= 1) if kernel == 2 else (shares == 0), (kernel, shares)
+    for b in range(B):
+        assert np.array_equal(res[2][b][0], res[0][b][0]) and np.array_equal(res[2][b][1], res[0][b][1]), b
+
+
 def test_single_launch_step_is_bit_identical(sd):
     """`fused_step=1` (k_step_split: solve and panel workgroups in one launch, the panels gathered beside the solve and
     released by a per-trajectory step counter) gives the results of the two-launch path bit for bit: ragged observation
