@@ -576,7 +576,7 @@ static int prof_event(ekf_handle* h, hipEvent_t* ev) {
 // it launches).
 struct PassPlan {
   int n_hi, e_hi, nkt, kernel, rs_workgroups;
-  bool streaming, long_few;
+  bool streaming, long_few, beside;                    // beside: the row-slab pass leaves CUs free for a solve beside it
 };
 static PassPlan plan_pass(const ekf_handle* h) {
   PassPlan p;
@@ -603,6 +603,12 @@ static PassPlan plan_pass(const ekf_handle* h) {
   // trajectories 256 us against 266 us with k_flush, 4 trajectories 166 / 164 us, 1 trajectory 97 / 52 us (pipeline
   // fills dominate)
   if (p.kernel < 0) p.kernel = (p.streaming && ((long)h->batch * slabs >= (long)h->cu_count || p.long_few)) ? 2 : 0;
+  // A few long trajectories on static shares: the pass leaves one CU per trajectory free, so that the next cadence's solve
+  // (one workgroup per trajectory) can run beside it (the look-ahead of ekf_stream_run); always, not only when a solve
+  // follows: the share table is built per workgroup count (N = 8000 x 1: 255 instead of 256 workgroups, 0.4 %).
+  p.beside = p.kernel == 2 && p.long_few && h->batch < 8 && h->opt_lookahead && h->opt_pass_workgroups == 0 &&
+             h->cu_count > 8 * h->batch;
+  if (p.beside) p.rs_workgroups = h->cu_count - h->batch;
   return p;
 }
 
@@ -754,10 +760,15 @@ static int enqueue_cadence(ekf_handle* h, int k, int g, int end, bool presolved,
   if (!(due || h->pending_k + 2 > KTOT)) return EKF_OK;
   // (worth it where the pass is the column-strip kernel -- the row-slab pass fills every CU by itself -- and long enough
   //  to pay for the gather and the two cross-stream hand-overs, ~25 us together: from ~48 MB of covariance.  N = 2000 x 1:
-  //  38.7 k -> 45.1 k steps/s, x 2: 57.6 k -> 61.9 k, x 4: 89.5 k -> 92.1 k; N = 500 x 1 and N = 20 x 1 lose 4 - 9 %)
+  //  38.7 k -> 45.1 k steps/s, x 2: 57.6 k -> 61.9 k, x 4: 89.5 k -> 92.1 k; N = 500 x 1 and N = 20 x 1 lose 4 - 9 %;
+  //  N = 8000 x 1 on static shares, the pass on 255 workgroups: 9.35 - 9.58 k -> 9.82 - 10.2 k)
   const int k2 = k + g, g2 = h->opt_lookahead ? cadence_length(h, k2, end, true) : 0;
   const PassPlan plan = plan_pass(h);
-  if (g2 < 2 || plan.kernel != 0 || (double)h->batch * 8.0 * plan.e_hi * plan.e_hi < 48.0e6) return flush_pending(h);
+  // ... or the row-slab pass on static shares that leaves the solves their CUs (a few long trajectories: N = 8000 x 1)
+  const bool small_pass = plan.kernel == 0 && (double)h->batch * 8.0 * plan.e_hi * plan.e_hi >= 48.0e6;
+  const bool shares_pass = plan.kernel == 2 && (plan.beside || (plan.long_few && h->batch < 8 && h->opt_pass_workgroups > 0 &&
+                                                                  h->opt_pass_workgroups + h->batch <= h->cu_count));
+  if (g2 < 2 || !(small_pass || shares_pass)) return flush_pending(h);
   // ---- look-ahead: gather (stream) -> { pass (second stream) | solve of the next cadence (stream) } -> join ----
   const int mcap2 = cap_for(h->stream_mhi[k2]);
   if (!h->dgbuf) HIP_TRY(h, hipMalloc(&h->dgbuf, sizeof(double) * cadence_gbuf_doubles() * h->batch));

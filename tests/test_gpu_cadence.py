@@ -296,6 +296,42 @@ def test_lookahead_solve_beside_the_pass(sd, N, B, m, steps):
     assert orc.rel_fro(res[1][0][0], om) < TIGHT and orc.rel_fro(res[1][0][1], oP) < TIGHT
 
 
+def test_lookahead_beside_the_row_slab_pass_on_static_shares(sd):
+    """A few long trajectories (N = 8000 x 1) take the row-slab pass on equal static shares, on one workgroup per trajectory
+    fewer than the chip has CUs, so that the next cadence's solve runs beside it as well.  Here at a size the oracle
+    handles, the shares forced through `pass_workgroups`: against `lookahead=0` to rounding, against the oracle, and the
+    launches really took that road (look-aheads counted, the last pass on a share table)."""
+    lib = sd.load_library()
+    lib.ekf_debug_last_pass_shares.argtypes = [C.c_void_p]
+    N, B, m, steps = 700, 3, 8, 27
+    n = 3 + 2 * N
+    streams = [orc.synthetic_stream(N, steps, m, 2300 + t) for t in range(B)]
+    starts = [dense_start(n, 2400 + t) for t in range(B)]
+    args = (stack(streams, 2), stack(streams, 3), stack(streams, 4), stack(streams, 5), stack(streams, 6))
+    res = {}
+    for la in (1, 0):
+        with sd.EkfSlam(n, batch=B) as f:
+            for name, value in (("active_bound", 0), ("pass_streaming", 1), ("pass_kernel", 2), ("pass_workgroups", 8),
+                                ("lookahead", la)):
+                f.set_option(name, value)
+            for b in range(B):
+                f.set_state(streams[b][0], starts[b], b)
+            f.run_stream(*args)
+            f.flush()
+            res[la] = [f.state(b) for b in range(B)]
+            assert [f.flags(b) for b in range(B)] == [0] * B
+            assert lib.ekf_debug_last_pass_shares(f._h) >= 1
+            assert (lookaheads(sd, f) >= 4) if la else (lookaheads(sd, f) == 0)
+    for b in range(B):
+        assert orc.rel_fro(res[1][b][0], res[0][b][0]) < PATH_TOL and orc.rel_fro(res[1][b][1], res[0][b][1]) < PATH_TOL
+    cfg = orc.EkfConfig()
+    s = streams[1]
+    om, oP = s[0].copy(), starts[1].copy()
+    for k in range(steps):
+        om, oP = orc.ekf_step_dense(om, oP, s[2][k], s[3][k], s[4][k], s[5][k], s[6][k], cfg)
+    assert orc.rel_fro(res[1][1][0], om) < TIGHT and orc.rel_fro(res[1][1][1], oP) < TIGHT
+
+
 def test_stream_run_in_pieces_with_flushes_and_downloads_in_between(sd):
     """`stream_run(first, count)` called in pieces that cut cadences (and look-ahead chains) anywhere, with `flush()`,
     `mean()` and `covariance_block()` between them: every piece starts from whatever is pending (a cadence only forms
