@@ -26,9 +26,10 @@ extern "C" {
 #define EKF_ERR_STATE (-3)    /* call not valid in the current state */
 
 #define EKF_MMAX 16           /* max landmarks per single device update pass (longer lists are split) */
-#define EKF_N_MAX_LIMIT 23167 /* largest n_max = 3 + 2N ekf_create accepts (N = 11582): the kernels address one
-                                 covariance with unsigned 32-bit byte offsets, so its padded rows x ld x 8 bytes
-                                 must stay below 4 GiB; larger values fail with EKF_ERR_ARG */
+#define EKF_N_MAX_LIMIT 21823 /* largest n_max = 3 + 2N ekf_create accepts (N = 10910): the kernels address one
+                                 covariance with unsigned 32-bit byte offsets, so what is allocated for it -- rows
+                                 (n_max rounded up to 64) x column panels of 4096 doubles, 8 bytes each -- must
+                                 stay below 4 GiB; larger values fail with EKF_ERR_ARG */
 
 /* sticky per-trajectory flags, ekf_status_flags() */
 #define EKF_FLAG_NONFINITE 1u /* a non-finite mean entry was produced (q = 0 at :466-469, singular S at :473) */

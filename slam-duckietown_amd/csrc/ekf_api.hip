@@ -82,6 +82,7 @@ struct ekf_handle {
   int* dfloor = nullptr;          // per trajectory floor of the active bound, applied by k_solve (see push_floor)
   std::vector<int> floor_host;    // what dfloor holds
   double *dF = nullptr, *dQ = nullptr, *dTmp = nullptr;   // dense path, allocated on first use
+  double* dPlin = nullptr;        // dense path with P in column panels: its row-major staging copy
   // device-side association (allocated on first use)
   int *dtagmap = nullptr, *dneff = nullptr;
   DetIn *d_det = nullptr, *h_det = nullptr;
@@ -121,6 +122,7 @@ struct ekf_handle {
   int cu_count = 0;
   int opt_rows_per_block = 0;     // 0 = auto (flush kernel: rows per workgroup, multiple of 16)
   int opt_pass_chunk = 0;         // 0 = auto (k_flush_rs: strips per unit)
+  int opt_share_order = 1;        // 1 = static shares dealt to the XCDs by starting column (order_pass_shares), 0 = as built
   int opt_pass_workgroups = 0;    // 0 = one per CU (k_flush_rs: persistent workgroups; fewer leaves CUs to other streams)
   int last_kernel = -1, last_nkt = 0, last_streaming = 0;   // what the last covariance pass launched
   int last_shares = 0;            // ... and whether it ran on equal static shares (k_flush_rs, a few long trajectories)
@@ -145,6 +147,26 @@ static int materialize(ekf_handle* h, int b);
     if (e_ != hipSuccess)                                                                  \
       return fail(h, EKF_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));      \
   } while (0)
+
+// Copies between a host matrix (row-major, `host_pitch` doubles per row) and the block [r0, r0 + rows) x [c0, c0 + cols) of
+// trajectory b's covariance in its device layout (ekf_device.h: row-major up to ld = 4096, column panels of 4096 doubles
+// beyond): one 2-D copy per column panel the block touches.  `other` = nullptr: the host side; else a device matrix in
+// plain row-major (the dense product's staging), copied device to device.
+static hipError_t copy_cov(ekf_handle* h, int b, double* host, int host_pitch, int r0, int c0, int rows, int cols, bool to_device,
+                           bool device_to_device = false) {
+  for (int p = c0 / PPW; p <= (c0 + cols - 1) / PPW; ++p) {
+    const int cs = std::max(c0, p * PPW), ce = std::min(c0 + cols, (p + 1) * PPW);
+    double* dev = h->dP + (size_t)b * h->pstride + p_index(h->ld, r0, cs);
+    double* hst = host + (cs - c0);
+    const size_t dpitch = sizeof(double) * (size_t)p_lds(h->ld), hpitch = sizeof(double) * (size_t)host_pitch;
+    const size_t width = sizeof(double) * (size_t)(ce - cs);
+    const hipMemcpyKind kind = device_to_device ? hipMemcpyDeviceToDevice : (to_device ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost);
+    const hipError_t e = to_device ? hipMemcpy2DAsync(dev, dpitch, hst, hpitch, width, (size_t)rows, kind, h->stream)
+                                   : hipMemcpy2DAsync(hst, hpitch, dev, dpitch, width, (size_t)rows, kind, h->stream);
+    if (e != hipSuccess) return e;
+  }
+  return hipSuccess;
+}
 
 extern "C" int ekf_config_default(ekf_config* cfg) {
   if (!cfg) return EKF_ERR_ARG;
@@ -174,7 +196,7 @@ static void free_all(ekf_handle* h) {
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   void* ptrs[] = {h->dP, h->dmu2[0], h->dmu2[1], h->dV, h->dW, h->ddacc2[0], h->ddacc2[1], h->dscratch, h->dn, h->dflags, h->dso, h->dfac,
-                  h->d_ring, h->d_stream, h->dF, h->dQ, h->dTmp, h->dtagmap, h->dneff, h->d_det, h->d_assoc_step, h->dfloor, h->dqueue, h->dready, h->dmbox,
+                  h->d_ring, h->d_stream, h->dF, h->dQ, h->dTmp, h->dPlin, h->dtagmap, h->dneff, h->d_det, h->d_assoc_step, h->dfloor, h->dqueue, h->dready, h->dmbox,
                   h->d_assoc_out, h->dcad, h->dshares, h->dgbuf};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (h->h_ring) (void)hipHostFree(h->h_ring);
@@ -199,11 +221,11 @@ extern "C" int ekf_create(int device, int n_max, int batch, const ekf_config* cf
   if (n_max < 3 || (n_max & 1) == 0) return fail(nullptr, EKF_ERR_ARG, "ekf_create: n_max must be 3 + 2*N");
   if (batch < 1) return fail(nullptr, EKF_ERR_ARG, "ekf_create: batch must be >= 1");
   // The kernels address one trajectory's covariance with unsigned 32-bit byte offsets (buffer instructions: k_flush_rs,
-  // k_solve's staging, k_gemm_f64's resources): rows x ld x 8 bytes must stay below 4 GiB.  Checked before the device is
+  // k_solve's staging, k_gemm_f64's resources): what is allocated for it must stay below 4 GiB.  Checked before the device is
   // looked for, so that the limit can be tested without one.
   {
-    const unsigned long long rows = ((unsigned long long)n_max + 63) / 64 * 64;
-    if (rows * rows * 8ull >= (1ull << 32))
+    const int rows = (n_max + 63) / 64 * 64;             // (= ld beyond 4096, where the covariance is kept in column panels)
+    if (n_max > EKF_N_MAX_LIMIT || (unsigned long long)p_alloc(rows, rows) * 8ull >= (1ull << 32))
       return fail(nullptr, EKF_ERR_ARG,
                   "ekf_create: n_max = " + std::to_string(n_max) + " exceeds EKF_N_MAX_LIMIT = " +
                       std::to_string(EKF_N_MAX_LIMIT) + " (one covariance must stay below 4 GiB: 32-bit byte offsets)");
@@ -237,7 +259,7 @@ extern "C" int ekf_create(int device, int n_max, int batch, const ekf_config* cf
     h->ld = p2;
   }
   h->batch = batch;
-  h->pstride = (long)h->rows * h->ld;
+  h->pstride = p_alloc(h->rows, h->ld);                // (column panels of 4096 doubles beyond ld = 4096: ekf_device.h)
   if (cfg) h->cfg = *cfg; else ekf_config_default(&h->cfg);
   const double s = h->cfg.motion_sigma, q = h->cfg.meas_sigma;
   h->dcfg.rd[0] = s * s;                        // src/replay_no_ros.py:421
@@ -273,8 +295,7 @@ extern "C" int ekf_create(int device, int n_max, int batch, const ekf_config* cf
   CREATE_TRY(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
   CREATE_TRY(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
   const size_t ldz = (size_t)h->ld;
-  const size_t rowz = (size_t)h->rows;
-  CREATE_TRY(hipMalloc(&h->dP, sizeof(double) * rowz * ldz * batch));
+  CREATE_TRY(hipMalloc(&h->dP, sizeof(double) * (size_t)h->pstride * batch));
   CREATE_TRY(hipMalloc(&h->dmu2[0], sizeof(double) * ldz * batch));
   CREATE_TRY(hipMalloc(&h->dmu2[1], sizeof(double) * ldz * batch));
   CREATE_TRY(hipMalloc(&h->dV, sizeof(double) * ldz * KTOT * batch));
@@ -297,7 +318,7 @@ extern "C" int ekf_create(int device, int n_max, int batch, const ekf_config* cf
   for (auto& ev : h->ring_ev) CREATE_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
   CREATE_TRY(hipEventCreate(&h->t0));
   CREATE_TRY(hipEventCreate(&h->t1));
-  CREATE_TRY(hipMemsetAsync(h->dP, 0, sizeof(double) * rowz * ldz * batch, h->stream));
+  CREATE_TRY(hipMemsetAsync(h->dP, 0, sizeof(double) * (size_t)h->pstride * batch, h->stream));
   CREATE_TRY(hipMemsetAsync(h->dmu2[0], 0, sizeof(double) * ldz * batch, h->stream));
   CREATE_TRY(hipMemsetAsync(h->dmu2[1], 0, sizeof(double) * ldz * batch, h->stream));
   CREATE_TRY(hipMemsetAsync(h->dV, 0, sizeof(double) * ldz * KTOT * batch, h->stream));
@@ -312,8 +333,7 @@ extern "C" int ekf_create(int device, int n_max, int batch, const ekf_config* cf
     std::vector<double> p3(3 * 3, 0.0);
     p3[0] = p3[4] = p3[8] = h->cfg.motion_sigma;
     for (int b = 0; b < batch; ++b)
-      CREATE_TRY(hipMemcpy2DAsync(h->dP + (size_t)b * h->pstride, sizeof(double) * ldz, p3.data(),
-                                  sizeof(double) * 3, sizeof(double) * 3, 3, hipMemcpyHostToDevice, h->stream));
+      CREATE_TRY(copy_cov(h, b, p3.data(), 3, 0, 0, 3, 3, true));
     CREATE_TRY(hipMemcpyAsync(h->dn, h->n.data(), sizeof(int) * batch, hipMemcpyHostToDevice, h->stream));
     CREATE_TRY(hipMemcpyAsync(h->dfloor, h->floor_host.data(), sizeof(int) * batch, hipMemcpyHostToDevice, h->stream));
     CREATE_TRY(hipStreamSynchronize(h->stream));
@@ -409,8 +429,7 @@ extern "C" int ekf_upload_state(ekf_handle* h, int b, const double* mu, const do
   HIP_TRY(h, hipSetDevice(h->device));
   if (int rc = flush_pending(h)) return rc;
   if (int rc = clear_internal(h, b)) return rc;
-  HIP_TRY(h, hipMemcpy2DAsync(h->dP + (size_t)b * h->pstride, sizeof(double) * h->ld, P, sizeof(double) * n,
-                              sizeof(double) * n, n, hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(h, copy_cov(h, b, const_cast<double*>(P), n, 0, 0, n, n, true));
   HIP_TRY(h, hipMemcpyAsync(h->dmu2[h->cur] + (size_t)b * h->ld, mu, sizeof(double) * n, hipMemcpyHostToDevice, h->stream));
   if (int rc = set_size(h, b, n)) return rc;
   h->neff[b] = n;                                      // arbitrary dense covariance: everything is active
@@ -455,8 +474,7 @@ extern "C" int ekf_download_state(ekf_handle* h, int b, double* mu, double* P, i
     if (int rc = materialize(h, b)) return rc;     // the covariance is P_base + pending ranks, upper triangle
   }
   if (P)
-    HIP_TRY(h, hipMemcpy2DAsync(P, sizeof(double) * n, h->dP + (size_t)b * h->pstride, sizeof(double) * h->ld,
-                                sizeof(double) * n, n, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, copy_cov(h, b, P, n, 0, 0, n, n, false));
   if (mu)
     HIP_TRY(h, hipMemcpyAsync(mu, h->dmu2[h->cur] + (size_t)b * h->ld, sizeof(double) * n, hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -471,8 +489,7 @@ extern "C" int ekf_download_block(ekf_handle* h, int b, int r0, int c0, int rows
   HIP_TRY(h, hipSetDevice(h->device));
   if (int rc = check_internal(h, b, "ekf_download_block")) return rc;
   if (int rc = materialize(h, b)) return rc;
-  HIP_TRY(h, hipMemcpy2DAsync(out, sizeof(double) * cols, h->dP + (size_t)b * h->pstride + (size_t)r0 * h->ld + c0,
-                              sizeof(double) * h->ld, sizeof(double) * cols, rows, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, copy_cov(h, b, out, cols, r0, c0, rows, cols, false));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   return EKF_OK;
 }
@@ -614,6 +631,28 @@ static PassPlan plan_pass(const ekf_handle* h) {
 
 // Apply the pending low-rank update to P_base:  P_base += W V + diag(dacc)  (one pass over P), on stream `st` (the
 // handle's own unless the look-ahead of ekf_stream_run sends it to the second one).
+// Which workgroup gets which static share.  build_pass_shares cuts the strips slab by slab, so consecutive shares are
+// consecutive pieces of the same rows: at any time the workgroups of an XCD (equal blockIdx % 8) sit on 32 different
+// column strips, every V strip they stage is used by one workgroup only, and V (80 ranks x ld doubles: 10 MB at N = 8000)
+// does not fit an XCD's 4 MB L2 -- each of the 15 876 strip visits of a pass fetches its 40 KB from the Infinity Cache
+// (650 MB per pass beside the 4.1 GB of P).  Workgroups advance at the same rate, so shares that START on the same column
+// stay on the same column: the shares are sorted by (trajectory, first column) and dealt to the XCDs in runs, and the 32
+// workgroups of an XCD walk (nearly) the same V strips together -- one fetch per XCD instead of one per workgroup.
+static void order_pass_shares(int workgroups, int pieces, std::vector<int>& table) {
+  std::vector<int> order(workgroups);
+  for (int w = 0; w < workgroups; ++w) order[w] = w;
+  auto key = [&](int w) { return ((long)table[(size_t)w * pieces * 4] << 32) + table[(size_t)w * pieces * 4 + 2]; };
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return key(a) < key(b); });
+  std::vector<int> slots;                              // blockIdx values XCD by XCD (workgroups go round-robin over the 8 XCDs)
+  slots.reserve(workgroups);
+  for (int x = 0; x < 8; ++x)
+    for (int w = x; w < workgroups; w += 8) slots.push_back(w);
+  std::vector<int> out(table.size(), 0);
+  for (int q = 0; q < workgroups; ++q)
+    std::copy_n(table.begin() + (size_t)order[q] * pieces * 4, (size_t)pieces * 4, out.begin() + (size_t)slots[q] * pieces * 4);
+  table.swap(out);
+}
+
 static int flush_pending(ekf_handle* h, hipStream_t st) {
   if (h->pending_k == 0) return EKF_OK;
   if (!st) st = h->stream;
@@ -624,6 +663,7 @@ static int flush_pending(ekf_handle* h, hipStream_t st) {
       const size_t words = (size_t)h->cu_count * pass_share_pieces() * 4;
       std::vector<int> table(words, 0);
       h->shares_ok = build_pass_shares(h->batch, p.e_hi, p.rs_workgroups, table.data());
+      if (h->shares_ok > 0 && h->opt_share_order) order_pass_shares(p.rs_workgroups, pass_share_pieces(), table);
       if (!h->dshares) HIP_TRY(h, hipMalloc(&h->dshares, sizeof(int) * words));
       // (rare: once per (batch, size); the table must be on the device before the launch below reads it)
       HIP_TRY(h, hipMemcpyAsync(h->dshares, table.data(), sizeof(int) * words, hipMemcpyHostToDevice, st));
@@ -1140,8 +1180,17 @@ extern "C" int ekf_predict_dense(ekf_handle* h, int b, const double* F, const do
     HIP_TRY(h, hipEventRecord(e0, h->stream));
   }
   h->neff[b] = n;                                      // a general F correlates everything
-  if (dense_propagate(h->stream, h->dP + (size_t)b * h->pstride, h->dTmp, h->dF, h->dQ, n, h->ld) != 0)
+  // the product works on plain row-major matrices: a covariance kept in column panels (ld > 4096) goes through a
+  // row-major copy (device to device, one 2-D copy per panel each way; 4 n^3 flop dwarf it)
+  double* Pdense = h->dP + (size_t)b * h->pstride;
+  if (p_panels(h->ld) > 1) {
+    if (!h->dPlin) HIP_TRY(h, hipMalloc(&h->dPlin, bytes));
+    HIP_TRY(h, copy_cov(h, b, h->dPlin, h->ld, 0, 0, n, n, false, true));
+    Pdense = h->dPlin;
+  }
+  if (dense_propagate(h->stream, Pdense, h->dTmp, h->dF, h->dQ, n, h->ld) != 0)
     return fail(h, EKF_ERR_HIP, "ekf_predict_dense: launch failed");
+  if (p_panels(h->ld) > 1) HIP_TRY(h, copy_cov(h, b, h->dPlin, h->ld, 0, 0, n, n, true, true));
   if (h->profile) HIP_TRY(h, hipEventRecord(e1, h->stream));
   HIP_TRY(h, hipGetLastError());
   HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -1256,7 +1305,7 @@ extern "C" long ekf_debug_cad(ekf_handle* h, int b, void* dst, long bytes) {
 }
 
 // (development aid, not declared in the header) raw device buffers of trajectory b, exactly as they stand -- no flush,
-// no mirror, no status check: which = 0 P_base (rows x ld), 1 V (80 x ld), 2 W (80 x ld, MFMA-tiled), 3 the mean buffer
+// no mirror, no status check: which = 0 P_base (device layout, ekf_device.h: rows x ld up to ld = 4096, column panels beyond), 1 V (80 x ld), 2 W (80 x ld, MFMA-tiled), 3 the mean buffer
 // the NEXT step reads, 4 the other mean buffer.  Returns the number of doubles the buffer holds (copies min(count, that)).
 extern "C" long ekf_debug_snapshot(ekf_handle* h, int b, int which, double* dst, long count) {
   if (!h || b < 0 || b >= h->batch || which < 0 || which > 4) return -1;
@@ -1312,6 +1361,12 @@ extern "C" int ekf_set_option(ekf_handle* h, const char* name, int value) {
   if (std::strcmp(name, "pass_chunk") == 0) {
     if (value < 0 || value > 4096) return fail(h, EKF_ERR_ARG, "pass_chunk out of range");
     h->opt_pass_chunk = value;
+    return EKF_OK;
+  }
+  if (std::strcmp(name, "pass_share_order") == 0) {
+    if (value != 0 && value != 1) return fail(h, EKF_ERR_ARG, "pass_share_order must be 0 or 1");
+    h->opt_share_order = value;
+    h->shares_key[0] = 0;                              // (the cached table is rebuilt)
     return EKF_OK;
   }
   if (std::strcmp(name, "fused_step") == 0) {

@@ -222,8 +222,8 @@ __global__ __launch_bounds__(64 * CAD_NW) void k_solve_cad(const double* __restr
         const int r = wave + CAD_NW * q;
         if (r < CU) {                                  // (wave-uniform)
           const int Cr = Cs[r];
-          gv0[q] = Pb[(long)min(Cr, Cl0) * ld + max(Cr, Cl0)];      // the upper triangle is authoritative
-          if (CU > 64) gv1[q] = Pb[(long)min(Cr, Cl1) * ld + max(Cr, Cl1)];
+          gv0[q] = Pb[p_index(ld, min(Cr, Cl0), max(Cr, Cl0))];     // the upper triangle is authoritative
+          if (CU > 64) gv1[q] = Pb[p_index(ld, min(Cr, Cl1), max(Cr, Cl1))];
         }
       }
     }
@@ -535,7 +535,7 @@ __device__ __forceinline__ void pose_epilogue(const CadOut& o, double* Pb, doubl
       Wb[wm_index(ld16, k, lane)] = 0.0;
     }
     Pb[lane] += o.ddpose[0][lane];                     // entry (0, l)
-    if (lane >= 1) Pb[ld + lane] += o.ddpose[1][lane]; // entry (1, l); (1, 0) lies below the diagonal
+    if (lane >= 1) Pb[p_lds(ld) + lane] += o.ddpose[1][lane];   // entry (1, l); (1, 0) lies below the diagonal
   }
   if (lane == 0) so[b].neff = o.neff;                  // what the covariance pass reads as this trajectory's bound
   if (b == 0 && lane < 8) queue[lane * RS_QSTRIDE] = 0u;
@@ -604,8 +604,8 @@ __global__ __launch_bounds__(64 * CAD_GW) void k_gather_cad(const double* __rest
     gv1[q] = 0.0;
     if (part == 0 && r < CU) {                         // (wave-uniform)
       const int Cr = Cs[r];
-      gv0[q] = Pb[(long)min(Cr, Cl0) * ld + max(Cr, Cl0)];
-      if (CU > 64) gv1[q] = Pb[(long)min(Cr, Cl1) * ld + max(Cr, Cl1)];
+      gv0[q] = Pb[p_index(ld, min(Cr, Cl0), max(Cr, Cl0))];
+      if (CU > 64) gv1[q] = Pb[p_index(ld, min(Cr, Cl1), max(Cr, Cl1))];
     }
   }
   // the factors at C_u for this part's ranks: lane = (position within a group of 8, rank); both loads of both groups of a
@@ -708,7 +708,7 @@ __global__ __launch_bounds__(64 * NW) void k_panels_cad(double* __restrict__ P, 
   double X[CU];
   if (live) {
 #pragma unroll
-    for (int a = 0; a < 3; ++a) X[a] = Pb[(long)min(a, ii) * ld + max(a, ii)];
+    for (int a = 0; a < 3; ++a) X[a] = Pb[p_index(ld, min(a, ii), max(a, ii))];
     // A landmark's two positions are two ADJACENT state indices c, c + 1.  For the state indices i <= c the entries
     // P(c, i), P(c + 1, i) are stored mirrored, as P_base(i, c), P_base(i, c + 1): side by side in row i.  Those column-
     // direction gathers touch a different cache line per lane (a CU takes about a cycle per line: 42 of this kernel's 92 us
@@ -718,16 +718,16 @@ __global__ __launch_bounds__(64 * NW) void k_panels_cad(double* __restrict__ P, 
     for (int a = 3; a < CU; a += 2) {
       const int c0 = o.C[a], c1 = o.C[a + 1];
 #ifdef CADP_SKIP_GATHER                                 /* diagnostic build: every gather reads the row direction */
-      X[a] = Pb[(long)min(c0, 2) * ld + ii];
-      X[a + 1] = Pb[(long)min(c1, 2) * ld + ii];
+      X[a] = Pb[p_index(ld, min(c0, 2), ii)];
+      X[a + 1] = Pb[p_index(ld, min(c1, 2), ii)];
 #else
-      if (c1 == c0 + 1 && i0 + 63 <= c0) {             // (uniform)
-        const v2d_u v = *reinterpret_cast<const v2d_u*>(Pb + (long)ii * ld + c0);
+      if (c1 == c0 + 1 && i0 + 63 <= c0 && (c1 & (PPW - 1)) != 0) {   // (uniform; the pair does not straddle two column panels)
+        const v2d_u v = *reinterpret_cast<const v2d_u*>(Pb + p_index(ld, ii, c0));
         X[a] = v.x;
         X[a + 1] = v.y;
       } else {
-        X[a] = Pb[(long)min(c0, ii) * ld + max(c0, ii)];
-        X[a + 1] = Pb[(long)min(c1, ii) * ld + max(c1, ii)];
+        X[a] = Pb[p_index(ld, min(c0, ii), max(c0, ii))];
+        X[a + 1] = Pb[p_index(ld, min(c1, ii), max(c1, ii))];
       }
 #endif
     }
@@ -829,8 +829,8 @@ __global__ __launch_bounds__(64 * NW) void k_panels_cad(double* __restrict__ P, 
       Vb[(long)k * ld + i] = 0.0;
       Wb[wm_index(ld16, k, i)] = 0.0;
     }
-    Pb[i] += d0;                                       // entry (0, i)
-    Pb[ld + i] += d1;                                  // entry (1, i)
+    Pb[p_col(ld, i)] += d0;                            // entry (0, i)
+    Pb[p_col(ld, i) + p_lds(ld)] += d1;                // entry (1, i)
     mu_out[(long)b * ld + i] = mu_in[(long)b * ld + i] + dm;
   }
   if (blockIdx.x == 0 && wave == 0) pose_epilogue<MCAP>(o, Pb, Vb, Wb, so, queue, b, ld, lane);
@@ -878,18 +878,18 @@ __global__ __launch_bounds__(256) void k_panels_cad_ks(double* __restrict__ P, d
   double XP[3], XL[2 * LP];
   if (live) {
 #pragma unroll
-    for (int k = 0; k < 3; ++k) XP[k] = Pb[(long)min(k, ii) * ld + max(k, ii)];
+    for (int k = 0; k < 3; ++k) XP[k] = Pb[p_index(ld, min(k, ii), max(k, ii))];
 #pragma unroll
     for (int pp = 0; pp < LP; ++pp) {
       const int a = 3 + 8 * pp + 2 * wave;
       const int c0 = o.C[min(a, CU)], c1 = o.C[min(a + 1, CU)];   // (C[CU] = 0: a position beyond the cadence's)
-      if (c1 == c0 + 1 && i0 + 63 <= c0) {             // (uniform) both mirrored: side by side in row i (see k_panels_cad)
-        const v2d_u v = *reinterpret_cast<const v2d_u*>(Pb + (long)ii * ld + c0);
+      if (c1 == c0 + 1 && i0 + 63 <= c0 && (c1 & (PPW - 1)) != 0) {   // (uniform) both mirrored: side by side in row i (see k_panels_cad)
+        const v2d_u v = *reinterpret_cast<const v2d_u*>(Pb + p_index(ld, ii, c0));
         XL[2 * pp] = v.x;
         XL[2 * pp + 1] = v.y;
       } else {
-        XL[2 * pp] = Pb[(long)min(c0, ii) * ld + max(c0, ii)];
-        XL[2 * pp + 1] = Pb[(long)min(c1, ii) * ld + max(c1, ii)];
+        XL[2 * pp] = Pb[p_index(ld, min(c0, ii), max(c0, ii))];
+        XL[2 * pp + 1] = Pb[p_index(ld, min(c1, ii), max(c1, ii))];
       }
     }
     const int cnt = G::rec_off(nsteps * MCAP) / 2;     // double2 units
@@ -999,8 +999,8 @@ __global__ __launch_bounds__(256) void k_panels_cad_ks(double* __restrict__ P, d
       Vb[(long)k * ld + i] = 0.0;
       Wb[wm_index(ld16, k, i)] = 0.0;
     }
-    Pb[i] += d0;                                       // entry (0, i)
-    Pb[ld + i] += d1;                                  // entry (1, i)
+    Pb[p_col(ld, i)] += d0;                            // entry (0, i)
+    Pb[p_col(ld, i) + p_lds(ld)] += d1;                // entry (1, i)
     mu_out[(long)b * ld + i] = mu_in[(long)b * ld + i] + dm;
   }
   if (blockIdx.x == 0 && wave == 0) pose_epilogue<MCAP>(o, Pb, Vb, Wb, so, queue, b, ld, lane);

@@ -16,6 +16,33 @@ constexpr int NKT = KTOT / 4;           // the same in MFMA k-tiles (v_mfma_f64_
 // to a whole k-tile (the step that is last so far zero-fills the pad ranks)
 __host__ __device__ constexpr int ranks_for(int mcap) { return 2 * mcap; }
 
+// ---- layout of one trajectory's P_base (round 4) ----
+// Row-major with row stride ld while ld <= 4096 (ld is then a power of two).  Beyond that the covariance is cut into
+// COLUMN PANELS of PPW = 4096 doubles: panel p holds the columns [4096 p, 4096 (p + 1)) of every row, row-major with a row
+// stride of exactly 4096 doubles (32 KB), panels ld x 4096 doubles apart (rows == ld there):
+//     index(i, j) = (j >> 12) * (ld * 4096) + i * min(ld, 4096) + (j & 4095)
+// -- one formula for both cases (j < ld <= 4096 leaves the panel term at zero).  Why: the sixteen 512-byte row segments of
+// a 16 x 64 tile of the covariance pass then lie 32 KB apart whatever the size of the state, the pitch the pass streams
+// best at (N = 2000, ld = 4096: 6.05 TB/s; with rows 128 KB apart at N = 8000, ld = 16064: 5.0 - 5.4 TB/s).  A 64-column
+// strip never straddles a panel (4096 is a multiple of 64), so a kernel that walks a row strip by strip only needs the
+// strip's column offset p_col(ld, j0) and the row stride p_lds(ld).  V, W and the mean keep the plain stride ld.
+constexpr int PPW = 4096;
+#ifdef P_ROWMAJOR_PROBE                                  /* diagnostic build: the plain row-major layout at every size (A/B timing) */
+__host__ __device__ __forceinline__ int p_lds(int ld) { return ld; }
+__host__ __device__ __forceinline__ long p_col(int ld, int j) { return j; }
+__host__ __device__ __forceinline__ unsigned p_col8(int ld, unsigned j) { return j * 8u; }
+#else
+__host__ __device__ __forceinline__ int p_lds(int ld) { return ld < PPW ? ld : PPW; }
+__host__ __device__ __forceinline__ long p_col(int ld, int j) { return (long)(j >> 12) * ((long)ld * PPW) + (j & (PPW - 1)); }
+// the same as a 32-bit byte offset (ekf_create bounds one covariance by 4 GiB)
+__host__ __device__ __forceinline__ unsigned p_col8(int ld, unsigned j) { return (j >> 12) * ((unsigned)ld * (unsigned)(PPW * 8)) + (j & (unsigned)(PPW - 1)) * 8u; }
+#endif
+__host__ __device__ __forceinline__ long p_index(int ld, int i, int j) { return p_col(ld, j) + (long)i * p_lds(ld); }
+// panels / doubles allocated per trajectory (every panel keeps all `rows` rows: downloads and the dense product get the
+// mirrored matrix in place)
+__host__ __device__ __forceinline__ int p_panels(int ld) { return ld <= PPW ? 1 : (ld + PPW - 1) / PPW; }
+__host__ __device__ __forceinline__ long p_alloc(int rows, int ld) { return ld <= PPW ? (long)rows * ld : (long)p_panels(ld) * rows * PPW; }
+
 constexpr int FLAG_PREDICT = 1;         // StepIn.flags
 constexpr int FLAG_UPDATE = 2;
 

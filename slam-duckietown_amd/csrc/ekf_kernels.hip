@@ -195,7 +195,7 @@ __device__ __forceinline__ void solve_body(SolveCore& L, const Fac& F, const dou
     gv[q] = 0.0;
     if (r < c) {                                       // (wave-uniform)
       const int Cr = __builtin_amdgcn_readlane(Cl, r);
-      gv[q] = Pb[(long)min(Cr, Cl) * ld + max(Cr, Cl)];                        // the upper triangle is authoritative
+      gv[q] = Pb[p_index(ld, min(Cr, Cl), max(Cr, Cl))];                       // the upper triangle is authoritative
     }
   }
   STAMP(o, 110);
@@ -706,9 +706,9 @@ __device__ __forceinline__ void panel_base_gather(const PanelIdx& t, const int* 
   for (int a = 0; a < CC; ++a) {
     const int row = Crow[a];
 #ifdef PANELS_SKIP_COLG                                 /* diagnostic build: no column-direction gathers */
-    X[a] = t.Pb[(long)min(row, t.i0) * t.ld + max(row, t.ii)];
+    X[a] = t.Pb[p_index(t.ld, min(row, t.i0), max(row, t.ii))];
 #else
-    X[a] = t.Pb[(long)min(row, t.ii) * t.ld + max(row, t.ii)];
+    X[a] = t.Pb[p_index(t.ld, min(row, t.ii), max(row, t.ii))];
 #endif
   }
 }
@@ -771,9 +771,9 @@ __device__ __forceinline__ void panels_finish(const PanelIdx& t, const SolveHead
   X[0] += d0;
   X[1] += d1;
   if (act) {
-    double* p0 = t.Pb + i;                             // entry (0, i)
+    double* p0 = t.Pb + p_col(ld, i);                  // entry (0, i)
     *p0 += d0;
-    if (i >= 1) p0[ld] += d1;                          // entry (1, i); (1, 0) lies below the diagonal
+    if (i >= 1) p0[p_lds(ld)] += d1;                   // entry (1, i); (1, 0) lies below the diagonal
   }
 #pragma unroll
   for (int a = 0; a < 3; ++a)
@@ -1071,9 +1071,9 @@ __device__ __forceinline__ void panels_mono(double* __restrict__ P, double* __re
     for (int a = 0; a < CC; ++a) {
       const int row = early ? __builtin_amdgcn_readlane(Cl, a) : o.C[a];
 #ifdef PANELS_SKIP_COLG                                 /* diagnostic build: no column-direction gathers */
-      X[a] = Pb[(long)min(row, i0) * ld + max(row, ii)];
+      X[a] = Pb[p_index(ld, min(row, i0), max(row, ii))];
 #else
-      X[a] = Pb[(long)min(row, ii) * ld + max(row, ii)];
+      X[a] = Pb[p_index(ld, min(row, ii), max(row, ii))];
 #endif
     }
   } else {
@@ -1252,9 +1252,9 @@ __device__ __forceinline__ void panels_mono(double* __restrict__ P, double* __re
   X[0] += d0;
   X[1] += d1;
   if (act) {
-    double* p0 = Pb + i;                               // entry (0, i)
+    double* p0 = Pb + p_col(ld, i);                    // entry (0, i)
     *p0 += d0;
-    if (i >= 1) p0[ld] += d1;                          // entry (1, i); (1, 0) lies below the diagonal
+    if (i >= 1) p0[p_lds(ld)] += d1;                   // entry (1, i); (1, 0) lies below the diagonal
   }
 #pragma unroll
   for (int a = 0; a < 3; ++a)
@@ -1635,10 +1635,11 @@ __global__ __launch_bounds__(256, 2) void k_flush(double* __restrict__ P, const 
   // store the compiler can count them, and waits for the tile it needs instead of draining the queue
   // (s_waitcnt vmcnt(0) would expose the previous tile's store latency and the W round trip every tile).
   double2 g[8];                                        // row-major registers of the tile in flight
-  const int jc = j0 + rc;                              // ld is a multiple of 64: the strip lies inside the row
+  const int lds = p_lds(ld);                           // row stride of P (ekf_device.h: column panels beyond ld = 4096)
+  double* Pj = Pb + p_col(ld, j0 + rc);                // this lane's two columns of row 0: the strip lies inside one panel
   auto gload = [&](int i0) {
 #pragma unroll
-    for (int q = 0; q < 8; ++q) g[q] = ld2<NT>(Pb + (long)(i0 + 2 * q + rr) * ld + jc);
+    for (int q = 0; q < 8; ++q) g[q] = ld2<NT>(Pj + (long)(i0 + 2 * q + rr) * lds);
   };
   gload(i_begin);
   const int i_last = i_begin + ((i_end - 1 - i_begin) & ~15);
@@ -1703,7 +1704,7 @@ __global__ __launch_bounds__(256, 2) void k_flush(double* __restrict__ P, const 
     for (int q = 0; q < 8; ++q) {
       const int row = i0 + 2 * q + rr;
       const double2 o = *reinterpret_cast<const double2*>(&T[(2 * q + rr) * FTS + rc]);
-      st2<NT>(Pb + (long)row * ld + jc, o);
+      st2<NT>(Pj + (long)row * lds, o);
     }
     WAVE_SYNC();
   }
@@ -1975,7 +1976,8 @@ __global__ __launch_bounds__(512, 2) void k_flush_rs(double* __restrict__ P, con
   auto cd_index = [&](int ct, int reg) { return ((ct & 1) ? cd_odd : cd_even) + 16 * (ct & ~1) + 256 * reg; };
   // rank k = wave + 8 i of a strip: k-tile 2 i + (wave >> 2), row wave & 3 of the fragment
   const int stage_base = ((wave >> 2) * 4 + lq) * 64 + (wave & 3) * 16 + li;
-  const unsigned loff = (unsigned)(rr * ld + rc) * 8u; // lane part of a tile address, bytes (rows 2q + rr, columns rc, rc + 1)
+  const unsigned pl8 = (unsigned)p_lds(ld) * 8u;       // bytes per row of P (ekf_device.h: column panels beyond ld = 4096)
+  const unsigned loff = (unsigned)rr * pl8 + (unsigned)rc * 8u;   // lane part of a tile address, bytes (rows 2q + rr, columns rc, rc + 1)
   const unsigned lane8 = (unsigned)lane * 8u;
 
   // next unit: own queue first, then the others (thread 0 only; -1 = every queue is empty).  While the own queue has
@@ -2053,8 +2055,8 @@ __global__ __launch_bounds__(512, 2) void k_flush_rs(double* __restrict__ P, con
     const double* Vb = V + (long)b * KTOT * ld;
     const double* Wb = W + (long)b * KTOT * ld;
     const __amdgpu_buffer_rsrc_t rsV = rs_rsrc(Vb), rsW = rs_rsrc(Wb);
-    const unsigned ld8 = (unsigned)ld * 8u;            // bytes per row
-    const unsigned prow = (unsigned)i0w * ld8;         // byte offset of this wave's first row inside the trajectory's P
+    const unsigned ld8 = (unsigned)ld * 8u;            // bytes per rank row of V
+    const unsigned prow = (unsigned)i0w * pl8;         // byte offset of this wave's first row inside the trajectory's P (panel 0)
     const double dd0 = dacc[4 * b], dd1 = dacc[4 * b + 1], dd2 = dacc[4 * b + 2];
 
     // Staging of a V strip: wave w moves the ranks w, w + 8, w + 16, ... (RPW of them) of the strip of step t (clamped
@@ -2063,9 +2065,19 @@ __global__ __launch_bounds__(512, 2) void k_flush_rs(double* __restrict__ P, con
     // address each, kept live across the whole tile loop).
     auto stage_load = [&](int t, auto i0_tag, auto cnt_tag, double* vs) {
       constexpr int I0 = decltype(i0_tag)::value, CNT = decltype(cnt_tag)::value;
+#ifdef RS_V_FIXED                                        /* diagnostic build: every strip stages the same 64 columns of V (cache-hot) */
+      const int j = 0 * t;
+#else
       const int j = j_last - 64 * min(t, S - 1);
+#endif
 #pragma unroll
+#ifdef RS_SKIP_V                                         /* diagnostic build (timing only): no V loads at all */
+      for (int i = 0; i < CNT; ++i) vs[i] = 1.0 + j;
+#elif defined(RS_V_STRIPMAJOR)                           /* diagnostic build (timing only): V read as if stored strip-major, [strip][rank][64] */
+      for (int i = 0; i < CNT; ++i) vs[i] = ldb8(rsV, lane8, (unsigned)(wave + 8 * (I0 + i)) * 512u + (unsigned)(j >> 6) * (unsigned)(KTOT * 512));
+#else
       for (int i = 0; i < CNT; ++i) vs[i] = ldb8(rsV, lane8, (unsigned)(wave + 8 * (I0 + i)) * ld8 + (unsigned)j * 8u);
+#endif
     };
     auto stage_store = [&](double* dst, auto i0_tag, auto cnt_tag, const double* vs) {
       constexpr int I0 = decltype(i0_tag)::value, CNT = decltype(cnt_tag)::value;
@@ -2100,7 +2112,9 @@ __global__ __launch_bounds__(512, 2) void k_flush_rs(double* __restrict__ P, con
     double2 g[8];                                      // row-major registers of the tile in flight
     // tile t of this wave; beyond its last tile the loads are pointed at 1 KB of the (read-only, cache resident)
     // SolveOut record instead: a select on the uniform base, offset and stride, no branch
-    auto tile_off = [&](int t) -> unsigned { return prow + (unsigned)(j_last - 64 * t) * 8u; };
+    auto tile_off = [&](int t) -> unsigned {           // (a 64-column strip lies inside one column panel)
+      return prow + p_col8(ld, (unsigned)(j_last - 64 * t));
+    };
     auto gload = [&](int t) {
 #ifdef RS_SKIP_PMEM                                     /* diagnostic build: the compute side alone */
       const bool ok = false;
@@ -2108,7 +2122,7 @@ __global__ __launch_bounds__(512, 2) void k_flush_rs(double* __restrict__ P, con
       const bool ok = t < Sw;
 #endif
       const __amdgpu_buffer_rsrc_t rs = rs_rsrc(ok ? (const void*)Pb : (const void*)so);
-      const unsigned off = ok ? tile_off(t) : 0u, ld8d = ok ? ld8 : 0u, loffd = ok ? loff : lane8 * 2u;
+      const unsigned off = ok ? tile_off(t) : 0u, ld8d = ok ? pl8 : 0u, loffd = ok ? loff : lane8 * 2u;
 #pragma unroll
       for (int q = 0; q < 8; ++q) g[q] = ldb16<NT>(rs, loffd, off + (unsigned)q * 2u * ld8d);
     };
@@ -2167,8 +2181,13 @@ __global__ __launch_bounds__(512, 2) void k_flush_rs(double* __restrict__ P, con
       // side operations in issue order: k-tile 0 issues only the loads of the strip (the result of tile t-1 is still
       // leaving the matrix pipe), the k-tiles [1, NKT - 1) share the rest evenly, the last k-tile only prefetches
       constexpr int NE = FIRST ? 0 : 4, NV = STAGE ? 1 : 0;
+#ifdef RS_EARLY_N3                                       /* the loads of tile t+2 right behind the image write of tile t+1 (their registers are free from there) */
+      constexpr int OVA = 0, OW0 = OVA + NV, OE1A = OW0 + NE, OE2A = OE1A + NE, OE1B = OE2A + NE, OE2B = OE1B + NE,
+                    OVB = OE2B + NE, ON1 = OVB + NV, ON3 = ON1 + 8, ON2 = ON3 + 8, OWB = ON2 + 16, NSIDE = OWB + NV;
+#else
       constexpr int OVA = 0, OW0 = OVA + NV, OE1A = OW0 + NE, OE2A = OE1A + NE, OE1B = OE2A + NE, OE2B = OE1B + NE,
                     OVB = OE2B + NE, ON1 = OVB + NV, ON2 = ON1 + 8, OWB = ON2 + 16, ON3 = OWB + NV, NSIDE = ON3 + 8;
+#endif
       const uint4v_t rsP = rs_words(Pb);
       const unsigned off_prev = tile_off(t - 1);       // tile t-1 (FIRST: unused)
 #ifdef RS_SKIP_PMEM
@@ -2177,7 +2196,7 @@ __global__ __launch_bounds__(512, 2) void k_flush_rs(double* __restrict__ P, con
       const bool ok2 = t + 2 < Sw;
 #endif
       const __amdgpu_buffer_rsrc_t rs2 = rs_rsrc(ok2 ? (const void*)Pb : (const void*)so);
-      const unsigned off2 = ok2 ? tile_off(t + 2) : 0u, ld8d = ok2 ? ld8 : 0u, loffd = ok2 ? loff : lane8 * 2u;
+      const unsigned off2 = ok2 ? tile_off(t + 2) : 0u, ld8d = ok2 ? pl8 : 0u, loffd = ok2 ? loff : lane8 * 2u;
       double* vnext = vbuf[(t + 1) & 1];
       auto side = [&](int o) {
         if constexpr (STAGE) {
@@ -2197,20 +2216,20 @@ __global__ __launch_bounds__(512, 2) void k_flush_rs(double* __restrict__ P, con
             if (ct == 3) RS_CBAR();
           }
           if (o >= OE1A && o < OE2A) r[o - OE1A] = *reinterpret_cast<const double2*>(&T[rm_base + 128 * (o - OE1A)]);
-          if (o >= OE2A && o < OE1B) stb16<NT>(rsP, loff, off_prev + (unsigned)(o - OE2A) * 2u * ld8, r[o - OE2A]);
+          if (o >= OE2A && o < OE1B) stb16<NT>(rsP, loff, off_prev + (unsigned)(o - OE2A) * 2u * pl8, r[o - OE2A]);
           if (o >= OE1B && o < OE2B) r[o - OE1B] = *reinterpret_cast<const double2*>(&T[rm_base + 128 * (o - OE1B + 4)]);
-          if (o >= OE2B && o < OVB) stb16<NT>(rsP, loff, off_prev + (unsigned)(o - OE2B + 4) * 2u * ld8, r[o - OE2B]);
+          if (o >= OE2B && o < OVB) stb16<NT>(rsP, loff, off_prev + (unsigned)(o - OE2B + 4) * 2u * pl8, r[o - OE2B]);
         }
-        if (o >= ON1 && o < ON2) {                     // tile t+1: row-major registers -> image
+        if (o >= ON1 && o < ON1 + 8) {                 // tile t+1: row-major registers -> image
           const int q = o - ON1;
           if (q == 0) RS_CBAR();
           *reinterpret_cast<double2*>(&T[rm_base + 128 * q]) = g[q];
           if (q == 7) RS_CBAR();
-        } else if (o >= ON2 && o < OWB) {              // ... -> C/D layout
+        } else if (o >= ON2 && o < ON2 + 16) {         // ... -> C/D layout
           const int e = o - ON2;
           accn[e >> 2][e & 3] = T[cd_index(e >> 2, e & 3)];
           if (e == 15) RS_CBAR();
-        } else if (o >= ON3 && o < NSIDE) {            // tile t+2: HBM -> row-major registers
+        } else if (o >= ON3 && o < ON3 + 8) {          // tile t+2: HBM -> row-major registers
           const int q = o - ON3;
           g[q] = ldb16<NT>(rs2, loffd, off2 + (unsigned)q * 2u * ld8d);
         }
@@ -2264,7 +2283,7 @@ __global__ __launch_bounds__(512, 2) void k_flush_rs(double* __restrict__ P, con
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
         const double2 o = *reinterpret_cast<const double2*>(&T[rm_base + 128 * q]);
-        stb16<NT>(rsP, loff, off_last + (unsigned)q * 2u * ld8, o);
+        stb16<NT>(rsP, loff, off_last + (unsigned)q * 2u * pl8, o);
       }
       RS_CBAR();
     };
@@ -2325,13 +2344,15 @@ __global__ __launch_bounds__(256) void k_predict_rc(double* __restrict__ P,
   if (j >= 3) {
     mu_out[(long)b * ld + j] = mu_in[(long)b * ld + j];     // k_solve wrote the pose entries
     if (j >= so[b].neff) return;                            // P(2, j) = 0 beyond the active bound
-    const double r2 = Pb[2 * (long)ld + j];                 // rows 0,1 of the upper triangle carry the mirrored
-    Pb[j] += g0 * r2;                                       // column op too
-    Pb[(long)ld + j] += g1 * r2;
+    double* pj = Pb + p_col(ld, j);                         // entry (0, j)
+    const int lds = p_lds(ld);
+    const double r2 = pj[2 * (long)lds];                    // rows 0,1 of the upper triangle carry the mirrored
+    pj[0] += g0 * r2;                                       // column op too
+    pj[lds] += g1 * r2;
   } else if (j == 0) {
     double X[3][3], Y[3][3];
     for (int r = 0; r < 3; ++r)
-      for (int c = 0; c < 3; ++c) X[r][c] = Pb[(long)min(r, c) * ld + max(r, c)];
+      for (int c = 0; c < 3; ++c) X[r][c] = Pb[p_index(ld, min(r, c), max(r, c))];
     for (int c = 0; c < 3; ++c) {
       X[0][c] += g0 * X[2][c];
       X[1][c] += g1 * X[2][c];
@@ -2343,7 +2364,7 @@ __global__ __launch_bounds__(256) void k_predict_rc(double* __restrict__ P,
       Y[r][r] += so[b].rd[r];
     }
     for (int r = 0; r < 3; ++r)
-      for (int c = r; c < 3; ++c) Pb[(long)r * ld + c] = Y[r][c];
+      for (int c = r; c < 3; ++c) Pb[p_index(ld, r, c)] = Y[r][c];
   }
 }
 
@@ -2362,12 +2383,12 @@ __global__ __launch_bounds__(256) void k_mirror(double* __restrict__ P, const in
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   for (int r = ty; r < 64; r += 4) {                    // source tile (rows tj, cols ti)
     const int row = tj * 64 + r, col = ti * 64 + tx;
-    T[r][tx] = (row < n && col < n) ? Pb[(long)row * ld + col] : 0.0;
+    T[r][tx] = (row < n && col < n) ? Pb[p_index(ld, row, col)] : 0.0;
   }
   __syncthreads();
   for (int r = ty; r < 64; r += 4) {
     const int row = ti * 64 + r, col = tj * 64 + tx;
-    if (row < n && col < n && col < row) Pb[(long)row * ld + col] = T[tx][r];
+    if (row < n && col < n && col < row) Pb[p_index(ld, row, col)] = T[tx][r];
   }
 }
 
@@ -2482,8 +2503,8 @@ __global__ __launch_bounds__(64) void k_associate(const DetIn* __restrict__ det,
   const int ld16 = ld >> 4;
   for (long e = lane; e < (long)n_new * dn; e += 64) {
     const int r = (int)(e / dn), q = n_old + (int)(e - (long)r * dn);
-    Pb[(long)r * ld + q] = (r == q) ? cfg.init_var : 0.0;
-    if (r < n_old) Pb[(long)q * ld + r] = 0.0;
+    Pb[p_index(ld, r, q)] = (r == q) ? cfg.init_var : 0.0;
+    if (r < n_old) Pb[p_index(ld, q, r)] = 0.0;
   }
   for (int e = lane; e < pending_k * dn; e += 64) {
     const int k = e / dn, q = n_old + (e - k * dn);
@@ -2522,8 +2543,8 @@ __global__ __launch_bounds__(256) void k_add_landmarks(double* __restrict__ Pb, 
   const long total = (long)n_new * k2;
   for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
     const int r = (int)(e / k2), q = n_old + (int)(e - (long)r * k2);
-    Pb[(long)r * ld + q] = (r == q) ? var : 0.0;   // new column block (incl. the new corner)
-    if (r < n_old) Pb[(long)q * ld + r] = 0.0;     // new row block
+    Pb[p_index(ld, r, q)] = (r == q) ? var : 0.0;  // new column block (incl. the new corner)
+    if (r < n_old) Pb[p_index(ld, q, r)] = 0.0;    // new row block
     if (r == 0) mub[q] = xy[q - n_old];
   }
 }
@@ -2533,7 +2554,7 @@ __global__ __launch_bounds__(256) void k_fill_diag(double* __restrict__ Pb, int 
   const long total = (long)n * n;
   for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
     const int r = (int)(e / n), c = (int)(e - (long)r * n);
-    Pb[(long)r * ld + c] = (r == c) ? diag[r] : 0.0;
+    Pb[p_index(ld, r, c)] = (r == c) ? diag[r] : 0.0;
   }
 }
 

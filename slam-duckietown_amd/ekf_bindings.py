@@ -33,7 +33,7 @@ EKF_MMAX = 16
 EKF_FLAG_NONFINITE = 1
 EKF_FLAG_ASSOC = 2
 EKF_FLAG_INTERNAL = 4             # a bounded wait of a single-launch step timed out: sync()/state()/mean() raise EkfError
-EKF_N_MAX_LIMIT = 23167           # largest n_max (one covariance stays below 4 GiB: 32-bit byte offsets in the kernels)
+EKF_N_MAX_LIMIT = 21823           # largest n_max (one covariance stays below 4 GiB: 32-bit byte offsets in the kernels)
 EKF_DMAX = 64
 EKF_TAGMAX = 1024
 

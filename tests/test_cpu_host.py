@@ -304,15 +304,17 @@ def test_store_hazard_guard_is_in_the_shipped_machine_code(sd):
 
 def test_create_rejects_sizes_beyond_the_32_bit_offsets(sd):
     """The kernels address one covariance with unsigned 32-bit byte offsets: ekf_create refuses an n_max whose padded
-    rows x ld x 8 bytes reach 4 GiB, before it looks for a device (so this runs without one)."""
+    allocation (rows x column panels of 4096 doubles) reaches 4 GiB, before it looks for a device (so this runs
+    without one)."""
     import ctypes
     from slam_duckietown_amd import ekf_bindings as eb
     lib = sd.load_library()
     text = open(os.path.join(ROOT, "include", "ekfslam_hip.h")).read()
     limit = int(re.search(r"#define EKF_N_MAX_LIMIT (\d+)", text).group(1))
     assert limit == eb.EKF_N_MAX_LIMIT and limit % 2 == 1
+    alloc = lambda rows: rows * (-(-rows // 4096)) * 4096 * 8   # rows x column panels of 4096 doubles (ekf_device.h)
     rows = (limit + 63) // 64 * 64
-    assert rows * rows * 8 < 2 ** 32 <= (rows + 64) ** 2 * 8
+    assert alloc(rows) < 2 ** 32 <= alloc(rows + 64)
     h = ctypes.c_void_p()
     for n_max in (limit + 2, 3 + 2 * 12000, 3 + 2 * 50000):
         assert lib.ekf_create(0, n_max, 1, None, ctypes.byref(h)) == -1          # EKF_ERR_ARG
@@ -336,7 +338,7 @@ def test_row_slab_pass_equal_shares_cover_every_strip_once(sd):
     lib = sd.load_library()
     lib.ekf_debug_pass_shares.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_int)]
     for batch, n, wgs in [(1, 16003, 256), (2, 16003, 256), (1, 16003, 240), (3, 12003, 256), (7, 16003, 256),
-                          (1, 23167, 256), (3, 1403, 8), (3, 1403, 5), (1, 4003, 8)]:
+                          (1, 21823, 256), (3, 1403, 8), (3, 1403, 5), (1, 4003, 8)]:
         out = np.zeros(wgs * 16 * 4, dtype=np.int32)
         longest = lib.ekf_debug_pass_shares(batch, n, wgs, out.ctypes.data_as(ctypes.POINTER(ctypes.c_int)))
         assert 1 <= longest <= 16, (batch, n, wgs, longest)

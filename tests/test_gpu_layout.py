@@ -1,0 +1,302 @@
+"""GPU parity of the COLUMN-PANEL layout of the covariance (round 4; slam-duckietown_amd/csrc/ekf_device.h):
+
+beyond ld = 4096 the device keeps P in column panels of 4096 doubles (row stride 32 KB whatever the size of the state),
+so every kernel that touches P -- gathers, in-place prediction rows, both forms of the covariance pass, mirror,
+augmentation, association, uploads / downloads, the dense product's staging -- addresses it through one helper.  The
+cases here sit ON the panel boundary: n = 4203 (two panels), landmarks whose two state indices are (4093, 4094),
+(4095, 4096) -- the pair the 16-byte mirrored gather must NOT take in one load -- and (4097, 4098), states that grow
+across column 4096, blocks and dense products that straddle it.  Everything is compared with the oracle
+(reference: src/replay_no_ros.py:341-360, :420-430, :436-480).
+"""
+import ctypes as C
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+
+from oracle import ekf_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+REL_TOL = 1e-6
+TIGHT = 1e-9
+PPW = 4096                                             # panel width (doubles)
+N_TWO = 2100                                           # n = 4203: panel 0 full, panel 1 holds 107 columns
+EDGE = [2045, 2046, 2047]                              # state indices (4093, 4094), (4095, 4096), (4097, 4098)
+
+
+@pytest.fixture(scope="module")
+def sd():
+    import slam_duckietown_amd as sd
+    sd.load_library()
+    return sd
+
+
+def cadences(sd, f):
+    lib = sd.load_library()
+    lib.ekf_debug_cadences.argtypes = [C.c_void_p, C.POINTER(C.c_long), C.POINTER(C.c_long)]
+    a, b = C.c_long(), C.c_long()
+    assert lib.ekf_debug_cadences(f._h, C.byref(a), C.byref(b)) == 0
+    return a.value, b.value
+
+
+def close(a, b, tol=TIGHT):
+    r = orc.rel_fro(a, b)
+    assert r < REL_TOL, f"rel Frobenius {r:.3e} exceeds the 1e-6 bar"
+    assert r < tol, f"rel Frobenius {r:.3e} exceeds the expected {tol:g}"
+
+
+def dense_start(n, seed, rank=6):
+    rng = np.random.default_rng(seed)
+    A = rng.normal(size=(n, rank)) * 0.3
+    P = A @ A.T
+    P[np.arange(n), np.arange(n)] += rng.uniform(0.5, 2.0, n)
+    return P
+
+
+def edge_stream(N, steps, m, seed):
+    """The synthetic stream of SURVEY 8(d) with its observations moved onto the panel boundary: every step sees the
+    three landmarks around column 4096 plus landmarks from both panels (the measurements belong to the landmarks
+    actually observed: they are re-generated from the stream's own truth through the oracle's helper)."""
+    s = list(orc.synthetic_stream(N, steps, m, seed))
+    rng = np.random.default_rng(1000 + seed)
+    mean0 = s[0]
+    idx = np.zeros((steps, m), dtype=np.int32)
+    zr, zb = np.zeros((steps, m)), np.zeros((steps, m))
+    pose = np.zeros(3)
+    for k in range(steps):
+        others = rng.choice(np.setdiff1d(np.arange(N), EDGE), size=m - 3, replace=False)
+        ids = np.concatenate([rng.permutation(EDGE), others]).astype(np.int32)
+        rng.shuffle(ids)
+        idx[k] = ids
+        # measurements: range / bearing of the landmark's initial mean seen from a slowly moving pose + noise -- any
+        # consistent values do, parity is against the oracle on the same numbers
+        pose = pose + np.array([0.004 * np.cos(pose[2]), 0.004 * np.sin(pose[2]), 0.02])
+        lx, ly = mean0[3 + 2 * ids], mean0[4 + 2 * ids]
+        dx, dy = lx - pose[0], ly - pose[1]
+        zr[k] = np.hypot(dx, dy) + rng.normal(0, 0.01, m)
+        zb[k] = np.arctan2(dy, dx) - pose[2] + rng.normal(0, 0.01, m)
+    s[4], s[5], s[6] = idx, zr, zb
+    return tuple(s)
+
+
+def oracle_run(stream, P0, steps=None):
+    cfg = orc.EkfConfig()
+    om, oP = stream[0].copy(), P0.copy()
+    for k in range(steps if steps is not None else len(stream[2])):
+        om, oP = orc.ekf_step_structured(om, oP, stream[2][k], stream[3][k], stream[4][k], stream[5][k], stream[6][k], cfg)
+    return om, oP
+
+
+def test_upload_download_roundtrip_across_the_panel_boundary(sd):
+    """What is uploaded comes back bit for bit (the upper triangle is authoritative), whole and in blocks that
+    straddle column 4096; two trajectories, so that the per-trajectory stride of the panelled allocation is used."""
+    n = 3 + 2 * N_TWO
+    rng = np.random.default_rng(3)
+    with sd.EkfSlam(n, batch=2) as f:
+        mats = []
+        for b in range(2):
+            A = rng.normal(size=(n, n))
+            S = np.triu(A) + np.triu(A, 1).T
+            mats.append(S)
+            f.set_state(rng.normal(size=n), S, b)
+        for b in range(2):
+            mu, P = f.state(b)
+            assert np.array_equal(P, mats[b])
+            for r0, c0, rows, cols in [(0, 0, 3, 3), (4090, 4090, 12, 12), (10, 4000, 5, 203), (4100, 0, 50, 4203),
+                                       (4095, 4095, 2, 2), (0, 4096, 4203, 1)]:
+                blk = f.covariance_block(r0, c0, rows, cols, b)
+                assert np.array_equal(blk, mats[b][r0:r0 + rows, c0:c0 + cols]), (b, r0, c0)
+
+
+@pytest.mark.parametrize("path", ["per_step", "fused", "per_step_rs", "fused_strips"])
+def test_steps_on_the_panel_boundary_against_the_oracle(sd, path):
+    """N = 2100 (n = 4203, two column panels), 8 observations per step of which three sit on the panel boundary, dense
+    start, two trajectories: the per-step kernels (k_solve / k_panels or the single-launch step) and the fused cadence
+    (k_solve_cad / k_panels_cad), each with the column-strip pass (k_flush) and the row-slab pass (k_flush_rs)."""
+    N, steps, m, B = N_TWO, 11, 8, 2
+    n = 3 + 2 * N
+    streams = [edge_stream(N, steps, m, 20 + t) for t in range(B)]
+    starts = [dense_start(n, 50 + t) for t in range(B)]
+    with sd.EkfSlam(n, batch=B) as f:
+        f.set_option("active_bound", 0)
+        f.set_option("pass_kernel", 2 if path in ("per_step_rs", "fused") else 0)
+        for b in range(B):
+            f.set_state(streams[b][0], starts[b], b)
+        args = [np.stack([s[i] for s in streams], 1) for i in (2, 3, 4, 5, 6)]
+        if path.startswith("fused"):
+            f.run_stream(*args)
+            cad, covered = cadences(sd, f)
+            assert cad >= 2 and covered >= 10
+        else:
+            for k in range(steps):
+                f.step([s[2][k] for s in streams], [s[3][k] for s in streams], [s[4][k] for s in streams],
+                       [s[5][k] for s in streams], [s[6][k] for s in streams])
+        for b in range(B):
+            mu, P = f.state(b)
+            assert f.flags(b) == 0
+            assert np.array_equal(P, P.T)
+            om, oP = oracle_run(streams[b], starts[b])
+            close(mu, om)
+            close(P, oP)
+            close(P[:, PPW - 2:PPW + 3], oP[:, PPW - 2:PPW + 3])      # the columns on either side of the boundary
+            close(P[PPW - 2:PPW + 3, :], oP[PPW - 2:PPW + 3, :])
+
+
+def test_both_passes_agree_bit_for_bit_on_two_panels(sd):
+    """k_flush and k_flush_rs on a panelled covariance: the same update bit for bit, 16 / 48 / 80 pending ranks, both
+    cache policies (as tests/test_gpu_parity.py::test_row_slab_pass_is_bit_identical does below 4096)."""
+    N, steps, m, B = N_TWO, 11, 8, 2
+    n = 3 + 2 * N
+    streams = [edge_stream(N, steps, m, 30 + t) for t in range(B)]
+    starts = [dense_start(n, 60 + t) for t in range(B)]
+    out = {}
+    for kernel in (0, 2):
+        for limit, streaming in ((16, 1), (48, 0), (80, 1)):
+            with sd.EkfSlam(n, batch=B) as f:
+                f.set_option("pass_kernel", kernel)
+                f.set_option("rank_limit", limit)
+                f.set_option("pass_streaming", streaming)
+                f.set_option("active_bound", 0)
+                for b, s in enumerate(streams):
+                    f.set_state(s[0], starts[b], b)
+                for k in range(steps):
+                    f.step([s[2][k] for s in streams], [s[3][k] for s in streams], [s[4][k] for s in streams],
+                           [s[5][k] for s in streams], [s[6][k] for s in streams])
+                out[kernel, limit] = [f.state(b) for b in range(B)]
+    for limit in (16, 48, 80):
+        for b in range(B):
+            assert np.array_equal(out[0, limit][b][0], out[2, limit][b][0])
+            assert np.array_equal(out[0, limit][b][1], out[2, limit][b][1]), (limit, b)
+    om, oP = oracle_run(streams[1], starts[1])
+    close(out[2, 80][1][0], om)
+    close(out[2, 80][1][1], oP)
+
+
+def test_state_growing_across_the_panel_boundary(sd):
+    """Augmentation (src/replay_no_ros.py:341-360) across column 4096, by `add_landmarks` (k_add_landmarks) and by the
+    device-side association (k_associate): the state grows from n = 4089 to 4103 in steps that straddle the boundary,
+    with steps in between, against the oracle's zero-padded growth."""
+    N0, N1 = 2043, 2050
+    n0, n1 = 3 + 2 * N0, 3 + 2 * N1
+    cfg = orc.EkfConfig()
+    rng = np.random.default_rng(8)
+    mean0 = np.concatenate([[0.0, 0.0, 0.0], rng.uniform(-1.0, 1.0, 2 * N0)])
+    P0 = dense_start(n0, 77)
+    new_xy = rng.uniform(-1.0, 1.0, (N1 - N0, 2))
+
+    def grow(mu, P, xy):
+        k = len(xy)
+        n = len(mu)
+        mu2 = np.concatenate([mu, xy.reshape(-1)])
+        P2 = np.zeros((n + 2 * k, n + 2 * k))
+        P2[:n, :n] = P
+        P2[np.arange(n, n + 2 * k), np.arange(n, n + 2 * k)] = cfg.landmark_init_var
+        return mu2, P2
+
+    def obs_of(mu, ids):
+        dx, dy = mu[3 + 2 * ids] - mu[0], mu[4 + 2 * ids] - mu[1]
+        return np.hypot(dx, dy) + 0.01, np.arctan2(dy, dx) - mu[2] + 0.005
+
+    with sd.EkfSlam(n1) as f:
+        f.set_state(mean0, P0)
+        om, oP = mean0.copy(), P0.copy()
+        # 1) three landmarks: n 4089 -> 4095 (just below the boundary), a step on old and new ones
+        f.add_landmarks(new_xy[:3])
+        om, oP = grow(om, oP, new_xy[:3])
+        ids = np.array([5, N0 + 2, 1000, N0], dtype=np.int32)
+        zr, zb = obs_of(om, ids)
+        f.step(0.004, 0.02, ids, zr, zb)
+        om, oP = orc.ekf_step_structured(om, oP, 0.004, 0.02, ids, zr, zb, cfg)
+        # 2) two more with ranks pending: n 4095 -> 4099, the first new pair is (4095, 4096)
+        f.add_landmarks(new_xy[3:5])
+        om, oP = grow(om, oP, new_xy[3:5])
+        ids = np.array([N0 + 3, N0 + 4, 7, N0 + 1], dtype=np.int32)
+        zr, zb = obs_of(om, ids)
+        f.step(0.004, 0.005, ids, zr, zb)
+        om, oP = orc.ekf_step_structured(om, oP, 0.004, 0.005, ids, zr, zb, cfg)
+        mu, P = f.state()
+        assert f.flags() == 0 and len(mu) == 3 + 2 * (N0 + 5)
+        close(mu, om)
+        close(P, oP)
+        assert np.array_equal(P, P.T)
+        # 3) the last two through the device-side association (tag ids = landmark numbers of a fresh table)
+        # The device's tag table holds ids in [0, 1024) -- fewer than this map has landmarks -- so only the two known
+        # landmarks of this window get a real id; every other landmark shares a filler id nobody detects (the C entry
+        # point takes "tag of landmark i" and lets the last duplicate win).
+        tags = [N0 + 5, 12, N0 + 6, N0 + 3]             # landmark numbers, in detection order; N0+5, N0+6 are new
+        tag_id = {j: 900 + i for i, j in enumerate(tags)}
+        arr = np.full(N0 + 5, 1023, dtype=np.int32)
+        arr[12], arr[N0 + 3] = tag_id[12], tag_id[N0 + 3]
+        lib = sd.load_library()
+        assert lib.ekf_upload_tag_index(f._h, 0, arr.ctypes.data_as(C.POINTER(C.c_int)), N0 + 5) == 0
+        ranges = np.array([0.7, 0.9, 1.1, 0.8])
+        bearings = np.array([0.3, -0.4, 0.1, 0.6])
+        win = [(0.0, [SimpleNamespace(tag_id=tag_id[j], pose_R=np.eye(3), pose_err=0.0,
+                                      pose_t=np.array([[-r * np.sin(bb)], [0.0], [r * np.cos(bb)]]))
+                      for j, r, bb in zip(tags, ranges, bearings)])]
+        f.step_detections(0.004, 0.02, win)
+        th = om[2]
+        xy = np.array([[om[0] + r * np.cos(b + th), om[1] + r * np.sin(b + th)] for r, b in zip(ranges[[0, 2]], bearings[[0, 2]])])
+        om, oP = grow(om, oP, xy)
+        ids = np.array(tags, dtype=np.int32)
+        # (range / bearing as the front end forms them from the averaged pose_t, src/replay_no_ros.py:321-330)
+        xr, yr = ranges * np.cos(bearings), ranges * np.sin(bearings)
+        om, oP = orc.ekf_step_structured(om, oP, 0.004, 0.02, ids, np.sqrt(xr ** 2 + yr ** 2), np.arctan2(yr, xr), cfg)
+        mu, P = f.state()
+        assert f.flags() == 0 and len(mu) == n1
+        ti = f.tag_index()
+        assert ti[tag_id[N0 + 5]] == N0 + 5 and ti[tag_id[N0 + 6]] == N0 + 6
+        close(mu, om)
+        close(P, oP)
+
+
+def test_predict_dense_on_two_panels(sd):
+    """`ekf_predict_dense` with the covariance in column panels (staged through a row-major copy) against NumPy dgemm
+    (src/replay_no_ros.py:430 with a general F), then a structured step on the result."""
+    n = 3 + 2 * N_TWO
+    rng = np.random.default_rng(5)
+    P0 = dense_start(n, 11)
+    F = np.eye(n) + rng.normal(size=(n, n)) * (0.1 / np.sqrt(n))
+    Nq = rng.normal(size=(n, 8)) * 0.05
+    Q = Nq @ Nq.T + np.diag(rng.uniform(0.01, 0.1, n))
+    s = edge_stream(N_TWO, 1, 8, 70)
+    with sd.EkfSlam(n) as f:
+        f.set_state(s[0], P0)
+        f.predict_dense(F, Q)
+        P = f.covariance()
+        ref = F @ P0 @ F.T + Q
+        close(P, ref, 1e-12)
+        f.step(s[2][0], s[3][0], s[4][0], s[5][0], s[6][0])
+        mu, P = f.state()
+    ref = np.triu(ref) + np.triu(ref, 1).T             # (the device keeps the upper triangle)
+    om, oP = orc.ekf_step_structured(s[0].copy(), ref, s[2][0], s[3][0], s[4][0], s[5][0], s[6][0], orc.EkfConfig())
+    close(mu, om)
+    close(P, oP)
+
+
+def test_prediction_only_steps_and_block_diagonal_start_on_two_panels(sd):
+    """k_predict_rc (nothing observed, nothing pending: rows 0, 1 only), k_fill_diag and the active bound on a
+    panelled covariance: a block-diagonal start, observations that reach across the boundary only late."""
+    N, m = N_TWO, 8
+    s = edge_stream(N, 6, m, 80)
+    n = len(s[0])
+    cfg = orc.EkfConfig()
+    with sd.EkfSlam(n) as f:
+        f.set_state_diag(s[0], s[1])
+        om, oP = s[0].copy(), np.diag(s[1])
+        for k in range(3):                             # predictions only
+            f.predict(s[2][k], s[3][k])
+            om, oP = orc.ekf_step_structured(om, oP, s[2][k], s[3][k], np.zeros(0, dtype=np.int32), np.zeros(0), np.zeros(0), cfg)
+        low = np.array([3, 900, 11, 512], dtype=np.int32)            # inside panel 0: the bound stays below 4096
+        dx, dy = om[3 + 2 * low] - om[0], om[4 + 2 * low] - om[1]
+        zr, zb = np.hypot(dx, dy), np.arctan2(dy, dx) - om[2]
+        f.step(s[2][3], s[3][3], low, zr, zb)
+        om, oP = orc.ekf_step_structured(om, oP, s[2][3], s[3][3], low, zr, zb, cfg)
+        for k in (4, 5):                               # now across the boundary
+            f.step(s[2][k], s[3][k], s[4][k], s[5][k], s[6][k])
+            om, oP = orc.ekf_step_structured(om, oP, s[2][k], s[3][k], s[4][k], s[5][k], s[6][k], cfg)
+        mu, P = f.state()
+        assert f.flags() == 0
+        close(mu, om)
+        close(P, oP)
