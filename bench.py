@@ -13,12 +13,19 @@ stream) are resident in HBM before the timed region.  torch is used only for the
 barrier / max-reduce (gloo); the product path is NumPy + ctypes -> HIP.
 
 The JSON line also carries
-  roofline      the covariance pass kernel: algorithmic bytes per launch (B * 16 n^2) / average launch
-                duration from HIP events on the kernel's own stream (a separate instrumented leg of K
-                steps so that event records do not perturb `value`)
+  roofline      the covariance pass kernel: algorithmic bytes per launch (B * 8 n (n + 1): one read + one
+                write of the stored upper triangle) / average launch duration from HIP event pairs on the
+                kernel's own stream around every launch of the pass INSIDE the timed region
   cpu_baseline  the oracle's reference-shaped dense NumPy step timed on this box's host cores (rank 0,
-                N = 1 only, a bounded sample)
-  single_trajectory  BASELINE config 3 (B = 1) steps/s, rank 0, N = 1 only.
+                N = 1 only, a bounded sample) at N = 2000, with N = 500, N = 20 (500 steps) and N = 12 under
+                `by_config`
+  single_trajectory  BASELINE config 3 (B = 1) steps/s; config1 / config2: N = 20 x 1 (500 steps), N = 500 x 1
+  online_step   the host-driven call surface: one `EkfSlam.step` per call (indices not known in advance,
+                no fused cadence), N = 2000 x 32 and x 1
+  drop_in       `EKF_pose_estimation` per call INCLUDING its 8 n^2-byte download (the reference's loop,
+                src/replay_no_ros.py:229-237), N = 12 (the reference's real map, :26), 500, 2000: ms per call
+  sclk_mhz      shader clock sampled during the headline's timed region (attributes box-to-box variance)
+  (rank 0, N = 1 only, except sclk_mhz and rank_dt_ms).
 """
 from __future__ import annotations
 
@@ -48,7 +55,7 @@ def make_streams(sd_syn, traj_ids, n_landmarks, steps, m):
     return streams, lin, ang, idx, zr, zb
 
 
-def time_filter(sd, sd_syn, shard, grp, device, traj_ids, n_landmarks, m, steps, warmup, profile_leg=True, options=()):
+def time_filter(sd, sd_syn, shard, grp, device, traj_ids, n_landmarks, m, steps, warmup, profile_leg=True, options=(), clock=None):
     """Returns (max-over-ranks seconds for `steps` steps, pass_ms_total, pass_launches, device_ms).
     The timed region is sharding.timed_region (device sync + barrier on both sides, max over ranks): the function
     the world_size-2 gloo test covers."""
@@ -75,7 +82,11 @@ def time_filter(sd, sd_syn, shard, grp, device, traj_ids, n_landmarks, m, steps,
         f.flush()                     # any covariance pass still pending belongs to the timed steps
         dev["ms"] = f.timer_end()     # HIP events on the handle's stream (synchronises it)
 
+    if clock is not None:
+        clock.start()                                  # the shader clock, sampled while the timed region runs
     dt = shard.timed_region(grp, run, f.sync, time.perf_counter)
+    if clock is not None:
+        clock.stop()
     dev_ms = dev["ms"]
     pass_ms, launches = 0.0, 0
     if profile_leg:
@@ -90,9 +101,92 @@ def time_filter(sd, sd_syn, shard, grp, device, traj_ids, n_landmarks, m, steps,
 
 
 def kernel_source_sha():
+    """Hash of everything the pass's launch shape and code depend on: all of csrc/*.hip and csrc/*.h (the kernel
+    lives in ekf_kernels.hip, its choice and launch shape in ekf_api.hip / ekf_cadence.hip, the layout in ekf_device.h)."""
+    import glob
     import hashlib
-    src = os.path.join(ROOT, "slam-duckietown_amd", "csrc", "ekf_kernels.hip")
-    return hashlib.sha256(open(src, "rb").read()).hexdigest()[:16]
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "slam-duckietown_amd", "csrc")
+    for path in sorted(glob.glob(os.path.join(d, "*.hip")) + glob.glob(os.path.join(d, "*.h"))):
+        h.update(os.path.basename(path).encode())
+        h.update(open(path, "rb").read())
+    return h.hexdigest()[:16]
+
+
+class ClockSampler:
+    """Shader clock (MHz) of the HIP device during a timed region, sampled from a host thread through librocm_smi64
+    (ctypes; the device is matched by PCI bus id).  Measurement aid only: every failure degrades to `None`."""
+
+    def __init__(self, device=0, period_s=0.002):
+        import ctypes as C
+        self.samples, self._stop, self._thread, self._ok = [], False, None, False
+        self.period_s = period_s
+        try:
+            smi = C.CDLL("librocm_smi64.so")
+            if smi.rsmi_init(C.c_uint64(0)) != 0:
+                return
+            count = C.c_uint32(0)
+            smi.rsmi_num_monitor_devices(C.byref(count))
+            want = None
+            try:
+                hip = C.CDLL("libamdhip64.so")
+                buf = C.create_string_buffer(64)
+                if hip.hipDeviceGetPCIBusId(buf, 64, int(device)) == 0:
+                    dom, bus, dev_fn = buf.value.decode().split(":")
+                    dv, fn = dev_fn.split(".")
+                    want = (int(dom, 16) << 32) | (int(bus, 16) << 8) | (int(dv, 16) << 3) | int(fn, 16)
+            except Exception:
+                want = None
+            self._ind = 0
+            for i in range(count.value):
+                bdf = C.c_uint64(0)
+                if smi.rsmi_dev_pci_id_get(C.c_uint32(i), C.byref(bdf)) == 0 and want is not None and \
+                        (bdf.value & 0xFFFFFFFF0000FFF8) == (want & 0xFFFFFFFF0000FFF8):   # domain, bus, device
+                    self._ind = i
+
+            class Freq(C.Structure):
+                _fields_ = [("has_deep_sleep", C.c_bool), ("num_supported", C.c_uint32), ("current", C.c_uint32),
+                            ("frequency", C.c_uint64 * 33)]
+            self._Freq, self._smi, self._C = Freq, smi, C
+            self._ok = self.read() is not None
+        except Exception:
+            self._ok = False
+
+    def read(self):
+        try:
+            f = self._Freq()
+            if self._smi.rsmi_dev_gpu_clk_freq_get(self._C.c_uint32(self._ind), 0, self._C.byref(f)) != 0:   # RSMI_CLK_TYPE_SYS
+                return None
+            if f.current >= 33:
+                return None
+            return f.frequency[f.current] / 1e6
+        except Exception:
+            return None
+
+    def start(self):
+        if self._ok and self._thread is None:
+            import threading
+
+            def loop():
+                while not self._stop:
+                    v = self.read()
+                    if v is not None:
+                        self.samples.append(v)
+                    time.sleep(self.period_s)
+            self._thread = threading.Thread(target=loop, daemon=True)
+            self._thread.start()
+
+    def stop(self):
+        self._stop = True
+        if self._thread is not None:
+            self._thread.join(timeout=2.0)
+
+    def summary(self):
+        if not self.samples:
+            return None
+        a = np.array(self.samples)
+        return {"min": float(a.min()), "mean": float(a.mean()), "max": float(a.max()), "samples": int(a.size),
+                "source": "rsmi_dev_gpu_clk_freq_get(RSMI_CLK_TYPE_SYS) sampled during the headline's timed region"}
 
 
 def pmc_traffic(key, options):
@@ -144,8 +238,10 @@ def dense_propagate_leg(sd, device, n_landmarks, reps=3):
 def config5_leg(sd, sd_syn, shard, grp, device, m, steps=100, warmup=20):
     """BASELINE config 5: N = 8000 landmarks (P = 2.05 GB), 1 trajectory, block-diagonal P0 -- the dense pass
     (every state index treated as correlated) against the skip-unobserved pass (active bound: rows / columns of landmarks
-    never observed are exactly zero off the diagonal and are skipped; bit-identical results,
-    tests/test_gpu_benchmarked_paths.py::test_config5_n8000_active_bound_bit_identical)."""
+    never observed are exactly zero off the diagonal and are skipped).  Both legs run the library's defaults (look-ahead
+    on): equal to rounding -- the bound itself is exact, bit for bit with `lookahead=0`
+    (tests/test_gpu_benchmarked_paths.py::test_config5_n8000_active_bound_bit_identical); the dense leg as timed here is
+    checked against the oracle by ::test_config5_n8000_dense_leg_as_benchmarked."""
     N = 8000
     n = 3 + 2 * N
     tri = n * (n + 1) / 2.0
@@ -168,20 +264,100 @@ def config5_leg(sd, sd_syn, shard, grp, device, m, steps=100, warmup=20):
     return out
 
 
-def cpu_baseline(n_landmarks, m, budget_s=25.0):
-    """Reference-shaped dense NumPy step (oracle/ekf_oracle.py::ekf_step_dense) on the host cores."""
+def stream_leg(sd, sd_syn, shard, grp, device, n_landmarks, m, steps, warmup, options, label):
+    """An uploaded stream of one trajectory (BASELINE configs 1 and 2 on the GPU): steps/s over `steps` steps."""
+    dt, pass_ms, launches, _ = time_filter(sd, sd_syn, shard, grp, device, [0], n_landmarks, m, steps, warmup, options=options)
+    return {"workload": f"N={n_landmarks}, m={m}, 1 trajectory, {steps} steps ({label})", "value": steps / dt,
+            "unit": "steps/s", "pass_avg_launch_ms": pass_ms / max(launches, 1), "pass_launches": launches,
+            "pass_kernel": getattr(time_filter, "last_pass_kernel", "")}
+
+
+def online_step_leg(sd, sd_syn, device, n_landmarks, batch, m, steps, warmup, options):
+    """The call surface north_star says "drops into the existing Duckietown loop": one host-driven `EkfSlam.step` per
+    EKF step (src/replay_no_ros.py:229-237, histogram_lane_filter_node.py:197-199 call the filter once per window) --
+    the landmark indices of the next steps are not known in advance, so no fused cadence; inputs cross the C ABI (and
+    PCIe: 352 B per trajectory) every call, the state stays in HBM.  Wall clock around `steps` calls + the final sync."""
+    n = 3 + 2 * n_landmarks
+    streams = [sd_syn.synthetic_stream(n_landmarks, warmup + steps, m, t) for t in range(batch)]
+    f = sd.EkfSlam(n, batch=batch, device=device)
+    for opt in options:
+        name, value = opt.split("=")
+        f.set_option(name, int(value))
+    for b, s in enumerate(streams):
+        f.set_state_diag(s[0], s[1], b)
+    cols = [[np.ascontiguousarray(np.stack([s[i][k] for s in streams])) for k in range(warmup + steps)] for i in (2, 3, 4, 5, 6)]
+
+    def one(k):
+        if batch == 1:
+            f.step(cols[0][k][0], cols[1][k][0], cols[2][k][0], cols[3][k][0], cols[4][k][0])
+        else:
+            f.step(cols[0][k], cols[1][k], list(cols[2][k]), list(cols[3][k]), list(cols[4][k]))
+
+    for k in range(warmup):
+        one(k)
+    f.flush()
+    f.sync()
+    t0 = time.perf_counter()
+    for k in range(warmup, warmup + steps):
+        one(k)
+    t_enq = time.perf_counter() - t0                   # host time to enqueue (the calls are asynchronous)
+    f.flush()
+    f.sync()
+    dt = time.perf_counter() - t0
+    assert not any(f.flags(b) for b in range(batch)) and np.isfinite(f.mean(0)).all()
+    f.close()
+    return {"workload": f"EkfSlam.step per call, N={n_landmarks}, m={m}, {batch} trajectories, {steps} calls",
+            "value": batch * steps / dt, "unit": "steps/s", "ms_per_call": dt / steps * 1e3,
+            "host_enqueue_ms_per_call": t_enq / steps * 1e3}
+
+
+def drop_in_leg(sd, sd_syn, n_landmarks, m, calls, warm):
+    """`EKF_pose_estimation(ang, lin, mean, cov, dt, detections, TAG_INDEX)` exactly as the reference's loop calls it
+    (src/replay_no_ros.py:229-237: the returned mean / covariance are passed back in): host association, the step on the
+    GPU, and the download of the n x n covariance EVERY call (8 n^2 bytes over PCIe) -- what a user who changes nothing
+    but the import gets.  Pre-sized state and TAG_INDEX (the reference's god mode, :140-157).  ms per call, median."""
+    from types import SimpleNamespace
+    mean0, diag0, lin, ang, idx, zr, zb = sd_syn.synthetic_stream(n_landmarks, warm + calls, m, 0)
+    tag_index = {1000 + i: i for i in range(n_landmarks)}
+    mean, cov = mean0.copy(), np.diag(diag0)
+    eye = np.eye(3)
+    times = []
+    for k in range(warm + calls):
+        xr, yr = zr[k] * np.cos(zb[k]), zr[k] * np.sin(zb[k])
+        tags = [SimpleNamespace(tag_id=1000 + int(i), pose_R=eye, pose_t=np.array([[-y], [0.0], [x]]), pose_err=0.0)
+                for i, x, y in zip(idx[k], xr, yr)]
+        t0 = time.perf_counter()
+        mean, cov, _tags = sd.EKF_pose_estimation(ang[k], lin[k], mean, cov, 0.7, [(float(k), tags)], tag_index)
+        if k >= warm:
+            times.append(time.perf_counter() - t0)
+    assert np.isfinite(mean).all() and np.isfinite(cov).all() and len(mean) == 3 + 2 * n_landmarks
+    med = float(np.median(times))
+    return {"workload": f"EKF_pose_estimation per call incl. the covariance download, N={n_landmarks}, m={m}, {calls} calls",
+            "ms_per_call": med * 1e3, "value": 1.0 / med, "unit": "steps/s", "download_bytes_per_call": 8 * len(mean) ** 2}
+
+
+def cpu_dense_steps(n_landmarks, m, steps, budget_s, min_steps):
+    """Median seconds per step of the oracle's reference-shaped dense NumPy step on the host cores."""
     from oracle import ekf_oracle as orc          # checker / baseline only
-    mean0, diag0, lin, ang, idx, zr, zb = orc.synthetic_stream(n_landmarks, 8, m, 0)
+    mean0, diag0, lin, ang, idx, zr, zb = orc.synthetic_stream(n_landmarks, steps, m, 0)
     cfg = orc.EkfConfig()
     mean, cov = mean0.copy(), np.diag(diag0)
     times = []
     t_all = time.perf_counter()
-    for k in range(8):
+    for k in range(steps):
         t0 = time.perf_counter()
         mean, cov = orc.ekf_step_dense(mean, cov, lin[k], ang[k], idx[k], zr[k], zb[k], cfg)
         times.append(time.perf_counter() - t0)
-        if time.perf_counter() - t_all > budget_s and len(times) >= 2:
+        if time.perf_counter() - t_all > budget_s and len(times) >= min_steps:
             break
+    return times
+
+
+def cpu_baseline(n_landmarks, m, budget_s=14.0):
+    """Reference-shaped dense NumPy step (oracle/ekf_oracle.py::ekf_step_dense) on the host cores: the headline size
+    (>= 3 steps), and under `by_config` SURVEY 8(d)'s other legs -- N = 500 (>= 10 steps), N = 20 (500 steps) -- plus
+    N = 12, m = 3 (the reference's real map, src/replay_no_ros.py:26) for the drop-in comparison."""
+    times = cpu_dense_steps(n_landmarks, m, 5, budget_s, 3)
     blas = "BLAS unknown"
     try:
         from threadpoolctl import threadpool_info
@@ -191,10 +367,17 @@ def cpu_baseline(n_landmarks, m, budget_s=25.0):
     except Exception:
         cores = os.cpu_count() or 1
     med = float(np.median(times))
+    by = {}
+    for key, (N2, m2, steps2, min2) in {"N500": (500, m, 12, 10), "N20": (20, m, 500, 500), "N12": (12, 3, 500, 500)}.items():
+        t2 = cpu_dense_steps(N2, m2, steps2, 6.0, min2)
+        med2 = float(np.median(t2))
+        by[key] = {"value": 1.0 / med2, "unit": "steps/s", "ms_per_step": med2 * 1e3,
+                   "sample": f"{len(t2)} steps of N={N2}, m={m2}, 1 trajectory, dense NumPy (oracle.ekf_step_dense), median"}
     return {"value": 1.0 / med, "unit": "steps/s", "cores": int(cores), "kind": "port",
             "sample": f"{len(times)} steps of N={n_landmarks}, m={m}, 1 trajectory, dense NumPy "
                       f"(oracle.ekf_step_dense), median {med * 1e3:.0f} ms/step; NumPy {np.__version__}, {blas}, "
-                      f"os.cpu_count() = {os.cpu_count()}"}
+                      f"os.cpu_count() = {os.cpu_count()}",
+            "by_config": by}
 
 
 def main():
@@ -240,9 +423,11 @@ def main():
     B = args.trajectories
     n = 3 + 2 * args.landmarks
     traj_ids = shard.shard_trajectories(B * world, world, rank)
+    clk = ClockSampler(local_rank)
     dt, pass_ms, launches, dev_ms = time_filter(sd, sd_syn, shard, grp, local_rank, traj_ids, args.landmarks, args.obs,
-                                                args.steps, args.warmup, options=args.option)
+                                                args.steps, args.warmup, options=args.option, clock=clk)
     value = shard.aggregate_steps_per_second(len(traj_ids) * args.steps, grp, dt)
+    rank_dts = grp.gather_over_ranks(getattr(shard.timed_region, "last_local_seconds", dt))
 
     out = None
     if rank == 0:
@@ -285,6 +470,10 @@ def main():
                                  "(0.65 ms alone) and the memory side (0.68 ms alone, 6.05 TB/s) of the row-slab pass are balanced "
                                  "(DESIGN.md section 4), see `mfma`"},
             "device_ms_per_step": dev_ms / args.steps,
+            # every rank's own elapsed time of the timed region (value uses their maximum): dispatch skew is visible
+            "rank_dt_ms": [x * 1e3 for x in rank_dts],
+            # the shader clock while the timed region ran (sampled every 2 ms from a host thread)
+            "sclk_mhz": clk.summary(),
         }
         if os.environ.get("EKFSLAM_HIP_VARIANT"):      # a diagnostic build of the library was timed: not a product number
             out["library_variant"] = os.environ["EKFSLAM_HIP_VARIANT"]
@@ -309,6 +498,16 @@ def main():
             # (config 5 before the dense GEMMs: after seconds of sustained matrix load the part holds a lower clock for a
             #  while, and a leg timed right behind them reads ~10 % low)
             out["config5"] = config5_leg(sd, sd_syn, shard, grp, local_rank, args.obs)
+            # BASELINE configs 1 and 2 on the GPU, the host-driven call surface and the drop-in function
+            out["config1"] = stream_leg(sd, sd_syn, shard, grp, local_rank, 20, args.obs, 500, 20, args.option,
+                                        "BASELINE config 1's size on the GPU")
+            out["config2"] = stream_leg(sd, sd_syn, shard, grp, local_rank, 500, args.obs, 500, 20, args.option,
+                                        "BASELINE config 2")
+            out["online_step"] = {
+                f"N{args.landmarks}_x{B}": online_step_leg(sd, sd_syn, local_rank, args.landmarks, B, args.obs, 100, 10, args.option),
+                f"N{args.landmarks}_x1": online_step_leg(sd, sd_syn, local_rank, args.landmarks, 1, args.obs, 200, 10, args.option)}
+            out["drop_in"] = {"N12": drop_in_leg(sd, sd_syn, 12, 3, 200, 10), "N500": drop_in_leg(sd, sd_syn, 500, args.obs, 40, 5),
+                              f"N{args.landmarks}": drop_in_leg(sd, sd_syn, args.landmarks, args.obs, 12, 3)}
             out["dense_propagate"] = dense_propagate_leg(sd, local_rank, args.landmarks)
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.landmarks, args.obs)

@@ -10,6 +10,9 @@
  * State layout at this boundary is the reference's own (src/replay_no_ros.py:69-70, :341-360):
  *   mu : (n,)   float64   [x, y, theta, l0x, l0y, ..., l(N-1)x, l(N-1)y],  n = 3 + 2N
  *   P  : (n,n)  float64   row-major (NumPy C order)
+ * On the device a covariance is kept as its upper triangle, row-major with a padded row stride up to n_max = 4096 and in
+ * column panels of 4096 doubles beyond (every row segment of a tile 32 KB from the next, whatever the size of the state);
+ * uploads and downloads translate -- the layout never shows at this boundary.
  * Device buffers are owned by the handle; host arrays are borrowed for the duration of a call.
  * A handle is not thread-safe: one handle per device per host thread.
  */
@@ -34,11 +37,13 @@ extern "C" {
 /* sticky per-trajectory flags, ekf_status_flags() */
 #define EKF_FLAG_NONFINITE 1u /* a non-finite mean entry was produced (q = 0 at :466-469, singular S at :473) */
 #define EKF_FLAG_INTERNAL 4u  /* a bounded wait inside a single-launch step timed out (the GPU did not run the solve
-                                 workgroup of the launch beside its panel workgroups for tens of ms).  The timed-out
-                                 workgroups write nothing, so that step did not happen as a whole and the trajectory's
-                                 state is undefined from there on: ekf_sync and ekf_download_* return EKF_ERR_STATE while
-                                 the flag is set.  Recovery: upload the trajectory again (ekf_upload_state* clears the
-                                 flag); ekf_set_option("fused_step", 0) selects the two-launch step, which has no wait. */
+                                 workgroup of the launch beside its panel workgroups for tens of ms).  A timed-out
+                                 wave writes nothing while other waves of the same step may have written: the
+                                 trajectory's state is UNDEFINED from there on, and ekf_sync and every ekf_download_*
+                                 (state, mean, block, tags, tag index) return EKF_ERR_STATE while the flag is set.  The
+                                 same status is returned, for every trajectory of the handle, after an enqueueing call
+                                 failed half way.  Recovery: upload the trajectory again (ekf_upload_state* clears the
+                                 condition); ekf_set_option("fused_step", 0) selects the two-launch step, which has no wait. */
 #define EKF_FLAG_ASSOC 2u     /* device-side association dropped a detection: tag id outside [0, 1024), state full,
                                  or more than EKF_MMAX distinct tags in one window */
 #define EKF_DMAX 64           /* detections per window for ekf_step_detections */
@@ -156,9 +161,13 @@ int ekf_profile_read(ekf_handle *h, double *pass_ms_total, long long *pass_launc
  * diagnostic: the solve never publishes its completion, every bounded wait times out with EKF_FLAG_INTERNAL),
  * "fused_cadence" (1 = ekf_stream_run replays all steps between two covariance passes -- up to 40 landmark updates,
  * src/replay_no_ros.py:368-480 for each -- with one solve launch and one panel launch; equal to the per-step kernels to
- * rounding (<= 1e-10 relative, tested), not bit for bit; 0 = one step at a time), "lookahead" (1 = where the pass is a
- * small launch, the next cadence's solve runs beside it on the handle's second stream; 0 = strictly in sequence);
- * unknown names fail. */
+ * rounding (1e-10 relative guaranteed, 1e-13 .. 1e-12 measured; the tests assert 1e-11), not bit for bit; 0 = one step at a time), "lookahead" (1 = where the pass is a
+ * small launch, the next cadence's solve runs beside it on the handle's second stream; 0 = strictly in sequence),
+ * "pass_share_order" (row-slab pass on static shares: 1 = shares dealt to the XCDs by starting column, 0 = as cut; same
+ * result bit for bit); unknown names fail.
+ * "fused_cadence" and "lookahead" change the ORDER in which a step's pending ranks are summed (and whether the look-ahead
+ * applies depends on the device's CU count and the size of the launch): results are equal to rounding across these
+ * settings and across devices, bit-identical only for a fixed setting on a fixed device type. */
 int ekf_set_option(ekf_handle *h, const char *name, int value);
 /* Which form of the covariance pass the last launch used (-1 = none yet; values as for "pass_kernel"), how many
  * MFMA k-tiles (4 pending ranks each) it applied, and whether it took the nontemporal (streaming) path. */

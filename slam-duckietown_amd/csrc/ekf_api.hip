@@ -102,8 +102,15 @@ struct ekf_handle {
                                   // (20 MFMA k-tiles: 15 of the V strip in registers, 5 in LDS)
   int opt_pass_kernel = -1;       // -1 = auto, 0 = k_flush (column strips), 2 = k_flush_rs (row slabs)
   unsigned* dqueue = nullptr;     // work-queue heads of k_flush_rs (zeroed before every launch)
-  int* dshares = nullptr;         // k_flush_rs, equal static shares (a few long trajectories): the piece table on the device
-  int shares_key[3] = {0, 0, 0};  // (batch, e_hi, workgroups) the table was built for
+  // k_flush_rs, equal static shares (a few long trajectories): the piece table.  Two copies on the device and in pinned
+  // host memory, used alternately: a rebuilt table is uploaded stream-ordered, without a host synchronisation, while the
+  // pass that read the previous one may still be running.
+  int* dshares2[2] = {nullptr, nullptr};
+  int* hshares2[2] = {nullptr, nullptr};
+  hipEvent_t shares_ev[2] = {nullptr, nullptr};   // the upload out of hshares2[i] has been executed
+  bool shares_ev_used[2] = {false, false};
+  int shares_cur = 0;
+  int shares_key[5] = {0, 0, 0, 0, 0};   // (batch, slabs, last strip, workgroups, order) the current table was built for
   int shares_ok = 0;              // pieces of its longest share (0: no table for this key -- the queue modes are used)
   unsigned* dready = nullptr;     // per trajectory: sequence number of the last solve that completed (k_step_split)
   SolveOut* dmbox = nullptr;      // per trajectory: that solve's header and records, written through (mailbox_publish)
@@ -129,6 +136,10 @@ struct ekf_handle {
   int opt_flush_every = 0;        // 0 = auto; k = flush the pending low-rank update after k steps
   int opt_streaming = -1;         // -1 = auto (by working-set size), 0 = resident kernel, 1 = nontemporal kernel
   std::vector<unsigned> flags_host;
+  unsigned* h_flags = nullptr;    // pinned: the sticky flags are read back with a stream-ordered copy
+  // Set when an enqueueing call failed half way (e.g. a launch of the look-ahead failed after the next cadence's solve had
+  // already run): the device state of every trajectory is undefined until it is uploaded again; see check_internal
+  std::vector<unsigned char> host_bad;
   std::string err;
 };
 
@@ -197,10 +208,15 @@ static void free_all(ekf_handle* h) {
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   void* ptrs[] = {h->dP, h->dmu2[0], h->dmu2[1], h->dV, h->dW, h->ddacc2[0], h->ddacc2[1], h->dscratch, h->dn, h->dflags, h->dso, h->dfac,
                   h->d_ring, h->d_stream, h->dF, h->dQ, h->dTmp, h->dPlin, h->dtagmap, h->dneff, h->d_det, h->d_assoc_step, h->dfloor, h->dqueue, h->dready, h->dmbox,
-                  h->d_assoc_out, h->dcad, h->dshares, h->dgbuf};
+                  h->d_assoc_out, h->dcad, h->dshares2[0], h->dshares2[1], h->dgbuf};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (h->h_ring) (void)hipHostFree(h->h_ring);
   if (h->h_det) (void)hipHostFree(h->h_det);
+  for (int i = 0; i < 2; ++i) {
+    if (h->hshares2[i]) (void)hipHostFree(h->hshares2[i]);
+    if (h->shares_ev[i]) (void)hipEventDestroy(h->shares_ev[i]);
+  }
+  if (h->h_flags) (void)hipHostFree(h->h_flags);
   for (auto& e : h->ring_ev) if (e) (void)hipEventDestroy(e);
   for (auto& e : h->prof_pool) (void)hipEventDestroy(e);
   if (h->t0) (void)hipEventDestroy(h->t0);
@@ -279,6 +295,7 @@ extern "C" int ekf_create(int device, int n_max, int batch, const ekf_config* cf
   h->neff.assign(batch, 3);
   h->neff_enq.assign(batch, 3);
   h->floor_host.assign(batch, 3);
+  h->host_bad.assign(batch, 0);
 
 #define CREATE_TRY(expr)                                                                  \
   do {                                                                                    \
@@ -315,6 +332,7 @@ extern "C" int ekf_create(int device, int n_max, int batch, const ekf_config* cf
   CREATE_TRY(hipMalloc(&h->dfac, sizeof(double) * FACS * batch));
   CREATE_TRY(hipMalloc(&h->d_ring, sizeof(StepIn) * batch * RING));
   CREATE_TRY(hipHostMalloc(&h->h_ring, sizeof(StepIn) * batch * RING, hipHostMallocDefault));
+  CREATE_TRY(hipHostMalloc(&h->h_flags, sizeof(unsigned) * batch, hipHostMallocDefault));
   for (auto& ev : h->ring_ev) CREATE_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
   CREATE_TRY(hipEventCreate(&h->t0));
   CREATE_TRY(hipEventCreate(&h->t1));
@@ -369,31 +387,47 @@ static int check_b(ekf_handle* h, int b, const char* fn) {
 }
 
 // A bounded wait of a single-launch step that ran into its limit leaves EKF_FLAG_INTERNAL on the trajectory: the
-// timed-out workgroups wrote nothing, so that step (and whatever was enqueued behind it) did not happen as a whole and
-// the trajectory's state is undefined until it is uploaded again (ekf_upload_state* clears the flag).  Every call that
-// hands results to the host reports it: EKF_ERR_STATE.  b < 0: any trajectory.  Synchronises the stream.
+// timed-out workgroups wrote nothing while others of the same step may have, so the trajectory's state is UNDEFINED from
+// there on, until it is uploaded again (ekf_upload_state* clears the flag).  The same holds -- for every trajectory of
+// the handle -- after an enqueueing call failed half way (host_bad).  Every call that hands results to the host reports
+// it: EKF_ERR_STATE.  b < 0: any trajectory.  Synchronises the handle's stream (the flags come back with a stream-ordered
+// copy into pinned memory, on that stream).
 static int check_internal(ekf_handle* h, int b, const char* fn) {
+  HIP_TRY(h, hipMemcpyAsync(h->h_flags, h->dflags, sizeof(unsigned) * h->batch, hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
-  h->flags_host.resize(h->batch);
-  HIP_TRY(h, hipMemcpy(h->flags_host.data(), h->dflags, sizeof(unsigned) * h->batch, hipMemcpyDeviceToHost));
-  for (int t = (b < 0 ? 0 : b); t < (b < 0 ? h->batch : b + 1); ++t)
-    if (h->flags_host[t] & EKF_FLAG_INTERNAL)
+  for (int t = (b < 0 ? 0 : b); t < (b < 0 ? h->batch : b + 1); ++t) {
+    if (h->host_bad[t])
+      return fail(h, EKF_ERR_STATE,
+                  std::string(fn) + ": an earlier call on this handle failed after part of its work had been enqueued; the "
+                      "state of trajectory " + std::to_string(t) + " is undefined: upload it again (ekf_upload_state / "
+                      "ekf_upload_state_diag)");
+    if (h->h_flags[t] & EKF_FLAG_INTERNAL)
       return fail(h, EKF_ERR_STATE,
                   std::string(fn) + ": trajectory " + std::to_string(t) +
-                      " carries EKF_FLAG_INTERNAL (a bounded wait inside a single-launch step timed out; the step wrote "
-                      "nothing, the state is undefined): upload the state again (ekf_upload_state / ekf_upload_state_diag) "
+                      " carries EKF_FLAG_INTERNAL (a bounded wait inside a single-launch step timed out; the state is "
+                      "undefined): upload the state again (ekf_upload_state / ekf_upload_state_diag) "
                       "and consider ekf_set_option(\"fused_step\", 0)");
+  }
   return EKF_OK;
 }
 // (an upload replaces mean and covariance of trajectory b entirely: the trajectory is good again)
 static int clear_internal(ekf_handle* h, int b) {
-  unsigned f = 0;
+  HIP_TRY(h, hipMemcpyAsync(h->h_flags, h->dflags + b, sizeof(unsigned), hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
-  HIP_TRY(h, hipMemcpy(&f, h->dflags + b, sizeof(unsigned), hipMemcpyDeviceToHost));
+  unsigned f = h->h_flags[0];
   if (f & EKF_FLAG_INTERNAL) {
     f &= ~EKF_FLAG_INTERNAL;
     HIP_TRY(h, hipMemcpy(h->dflags + b, &f, sizeof(unsigned), hipMemcpyHostToDevice));
   }
+  h->host_bad[b] = 0;
+  return EKF_OK;
+}
+// Stepping calls refuse a handle whose state is undefined after a half-enqueued failure (no synchronisation).
+static int check_host_bad(ekf_handle* h, const char* fn) {
+  for (int t = 0; t < h->batch; ++t)
+    if (h->host_bad[t])
+      return fail(h, EKF_ERR_STATE, std::string(fn) + ": an earlier call on this handle failed after part of its work had "
+                                        "been enqueued; upload every trajectory again before stepping");
   return EKF_OK;
 }
 
@@ -638,7 +672,8 @@ static PassPlan plan_pass(const ekf_handle* h) {
 // (650 MB per pass beside the 4.1 GB of P).  Workgroups advance at the same rate, so shares that START on the same column
 // stay on the same column: the shares are sorted by (trajectory, first column) and dealt to the XCDs in runs, and the 32
 // workgroups of an XCD walk (nearly) the same V strips together -- one fetch per XCD instead of one per workgroup.
-static void order_pass_shares(int workgroups, int pieces, std::vector<int>& table) {
+static void order_pass_shares(int workgroups, int pieces, int* table_ptr, size_t words) {
+  std::vector<int> table(table_ptr, table_ptr + words);
   std::vector<int> order(workgroups);
   for (int w = 0; w < workgroups; ++w) order[w] = w;
   auto key = [&](int w) { return ((long)table[(size_t)w * pieces * 4] << 32) + table[(size_t)w * pieces * 4 + 2]; };
@@ -650,7 +685,7 @@ static void order_pass_shares(int workgroups, int pieces, std::vector<int>& tabl
   std::vector<int> out(table.size(), 0);
   for (int q = 0; q < workgroups; ++q)
     std::copy_n(table.begin() + (size_t)order[q] * pieces * 4, (size_t)pieces * 4, out.begin() + (size_t)slots[q] * pieces * 4);
-  table.swap(out);
+  std::copy(out.begin(), out.end(), table_ptr);
 }
 
 static int flush_pending(ekf_handle* h, hipStream_t st) {
@@ -659,20 +694,32 @@ static int flush_pending(ekf_handle* h, hipStream_t st) {
   const PassPlan p = plan_pass(h);
   const int* shares = nullptr;
   if (p.kernel == 2 && p.long_few) {
-    if (h->shares_key[0] != h->batch || h->shares_key[1] != p.e_hi || h->shares_key[2] != p.rs_workgroups) {
+    // build_pass_shares depends on the size only through the number of slabs and the last strip: with the active bound
+    // on and a growing map the bound changes at almost every pass, the table only when it crosses a strip
+    const int nrb = (p.e_hi + 127) / 128, s_last = (p.e_hi - 1) >> 6;
+    const int key[5] = {h->batch, nrb, s_last, p.rs_workgroups, h->opt_share_order};
+    if (std::memcmp(key, h->shares_key, sizeof key) != 0) {
       const size_t words = (size_t)h->cu_count * pass_share_pieces() * 4;
-      std::vector<int> table(words, 0);
-      h->shares_ok = build_pass_shares(h->batch, p.e_hi, p.rs_workgroups, table.data());
-      if (h->shares_ok > 0 && h->opt_share_order) order_pass_shares(p.rs_workgroups, pass_share_pieces(), table);
-      if (!h->dshares) HIP_TRY(h, hipMalloc(&h->dshares, sizeof(int) * words));
-      // (rare: once per (batch, size); the table must be on the device before the launch below reads it)
-      HIP_TRY(h, hipMemcpyAsync(h->dshares, table.data(), sizeof(int) * words, hipMemcpyHostToDevice, st));
-      HIP_TRY(h, hipStreamSynchronize(st));
-      h->shares_key[0] = h->batch;
-      h->shares_key[1] = p.e_hi;
-      h->shares_key[2] = p.rs_workgroups;
+      const int nb = h->shares_cur ^ 1;
+      if (!h->dshares2[nb]) {
+        HIP_TRY(h, hipMalloc(&h->dshares2[nb], sizeof(int) * words));
+        HIP_TRY(h, hipHostMalloc(&h->hshares2[nb], sizeof(int) * words, hipHostMallocDefault));
+        std::memset(h->hshares2[nb], 0, sizeof(int) * words);
+        HIP_TRY(h, hipEventCreateWithFlags(&h->shares_ev[nb], hipEventDisableTiming));
+      }
+      // (the pinned copy is free once its previous upload has been executed: two tables back, long ago)
+      if (h->shares_ev_used[nb]) HIP_TRY(h, hipEventSynchronize(h->shares_ev[nb]));
+      h->shares_ok = build_pass_shares(h->batch, p.e_hi, p.rs_workgroups, h->hshares2[nb]);
+      if (h->shares_ok > 0 && h->opt_share_order) order_pass_shares(p.rs_workgroups, pass_share_pieces(), h->hshares2[nb], words);
+      // stream-ordered: the launch below, on the same stream, reads the table after the copy; the pass that read the
+      // other table -- possibly still running on the handle's other stream -- is not touched
+      HIP_TRY(h, hipMemcpyAsync(h->dshares2[nb], h->hshares2[nb], sizeof(int) * words, hipMemcpyHostToDevice, st));
+      HIP_TRY(h, hipEventRecord(h->shares_ev[nb], st));
+      h->shares_ev_used[nb] = true;
+      h->shares_cur = nb;
+      std::memcpy(h->shares_key, key, sizeof key);
     }
-    if (h->shares_ok > 0) shares = h->dshares;
+    if (h->shares_ok > 0) shares = h->dshares2[h->shares_cur];
   }
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (h->profile) {
@@ -822,10 +869,20 @@ static int enqueue_cadence(ekf_handle* h, int k, int g, int end, bool presolved,
   launch_solve_cad(h->stream, mcap2, h->dP, h->dmu2[h->cur], h->dmu2[h->cur ^ 1], h->ddacc2[h->dcur ^ 1], h->dn,
                    h->d_stream + (size_t)k2 * h->batch, h->batch, g2, h->dcad, h->dflags, h->dfloor, h->dcfg, h->ld,
                    h->pstride, h->dgbuf, (((h->pending_k + 3) & ~3) + 7) / 8);
-  HIP_TRY(h, hipGetLastError());
-  if (int rc = flush_pending(h, h->aux)) return rc;
-  HIP_TRY(h, hipEventRecord(h->ev_join, h->aux));
-  HIP_TRY(h, hipStreamWaitEvent(h->stream, h->ev_join, 0));   // whatever follows on the handle's stream follows the pass
+  // From here on the next cadence's solve has overwritten dcad, the pose mean and the pending-noise buffer: a failure
+  // below cannot be undone.  Whatever happens the two streams are joined again, and a failure marks every trajectory
+  // undefined (EKF_ERR_STATE from then on, until it is uploaded again).
+  int rc = EKF_OK;
+  if (hipGetLastError() != hipSuccess) rc = fail(h, EKF_ERR_HIP, "look-ahead: launch of the next cadence's solve failed");
+  if (rc == EKF_OK) rc = flush_pending(h, h->aux);
+  const hipError_t ej = hipEventRecord(h->ev_join, h->aux);
+  const hipError_t ew = ej == hipSuccess ? hipStreamWaitEvent(h->stream, h->ev_join, 0) : ej;   // whatever follows on the handle's stream follows the pass
+  if (rc == EKF_OK && ew != hipSuccess) rc = fail(h, EKF_ERR_HIP, std::string("look-ahead: joining the streams failed: ") + hipGetErrorString(ew));
+  if (rc != EKF_OK) {
+    (void)hipStreamSynchronize(h->aux);
+    std::fill(h->host_bad.begin(), h->host_bad.end(), (unsigned char)1);
+    return rc;
+  }
   h->lookaheads += 1;
   *next_presolved = true;
   return EKF_OK;
@@ -870,6 +927,7 @@ static void fill_step(StepIn& s, int n_b, int& bound, double lin, double ang, in
 static int do_step(ekf_handle* h, int base_flags, const double* lin, const double* ang, const int* idx,
                    const double* range, const double* bearing, const int* m, int stride) {
   if (!h) return EKF_ERR_ARG;
+  if (int rc = check_host_bad(h, "ekf_step")) return rc;
   if (int rc = refresh_sizes(h)) return rc;
   const bool upd = (base_flags & FLAG_UPDATE) != 0, pred = (base_flags & FLAG_PREDICT) != 0;
   if (pred && (!lin || !ang)) return fail(h, EKF_ERR_ARG, "NULL lin/ang");
@@ -942,6 +1000,7 @@ extern "C" int ekf_step_detections(ekf_handle* h, const double* lin, const doubl
                                    const int* tag_id, const double* pose_t, const double* pose_err, int stride) {
   if (!h) return EKF_ERR_ARG;
   if (!lin || !ang || !count || stride < 0) return fail(h, EKF_ERR_ARG, "ekf_step_detections: NULL array");
+  if (int rc = check_host_bad(h, "ekf_step_detections")) return rc;
   if (int rc = assoc_init(h)) return rc;
   HIP_TRY(h, hipSetDevice(h->device));
   if (int rc = push_floor(h, false)) return rc;
@@ -1001,6 +1060,7 @@ extern "C" int ekf_download_tags(ekf_handle* h, int b, int* m, int* idx, int* ta
   if (int rc = check_b(h, b, "ekf_download_tags")) return rc;
   if (!h->d_assoc_out) return fail(h, EKF_ERR_STATE, "ekf_download_tags: no device-side association has run");
   HIP_TRY(h, hipSetDevice(h->device));
+  if (int rc = check_internal(h, b, "ekf_download_tags")) return rc;
   AssocOut a;
   HIP_TRY(h, hipMemcpyAsync(&a, h->d_assoc_out + b, sizeof(a), hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -1022,6 +1082,7 @@ extern "C" int ekf_download_tag_index(ekf_handle* h, int b, int* tag_of_index, i
   if (!n_landmarks) return fail(h, EKF_ERR_ARG, "ekf_download_tag_index: NULL");
   if (int rc = assoc_init(h)) return rc;
   HIP_TRY(h, hipSetDevice(h->device));
+  if (int rc = check_internal(h, b, "ekf_download_tag_index")) return rc;
   std::vector<int> tm(TAGMAX);
   HIP_TRY(h, hipMemcpyAsync(tm.data(), h->dtagmap + (size_t)b * TAGMAX, sizeof(int) * TAGMAX, hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -1118,6 +1179,7 @@ extern "C" int ekf_stream_upload(ekf_handle* h, int steps, const double* lin, co
 
 extern "C" int ekf_stream_run(ekf_handle* h, int first, int count) {
   if (!h) return EKF_ERR_ARG;
+  if (int rc = check_host_bad(h, "ekf_stream_run")) return rc;
   if (int rc = refresh_sizes(h)) return rc;
   if (first < 0 || count < 0 || first + count > h->stream_steps)
     return fail(h, EKF_ERR_STATE, "ekf_stream_run: range outside the uploaded stream");
@@ -1365,8 +1427,7 @@ extern "C" int ekf_set_option(ekf_handle* h, const char* name, int value) {
   }
   if (std::strcmp(name, "pass_share_order") == 0) {
     if (value != 0 && value != 1) return fail(h, EKF_ERR_ARG, "pass_share_order must be 0 or 1");
-    h->opt_share_order = value;
-    h->shares_key[0] = 0;                              // (the cached table is rebuilt)
+    h->opt_share_order = value;                        // (part of the cached table's key: it is rebuilt)
     return EKF_OK;
   }
   if (std::strcmp(name, "fused_step") == 0) {

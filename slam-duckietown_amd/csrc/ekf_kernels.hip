@@ -2065,19 +2065,9 @@ __global__ __launch_bounds__(512, 2) void k_flush_rs(double* __restrict__ P, con
     // address each, kept live across the whole tile loop).
     auto stage_load = [&](int t, auto i0_tag, auto cnt_tag, double* vs) {
       constexpr int I0 = decltype(i0_tag)::value, CNT = decltype(cnt_tag)::value;
-#ifdef RS_V_FIXED                                        /* diagnostic build: every strip stages the same 64 columns of V (cache-hot) */
-      const int j = 0 * t;
-#else
       const int j = j_last - 64 * min(t, S - 1);
-#endif
 #pragma unroll
-#ifdef RS_SKIP_V                                         /* diagnostic build (timing only): no V loads at all */
-      for (int i = 0; i < CNT; ++i) vs[i] = 1.0 + j;
-#elif defined(RS_V_STRIPMAJOR)                           /* diagnostic build (timing only): V read as if stored strip-major, [strip][rank][64] */
-      for (int i = 0; i < CNT; ++i) vs[i] = ldb8(rsV, lane8, (unsigned)(wave + 8 * (I0 + i)) * 512u + (unsigned)(j >> 6) * (unsigned)(KTOT * 512));
-#else
       for (int i = 0; i < CNT; ++i) vs[i] = ldb8(rsV, lane8, (unsigned)(wave + 8 * (I0 + i)) * ld8 + (unsigned)j * 8u);
-#endif
     };
     auto stage_store = [&](double* dst, auto i0_tag, auto cnt_tag, const double* vs) {
       constexpr int I0 = decltype(i0_tag)::value, CNT = decltype(cnt_tag)::value;
@@ -2181,13 +2171,10 @@ __global__ __launch_bounds__(512, 2) void k_flush_rs(double* __restrict__ P, con
       // side operations in issue order: k-tile 0 issues only the loads of the strip (the result of tile t-1 is still
       // leaving the matrix pipe), the k-tiles [1, NKT - 1) share the rest evenly, the last k-tile only prefetches
       constexpr int NE = FIRST ? 0 : 4, NV = STAGE ? 1 : 0;
-#ifdef RS_EARLY_N3                                       /* the loads of tile t+2 right behind the image write of tile t+1 (their registers are free from there) */
+      // (the loads of tile t+2 go out right behind the image write of tile t+1 -- their registers are free from there --
+      //  not at the end of the tile: worth ~1 % of the pass, profiles/r04_pass_layout.txt)
       constexpr int OVA = 0, OW0 = OVA + NV, OE1A = OW0 + NE, OE2A = OE1A + NE, OE1B = OE2A + NE, OE2B = OE1B + NE,
                     OVB = OE2B + NE, ON1 = OVB + NV, ON3 = ON1 + 8, ON2 = ON3 + 8, OWB = ON2 + 16, NSIDE = OWB + NV;
-#else
-      constexpr int OVA = 0, OW0 = OVA + NV, OE1A = OW0 + NE, OE2A = OE1A + NE, OE1B = OE2A + NE, OE2B = OE1B + NE,
-                    OVB = OE2B + NE, ON1 = OVB + NV, ON2 = ON1 + 8, OWB = ON2 + 16, ON3 = OWB + NV, NSIDE = ON3 + 8;
-#endif
       const uint4v_t rsP = rs_words(Pb);
       const unsigned off_prev = tile_off(t - 1);       // tile t-1 (FIRST: unused)
 #ifdef RS_SKIP_PMEM

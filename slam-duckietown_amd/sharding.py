@@ -91,6 +91,17 @@ class RankGroup:
         self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM)
         return float(t.item())
 
+    def gather_over_ranks(self, x: float) -> List[float]:
+        """Every rank's value, in rank order, on every rank (the benchmark reports each rank's own elapsed time beside
+        the maximum, so that dispatch skew between the GPUs of a node is visible)."""
+        if self._dist is None:
+            return [float(x)]
+        import torch
+        mine = torch.tensor([float(x)], dtype=torch.float64)
+        out = [torch.zeros(1, dtype=torch.float64) for _ in range(self.world)]
+        self._dist.all_gather(out, mine)
+        return [float(t.item()) for t in out]
+
     def close(self):
         if self._dist is not None:
             self._dist.barrier()
@@ -107,6 +118,7 @@ def timed_region(group: RankGroup, run: Callable[[], None], sync: Callable[[], N
     sync()
     dt = clock() - t0
     group.barrier()
+    timed_region.last_local_seconds = dt               # this rank's own elapsed time (see RankGroup.gather_over_ranks)
     return group.max_over_ranks(dt)
 
 

@@ -152,36 +152,61 @@ RANK_SCRIPT = textwrap.dedent("""
     sys.path.insert(0, {root!r})
     import slam_duckietown_amd.sharding as shard
     grp = shard.RankGroup()
-    ids = shard.shard_trajectories(10, grp.world, grp.rank)
+    ids = shard.shard_trajectories(int(os.environ["EKF_TEST_TRAJECTORIES"]), grp.world, grp.rank)
     work = 0.05 * (grp.rank + 1)
     dt = shard.timed_region(grp, lambda: time.sleep(work), lambda: None, time.perf_counter)
     total = shard.aggregate_steps_per_second(len(ids) * 7, grp, dt) * dt
-    print(json.dumps(dict(rank=grp.rank, ids=ids, dt=dt, total=total)), flush=True)
+    own = shard.timed_region.last_local_seconds
+    per_rank = grp.gather_over_ranks(own)
+    print(json.dumps(dict(rank=grp.rank, ids=ids, dt=dt, total=total, own=own, per_rank=per_rank)), flush=True)
     grp.close()
 """)
 
 
-def test_two_rank_gloo_sharding_and_timing(tmp_path):
-    """world_size 2 over gloo on the CPU: disjoint shards, max-over-ranks time, summed units."""
+def run_ranks(tmp_path, world, trajectories):
+    import json
+    import socket
     script = tmp_path / "rank.py"
     script.write_text(RANK_SCRIPT.format(root=ROOT))
-    import socket
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     procs = []
-    for r in range(2):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port))
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), EKF_TEST_TRAJECTORIES=str(trajectories), OMP_NUM_THREADS="1")
         procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, text=True))
     outs = []
     for p in procs:
-        out, _ = p.communicate(timeout=240)
+        out, _ = p.communicate(timeout=300)
         assert p.returncode == 0
-        import json
         outs.append(json.loads(out.strip().splitlines()[-1]))
     outs.sort(key=lambda o: o["rank"])
+    return outs
+
+
+def test_two_rank_gloo_sharding_and_timing(tmp_path):
+    """world_size 2 over gloo on the CPU: disjoint shards, max-over-ranks time, summed units."""
+    outs = run_ranks(tmp_path, 2, 10)
     assert outs[0]["ids"] + outs[1]["ids"] == list(range(10))
     assert abs(outs[0]["dt"] - outs[1]["dt"]) < 1e-12 and outs[0]["dt"] >= 0.1     # slower rank's time on both
     assert abs(outs[0]["total"] - 70.0) < 1e-9
+    assert outs[0]["per_rank"] == outs[1]["per_rank"] == [outs[0]["own"], outs[1]["own"]]
+    assert outs[0]["own"] < outs[1]["own"] == outs[0]["dt"]
+
+
+def test_eight_rank_gloo_at_the_real_shape(tmp_path):
+    """BASELINE config 4 as the driver's SCALE run launches it: world_size 8, 256 trajectories (seeds 1234 ..
+    1489) -> 32 contiguous ids per rank, the timed region's max over ranks on every rank, every rank's own time gathered
+    in rank order (what bench.py reports as rank_dt_ms), units summed over all ranks.  gloo on the CPU, no GPU."""
+    outs = run_ranks(tmp_path, 8, 256)
+    assert [o["rank"] for o in outs] == list(range(8))
+    for r, o in enumerate(outs):
+        assert o["ids"] == list(range(32 * r, 32 * r + 32))
+        assert o["per_rank"] == outs[0]["per_rank"] and len(o["per_rank"]) == 8
+        assert abs(o["per_rank"][r] - o["own"]) < 1e-15
+        assert abs(o["dt"] - max(o["per_rank"])) < 1e-12 and o["dt"] >= 0.4        # rank 7 sleeps 0.4 s
+        assert abs(o["total"] - 256 * 7) < 1e-6
+    own = outs[0]["per_rank"]
+    assert all(own[r] < own[r + 1] for r in range(7))                              # the skew is visible rank by rank
 
 
 def test_header_is_plain_c_and_links_against_the_library(tmp_path):

@@ -1,13 +1,18 @@
-"""GPU parity of the EXACT kernel instantiations and sizes bench.py runs (BASELINE configs 3, 4, 5):
+"""GPU parity of the EXACT kernel instantiations and sizes bench.py runs (BASELINE configs 3, 4, 5), with the path
+asserted (a regression in the cadence / pass planning that silently fell back to other kernels must turn these red):
 
-* N=2000 x 32 trajectories, default cadence: the streaming 80-rank covariance pass `k_flush<15,5,true>`
-  (two full passes + an odd tail), dense covariances, against `oracle.ekf_step_structured`;
-* the same instantiation forced at N=300 against the reference-shaped dense path;
+* N=2000 x 32 trajectories, default options as bench.py sets them: two fused cadences of 5 steps (`k_solve_cad<8>` +
+  `k_panels_cad<8,4>`), each followed by the streaming 80-rank row-slab pass `k_flush_rs<20,true>`, plus a one-step
+  tail; dense covariances, against `oracle.ekf_step_structured`;
+* the streaming 80-rank column-strip instantiation `k_flush<15,5,true>` forced at N=300 against the reference-shaped
+  dense path;
 * `ekf_predict_dense` at n=4003 against NumPy dgemm;
-* N=8000 with and without the active bound, bit for bit;
+* N=8000 x 1 as bench.py's `config5.dense` leg runs it (row-slab pass on equal static shares on 255 workgroups, the next
+  cadence's solve beside it) against the oracle on the active part; with and without the active bound, bit for bit;
 * two handles driven from two host threads.
 Reference: src/replay_no_ros.py:430 (propagation), :473-480 (gain, mean and covariance update).
 """
+import ctypes as C
 import threading
 
 import numpy as np
@@ -34,6 +39,18 @@ def close(a, b, tol=TIGHT):
     assert r < tol, f"rel Frobenius {r:.3e} exceeds the expected {tol:g}"
 
 
+def debug_counters(sd, f):
+    """(fused cadences, steps they covered, look-aheads, pieces of the longest static share of the last pass or 0)."""
+    lib = sd.load_library()
+    lib.ekf_debug_cadences.argtypes = [C.c_void_p, C.POINTER(C.c_long), C.POINTER(C.c_long)]
+    lib.ekf_debug_lookaheads.argtypes = [C.c_void_p]
+    lib.ekf_debug_lookaheads.restype = C.c_long
+    lib.ekf_debug_last_pass_shares.argtypes = [C.c_void_p]
+    a, b = C.c_long(), C.c_long()
+    assert lib.ekf_debug_cadences(f._h, C.byref(a), C.byref(b)) == 0
+    return a.value, b.value, lib.ekf_debug_lookaheads(f._h), lib.ekf_debug_last_pass_shares(f._h)
+
+
 def dense_start(n, seed):
     """A dense SPD covariance (diagonal + rank 8) so that every tile of the pass receives a non-zero update."""
     rng = np.random.default_rng(seed)
@@ -45,10 +62,10 @@ def dense_start(n, seed):
 
 def test_config4_shard_n2000_x32_default_cadence(sd):
     """BASELINE config 4's per-GPU shard exactly as bench.py runs it (N=2000, m=8, 32 trajectories, active bound
-    off, default cadence = 5 steps per 80-rank streaming pass): 11 steps = two full `k_flush<15,5,true>` launches
-    plus a one-step tail.  Trajectories 0-2 start from three different dense covariances and are compared with
-    the O(n^2) oracle; trajectory b > 2 repeats trajectory b % 3, so all 32 are checked -- bit for bit -- against
-    an oracle-checked one, wherever they sit in the launch (blockIdx.z)."""
+    off, default cadence = 5 steps per 80-rank streaming pass): 11 steps = two fused cadences of 5 steps, each with its
+    `k_flush_rs<20,true>` launch, plus a one-step tail -- asserted, not assumed.  Trajectories 0-2 start from three
+    different dense covariances and are compared with the O(n^2) oracle; trajectory b > 2 repeats trajectory b % 3, so
+    all 32 are checked -- bit for bit -- against an oracle-checked one, wherever they sit in the launch."""
     N, steps, m, B, K = 2000, 11, 8, 32, 3
     n = 3 + 2 * N
     cfg = orc.EkfConfig()
@@ -69,6 +86,11 @@ def test_config4_shard_n2000_x32_default_cadence(sd):
         f.run_stream(np.stack([s[2] for s in pick], 1), np.stack([s[3] for s in pick], 1),
                      np.stack([s[4] for s in pick], 1), np.stack([s[5] for s in pick], 1),
                      np.stack([s[6] for s in pick], 1))
+        # the path bench.py times: two fused cadences covering 10 steps, the last full pass the row-slab kernel at 20 k-tiles
+        # (the one-step tail is still pending here: its pass runs with the first download below)
+        cad, covered, _, shares = debug_counters(sd, f)
+        assert (cad, covered) == (2, 10)
+        assert f.last_pass() == "ekf::k_flush_rs<20, true>" and shares == 0
         got = {}
         for b in range(B):
             mu, P = f.state(b)
@@ -161,6 +183,40 @@ def test_config5_n8000_active_bound_bit_identical(sd):
         om, oP = orc.ekf_step_structured(om, oP, lin[k], ang[k], idx[k], zr[k], zb[k], cfg)
     close(out[0][0][:top], om)
     close(P[:top, :top], oP)
+
+
+def test_config5_n8000_dense_leg_as_benchmarked(sd):
+    """What bench.py's `config5.dense` leg runs, at full size and with ITS options (active_bound = 0, everything else
+    default): fused cadences, the row-slab pass on equal static shares on one workgroup per CU minus one, the next
+    cadence's solve beside it (look-ahead) -- each asserted -- against the O(n^2) oracle on the active part (the
+    observations stay inside the first 3000 landmarks, so the rest of the block-diagonal start must come back untouched)."""
+    N, steps, m = 8000, 12, 8
+    mean0, diag0, lin, ang, idx, zr, zb = orc.synthetic_stream(N, steps, m, 9)
+    idx = (idx * 37 + 5) % 3000
+    n = len(mean0)
+    top = 3 + 2 * (int(idx.max()) + 1)
+    with sd.EkfSlam(n) as f:
+        f.set_option("active_bound", 0)
+        f.set_state_diag(mean0, diag0)
+        f.run_stream(lin, ang, idx, zr, zb)
+        cad, covered, lookaheads, shares = debug_counters(sd, f)
+        assert (cad, covered) == (3, 12) and lookaheads >= 1
+        assert f.last_pass() == "ekf::k_flush_rs<20, true>" and shares >= 1
+        mu, P = f.state()
+        assert f.flags() == 0
+    assert np.array_equal(P, P.T)
+    assert not P[top:, :top].any()                                        # never correlated: exactly zero
+    off = P[top:, top:].copy()
+    assert np.array_equal(np.diag(off), diag0[top:])
+    off[np.arange(n - top), np.arange(n - top)] = 0.0
+    assert not off.any()
+    cfg = orc.EkfConfig()
+    om, oP = mean0[:top].copy(), np.diag(diag0[:top])
+    for k in range(steps):
+        om, oP = orc.ekf_step_structured(om, oP, lin[k], ang[k], idx[k], zr[k], zb[k], cfg)
+    close(mu[:top], om)
+    close(P[:top, :top], oP)
+    assert np.array_equal(mu[top:], mean0[top:])
 
 
 def test_two_handles_from_two_host_threads(sd):

@@ -4,9 +4,10 @@ two covariance passes as one solve launch + one panel launch.
 The recurrences are those of the per-step kernels (src/replay_no_ros.py:368-480: motion model, P <- G P G^T + R, per
 landmark H, S, K, mean and covariance update) in a different summation order -- the effect of the cadence's earlier
 ranks is carried in registers instead of re-read from V and W -- so the two paths agree to rounding, not bit for bit.
-Stated tolerance: 1e-10 relative Frobenius between the paths (measured: 1e-15 .. 1e-13 from dense, well-conditioned
-starts; up to 1.2e-12 from the block-diagonal start, whose 1e4 landmark variances against a 0.49 measurement noise
-amplify a last-bit difference by four orders of magnitude), and the usual 1e-9 / 1e-6 against the oracle (the
+Stated tolerance: 1e-11 relative Frobenius between the paths in these tests (measured: 1e-15 .. 1e-13 from dense,
+well-conditioned starts; up to 1.2e-12 from the block-diagonal start, whose 1e4 landmark variances against a 0.49
+measurement noise amplify a last-bit difference by four orders of magnitude; the header guarantees 1e-10), and the usual
+1e-9 / 1e-6 against the oracle (the
 reference-shaped dense NumPy path, pinned to the reference's golden vectors).
 """
 import ctypes as C
@@ -19,7 +20,7 @@ from tests import golden_util as gu
 
 pytestmark = pytest.mark.gpu
 
-PATH_TOL = 1e-10
+PATH_TOL = 1e-11
 TIGHT = 1e-9
 
 
@@ -71,7 +72,7 @@ def stack(streams, i):
                                          (257, 2, 4, 23), (120, 2, 16, 5), (700, 9, 8, 10)])
 def test_fused_cadence_equals_the_per_step_path_and_the_oracle(sd, N, B, m, steps):
     """Every rank-slot size (1, 2, 4, 8, 16 landmarks per step), whole cadences plus a tail, dense starting
-    covariances, latency and throughput shapes of the panel launch: fused == per-step to 1e-12, == oracle to 1e-9."""
+    covariances, latency and throughput shapes of the panel launch: fused == per-step to PATH_TOL (1e-10 guaranteed by the header, 1e-13 .. 1e-12 measured), == oracle to 1e-9."""
     n = 3 + 2 * N
     streams = [orc.synthetic_stream(N, steps, m, 300 + t) for t in range(B)]
     starts = [dense_start(n, 400 + t) for t in range(B)]
@@ -266,7 +267,7 @@ def test_lookahead_solve_beside_the_pass(sd, N, B, m, steps):
     """Small launches with at least ~48 MB of covariance (N = 1250 x 1, 700 x 4, 900 x 2, 1000 x 2 here): the solve of the
     next cadence runs beside the covariance pass of this one (its block gathered
     from P_base and the still pending ranks by k_gather_cad, the pass on the handle's second stream).  Against the same
-    stream without it (`lookahead=0`: every solve behind its pass) to 1e-12, against the oracle to 1e-9; dense starting
+    stream without it (`lookahead=0`: every solve behind its pass) to PATH_TOL, against the oracle to 1e-9; dense starting
     covariances, so that the gathered block carries every term (base, ranks, pending pose noise)."""
     n = 3 + 2 * N
     streams = [orc.synthetic_stream(N, steps, m, 1200 + t) for t in range(B)]
