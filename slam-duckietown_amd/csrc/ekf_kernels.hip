@@ -1753,29 +1753,25 @@ __device__ __forceinline__ double2 ldb16(__amdgpu_buffer_rsrc_t rs, unsigned lan
 // hazard recogniser adds the wait states for global/flat stores and for buffer stores WITHOUT an SGPR offset only (it
 // assumes the SGPR read covers it); on gfx950 the form used here (offen + SGPR soffset) was caught corrupting the low
 // mantissa bits of the odd columns of a tile's last row pair (`buffer_store_dwordx4 v[76:79]` followed by
-// `v_add_u32 v78`).  Store and wait states therefore come out of ONE inline-asm block: nothing can be scheduled
-// between them (tests/test_cpu_host.py scans the shipped machine code for it).  The compiler does not count an
-// inline-asm store in vmcnt, so its waits for later loads also cover these stores; measured against the builtin store
-// followed by a separate `s_nop` and against wait states tied to the data registers by an asm input: 715-720 us,
-// 713-723 us, 721 us for the 80-rank pass at N=2000 x 32 -- no difference (profiles/r03_store_forms.txt).  The resource goes in as four plain words (an opaque
-// __amdgpu_buffer_rsrc_t cannot be an asm operand): base, base_hi | stride 0, num_records = 2^32 - 1 (no range check:
-// ekf_create bounds the size of a covariance), DST_SEL/format word 0x00020000 as rs_rsrc makes it.
-__device__ __forceinline__ uint4v_t rs_words(const void* base) {
-  const unsigned long long p = reinterpret_cast<unsigned long long>(base);
-  return uint4v_t{(unsigned)p, (unsigned)(p >> 32) & 0xffffu, 0xffffffffu, 0x00020000u};
-}
+// `v_add_u32 v78`).  The guard (round 4 form): the store is the compiler's own builtin, and the two wait states are an
+// asm statement that (a) clobbers memory -- so it stays behind the store -- and (b) takes the store's data registers as
+// INPUTS -- so no instruction that overwrites them can be scheduled in front of it.  Whatever the scheduler puts between
+// store and s_nop can therefore only add wait states; tools/isa_lint.py checks on the shipped machine code that no
+// writer of a store's data registers follows it within two wait states.
+// Round 3 emitted store + s_nop as ONE inline-asm block.  The compiler does not count an inline-asm store in vmcnt, so
+// every wait for a LOAD issued before such stores also waited for the stores (in-order counter): the pass lost 6 - 18 us
+// (N = 2000 x 32, same box, interleaved runs: 744 us with the builtin store against 751 - 762 us with the asm block --
+// profiles/r04_pass_drift.txt; round 3 had measured "no difference" on single runs).
 template <bool NT>
-__device__ __forceinline__ void stb16(uint4v_t rs, unsigned lane_bytes, unsigned tile_bytes, double2 v) {
+__device__ __forceinline__ void stb16(__amdgpu_buffer_rsrc_t rs, unsigned lane_bytes, unsigned tile_bytes, double2 v) {
 #ifdef RS_SKIP_PMEM
   if (v.x == 1.2345e-300) /* never: keeps the value alive, drops the traffic */
 #endif
   {
   const uint2v_t a = __builtin_bit_cast(uint2v_t, v.x), b = __builtin_bit_cast(uint2v_t, v.y);
   const uint4v_t d{a.x, a.y, b.x, b.y};
-  if (NT)
-    asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen nt\n\ts_nop 1" ::"v"(d), "v"(lane_bytes), "s"(rs), "s"(tile_bytes) : "memory");
-  else
-    asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen\n\ts_nop 1" ::"v"(d), "v"(lane_bytes), "s"(rs), "s"(tile_bytes) : "memory");
+  __builtin_amdgcn_raw_buffer_store_b128(d, rs, (int)lane_bytes, (int)tile_bytes, NT ? 2 : 0);
+  asm volatile("s_nop 1" ::"v"(d) : "memory");
   }
 }
 #define RS_CBAR() asm volatile("" ::: "memory")
@@ -1948,7 +1944,10 @@ int debug_pass_units(int batch, int nrb, int nch, int mode, int* out, int cap) {
   return total;
 }
 
-template <int NKT, bool NT>
+// PAN: the covariance lies in column panels (ld > 4096); otherwise the column offset of a strip is plain j * 8 -- the
+// panel arithmetic (a shift, a multiplication and a mask per tile, all scalar) is compiled out for the sizes that do not
+// need it: it cost the N = 2000 x 32 pass 5 - 10 us (profiles/r04_pass_drift.txt).
+template <int NKT, bool NT, bool PAN>
 __global__ __launch_bounds__(512, 2) void k_flush_rs(double* __restrict__ P, const double* __restrict__ V,
                                                      const double* __restrict__ W,
                                                      const double* __restrict__ dacc,
@@ -1976,7 +1975,7 @@ __global__ __launch_bounds__(512, 2) void k_flush_rs(double* __restrict__ P, con
   auto cd_index = [&](int ct, int reg) { return ((ct & 1) ? cd_odd : cd_even) + 16 * (ct & ~1) + 256 * reg; };
   // rank k = wave + 8 i of a strip: k-tile 2 i + (wave >> 2), row wave & 3 of the fragment
   const int stage_base = ((wave >> 2) * 4 + lq) * 64 + (wave & 3) * 16 + li;
-  const unsigned pl8 = (unsigned)p_lds(ld) * 8u;       // bytes per row of P (ekf_device.h: column panels beyond ld = 4096)
+  const unsigned pl8 = (unsigned)(PAN ? p_lds(ld) : ld) * 8u;   // bytes per row of P (ekf_device.h: column panels beyond ld = 4096)
   const unsigned loff = (unsigned)rr * pl8 + (unsigned)rc * 8u;   // lane part of a tile address, bytes (rows 2q + rr, columns rc, rc + 1)
   const unsigned lane8 = (unsigned)lane * 8u;
 
@@ -2103,7 +2102,8 @@ __global__ __launch_bounds__(512, 2) void k_flush_rs(double* __restrict__ P, con
     // tile t of this wave; beyond its last tile the loads are pointed at 1 KB of the (read-only, cache resident)
     // SolveOut record instead: a select on the uniform base, offset and stride, no branch
     auto tile_off = [&](int t) -> unsigned {           // (a 64-column strip lies inside one column panel)
-      return prow + p_col8(ld, (unsigned)(j_last - 64 * t));
+      const unsigned j = (unsigned)(j_last - 64 * t);
+      return prow + (PAN ? p_col8(ld, j) : j * 8u);
     };
     auto gload = [&](int t) {
 #ifdef RS_SKIP_PMEM                                     /* diagnostic build: the compute side alone */
@@ -2173,9 +2173,14 @@ __global__ __launch_bounds__(512, 2) void k_flush_rs(double* __restrict__ P, con
       constexpr int NE = FIRST ? 0 : 4, NV = STAGE ? 1 : 0;
       // (the loads of tile t+2 go out right behind the image write of tile t+1 -- their registers are free from there --
       //  not at the end of the tile: worth ~1 % of the pass, profiles/r04_pass_layout.txt)
+#ifdef RS_LATE_N3                                        /* diagnostic build: round 3's order, the loads of tile t+2 last */
+      constexpr int OVA = 0, OW0 = OVA + NV, OE1A = OW0 + NE, OE2A = OE1A + NE, OE1B = OE2A + NE, OE2B = OE1B + NE,
+                    OVB = OE2B + NE, ON1 = OVB + NV, ON2 = ON1 + 8, OWB = ON2 + 16, ON3 = OWB + NV, NSIDE = ON3 + 8;
+#else
       constexpr int OVA = 0, OW0 = OVA + NV, OE1A = OW0 + NE, OE2A = OE1A + NE, OE1B = OE2A + NE, OE2B = OE1B + NE,
                     OVB = OE2B + NE, ON1 = OVB + NV, ON3 = ON1 + 8, ON2 = ON3 + 8, OWB = ON2 + 16, NSIDE = OWB + NV;
-      const uint4v_t rsP = rs_words(Pb);
+#endif
+      const __amdgpu_buffer_rsrc_t rsP = rs_rsrc(Pb);
       const unsigned off_prev = tile_off(t - 1);       // tile t-1 (FIRST: unused)
 #ifdef RS_SKIP_PMEM
       const bool ok2 = false;
@@ -2265,7 +2270,7 @@ __global__ __launch_bounds__(512, 2) void k_flush_rs(double* __restrict__ P, con
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg) T[cd_index(ct, rg)] = acc[ct][rg];
       RS_CBAR();
-      const uint4v_t rsP = rs_words(Pb);
+      const __amdgpu_buffer_rsrc_t rsP = rs_rsrc(Pb);
       const unsigned off_last = tile_off(Sw - 1);
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
@@ -2652,13 +2657,13 @@ void launch_flush(hipStream_t st, bool streaming, double* P, const double* V, co
 }
 
 // the row-slab form of the pass (k_flush_rs): persistent workgroups, `queue` = 8 x RS_QSTRIDE zeroed words
-template <int NKT, bool NT>
+template <int NKT, bool NT, bool PAN>
 static void launch_flush_rs_t(hipStream_t st, double* P, const double* V, const double* W, const double* dacc,
                               const int* nact, const SolveOut* so, int ld, long pstride, int batch, int n_hi, int nkt,
                               int workgroups, unsigned* queue, int chunk, const int* shares) {
   const int nrb = (n_hi + RS_ROWS - 1) / RS_ROWS;
   if (shares) {                                        // equal static shares (mode 4): one per workgroup
-    hipLaunchKernelGGL((k_flush_rs<NKT, NT>), dim3((unsigned)workgroups), dim3(512), 0, st, P, V, W, dacc, nact, so, ld,
+    hipLaunchKernelGGL((k_flush_rs<NKT, NT, PAN>), dim3((unsigned)workgroups), dim3(512), 0, st, P, V, W, dacc, nact, so, ld,
                        pstride, nkt, batch, nrb, 1, 0, 4, queue, shares);
     return;
   }
@@ -2699,7 +2704,7 @@ static void launch_flush_rs_t(hipStream_t st, double* P, const double* V, const 
     }
   }
   const long units = (long)nrb * (mode == 0 ? nch : mode == 3 ? 2 : 1) * batch;   // (modes 1, 2: at least; only the grid size depends on it)
-  hipLaunchKernelGGL((k_flush_rs<NKT, NT>), dim3((unsigned)std::min<long>(workgroups, units)), dim3(512), 0, st, P, V, W,
+  hipLaunchKernelGGL((k_flush_rs<NKT, NT, PAN>), dim3((unsigned)std::min<long>(workgroups, units)), dim3(512), 0, st, P, V, W,
                      dacc, nact, so, ld, pstride, nkt, batch, nrb, nch, cs, mode, queue, nullptr);
 }
 
@@ -2708,8 +2713,13 @@ void launch_flush_rs(hipStream_t st, bool streaming, double* P, const double* V,
                      int workgroups, unsigned* queue, int chunk, const int* shares) {
 #define EKF_FLUSH_RS(N)                                                                                   \
   do {                                                                                                    \
-    if (streaming) launch_flush_rs_t<N, true>(st, P, V, W, dacc, nact, so, ld, pstride, batch, n_hi, nkt, workgroups, queue, chunk, shares); \
-    else launch_flush_rs_t<N, false>(st, P, V, W, dacc, nact, so, ld, pstride, batch, n_hi, nkt, workgroups, queue, chunk, shares);          \
+    if (ld > PPW) {                                                                                       \
+      if (streaming) launch_flush_rs_t<N, true, true>(st, P, V, W, dacc, nact, so, ld, pstride, batch, n_hi, nkt, workgroups, queue, chunk, shares); \
+      else launch_flush_rs_t<N, false, true>(st, P, V, W, dacc, nact, so, ld, pstride, batch, n_hi, nkt, workgroups, queue, chunk, shares);          \
+    } else {                                                                                              \
+      if (streaming) launch_flush_rs_t<N, true, false>(st, P, V, W, dacc, nact, so, ld, pstride, batch, n_hi, nkt, workgroups, queue, chunk, shares); \
+      else launch_flush_rs_t<N, false, false>(st, P, V, W, dacc, nact, so, ld, pstride, batch, n_hi, nkt, workgroups, queue, chunk, shares);          \
+    }                                                                                                     \
   } while (0)
   if (nkt <= 4) EKF_FLUSH_RS(4);
   else if (nkt <= 8) EKF_FLUSH_RS(8);

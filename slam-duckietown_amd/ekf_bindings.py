@@ -439,7 +439,8 @@ class EkfSlam:
         return ms.value, cnt.value
 
     def last_pass(self) -> str:
-        """Name of the kernel the last covariance pass launched (e.g. ``ekf::k_flush_rs<20, true>``, as rocprofv3 prints it), '' if none yet."""
+        """Name of the kernel the last covariance pass launched (e.g. ``ekf::k_flush_rs<20, true, false>``: k-tiles,
+        nontemporal, column-panel layout -- as rocprofv3 prints it), '' if none yet."""
         k, t, st = C.c_int(), C.c_int(), C.c_int()
         self._check(self._lib.ekf_last_pass(self._h, C.byref(k), C.byref(t), C.byref(st)))
         if k.value < 0:
@@ -447,7 +448,7 @@ class EkfSlam:
         nt = "true" if st.value else "false"
         tiles = next(x for x in (4, 8, 12, 16, 20) if x >= t.value)
         if k.value == 2:
-            return f"ekf::k_flush_rs<{tiles}, {nt}>"
+            return f"ekf::k_flush_rs<{tiles}, {nt}, {'true' if self.n_max > 4096 else 'false'}>"
         regs = {4: (4, 0), 8: (8, 0), 12: (12, 0), 16: (16, 0), 20: (15, 5)}[tiles]
         return f"ekf::k_flush<{regs[0]}, {regs[1]}, {nt}>"
 

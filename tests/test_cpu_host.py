@@ -311,14 +311,15 @@ def test_row_slab_pass_hands_out_every_unit_exactly_once(sd):
 
 def test_store_hazard_guard_is_in_the_shipped_machine_code(sd):
     """The 16-byte buffer stores of the row-slab pass (offen + SGPR soffset: the form LLVM's hazard recogniser does not
-    cover) must each be followed immediately by their wait states in the library that ships --
-    checked on the disassembly of the gfx950 code objects inside libekfslam_hip.so, not on the source."""
+    cover): in the library that ships no instruction may overwrite a store's data registers within
+    two wait states of the store -- checked on the disassembly of the gfx950 code objects inside libekfslam_hip.so, not
+    on the source."""
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import isa_lint
     stores, gaps, bad = isa_lint.lint(sd.library_path())
     assert stores >= 500, f"only {stores} guarded stores found: did the pass kernel change its store form?"
     assert not bad, "\n".join(bad)
-    assert gaps == 0, f"{gaps} stores with instructions scheduled between them and their s_nop"
+    assert isa_lint.wait_states("s_nop 1") == 2 and isa_lint.wait_states("v_mov_b32_e32 v1, v2") == 1
     # the scanner itself: a VALU write of a data register between store and nop is what it exists to catch
     assert isa_lint.writes_vgpr("v_add_u32_e32 v78, v1, v2", 76, 79)
     assert isa_lint.writes_vgpr("ds_read_b128 v[76:79], v248 offset:4096", 64, 76)

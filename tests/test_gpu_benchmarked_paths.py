@@ -90,7 +90,7 @@ def test_config4_shard_n2000_x32_default_cadence(sd):
         # (the one-step tail is still pending here: its pass runs with the first download below)
         cad, covered, _, shares = debug_counters(sd, f)
         assert (cad, covered) == (2, 10)
-        assert f.last_pass() == "ekf::k_flush_rs<20, true>" and shares == 0
+        assert f.last_pass() == "ekf::k_flush_rs<20, true, false>" and shares == 0
         got = {}
         for b in range(B):
             mu, P = f.state(b)
@@ -201,7 +201,7 @@ def test_config5_n8000_dense_leg_as_benchmarked(sd):
         f.run_stream(lin, ang, idx, zr, zb)
         cad, covered, lookaheads, shares = debug_counters(sd, f)
         assert (cad, covered) == (3, 12) and lookaheads >= 1
-        assert f.last_pass() == "ekf::k_flush_rs<20, true>" and shares >= 1
+        assert f.last_pass() == "ekf::k_flush_rs<20, true, true>" and shares >= 1
         mu, P = f.state()
         assert f.flags() == 0
     assert np.array_equal(P, P.T)

@@ -3,10 +3,12 @@
 
 The store-data hazard (`stb16` in ekf_kernels.hip): on gfx950 a `buffer_store_dwordx4 ... offen` with an
 SGPR soffset reads its data VGPRs in two passes, and a vector instruction issued right behind it that writes one of them
-can overtake the second pass.  LLVM's hazard recogniser only covers the forms without an SGPR soffset, so the kernels
-emit the store and its two wait states from one inline-asm block.  This tool checks the machine code that actually
-ships: every such store is followed IMMEDIATELY by `s_nop N` (N >= 1), and -- the weaker property that matters should
-the first ever fail -- no instruction between a store and its first `s_nop` writes a VGPR of the store's data tuple.
+can overtake the second pass.  LLVM's hazard recogniser only covers the forms without an SGPR soffset, so the kernel
+follows every such store with an `s_nop 1` that is ordered behind the store (memory clobber) and in front of every
+instruction that overwrites the store's data registers (they are inputs of the asm statement).  This tool checks the
+machine code that actually ships: walking forward from every such store, no instruction may write a VGPR of the
+store's data tuple before at least WAIT_STATES = 2 wait states have gone by (`s_nop N` counts N + 1, any other
+instruction 1), and no branch may come before that either.
 
   python3 tools/isa_lint.py [path/to/libekfslam_hip.so]      exit status 1 on a violation
 """
@@ -80,8 +82,16 @@ def writes_vgpr(ins, lo, hi):
     return r is not None and not (r[1] < lo or r[0] > hi)
 
 
+WAIT_STATES = 2
+
+
+def wait_states(ins):
+    m = re.fullmatch(r"s_nop (\d+)", ins)
+    return int(m.group(1)) + 1 if m else 1
+
+
 def lint(lib_path):
-    """Returns (stores checked, stores with something between them and their s_nop, violations as text)."""
+    """Returns (stores checked, stores whose NEXT instruction is not their s_nop, violations as text)."""
     stores = gaps = 0
     bad = []
     for name, ins in disassemble(lib_path):
@@ -94,17 +104,22 @@ def lint(lib_path):
                 continue                                   # forms the compiler's own hazard recogniser covers
             stores += 1
             lo, hi = vgpr_range(ops[0])
-            j = k + 1
-            while j < len(ins) and not re.fullmatch(r"s_nop [1-9]\d*", ins[j]):
-                if ins[j].startswith(("s_endpgm", "s_branch", "s_cbranch", "s_setpc")) or writes_vgpr(ins[j], lo, hi):
-                    bad.append(f"{name}: `{text}` is followed by `{ins[j]}` before any s_nop")
-                    break
-                j += 1
-            else:
-                if j >= len(ins):
-                    bad.append(f"{name}: `{text}` has no s_nop behind it")
-            if j != k + 1:
+            if k + 1 >= len(ins) or not re.fullmatch(r"s_nop [1-9]\d*", ins[k + 1]):
                 gaps += 1
+            waited, j = 0, k + 1
+            while waited < WAIT_STATES:
+                if j >= len(ins):
+                    bad.append(f"{name}: `{text}` runs off the end of the function within {WAIT_STATES} wait states")
+                    break
+                if ins[j].startswith(("s_branch", "s_cbranch", "s_setpc", "s_endpgm")):
+                    if not ins[j].startswith("s_endpgm"):
+                        bad.append(f"{name}: `{text}` is followed by `{ins[j]}` after {waited} wait state(s)")
+                    break
+                if writes_vgpr(ins[j], lo, hi):
+                    bad.append(f"{name}: `{text}` is followed by `{ins[j]}` after {waited} wait state(s)")
+                    break
+                waited += wait_states(ins[j])
+                j += 1
     return stores, gaps, bad
 
 
@@ -112,8 +127,8 @@ if __name__ == "__main__":
     here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(here, "slam-duckietown_amd", "libekfslam_hip.so")
     n, gaps, bad = lint(path)
-    print(f"{path}: {n} buffer_store_dwordx4 (offen + SGPR soffset), {gaps} not immediately followed by s_nop, "
-          f"{len(bad)} violations")
+    print(f"{path}: {n} buffer_store_dwordx4 (offen + SGPR soffset), {gaps} with other instructions in front of their s_nop "
+          f"(harmless: they only add wait states), {len(bad)} violations")
     for b in bad:
         print("  " + b)
-    sys.exit(1 if bad or gaps else 0)
+    sys.exit(1 if bad else 0)
