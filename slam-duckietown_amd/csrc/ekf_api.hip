@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "ekf_device.h"
+#include "ekf_host_plan.h"
 
 namespace ekf {
 void launch_solve(hipStream_t, const double*, const double*, const double*, const double*, double*, const double*,
@@ -26,10 +27,7 @@ void launch_flush(hipStream_t, bool, double*, const double*, const double*, cons
                   const SolveOut*, int, long, int, int, int, int);
 void launch_flush_rs(hipStream_t, bool, double*, const double*, const double*, const double*, const int*,
                      const SolveOut*, int, long, int, int, int, int, unsigned*, int, const int*);
-int build_pass_shares(int batch, int n_hi, int workgroups, int* out);
-int pass_share_pieces();
 int flush_rs_queue_words();
-int debug_pass_units(int batch, int nrb, int nch, int mode, int* out, int cap);
 void launch_predict_rc(hipStream_t, double*, const double*, double*, const int*, const SolveOut*, int, long,
                        int, int);
 void launch_add_landmarks(hipStream_t, double*, double*, int, int, int, double, const double*);
@@ -38,7 +36,6 @@ void launch_associate(hipStream_t, const DetIn*, int*, int*, int*, double*, doub
                       AssocOut*, unsigned*, const AssocConfig&, int, long, int, int, int);
 void launch_fill_diag(hipStream_t, double*, int, int, const double*);
 int dense_propagate(hipStream_t, double* P, double* tmp, const double* F, const double* Q, int n, int ld);
-int cadence_steps_max(int mcap);
 void launch_solve_cad(hipStream_t, int, const double*, const double*, double*, double*, const int*, const StepIn*, int, int,
                       CadOut*, unsigned*, const int*, const DeviceConfig&, int, long, const double*, int);
 void launch_gather_cad(hipStream_t, int, const double*, const double*, const double*, const double*, const StepIn*, int, int,
@@ -53,16 +50,12 @@ using namespace ekf;
 static thread_local std::string g_create_error;
 constexpr int RING = 16;
 
-struct ekf_handle {
-  int device = 0, n_max = 0, ld = 0, rows = 0, batch = 0;
-  long pstride = 0;
-  ekf_config cfg{};
+struct ekf_handle : ekf::HostPlan {
   DeviceConfig dcfg{};
   hipStream_t stream = nullptr;
   double *dP = nullptr, *dV = nullptr, *dW = nullptr, *dscratch = nullptr;
   double* ddacc2[2] = {nullptr, nullptr};  // pending pose-block noise, double-buffered like the mean
   int dcur = 0;
-  int pending_k = 0, pending_steps = 0;   // ranks / steps appended to (V, W) since the last flush
   double* dmu2[2] = {nullptr, nullptr};   // the mean is double-buffered: a step reads [cur], writes [cur^1]
   int cur = 0;
   int* dn = nullptr;
@@ -75,12 +68,7 @@ struct ekf_handle {
   int ring_pos = 0;
   StepIn* d_stream = nullptr;
   size_t stream_cap = 0;
-  int stream_steps = 0;
-  std::vector<int> stream_mhi;
-  std::vector<int> stream_own;    // per (step, trajectory): active bound from the stream's OWN observations up to that step
-  std::vector<int> stream_maxlm;  // per trajectory: landmarks the stream needs in the state (largest index + 1)
   int* dfloor = nullptr;          // per trajectory floor of the active bound, applied by k_solve (see push_floor)
-  std::vector<int> floor_host;    // what dfloor holds
   double *dF = nullptr, *dQ = nullptr, *dTmp = nullptr;   // dense path, allocated on first use
   double* dPlin = nullptr;        // dense path with P in column panels: its row-major staging copy
   // device-side association (allocated on first use)
@@ -89,18 +77,10 @@ struct ekf_handle {
   StepIn* d_assoc_step = nullptr;
   AssocOut* d_assoc_out = nullptr;
   AssocConfig acfg{};
-  bool sizes_dirty = false;       // the device grew the state: h->n / h->neff must be read back before use
-  std::vector<int> n;
-  std::vector<int> neff_enq;      // active bound of the last ENQUEUED step (what dso[b].neff holds)
-  std::vector<int> neff;          // active bound per trajectory (<= n): indices beyond were never correlated
-  int opt_active_bound = 1;       // 0 = always treat the whole state as active
   hipEvent_t t0 = nullptr, t1 = nullptr;
   bool profile = false;
   std::vector<hipEvent_t> prof_pool;
   size_t prof_used = 0;
-  int opt_rank_limit = KTOT;      // automatic cadence: flush when the next step would exceed this many ranks
-                                  // (20 MFMA k-tiles: 15 of the V strip in registers, 5 in LDS)
-  int opt_pass_kernel = -1;       // -1 = auto, 0 = k_flush (column strips), 2 = k_flush_rs (row slabs)
   unsigned* dqueue = nullptr;     // work-queue heads of k_flush_rs (zeroed before every launch)
   // k_flush_rs, equal static shares (a few long trajectories): the piece table.  Two copies on the device and in pinned
   // host memory, used alternately: a rebuilt table is uploaded stream-ordered, without a host synchronisation, while the
@@ -115,26 +95,16 @@ struct ekf_handle {
   unsigned* dready = nullptr;     // per trajectory: sequence number of the last solve that completed (k_step_split)
   SolveOut* dmbox = nullptr;      // per trajectory: that solve's header and records, written through (mailbox_publish)
   unsigned step_seq = 0;          // sequence number of the last single-launch step
-  int opt_fused_step = 1;         // 1 = one launch per step where the launch is small (k_step_split), 0 = always two
-  int opt_fused_cadence = 1;      // 1 = uploaded streams run whole cadences as one solve + one panel launch (ekf_cadence.hip)
   CadOut* dcad = nullptr;         // per trajectory: head + per-landmark records of the cadence in flight (allocated on first use)
   long cadences = 0, cadence_steps = 0;   // statistics: fused cadences launched, steps they covered
   // look-ahead (small launches): the solve of the next cadence runs on the handle's stream beside the covariance pass of
   // this one, which goes to a second stream between two events; see ekf_stream_run
-  int opt_lookahead = 1;
   hipStream_t aux = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   double* dgbuf = nullptr;        // per trajectory: the next cadence's block, gathered while this one's ranks are pending
   long lookaheads = 0;
-  int cu_count = 0;
-  int opt_rows_per_block = 0;     // 0 = auto (flush kernel: rows per workgroup, multiple of 16)
-  int opt_pass_chunk = 0;         // 0 = auto (k_flush_rs: strips per unit)
-  int opt_share_order = 1;        // 1 = static shares dealt to the XCDs by starting column (order_pass_shares), 0 = as built
-  int opt_pass_workgroups = 0;    // 0 = one per CU (k_flush_rs: persistent workgroups; fewer leaves CUs to other streams)
   int last_kernel = -1, last_nkt = 0, last_streaming = 0;   // what the last covariance pass launched
   int last_shares = 0;            // ... and whether it ran on equal static shares (k_flush_rs, a few long trajectories)
-  int opt_flush_every = 0;        // 0 = auto; k = flush the pending low-rank update after k steps
-  int opt_streaming = -1;         // -1 = auto (by working-set size), 0 = resident kernel, 1 = nontemporal kernel
   std::vector<unsigned> flags_host;
   unsigned* h_flags = nullptr;    // pinned: the sticky flags are read back with a stream-ordered copy
   // Set when an enqueueing call failed half way (e.g. a launch of the look-ahead failed after the next cadence's solve had
@@ -561,58 +531,6 @@ extern "C" int ekf_add_landmarks(ekf_handle* h, int b, int first_index, const do
 }
 
 // ---- step machinery -------------------------------------------------------------------------
-static int cap_for(int m) { return m <= 1 ? 1 : m <= 2 ? 2 : m <= 4 ? 4 : m <= 8 ? 8 : 16; }
-
-// Rows per workgroup of k_flush: every wave re-reads its V strip (K x 1 KiB, from L2) per row block, so
-// the block must be long where many ranks are pending, and short enough to give every CU several waves.
-// Streaming launches with at least four 256-row workgroups per CU (big batches when k_flush is forced; N=8000): 256
-// rows, tuned in round 1 (N=8000, 1 trajectory: 445 us against 488 us with 96 rows).
-// Launches of several rounds of workgroups per CU: 96 rows.  Small launches leave the CUs with one to three workgroups
-// each (two resident at a time) and the pass takes as long as the busiest CU, roughly (rows of a block) x (0.2 + load),
-// load = workgroups per CU, rounded up to the next half where it is below that: the block height minimising it is
-// taken.  N=2000, 1 trajectory: 80 rows (441 workgroups) 46 us, against 52 us with 96 rows (367) and 55 us with 64
-// (543); N=500, 1 trajectory: 64 rows, 23 us against 30 us; N=2000, 2 / 4 / 6 trajectories (streaming): 96 rows 84 /
-// 135 / 199 us against 108 / 164 / 208 us with 256 (profiles/r02_rows_per_block.txt).
-static int flush_workgroups(int n_hi, int rows_per_block) {
-  const int gx = (n_hi + 255) / 256, gy = (n_hi + rows_per_block - 1) / rows_per_block;
-  int total = 0;                                       // (the launcher's count: workgroups that reach the upper triangle)
-  for (int by = 0; by < gy; ++by) total += std::max(0, gx - (by * rows_per_block) / 256);
-  return total;
-}
-static int flush_rows_per_block(const ekf_handle* h, bool streaming, int n_hi) {
-  if (h->opt_rows_per_block > 0) return (h->opt_rows_per_block + 15) / 16 * 16;
-  const long cus = h->cu_count;
-  if (streaming && (long)flush_workgroups(n_hi, 256) * h->batch >= 4 * cus) {
-    // 256 rows, or 512 where that fills its rounds of 2 x CUs workgroups better (N=8000, 1 trajectory: 1024 workgroups
-    // = two full rounds, 421 us against 454 us with 256 rows = 2016 workgroups; 2 trajectories 840 / 852 us)
-    const long slots = 2 * cus;
-    auto fill = [&](int r) {
-      const long w = (long)flush_workgroups(n_hi, r) * h->batch;
-      return (double)w / (double)((w + slots - 1) / slots * slots);
-    };
-    if ((long)flush_workgroups(n_hi, 512) * h->batch >= 2 * slots && fill(512) > fill(256) + 0.01) return 512;
-    return 256;
-  }
-  if ((long)flush_workgroups(n_hi, 96) * h->batch > 5 * cus / 2) return 96;
-  int best = 96;
-  double best_cost = 0.0;
-  for (int r = 64; r <= 256; r += 16) {
-    const double load = (double)flush_workgroups(n_hi, r) * h->batch / (double)cus;
-    const double cost = r * (0.2 + std::max(load, std::ceil(load) - 0.5));
-    if (best_cost == 0.0 || cost < best_cost) {
-      best_cost = cost;
-      best = r;
-    }
-  }
-  return best;
-}
-
-// The covariances of the batch stream through HBM when they cannot stay in the 256 MiB Infinity Cache.
-static bool streaming_pass(const ekf_handle* h, int n_hi) {
-  if (h->opt_streaming >= 0) return h->opt_streaming != 0;
-  return (double)h->batch * 8.0 * n_hi * n_hi > 192.0e6;
-}
-
 static int prof_event(ekf_handle* h, hipEvent_t* ev) {
   if (h->prof_used == h->prof_pool.size()) {
     hipEvent_t e;
@@ -623,71 +541,8 @@ static int prof_event(ekf_handle* h, hipEvent_t* ev) {
   return EKF_OK;
 }
 
-// What the next covariance pass will launch (decided from the handle's state alone, so that the caller can ask before
-// it launches).
-struct PassPlan {
-  int n_hi, e_hi, nkt, kernel, rs_workgroups;
-  bool streaming, long_few, beside;                    // beside: the row-slab pass leaves CUs free for a solve beside it
-};
-static PassPlan plan_pass(const ekf_handle* h) {
-  PassPlan p;
-  p.n_hi = h->sizes_dirty ? h->n_max : *std::max_element(h->n.begin(), h->n.end());
-  p.e_hi = 3;                                          // the grid covers the largest active bound of the batch
-  for (int b = 0; b < h->batch; ++b) p.e_hi = std::max(p.e_hi, std::min(h->n[b], h->neff_enq[b]));
-  if (h->sizes_dirty) p.e_hi = h->n_max;
-  p.streaming = streaming_pass(h, p.n_hi);
-  p.nkt = (h->pending_k + 3) / 4;
-  p.kernel = h->opt_pass_kernel;
-  p.rs_workgroups = h->opt_pass_workgroups > 0 ? std::min(h->opt_pass_workgroups, h->cu_count) : h->cu_count;
-  // A few LONG trajectories (N = 8000 x 1: 126 slabs of up to 251 strips for 256 CUs): the row-slab pass with one equal
-  // static share of the strips per workgroup (build_pass_shares) -- where a share is long enough (>= 40 strips) for
-  // the pipeline fills at its piece boundaries not to matter.  The same for 10 .. 14 trajectories, where the queues
-  // hold one to two whole slabs per workgroup and cannot balance them (N = 2000, 80 ranks, queues -> shares: x 10
-  // 290 -> 261 us, x 11 321 -> 289, x 12 334 -> 303, x 13 350 -> 335, x 14 352 -> 346; N = 3000 x 12 753 -> 706;
-  // 8, 9, 15 - 17 and from 23 on the queues are as good or better, 18 - 22 gain 2 - 5 % at N = 2000 but lose at N = 3000:
-  // profiles/r03_pass_vs_batch.txt).
-  const long slabs = (p.e_hi + 127) / 128, s_last = (p.e_hi - 1) >> 6;
-  const long strips = (long)h->batch * (slabs * (s_last + 1) - slabs * (slabs - 1));
-  p.long_few = (h->batch < 8 || (h->batch >= 10 && h->batch <= 14)) && h->opt_pass_chunk == 0 && strips >= 40L * p.rs_workgroups;
-  // auto: the row-slab form where the batch streams through HBM and has at least one 128-row slab per CU (below
-  // three per CU the slabs are cut into chunks of strips) or is a few long trajectories; measured at N=2000: 8
-  // trajectories 256 us against 266 us with k_flush, 4 trajectories 166 / 164 us, 1 trajectory 97 / 52 us (pipeline
-  // fills dominate)
-  if (p.kernel < 0) p.kernel = (p.streaming && ((long)h->batch * slabs >= (long)h->cu_count || p.long_few)) ? 2 : 0;
-  // A few long trajectories on static shares: the pass leaves one CU per trajectory free, so that the next cadence's solve
-  // (one workgroup per trajectory) can run beside it (the look-ahead of ekf_stream_run); always, not only when a solve
-  // follows: the share table is built per workgroup count (N = 8000 x 1: 255 instead of 256 workgroups, 0.4 %).
-  p.beside = p.kernel == 2 && p.long_few && h->batch < 8 && h->opt_lookahead && h->opt_pass_workgroups == 0 &&
-             h->cu_count > 8 * h->batch;
-  if (p.beside) p.rs_workgroups = h->cu_count - h->batch;
-  return p;
-}
-
 // Apply the pending low-rank update to P_base:  P_base += W V + diag(dacc)  (one pass over P), on stream `st` (the
 // handle's own unless the look-ahead of ekf_stream_run sends it to the second one).
-// Which workgroup gets which static share.  build_pass_shares cuts the strips slab by slab, so consecutive shares are
-// consecutive pieces of the same rows: at any time the workgroups of an XCD (equal blockIdx % 8) sit on 32 different
-// column strips, every V strip they stage is used by one workgroup only, and V (80 ranks x ld doubles: 10 MB at N = 8000)
-// does not fit an XCD's 4 MB L2 -- each of the 15 876 strip visits of a pass fetches its 40 KB from the Infinity Cache
-// (650 MB per pass beside the 4.1 GB of P).  Workgroups advance at the same rate, so shares that START on the same column
-// stay on the same column: the shares are sorted by (trajectory, first column) and dealt to the XCDs in runs, and the 32
-// workgroups of an XCD walk (nearly) the same V strips together -- one fetch per XCD instead of one per workgroup.
-static void order_pass_shares(int workgroups, int pieces, int* table_ptr, size_t words) {
-  std::vector<int> table(table_ptr, table_ptr + words);
-  std::vector<int> order(workgroups);
-  for (int w = 0; w < workgroups; ++w) order[w] = w;
-  auto key = [&](int w) { return ((long)table[(size_t)w * pieces * 4] << 32) + table[(size_t)w * pieces * 4 + 2]; };
-  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return key(a) < key(b); });
-  std::vector<int> slots;                              // blockIdx values XCD by XCD (workgroups go round-robin over the 8 XCDs)
-  slots.reserve(workgroups);
-  for (int x = 0; x < 8; ++x)
-    for (int w = x; w < workgroups; w += 8) slots.push_back(w);
-  std::vector<int> out(table.size(), 0);
-  for (int q = 0; q < workgroups; ++q)
-    std::copy_n(table.begin() + (size_t)order[q] * pieces * 4, (size_t)pieces * 4, out.begin() + (size_t)slots[q] * pieces * 4);
-  std::copy(out.begin(), out.end(), table_ptr);
-}
-
 static int flush_pending(ekf_handle* h, hipStream_t st) {
   if (h->pending_k == 0) return EKF_OK;
   if (!st) st = h->stream;
@@ -801,19 +656,6 @@ static int enqueue_pass(ekf_handle* h, const StepIn* d_in, int m_hi) {
   return EKF_OK;
 }
 
-// How many steps of the uploaded stream, starting at step k, can run as one fused cadence (0 = none).
-static int cadence_length(const ekf_handle* h, int k, int end, bool after_pass = false) {
-  if (!h->opt_fused_cadence || (h->pending_k != 0 && !after_pass) || h->sizes_dirty || k >= end) return 0;
-  const int m0 = h->stream_mhi[k];
-  if (m0 < 1) return 0;
-  const int mcap = cap_for(m0), ktp = ranks_for(mcap);
-  int g = std::min(end - k, cadence_steps_max(mcap));
-  g = std::min(g, h->opt_flush_every > 0 ? h->opt_flush_every : h->opt_rank_limit / ktp);   // the pass cadence
-  for (int t = 1; t < g; ++t)
-    if (h->stream_mhi[k + t] < 1 || cap_for(h->stream_mhi[k + t]) != mcap) g = t;
-  return g;
-}
-
 // Steps [k, k + g) of the uploaded stream as one cadence; the covariance pass follows when it is due.
 // Look-ahead (small launches, where the covariance pass -- the column-strip kernel -- leaves CUs free): when the pass is
 // due and the steps behind it form a cadence too, that cadence's solve does not wait for the pass.  Its block
@@ -888,42 +730,6 @@ static int enqueue_cadence(ekf_handle* h, int k, int g, int end, bool presolved,
   return EKF_OK;
 }
 
-// Validate one trajectory's whole observation list (all device passes of it) before any handle state changes:
-// indices inside the current state, no index twice (the reference keys observations by landmark index,
-// replay_no_ros.py:312-313).
-static int validate_obs(ekf_handle* h, int b, const int* idx, int m, std::vector<unsigned char>& seen) {
-  const int n_lm = (h->n[b] - 3) / 2;
-  seen.assign((size_t)std::max(n_lm, 1), 0);
-  for (int i = 0; i < m; ++i) {
-    const int id = idx[i];
-    if (id < 0 || id >= n_lm) return fail(h, EKF_ERR_ARG, "landmark index outside the current state (add_landmarks first)");
-    if (seen[id]) return fail(h, EKF_ERR_ARG, "duplicate landmark index in one update (the reference keys observations by index, replay_no_ros.py:312-313)");
-    seen[id] = 1;
-  }
-  return EKF_OK;
-}
-
-// Fill StepIn for pass `p` (landmarks [p*MMAX, ...)) of a validated list; `bound` is the trajectory's running
-// active bound (monotone): an observed landmark and everything below it may be correlated from now on.
-static void fill_step(StepIn& s, int n_b, int& bound, double lin, double ang, int flags, const int* idx,
-                      const double* range, const double* bearing, int m, int p) {
-  s.lin = lin;
-  s.ang = ang;
-  s.flags = flags;
-  const int lo = p * MMAX, cnt = std::max(0, std::min(m - lo, MMAX));
-  s.m = cnt;
-  for (int i = 0; i < cnt; ++i) {
-    s.idx[i] = idx[lo + i];
-    s.range[i] = range[lo + i];
-    s.bearing[i] = bearing[lo + i];
-  }
-  for (int i = cnt; i < MMAX; ++i) { s.idx[i] = 0; s.range[i] = 0.0; s.bearing[i] = 0.0; }
-  for (int i = 0; i < cnt; ++i) bound = std::max(bound, 3 + 2 * (s.idx[i] + 1));
-  bound = std::min(bound, n_b);
-  s.neff = bound;                                      // (k_solve raises it to the handle's floor, see push_floor)
-  s.pad = 0;
-}
-
 static int do_step(ekf_handle* h, int base_flags, const double* lin, const double* ang, const int* idx,
                    const double* range, const double* bearing, const int* m, int stride) {
   if (!h) return EKF_ERR_ARG;
@@ -942,7 +748,7 @@ static int do_step(ekf_handle* h, int base_flags, const double* lin, const doubl
   if (m_hi > 0) {                                      // everything is checked before any handle state changes
     std::vector<unsigned char> seen;
     for (int b = 0; b < h->batch; ++b)
-      if (int rc = validate_obs(h, b, idx + (long)b * stride, m[b], seen)) return rc;
+      if (const char* why = validate_obs(h, b, idx + (long)b * stride, m[b], seen)) return fail(h, EKF_ERR_ARG, why);
   }
   HIP_TRY(h, hipSetDevice(h->device));
   if (int rc = push_floor(h, false)) return rc;
@@ -1142,7 +948,7 @@ extern "C" int ekf_stream_upload(ekf_handle* h, int steps, const double* lin, co
       if (m[e] < 0 || m[e] > stride) return fail(h, EKF_ERR_ARG, "ekf_stream_upload: m out of range");
       if (mb > 0 && (!idx || !range || !bearing)) return fail(h, EKF_ERR_ARG, "ekf_stream_upload: NULL observation arrays");
       if (mb > 0)
-        if (int rc = validate_obs(h, b, idx + e * stride, mb, seen)) return rc;
+        if (const char* why = validate_obs(h, b, idx + e * stride, mb, seen)) return fail(h, EKF_ERR_ARG, why);
     }
   std::vector<StepIn> host(count);
   h->stream_mhi.assign(steps, 0);

@@ -1009,7 +1009,6 @@ __global__ __launch_bounds__(256) void k_panels_cad_ks(double* __restrict__ P, d
 // ---------------------------------------------------------------------------------------------
 // launchers (called from ekf_api.hip)
 // ---------------------------------------------------------------------------------------------
-int cadence_steps_max(int mcap) { return CAD_SLOTS / mcap; }
 
 long cadence_gbuf_doubles() { return (long)CAD_GP * CAD_ROWS * CAD_CS; }   // per trajectory: CAD_GP parts
 

@@ -1,6 +1,12 @@
 // Shared host/device records of the EKF-SLAM core (gfx950 only).
 #pragma once
+#ifdef EKF_HOST_ONLY                                     /* plain g++ (the sanitizer build of the host logic, tests/host_plan_check.cpp) */
+#define __host__
+#define __device__
+#define __forceinline__ inline
+#else
 #include <hip/hip_runtime.h>
+#endif
 #include <cstddef>
 #include "../../include/ekfslam_hip.h"
 

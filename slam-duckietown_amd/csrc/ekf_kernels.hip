@@ -37,6 +37,7 @@
 #endif
 
 #include "ekf_devfn.h"
+#include "ekf_host_plan.h"
 
 namespace ekf {
 
@@ -1733,7 +1734,6 @@ __global__ __launch_bounds__(256, 2) void k_flush(double* __restrict__ P, const 
 // towards the diagonal: the slabs of a trajectory start on the same V strip.
 // The accumulation order per element is k_flush's (k-tiles ascending): the two kernels agree bit for bit.
 // ---------------------------------------------------------------------------------------------
-constexpr int RS_ROWS = 128;            // rows of a slab = 8 waves x 16
 
 // Global accesses of k_flush_rs are buffer instructions: (128-bit resource in SGPRs: wave-uniform base) + (SGPR byte
 // offset: the tile) + (ONE 32-bit VGPR: the lane's place inside the tile).  64-bit per-lane pointers for the eight
@@ -1790,160 +1790,7 @@ __device__ __forceinline__ void stb16(__amdgpu_buffer_rsrc_t rs, unsigned lane_b
 #define RS_STAMP(k) do { } while (0)
 #endif
 
-// ---- the work queues of k_flush_rs (one per XCD): how many units queue g2 holds and which unit its u-th one is ----
-// By `mode`:
-//   0  uniform ("pass_chunk" set, or fewer than 8 trajectories): trajectories g2, g2 + 8, ..., every slab in `nch`
-//      chunks, chunk-major;
-//   1  pairs (batch a multiple of 8): trajectories g2, g2 + 8, ... one after the other, whole slabs longest
-//      first -- the workgroup that got the longest slab of one trajectory gets the shortest of the next; the last of
-//      an odd number (8 trajectories: the only one) has no partner and its slabs, only they, are cut into `nch` chunks;
-//   2  dealt (any other batch): the queue's own trajectories among the first 8 * (batch / 8), plus the slabs
-//      rb = (g2 - j) mod 8, + 8, ... of each of the batch-modulo-8 last trajectories j -- every queue carries the same
-//      work -- whole slabs, longest first over ALL of them (slab index major): list scheduling in that order is
-//      as good as the longest slab allows; the price is that an XCD walks the V strips of several trajectories at
-//      once (1-3 % on the batches where mode 1 applies, hence not used there).  N=2000, 20 trajectories: 496 us
-//      against 524 us with mode 1, 28: 662 against 700; 24 (mode 1): 560 against 584 with mode 2.
-//   3  dealt halves (8 < batch <= 12, where one trajectory per queue leaves a workgroup less than two slabs): as mode 2,
-//      but every slab in two chunks of cs = 2 h strips; chunk 1 of slab rb is as long as slab rb + h, so handing out
-//      "chunk 0 of slab v, chunk 1 of slab v - h" for v = 0, 1, ... is again longest first.  (`nch` carries h.)
-// A unit is (trajectory * nrb + slab) * 1024 + chunk, chunk = 1023 for a whole slab.  Plain integer functions, also
-// compiled for the host: tests/test_cpu_host.py enumerates them through ekf_debug_pass_units and checks that every
-// (trajectory, slab, chunk) comes exactly once.
-__host__ __device__ inline int rs_queue_count(int g2, int batch, int nrb, int nch, int mode) {
-  const int upt = nrb * nch;
-  if (mode == 3) return 2 * rs_queue_count(g2, batch, nrb, 1, 2);
-  if (mode == 2) {
-    const int nfull = batch >> 3, nleft = batch & 7;
-    int dealt = 0;                                     // slabs rb < nrb with ((g2 - rb) & 7) < nleft
-    for (int j = 0; j < nleft; ++j) {
-      const int r0 = (g2 - j) & 7;
-      dealt += (r0 < nrb) ? ((nrb - r0 + 7) >> 3) : 0;
-    }
-    return nfull * nrb + dealt;
-  }
-  const int tq = (g2 < batch) ? ((batch - g2 + 7) >> 3) : 0;
-  if (mode == 0) return tq * upt;
-  const int lone = tq & 1;
-  return (tq - lone) * nrb + lone * upt;
-}
-__host__ __device__ inline int rs_queue_unit(int g2, int u, int batch, int nrb, int nch, int mode) {
-  const int upt = nrb * nch;
-  int r = u;
-  if (mode == 3) {
-    const int nfull = batch >> 3, nleft = batch & 7, h = nch;
-    for (int v = 0; v < nrb + h; ++v) {                // (a few dozen iterations, once per unit, one thread)
-      for (int chunk = 0; chunk < 2; ++chunk) {
-        const int rb = v - chunk * h;
-        if (rb < 0 || rb >= nrb) continue;
-        const int j = (g2 - rb) & 7;
-        const int ci = nfull + (j < nleft ? 1 : 0);
-        if (r < ci) return ((r < nfull ? g2 + 8 * r : 8 * nfull + j) * nrb + rb) * 1024 + chunk;
-        r -= ci;
-      }
-    }
-    return -1;                                         // (not reached for u < rs_queue_count)
-  }
-  if (mode == 0) {
-    const int t = r / upt;
-    r -= t * upt;
-    return ((g2 + 8 * t) * nrb + r % nrb) * 1024 + (nch > 1 ? r / nrb : 1023);
-  }
-  if (mode == 2) {
-    // slab-index major: a block of 8 consecutive slabs holds 8 * nfull own units and nleft dealt ones
-    const int nfull = batch >> 3, nleft = batch & 7;
-    const int per = 8 * nfull + nleft, blk = r / per;
-    r -= blk * per;
-    for (int i = 0; i < 8; ++i) {
-      const int rb = 8 * blk + i, j = (g2 - rb) & 7;
-      const int ci = nfull + (j < nleft ? 1 : 0);
-      if (r < ci) return ((r < nfull ? g2 + 8 * r : 8 * nfull + j) * nrb + rb) * 1024 + 1023;
-      r -= ci;
-    }
-    return -1;                                         // (not reached for u < rs_queue_count)
-  }
-  const int tq = (g2 < batch) ? ((batch - g2 + 7) >> 3) : 0;
-  const int whole = (tq - (tq & 1)) * nrb;
-  if (r < whole) return ((g2 + 8 * (r / nrb)) * nrb + r % nrb) * 1024 + 1023;
-  r -= whole;
-  return ((g2 + 8 * (tq - 1)) * nrb + r % nrb) * 1024 + r / nrb;
-}
-// ---- mode 4: equal static shares (a few LONG trajectories, e.g. N = 8000 x 1: 126 slabs for 256 CUs) ----
-// Whole slabs cannot balance 256 workgroups there, and dynamically handed-out chunks end in a tail as long as a chunk
-// while every unit boundary costs about two strips' worth (pipeline fill and drain).  So the batch's strips -- trajectory
-// by trajectory, slab by slab, each slab from its right end to the diagonal -- are cut into one contiguous share per
-// workgroup of equal COST (strips + RS_PIECE_COST per piece): a share is a handful of pieces (trajectory, slab, first
-// strip, strips), at most RS_PIECES.  No queue, no atomics; the table depends on (batch, n_hi, workgroups) only and is
-// cached on the device.  Returns the pieces of the longest share, 0 if some share would need more than RS_PIECES.
-// (Groups of 2 / 4 / 8 workgroups walking ADJACENT strips of the same rows in step -- longer contiguous row segments in
-//  flight at any time -- were measured at N = 8000 x 1: 401 / 439 / 471 us against 391 us: not adopted.)
-constexpr int RS_PIECES = 16;
-constexpr int RS_PIECE_COST = 2;
-int build_pass_shares(int batch, int n_hi, int workgroups, int* out /* workgroups x RS_PIECES x 4 */) {
-  const int nrb = (n_hi + RS_ROWS - 1) / RS_ROWS, s_last = (n_hi - 1) >> 6;
-  long rem_strips = 0;
-  for (int rb = 0; rb < nrb; ++rb) rem_strips += s_last - 2 * rb + 1;
-  rem_strips *= batch;
-  long rem_slabs = (long)batch * nrb;                  // slabs not yet started
-  for (int i = 0; i < workgroups * RS_PIECES * 4; ++i) out[i] = 0;
-  int w = 0, k = 0, longest = 0;
-  // what a share may cost: what is left (strips + a piece per slab still to start + a piece per share still to open,
-  // the continuation of a slab cut by a share boundary) over the shares left -- recomputed whenever a share is opened
-  auto budget_now = [&](int slab_left) {
-    const long left = rem_strips + RS_PIECE_COST * (rem_slabs + (slab_left > 0 ? 1 : 0) + (workgroups - w - 1));
-    return (double)left / (double)(workgroups - w);
-  };
-  double budget = budget_now(0), used = 0.0;
-  for (int b = 0; b < batch; ++b)
-    for (int v = 0; v < nrb; ++v) {
-      // slabs of a trajectory alternately from both ends (longest, shortest, second longest, ...): the many short slabs
-      // near the diagonal's end do not pile up in one share
-      const int rb = (v & 1) ? nrb - 1 - (v >> 1) : (v >> 1);
-      int S = s_last - 2 * rb + 1, start = 0;
-      --rem_slabs;
-      while (S > 0) {
-        if (k > 0 && used + RS_PIECE_COST + 1 > budget && w + 1 < workgroups) {   // no room for even one strip: next share
-          ++w;
-          k = 0;
-          used = 0.0;
-          budget = budget_now(S);
-        }
-        const int room = w + 1 < workgroups ? (int)(budget - used - RS_PIECE_COST + 0.5) : S;
-        const int cnt = room < 1 ? 1 : (room < S ? room : S);
-        if (k >= RS_PIECES) return 0;
-        int* pc = out + ((long)w * RS_PIECES + k) * 4;
-        pc[0] = b;
-        pc[1] = rb;
-        pc[2] = start;
-        pc[3] = cnt;
-        ++k;
-        longest = k > longest ? k : longest;
-        used += cnt + RS_PIECE_COST;
-        start += cnt;
-        S -= cnt;
-        rem_strips -= cnt;
-        if (S > 0 && w + 1 < workgroups) {             // the slab goes on in the next share
-          ++w;
-          k = 0;
-          used = 0.0;
-          budget = budget_now(S);
-        }
-      }
-    }
-  return longest;
-}
-int pass_share_pieces() { return RS_PIECES; }
-
-// (test hook) all units of all queues in hand-out order; returns their number (may exceed cap)
-int debug_pass_units(int batch, int nrb, int nch, int mode, int* out, int cap) {
-  int total = 0;
-  for (int g2 = 0; g2 < 8; ++g2) {
-    const int cnt = rs_queue_count(g2, batch, nrb, nch, mode);
-    for (int u = 0; u < cnt; ++u, ++total)
-      if (total < cap) out[total] = rs_queue_unit(g2, u, batch, nrb, nch, mode);
-  }
-  return total;
-}
-
+// (the work queues and the equal static shares of k_flush_rs: plain integer code for host and device, ekf_host_plan.h)
 // PAN: the covariance lies in column panels (ld > 4096); otherwise the column offset of a strip is plain j * 8 -- the
 // panel arithmetic (a shift, a multiplication and a mask per tile, all scalar) is compiled out for the sizes that do not
 // need it: it cost the N = 2000 x 32 pass 5 - 10 us (profiles/r04_pass_drift.txt).

@@ -195,6 +195,11 @@ class EkfSlam:
             msg = self._lib.ekf_last_error(None).decode()
             self._h = C.c_void_p()
             raise EkfError(f"ekf_create failed ({rc}): {msg}")
+        # windows beyond the device front end's limits are associated on the host (step_detections): per trajectory, the
+        # complete TAG_INDEX while it holds ids the device table cannot (>= 1024), and the last host-made tags_positions
+        self._assoc_gate, self._assoc_ignore = self.config.gate_range, tuple(self.config.ignore_tags)
+        self._host_index = {}
+        self._host_tags = {}
 
     # -- plumbing ------------------------------------------------------------------------------
     def _check(self, rc: int):
@@ -330,22 +335,42 @@ class EkfSlam:
         ig = _i32(list(ignore_tags)) if len(ignore_tags) else None
         self._check(self._lib.ekf_set_association(self._h, float(gate_range), _p(ig, _ip) if ig is not None else None,
                                                   len(ignore_tags)))
+        self._assoc_gate, self._assoc_ignore = float(gate_range), tuple(int(t) for t in ignore_tags)
+
+    def _window_fits_device(self, win, index_len_hint=None) -> bool:
+        """Whether one trajectory's window stays inside the device front end's limits: at most EKF_DMAX detections, at
+        most EKF_MMAX distinct tags behind IGNORE_TAGS and the gate (src/replay_no_ros.py:286-289), tag ids in [0, 1024)."""
+        ids, count, gate2 = [], 0, self._assoc_gate ** 2
+        for _stamp, tags in win:
+            for tag in tags:
+                count += 1
+                t = np.asarray(tag.pose_t, dtype=np.float64).ravel()
+                if tag.tag_id in self._assoc_ignore or t[2] ** 2 + t[0] ** 2 > gate2:
+                    continue
+                if tag.tag_id not in ids:
+                    ids.append(tag.tag_id)
+        return count <= EKF_DMAX and len(ids) <= EKF_MMAX and all(0 <= int(t) < EKF_TAGMAX for t in ids)
 
     def step_detections(self, lin, ang, detections):
         """One window of raw detections per trajectory: the reference's ``[(timestamp, [tag, ...])]`` list
         (src/replay_no_ros.py:280-284), or a list of such lists for a batch.  Association, the 1.5 m gate,
         per-tag averaging, augmentation, prediction and update all run on the GPU.
 
-        Limits of the device front end (the reference has none): tag ids in [0, 1024), at most 64 detections
-        and 16 distinct tags per window, and the map must fit ``n_max``.  A detection beyond them is dropped
-        and the sticky ``EKF_FLAG_ASSOC`` is raised on the device; ``tags_positions()`` (which synchronises
-        anyway) then raises ``EkfError``.  ``replay.GpuBackend`` checks the limits on the host first and
-        regrows the state / takes the host association for such a window instead."""
+        The device front end has limits the reference's dictionaries do not (:280-301): tag ids in [0, 1024), at most 64
+        detections and 16 distinct tags per window.  Every window is checked against them on the host first; when a
+        trajectory's window does not fit -- or its TAG_INDEX already holds an id the device table cannot -- the CALL takes
+        the host association (``frontend.associate``: no limits), augmentation through ``add_landmarks`` and the update
+        through ``step`` (which splits lists of more than 16 landmarks), and the device's table follows the host's
+        afterwards where its ids allow.  Same results either way (tests/test_gpu_api_regressions.py).  Only the capacity
+        stays fixed: a map that would outgrow ``n_max`` raises ``EkfError`` before anything is enqueued."""
         lin, ang = self._per_traj(lin, "lin"), self._per_traj(ang, "ang")
         if self.batch == 1 and (len(detections) == 0 or isinstance(detections[0], tuple)):
             detections = [detections]
         if len(detections) != self.batch:
             raise ValueError("detections: one window per trajectory expected")
+        if self._host_index or not all(self._window_fits_device(win) for win in detections):
+            return self._step_detections_host(lin, ang, detections)
+        self._host_tags.clear()
         flat = [[tag for _stamp, tags in win for tag in tags] for win in detections]
         count = np.array([len(w) for w in flat], dtype=np.int32)
         stride = max(1, int(count.max()))
@@ -360,8 +385,45 @@ class EkfSlam:
         self._check(self._lib.ekf_step_detections(self._h, _p(lin), _p(ang), _p(count, _ip), _p(ids, _ip), _p(pt), _p(pe),
                                                   stride))
 
+    def _step_detections_host(self, lin, ang, detections):
+        """The same window through the host association (see step_detections): what the reference does at :280-360 with
+        its unbounded dictionaries, then the device's augmentation and update."""
+        indices, tags_all = [], []
+        for b, win in enumerate(detections):                       # everything is checked before anything is enqueued
+            index = dict(self._host_index[b]) if b in self._host_index else self.tag_index(b)
+            n_old = self.size(b)
+            if 3 + 2 * len(index) != n_old:
+                # landmarks added without a tag (add_landmarks / set_state): give them ids no detector produces
+                for j in range((n_old - 3) // 2):
+                    if j not in index.values():
+                        index[-1 - j] = j
+            tags = associate(win, index, self.mean(b)[:3], self._assoc_gate, self._assoc_ignore)
+            if 3 + 2 * len(index) > self.n_max:
+                raise EkfError(f"step_detections: trajectory {b}'s map would grow to {len(index)} landmarks, beyond this "
+                               f"handle's capacity n_max = {self.n_max}")
+            indices.append(index)
+            tags_all.append(tags)
+        for b, (index, tags) in enumerate(zip(indices, tags_all)):
+            n_old, n_new = self.size(b), 3 + 2 * len(index)
+            new_xy = [(tags[(i - 3) // 2][0], tags[(i - 3) // 2][1]) for i in range(n_old, n_new, 2)]   # (:355-360)
+            if new_xy:
+                self.add_landmarks(np.array(new_xy), b)
+        idx = [list(t.keys()) for t in tags_all]
+        self.step(lin, ang, idx, [[t[k][4] for k in ks] for t, ks in zip(tags_all, idx)],
+                  [[t[k][5] for k in ks] for t, ks in zip(tags_all, idx)])
+        for b, (index, tags) in enumerate(zip(indices, tags_all)):
+            self._host_tags[b] = tags
+            real = {t: j for t, j in index.items() if t >= 0}
+            if len(real) == len(index) and all(t < EKF_TAGMAX for t in real):
+                self.set_tag_index(real, b)                        # the device table can hold it: it follows the host's
+                self._host_index.pop(b, None)
+            else:
+                self._host_index[b] = index                        # ids beyond the device table: the host stays in charge
+
     def tags_positions(self, b: int = 0) -> dict:
         """What EKF_pose_estimation returns as its third value for the last window (:331-337), update order."""
+        if b in self._host_tags:                                   # the last window was associated on the host
+            return dict(self._host_tags[b])
         m = C.c_int()
         idx, tid = np.zeros(EKF_MMAX, dtype=np.int32), np.zeros(EKF_MMAX, dtype=np.int32)
         arrs = [np.zeros(EKF_MMAX) for _ in range(5)]
@@ -374,7 +436,10 @@ class EkfSlam:
         return {int(idx[i]): [xw[i], yw[i], err[i], int(tid[i]), rng[i], brg[i]] for i in range(m.value)}
 
     def tag_index(self, b: int = 0) -> dict:
-        """The device's TAG_INDEX: {tag_id: landmark index} (:294-295)."""
+        """TAG_INDEX of trajectory b: {tag_id: landmark index} (:294-295) -- the device's table, or the host's while it
+        holds ids the device table cannot (see step_detections)."""
+        if b in self._host_index:
+            return {t: j for t, j in self._host_index[b].items() if t >= 0}
         cap = max(1, (self.n_max - 3) // 2)
         tags = np.full(cap, -1, dtype=np.int32)
         cnt = C.c_int()

@@ -309,6 +309,34 @@ def test_row_slab_pass_hands_out_every_unit_exactly_once(sd):
                     assert sizes[0] == batch * nrb
 
 
+def test_host_planning_logic_under_the_sanitizers(tmp_path):
+    """SURVEY.md section 5 ("-fsanitize=address,undefined host build"): the host-side planning logic the library ships
+    (csrc/ekf_host_plan.h + the layout helpers of csrc/ekf_device.h: work queues and equal static shares of the row-slab
+    pass, pass / cadence planning, step records and their active bound, validation of observation lists, the
+    covariance's device layout) compiled with plain g++ under AddressSanitizer + UndefinedBehaviorSanitizer and run
+    through tests/host_plan_check.cpp: the enumerations of the tests above plus randomised (batch, size, option,
+    m-sequence) invariants of `plan_pass` / `cadence_length` / `fill_step` / `validate_obs`.  CPU only."""
+    import shutil
+    if shutil.which("g++") is None:
+        pytest.skip("g++ is not available")
+    exe = tmp_path / "host_plan_check"
+    cmd = ["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-DEKF_HOST_ONLY",
+           "-Wall", "-Werror", "-I", os.path.join(ROOT, "slam-duckietown_amd", "csrc"), "-I", os.path.join(ROOT, "include"),
+           os.path.join(ROOT, "tests", "host_plan_check.cpp"), "-o", str(exe)]
+    built = subprocess.run(cmd, capture_output=True, text=True)
+    assert built.returncode == 0, built.stderr
+    run = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300,
+                         env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1"))
+    assert run.returncode == 0, run.stdout + run.stderr
+    assert "checks passed" in run.stdout and "runtime error" not in run.stderr and "AddressSanitizer" not in run.stderr
+    # the library itself is built from the same header (a stale copy would make this test vacuous)
+    api = open(os.path.join(ROOT, "slam-duckietown_amd", "csrc", "ekf_api.hip")).read()
+    assert '#include "ekf_host_plan.h"' in api and "struct ekf_handle : ekf::HostPlan" in api
+    for fn in ("plan_pass", "cadence_length", "fill_step", "validate_obs", "build_pass_shares", "order_pass_shares"):
+        assert re.search(r"\b%s\(" % fn, api), fn                      # called from the API ...
+        assert not re.search(r"^(static|inline)[^\n;]*\b%s\(" % fn, api, flags=re.M), fn   # ... and defined only in the header
+
+
 def test_store_hazard_guard_is_in_the_shipped_machine_code(sd):
     """The 16-byte buffer stores of the row-slab pass (offen + SGPR soffset: the form LLVM's hazard recogniser does not
     cover): in the library that ships no instruction may overwrite a store's data registers within

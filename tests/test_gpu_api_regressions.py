@@ -172,12 +172,27 @@ def _tag(i, x, z):
     return NS(tag_id=i, pose_R=np.eye(3), pose_t=np.array([[x], [0.0], [z]]), pose_err=0.0)
 
 
+def _raw_step_detections(sd, f, lin, ang, tags):
+    """The C entry point itself (one trajectory, one frame), past EkfSlam.step_detections' host-side check of the
+    device front end's limits."""
+    import ctypes as C
+    dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int)
+    count = np.array([len(tags)], dtype=np.int32)
+    ids = np.array([[t.tag_id for t in tags]], dtype=np.int32)
+    pt = np.array([[np.asarray(t.pose_t, dtype=np.float64).ravel()[:3] for t in tags]])
+    pe = np.array([[t.pose_err for t in tags]], dtype=np.float64)
+    la, aa = np.array([lin]), np.array([ang])
+    return sd.load_library().ekf_step_detections(f._h, la.ctypes.data_as(dp), aa.ctypes.data_as(dp), count.ctypes.data_as(ip),
+                                                 ids.ctypes.data_as(ip), pt.ctypes.data_as(dp), pe.ctypes.data_as(dp), len(tags))
+
+
 def test_device_association_drops_before_indexing(sd):
-    """17 distinct tags in one window: the 17th is dropped BEFORE it is given a landmark index (no uninitialised
-    landmark enters the state), the sticky flag is raised and tags_positions() reports it."""
+    """The C ABI's device front end with 17 distinct tags in one window: the 17th is dropped BEFORE it is given a
+    landmark index (no uninitialised landmark enters the state), the sticky flag is raised and tags_positions()
+    reports it.  (`EkfSlam.step_detections` checks the limits on the host and never sends such a window: next test.)"""
     tags = [_tag(100 + i, -0.4 + 0.05 * i, 0.6 + 0.01 * i) for i in range(17)]
     with sd.EkfSlam(3 + 2 * 40) as f:
-        f.step_detections(0.01, 0.0, [(0.0, tags)])
+        assert _raw_step_detections(sd, f, 0.01, 0.0, tags) == 0
         assert f.size() == 3 + 2 * 16
         assert f.tag_index() == {100 + i: i for i in range(16)}
         assert f.flags() & 2
@@ -185,6 +200,80 @@ def test_device_association_drops_before_indexing(sd):
             f.tags_positions()
         mu = f.mean()
         assert np.isfinite(mu).all() and (np.abs(mu[3:]) > 0).any()
+
+
+def test_step_detections_beyond_the_device_limits(sd):
+    """The reference's dictionaries are unbounded (src/replay_no_ros.py:280-301).  `EkfSlam.step_detections` on windows the
+    device front end cannot take -- 20 distinct tags and 100 detections in one window, tag ids beyond 1024 -- associates
+    on the host instead, with the same results as the reference-shaped oracle (`associate` + augmentation + dense step);
+    windows that fit go to the device again once the table can hold the map; a window mixing both kinds of id keeps the
+    host in charge.  Two trajectories, so that one over-limit window takes the whole call."""
+    rng = np.random.default_rng(12)
+    cfg = orc.EkfConfig()
+
+    def window(ids, frames, k):
+        """`frames` frames, every tag in each (repeated detections are averaged, :315), one beyond the gate, one twice."""
+        out = []
+        for fr in range(frames):
+            tags = [_tag(int(i), float(base_x[i] + rng.normal(0, 0.004)), float(base_z[i] + rng.normal(0, 0.004))) for i in ids]
+            if fr == 0:
+                tags.append(_tag(777, 1.4, 1.4))                   # 1.98 m away: gated (:289), never indexed
+            out.append((k + 0.1 * fr, tags))
+        return out
+
+    all_ids = [3, 1500, 7, 2047, 11, 1024, 5, 9, 4000, 13, 17, 19, 23, 29, 31, 37, 41, 43, 47, 53, 59, 61, 67, 71]
+    base_x = {i: float(rng.uniform(-0.5, 0.5)) for i in all_ids}
+    base_z = {i: float(rng.uniform(0.4, 1.1)) for i in all_ids}
+    small = [i for i in all_ids if i < 1024]
+    plan = [
+        (small[:5], 2),            # fits the device: 5 tags, 12 detections
+        (all_ids[:20], 5),         # 20 distinct tags, 101 detections, ids >= 1024: host
+        (small[2:9], 3),           # would fit the device -- but the map now holds ids the device table cannot: host
+        (all_ids[4:24], 5),        # 20 tags again, four of them new
+    ]
+    with sd.EkfSlam(3 + 2 * 40, batch=2) as f:
+        om = [np.zeros(3), np.zeros(3)]
+        oP = [np.eye(3) * 0.1, np.eye(3) * 0.1]
+        oti = [{}, {}]
+        for k, (ids, frames) in enumerate(plan):
+            wins = [window(ids, frames, k), window(ids[::-1], frames, k)]            # trajectory 1 sees them in reverse order
+            lin, ang = 0.004, (0.02 if k % 2 else 0.005)
+            f.step_detections(lin, ang, wins)
+            for b in range(2):
+                om[b], oP[b], otags = orc.ekf_pose_estimation_dense(ang, lin, om[b], oP[b], 0.7, wins[b], oti[b], cfg)
+                got = f.tags_positions(b)
+                assert list(got.keys()) == list(otags.keys())
+                for j in otags:
+                    assert got[j][3] == otags[j][3]
+                    assert np.allclose([got[j][q] for q in (0, 1, 4, 5)], [otags[j][q] for q in (0, 1, 4, 5)], rtol=0, atol=1e-12)
+                assert f.tag_index(b) == oti[b]
+                mu, P = f.state(b)
+                assert f.flags(b) == 0 and len(mu) == 3 + 2 * len(oti[b])
+                close(mu, om[b])
+                close(P, oP[b])
+        assert len(oti[0]) == 24 and 777 not in oti[0]
+        # a map the handle cannot hold is refused before anything is enqueued
+        more = [_tag(5000 + i, 0.01 * i, 0.5) for i in range(20)]
+        before = [f.state(b) for b in range(2)]
+        with pytest.raises(sd.EkfError, match="capacity"):
+            f.step_detections(0.004, 0.02, [[(9.0, more)], [(9.0, more)]])
+        for b in range(2):
+            assert np.array_equal(f.state(b)[1], before[b][1]) and f.size(b) == len(before[b][0])
+    # below the limits and with small ids the device path is the one that runs (the host overlay is dropped again)
+    with sd.EkfSlam(3 + 2 * 40) as f:
+        w17 = [(0.0, [_tag(100 + i, -0.4 + 0.05 * i, 0.6 + 0.01 * i) for i in range(17)])]
+        f.step_detections(0.004, 0.02, w17)                          # 17 tags: host, then the device table follows
+        assert f.flags() == 0 and f.size() == 3 + 2 * 17 and not f._host_index
+        w3 = [(1.0, [_tag(100 + i, -0.4 + 0.05 * i, 0.61 + 0.01 * i) for i in (2, 16, 5)] + [_tag(300, 0.2, 0.9)])]
+        om, oP, oti = np.zeros(3), np.eye(3) * 0.1, {}
+        om, oP, _ = orc.ekf_pose_estimation_dense(0.02, 0.004, om, oP, 0.7, w17, oti, cfg)
+        f.step_detections(0.004, 0.02, w3)                           # device path: the table it was handed knows all 17
+        assert not f._host_tags
+        om, oP, ot = orc.ekf_pose_estimation_dense(0.02, 0.004, om, oP, 0.7, w3, oti, cfg)
+        assert f.tag_index() == oti and list(f.tags_positions().keys()) == list(ot.keys())
+        mu, P = f.state()
+        close(mu, om)
+        close(P, oP)
 
 
 def test_gpu_backend_device_association_beyond_the_device_limits(sd):
