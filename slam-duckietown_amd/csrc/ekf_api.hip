@@ -32,6 +32,7 @@ void launch_predict_rc(hipStream_t, double*, const double*, double*, const int*,
                        int, int);
 void launch_add_landmarks(hipStream_t, double*, double*, int, int, int, double, const double*);
 void launch_mirror(hipStream_t, double*, const int*, int, long, int, int);
+void launch_pack_small(hipStream_t, const double*, const double*, const unsigned*, int, int, double*);
 void launch_associate(hipStream_t, const DetIn*, int*, int*, int*, double*, double*, double*, double*, StepIn*,
                       AssocOut*, unsigned*, const AssocConfig&, int, long, int, int, int);
 void launch_fill_diag(hipStream_t, double*, int, int, const double*);
@@ -49,6 +50,7 @@ using namespace ekf;
 
 static thread_local std::string g_create_error;
 constexpr int RING = 16;
+constexpr int PACK_SMALL_N = 131;        // states up to 64 landmarks are downloaded by k_pack_small (137 KB of pinned memory)
 
 struct ekf_handle : ekf::HostPlan {
   DeviceConfig dcfg{};
@@ -107,6 +109,7 @@ struct ekf_handle : ekf::HostPlan {
   int last_shares = 0;            // ... and whether it ran on equal static shares (k_flush_rs, a few long trajectories)
   std::vector<unsigned> flags_host;
   unsigned* h_flags = nullptr;    // pinned: the sticky flags are read back with a stream-ordered copy
+  double* h_pack = nullptr;       // pinned: where k_pack_small leaves a small state (n x n covariance, mean, flags)
   // Set when an enqueueing call failed half way (e.g. a launch of the look-ahead failed after the next cadence's solve had
   // already run): the device state of every trajectory is undefined until it is uploaded again; see check_internal
   std::vector<unsigned char> host_bad;
@@ -187,6 +190,7 @@ static void free_all(ekf_handle* h) {
     if (h->shares_ev[i]) (void)hipEventDestroy(h->shares_ev[i]);
   }
   if (h->h_flags) (void)hipHostFree(h->h_flags);
+  if (h->h_pack) (void)hipHostFree(h->h_pack);
   for (auto& e : h->ring_ev) if (e) (void)hipEventDestroy(e);
   for (auto& e : h->prof_pool) (void)hipEventDestroy(e);
   if (h->t0) (void)hipEventDestroy(h->t0);
@@ -473,6 +477,20 @@ extern "C" int ekf_download_state(ekf_handle* h, int b, double* mu, double* P, i
   if (int rc = check_b(h, b, "ekf_download_state")) return rc;
   if (n != h->n[b]) return fail(h, EKF_ERR_ARG, "ekf_download_state: n does not match the state size");
   HIP_TRY(h, hipSetDevice(h->device));
+  if (P && mu && n <= PACK_SMALL_N) {
+    // a small state: flush, then ONE kernel writes covariance (mirrored from the stored triangle), mean and flags into
+    // pinned host memory; one synchronisation for everything (see k_pack_small)
+    if (h->host_bad[b]) return check_internal(h, b, "ekf_download_state");
+    if (int rc = flush_pending(h)) return rc;
+    if (!h->h_pack) HIP_TRY(h, hipHostMalloc(&h->h_pack, sizeof(double) * ((size_t)PACK_SMALL_N * PACK_SMALL_N + PACK_SMALL_N + 1), hipHostMallocDefault));
+    launch_pack_small(h->stream, h->dP + (size_t)b * h->pstride, h->dmu2[h->cur] + (size_t)b * h->ld, h->dflags + b, h->ld, n, h->h_pack);
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if ((unsigned)h->h_pack[(size_t)n * n + n] & EKF_FLAG_INTERNAL) return check_internal(h, b, "ekf_download_state");
+    std::memcpy(P, h->h_pack, sizeof(double) * (size_t)n * n);
+    std::memcpy(mu, h->h_pack + (size_t)n * n, sizeof(double) * n);
+    return EKF_OK;
+  }
   if (int rc = check_internal(h, b, "ekf_download_state")) return rc;
   if (P) {
     if (int rc = materialize(h, b)) return rc;     // the covariance is P_base + pending ranks, upper triangle

@@ -590,7 +590,9 @@ def EKF_pose_estimation(angular_displacement, linear_displacement, motion_model_
     f.step(linear_displacement, angular_displacement, idx,
            [tags_positions[k][4] for k in idx], [tags_positions[k][5] for k in idx])
     mean, cov = f.state()
-    if f.flags() & EKF_FLAG_NONFINITE:
+    # (q == 0 or a singular S leave NaN in the mean, like NumPy's 0/0 at :466-469 -- the sticky device flag says the same,
+    #  but asking for it costs a round trip per call)
+    if not np.isfinite(mean).all():
         warnings.warn("EKF_pose_estimation: non-finite state (q == 0 or singular S)", RuntimeWarning)
     d.mean_obj, d.cov_obj = mean, cov
     d.mean_copy, d.cov_sums = mean.copy(), _cov_sums(cov)
