@@ -256,6 +256,7 @@ def config5_leg(sd, sd_syn, shard, grp, device, m, steps=100, warmup=20):
             gbs = 16.0 * tri / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
             leg.update({"pass_achieved_GBs": gbs, "pass_frac_of_hbm_peak": gbs / HBM_PEAK_GBS,
                         "alg_bytes_per_launch": 16.0 * tri})
+            leg.update(pmc_traffic(f"N{N}_B1", []))
         else:
             leg["note"] = ("the pass covers the active triangle only: after warmup + steps the highest observed landmark "
                            f"is {m * (warmup + steps)} of {N}")

@@ -1721,13 +1721,17 @@ __global__ __launch_bounds__(256, 2) void k_flush(double* __restrict__ P, const 
 // LDS transposes:
 //   while tile t is in the matrix pipe (4 * NKT MFMAs on `acc`), the same wave
 //     . sends the result of tile t-1 (parked in its LDS image) to HBM as 16-byte row segments,
-//     . turns tile t+1 (already in registers, row-major) into the C/D layout through the image -> `accn`,
-//     . issues the HBM loads of tile t+2,
+//     . writes tile t+1 (already in registers, row-major) into the image, issues the HBM loads of tile t+2 into the
+//       registers that frees (round 4: right there, not at the end of the tile), and reads the image back in the
+//       C/D layout -> `accn`,
 //     . stages its share of the V strip of step t+1 into the other half of the strip buffer;
 //   at the tile boundary: one workgroup barrier (s_barrier only: nothing in flight is drained), acc -> image,
 //   acc <- accn.
 // Every global access inside the pipelined loop is unconditional (loads beyond the end of a slab are pointed at a
-// small cache-resident dummy, by a select, not a branch) so that the compiler can count what is in flight.
+// small cache-resident dummy, by a select, not a branch) and a compiler builtin, stores included (an inline-asm store
+// is invisible to the compiler's vmcnt bookkeeping: see stb16), so that the compiler can count what is in flight.
+// The covariance's layout (ekf_device.h): row-major up to ld = 4096, column panels of 4096 doubles beyond -- a tile's
+// sixteen row segments are 32 KB apart at every size (N = 8000: 5.0-5.4 -> 5.4-5.8 TB/s, profiles/r04_pass_layout.txt).
 // Work distribution: persistent workgroups (one per CU: 144 KB of LDS), units = (trajectory, 128-row slab) handed
 // out longest first from per-XCD queues (trajectory b belongs to queue b % 8: the slabs of a trajectory share V and
 // run on one L2; an idle workgroup steals from the other queues).  A slab is walked from the right end of its rows

@@ -3,7 +3,7 @@
 tools/profile_round.sh: `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE`, separate runs, counters in KiB.
 FETCH_SIZE is doubled (gfx950 reports half of the bytes of wide coalesced reads, MI355X_MICROARCH.md section HBM);
 WRITE_SIZE is exact for 16-B-per-lane streaming stores.  The entry is stamped with a hash of the kernel source
-so that bench.py can tell when it has gone stale.
+so that bench.py can tell when it has gone stale (the stamp covers every file under csrc/).
 
   python3 tools/update_traffic.py gpurun_out/prof_round 2000 [--tag r02]
 """
@@ -31,8 +31,9 @@ def main():
     out_dir, landmarks = sys.argv[1], int(sys.argv[2])
     tag = sys.argv[sys.argv.index("--tag") + 1] if "--tag" in sys.argv else "r02"
     n = 3 + 2 * landmarks
-    src = os.path.join(ROOT, "slam-duckietown_amd", "csrc", "ekf_kernels.hip")
-    sha = hashlib.sha256(open(src, "rb").read()).hexdigest()[:16]
+    sys.path.insert(0, ROOT)
+    import bench                                   # the stamp bench.py checks: a hash over all of csrc/*.hip and csrc/*.h
+    sha = bench.kernel_source_sha()
     path = os.path.join(ROOT, "profiles", "pass_traffic.json")
     data = json.load(open(path)) if os.path.exists(path) else {}
     for B, suffix in ((32, "b32"), (1, "b1")):
