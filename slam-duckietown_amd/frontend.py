@@ -37,24 +37,45 @@ def associate(detections, tag_index: Dict[int, int], pose, gate_range: float = 1
     first appearance -- which is the order the update processes them in (:436).
     The world-frame guess uses ``pose`` BEFORE the prediction (:331-332).
     """
+    # Sums instead of lists of arrays: `np.mean(list_of_(3,1)_arrays, axis=0)` (:315) adds the frames in order and divides by
+    # their number -- the same additions, in the same order, on Python floats (only pose_t[0] and pose_t[2] are ever used,
+    # :321); the errors are averaged the same way up to 7 detections (NumPy sums short 1-D arrays sequentially; from 8 on it
+    # sums pairwise, and np.mean itself is called to stay bit-identical).  What costs time here is Python, not arithmetic:
+    # this function is a third of a drop-in call at the reference's map size.
+    gate2 = gate_range ** 2
     seen: Dict[int, List] = {}
     for _stamp, tags in detections:
         for tag in tags:
-            if tag.tag_id in ignore_tags:
+            tid = tag.tag_id
+            if tid in ignore_tags:
                 continue
-            if tag.pose_t[2][0] ** 2 + tag.pose_t[0][0] ** 2 > gate_range ** 2:
+            t = tag.pose_t
+            tx, tz = float(t[0][0]), float(t[2][0])
+            if tz * tz + tx * tx > gate2:
                 continue
-            if tag.tag_id not in tag_index:
-                tag_index[tag.tag_id] = len(tag_index)
-            seen.setdefault(tag_index[tag.tag_id], []).append((tag.pose_t, tag.pose_err))
-    id_of = {v: k for k, v in tag_index.items()}
+            lm = tag_index.get(tid)
+            if lm is None:
+                lm = tag_index[tid] = len(tag_index)
+            acc = seen.get(lm)
+            if acc is None:
+                seen[lm] = [tx, tz, [tag.pose_err], tid]
+            else:
+                acc[0] += tx
+                acc[1] += tz
+                acc[2].append(tag.pose_err)
     x0, y0, th = float(pose[0]), float(pose[1]), float(pose[2])
     result = {}
-    for lm, obs in seen.items():
-        t = np.mean([o[0] for o in obs], axis=0)
-        err = np.mean([o[1] for o in obs], axis=0)
-        x_r, y_r = t[2][0], -t[0][0]
+    for lm, (sx, sz, errs, tid) in seen.items():
+        k = len(errs)
+        if k < 8:
+            e = errs[0]
+            for v in errs[1:]:
+                e = e + v
+            err = np.float64(e) / k
+        else:
+            err = np.mean(errs, axis=0)
+        x_r, y_r = np.float64(sz / k), np.float64(-(sx / k))
         rng = np.sqrt(x_r ** 2 + y_r ** 2)
         brg = np.arctan2(y_r, x_r)
-        result[lm] = [x0 + rng * np.cos(brg + th), y0 + rng * np.sin(brg + th), err, id_of[lm], rng, brg]
+        result[lm] = [x0 + rng * np.cos(brg + th), y0 + rng * np.sin(brg + th), err, tid, rng, brg]
     return result

@@ -21,6 +21,8 @@ def main():
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--option", action="append", default=[])
     ap.add_argument("--nmax", type=int, default=0, help="capacity of the handle (sets the row stride ld = ceil(nmax / 64) * 64)")
+    ap.add_argument("--dense-start", action="store_true", help="start from a dense covariance (diagonal + rank 8): every entry of "
+                    "V / W is non-zero from the first step on -- fp64 MFMA power, and with it the clock, depends on the operands")
     args = ap.parse_args()
     import slam_duckietown_amd as sd
     import slam_duckietown_amd.synthetic as syn
@@ -33,7 +35,15 @@ def main():
         k, v = o.split("=")
         f.set_option(k, int(v))
     for b, s in enumerate(streams):
-        f.set_state_diag(s[0], s[1], b)
+        if args.dense_start:
+            rng = np.random.default_rng(b)
+            A = rng.normal(size=(n, 8)) * 0.3
+            P = A @ A.T
+            P[np.arange(n), np.arange(n)] += rng.uniform(0.5, 2.0, n)
+            f.set_state(s[0], P, b)
+            del P
+        else:
+            f.set_state_diag(s[0], s[1], b)
     f.stream_upload(*[np.stack([s[i] for s in streams], 1) for i in (2, 3, 4, 5, 6)])
     f.stream_run(0, 10)
     f.flush()
@@ -44,7 +54,7 @@ def main():
     ms, cnt = f.profile_read()
     tri = n * (n + 1) / 2.0
     per = ms / max(cnt, 1)
-    print(f"variant={os.environ.get('EKFSLAM_HIP_VARIANT', 'default'):10s} options={args.option} nmax={args.nmax} launches={cnt} "
+    print(f"variant={os.environ.get('EKFSLAM_HIP_VARIANT', 'default'):10s} options={args.option} nmax={args.nmax} {'dense start ' if args.dense_start else ''}launches={cnt} "
           f"avg={per * 1e3:8.1f} us  {B * 16.0 * tri / (per * 1e-3) / 1e12:6.3f} TB/s algorithmic")
     f.close()
 
