@@ -457,8 +457,14 @@ def secondary_leg(name, args):
                        "value": B * steps / dts, "unit": "steps/s", "pass_avg_launch_ms": avg, "pass_launches": ls,
                        "pass_frac_of_hbm_peak": (B * 16.0 * tri / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS) if avg > 0 else 0.0}}
     if name == "config1":
-        return {name: stream_leg(sd, sd_syn, shard, grp, dev, 20, args.obs, 500, 20, args.option,
-                                 "BASELINE config 1's size on the GPU")}
+        # N = 20 fits a CU's LDS: the small-state path (csrc/ekf_small.hip) runs the whole stream as ONE launch, P resident in LDS;
+        # a bank of such filters (a Monte-Carlo run at the reference's map size) is one workgroup per trajectory
+        leg = stream_leg(sd, sd_syn, shard, grp, dev, 20, args.obs, 500, 20, args.option, "BASELINE config 1's size on the GPU")
+        dtb, _, _, _ = time_filter(sd, sd_syn, shard, grp, dev, list(range(256)), 20, args.obs, 500, 20, profile_leg=False,
+                                   options=args.option)
+        leg["bank_of_256"] = {"workload": "N=20, m=8, 256 trajectories (one workgroup each), 500 steps", "value": 256 * 500 / dtb,
+                              "unit": "steps/s"}
+        return {name: leg}
     if name == "config2":
         return {name: stream_leg(sd, sd_syn, shard, grp, dev, 500, args.obs, 500, 20, args.option, "BASELINE config 2")}
     if name == "online_step":

@@ -3,6 +3,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -33,6 +34,9 @@ void launch_predict_rc(hipStream_t, double*, const double*, double*, const int*,
 void launch_add_landmarks(hipStream_t, double*, double*, int, int, int, double, const double*);
 void launch_mirror(hipStream_t, double*, const int*, int, long, int, int);
 void launch_pack_small(hipStream_t, const double*, const double*, const unsigned*, int, int, double*);
+int small_state_limit();
+int launch_small_stream(hipStream_t, double*, const double*, double*, const int*, const StepIn*, int, int, unsigned*,
+                        const DeviceConfig&, int, long, int);
 void launch_associate(hipStream_t, const DetIn*, int*, int*, int*, double*, double*, double*, double*, StepIn*,
                       AssocOut*, unsigned*, const AssocConfig&, int, long, int, int, int);
 void launch_fill_diag(hipStream_t, double*, int, int, const double*);
@@ -105,6 +109,7 @@ struct ekf_handle : ekf::HostPlan {
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   double* dgbuf = nullptr;        // per trajectory: the next cadence's block, gathered while this one's ranks are pending
   long lookaheads = 0;
+  long small_launches = 0;        // statistics: launches of the small-state path (k_small_stream)
   int last_kernel = -1, last_nkt = 0, last_streaming = 0;   // what the last covariance pass launched
   int last_shares = 0;            // ... and whether it ran on equal static shares (k_flush_rs, a few long trajectories)
   std::vector<unsigned> flags_host;
@@ -251,6 +256,7 @@ extern "C" int ekf_create(int device, int n_max, int batch, const ekf_config* cf
   h->batch = batch;
   h->pstride = p_alloc(h->rows, h->ld);                // (column panels of 4096 doubles beyond ld = 4096: ekf_device.h)
   if (cfg) h->cfg = *cfg; else ekf_config_default(&h->cfg);
+  if (const char* e = std::getenv("EKFSLAM_HIP_SMALL_STATE")) h->opt_small_state = std::atoi(e) != 0;   // (tests pin the general kernels at small sizes)
   const double s = h->cfg.motion_sigma, q = h->cfg.meas_sigma;
   h->dcfg.rd[0] = s * s;                        // src/replay_no_ros.py:421
   h->dcfg.rd[1] = s * s;
@@ -619,8 +625,25 @@ static int flush_pending(ekf_handle* h, hipStream_t st) {
 }
 static int flush_pending(ekf_handle* h) { return flush_pending(h, nullptr); }
 
+// The small-state path (ekf_small.hip): a filter bank whose covariances fit the LDS of a CU runs `nsteps` steps per trajectory
+// inside one workgroup, P resident in LDS; nothing is ever pending on it.
+static bool small_path(const ekf_handle* h) {
+  return h->opt_small_state && h->n_max <= small_state_limit() && h->pending_k == 0;
+}
+static int enqueue_small(ekf_handle* h, const StepIn* d_in, int nsteps) {
+  const int n_hi = h->sizes_dirty ? h->n_max : *std::max_element(h->n.begin(), h->n.end());
+  if (launch_small_stream(h->stream, h->dP, h->dmu2[h->cur], h->dmu2[h->cur ^ 1], h->dn, d_in, h->batch, nsteps, h->dflags,
+                          h->dcfg, h->ld, h->pstride, n_hi) != 0)
+    return fail(h, EKF_ERR_HIP, "small-state launch: hipFuncSetAttribute failed");
+  HIP_TRY(h, hipGetLastError());
+  h->cur ^= 1;
+  h->small_launches += 1;
+  return EKF_OK;
+}
+
 // Enqueue one device pass with inputs already at d_in (StepIn[batch]); m_hi = max m over the batch.
 static int enqueue_pass(ekf_handle* h, const StepIn* d_in, int m_hi) {
+  if (small_path(h)) return enqueue_small(h, d_in, 1);
   const int n_hi = h->sizes_dirty ? h->n_max : *std::max_element(h->n.begin(), h->n.end());
   const int mcap = cap_for(m_hi);
   const int ktp = ranks_for(mcap);
@@ -1012,6 +1035,15 @@ extern "C" int ekf_stream_run(ekf_handle* h, int first, int count) {
       return fail(h, EKF_ERR_STATE, "ekf_stream_run: the uploaded stream observes landmarks the current state does not have");
   HIP_TRY(h, hipSetDevice(h->device));
   if (int rc = push_floor(h, true)) return rc;
+  if (small_path(h) && count > 0) {
+    // the whole range as ONE launch (in pieces of 4096 steps: a bounded kernel), P resident in LDS across all its steps
+    for (int k = first; k < first + count; k += 4096)
+      if (int rc = enqueue_small(h, h->d_stream + (size_t)k * h->batch, std::min(4096, first + count - k))) return rc;
+    for (int b = 0; b < h->batch; ++b)
+      h->neff[b] = std::max(h->neff[b], std::min(h->n[b], h->stream_own[(size_t)(first + count - 1) * h->batch + b]));
+    h->neff_enq = h->neff;
+    return EKF_OK;
+  }
   bool presolved = false;                              // the cadence that starts at k has its solve enqueued already (look-ahead)
   for (int k = first; k < first + count;) {
     // A whole cadence at once where nothing is pending: the steps up to the next covariance pass as one solve launch
@@ -1180,6 +1212,8 @@ extern "C" int ekf_debug_cadences(ekf_handle* h, long* cadences, long* steps) {
 }
 // (development aid, not declared in the header) how many of them had their solve run beside the previous covariance pass
 extern "C" long ekf_debug_lookaheads(ekf_handle* h) { return h ? h->lookaheads : -1; }
+// (development aid, not declared in the header) launches of the small-state path so far
+extern "C" long ekf_debug_small_launches(ekf_handle* h) { return h ? h->small_launches : -1; }
 
 // (development aid, not declared in the header) the fused cadence's record of trajectory b (head + per-landmark records)
 extern "C" long ekf_debug_cad(ekf_handle* h, int b, void* dst, long bytes) {
@@ -1247,6 +1281,13 @@ extern "C" int ekf_set_option(ekf_handle* h, const char* name, int value) {
   if (std::strcmp(name, "pass_chunk") == 0) {
     if (value < 0 || value > 4096) return fail(h, EKF_ERR_ARG, "pass_chunk out of range");
     h->opt_pass_chunk = value;
+    return EKF_OK;
+  }
+  if (std::strcmp(name, "small_state") == 0) {
+    if (value != 0 && value != 1) return fail(h, EKF_ERR_ARG, "small_state must be 0 or 1");
+    HIP_TRY(h, hipSetDevice(h->device));
+    if (int rc = flush_pending(h)) return rc;          // (the small-state path runs only with nothing pending)
+    h->opt_small_state = value;
     return EKF_OK;
   }
   if (std::strcmp(name, "pass_share_order") == 0) {

@@ -69,14 +69,16 @@ class Model:
         self.cov = cov
 
 
-@pytest.mark.parametrize("seed,n_lm,batch", [(0, 30, 1), (1, 70, 2), (2, 140, 3), (3, 260, 1), (4, 45, 2), (5, 400, 1)])
-def test_random_mixed_api_sequences_against_the_oracle(sd, seed, n_lm, batch):
+@pytest.mark.parametrize("seed,n_lm,batch,small", [(0, 30, 1, 0), (1, 70, 2, 0), (2, 140, 3, 0), (3, 260, 1, 0), (4, 45, 2, 0),
+                                                   (5, 400, 1, 0), (6, 30, 2, 1), (7, 50, 3, 1), (8, 12, 1, 1)])
+def test_random_mixed_api_sequences_against_the_oracle(sd, seed, n_lm, batch, small):
     rng = np.random.default_rng(1000 + seed)
     cfg = orc.EkfConfig()
     models = [Model(rng, n_lm, cfg) for _ in range(batch)]
     cap = 3 + 2 * (n_lm + 12)
     ops_done = []
     with sd.EkfSlam(cap, batch=batch) as f:
+        f.set_option("small_state", small)           # (small: the whole state in LDS, csrc/ekf_small.hip; needs n_max <= 131)
         for b, mdl in enumerate(models):
             if rng.random() < 0.5:
                 f.set_state_diag(mdl.mean, mdl.diag, b)

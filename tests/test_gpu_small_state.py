@@ -1,0 +1,239 @@
+"""GPU parity of the SMALL-STATE path (slam-duckietown_amd/csrc/ekf_small.hip): filters whose covariance fits a CU's LDS
+(n_max <= 131: up to 64 landmarks; the reference's real map has 12, src/replay_no_ros.py:26) run every step -- or a whole
+uploaded stream -- inside one workgroup with P resident in LDS.  Same arithmetic as the reference (simple-form update,
+sequential re-linearisation, src/replay_no_ros.py:368-480), so the cases are the reference's own golden vectors: the N = 20 and
+N = 50 streams, the whole-function replay fixtures through the drop-in and through the device-side association, the flag
+variants, q = 0, augmentation, banks of trajectories of different size -- each asserted to have taken the small-state kernel.
+(tests/conftest.py pins every OTHER test module to the general kernels.)
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from oracle import ekf_oracle as orc
+from tests import golden_util as gu
+
+pytestmark = pytest.mark.gpu
+
+REL_TOL = 1e-6
+TIGHT = 1e-9
+
+
+@pytest.fixture(scope="module")
+def sd():
+    import slam_duckietown_amd as sd
+    sd.load_library()
+    return sd
+
+
+def close(a, b, tol=TIGHT):
+    r = orc.rel_fro(a, b)
+    assert r < REL_TOL, f"rel Frobenius {r:.3e} exceeds the 1e-6 bar"
+    assert r < tol, f"rel Frobenius {r:.3e} exceeds the expected {tol:g}"
+
+
+def small_launches(sd, f):
+    lib = sd.load_library()
+    lib.ekf_debug_small_launches.argtypes = [C.c_void_p]
+    lib.ekf_debug_small_launches.restype = C.c_long
+    return lib.ekf_debug_small_launches(f._h)
+
+
+def test_small_state_is_the_default_up_to_64_landmarks(sd, monkeypatch):
+    monkeypatch.delenv("EKFSLAM_HIP_SMALL_STATE", raising=False)
+    s = orc.synthetic_stream(20, 3, 8, 0)
+    for n_max, expect in ((43, 3), (131, 3), (133, 0)):
+        with sd.EkfSlam(n_max) as f:
+            f.set_state_diag(s[0], s[1])
+            for k in range(3):
+                f.step(s[2][k], s[3][k], s[4][k], s[5][k], s[6][k])
+            assert small_launches(sd, f) == expect
+            f.set_option("small_state", 0)
+            f.step(s[2][0], s[3][0], s[4][0], s[5][0], s[6][0])
+            assert small_launches(sd, f) == expect
+
+
+@pytest.mark.parametrize("case", ["stream_n20_m8", "stream_n20_m1", "stream_n50_m8"])
+def test_golden_streams_step_by_step(sd, case):
+    """The reference's own outputs, every step (BASELINE config 1: N = 20, 500 steps), one launch per step."""
+    g = gu.load(case)
+    n = len(g["mean0"])
+    kept = {int(s): i for i, s in enumerate(g["out_cov_steps"])}
+    with sd.EkfSlam(n) as f:
+        f.set_option("small_state", 1)
+        f.set_state_diag(g["mean0"], g["diag0"])
+        for k in range(len(g["lin"])):
+            f.step(g["lin"][k], g["ang"][k], g["idx"][k], g["zr"][k], g["zb"][k])
+            close(f.mean(), g["out_mean"][k])
+            if k in kept:
+                P = f.covariance()
+                close(P, g["out_cov"][kept[k]])
+                assert np.array_equal(P, P.T)
+        assert f.flags() == 0 and small_launches(sd, f) == len(g["lin"])
+
+
+@pytest.mark.parametrize("case", ["stream_n20_m8", "stream_n50_m8"])
+def test_golden_streams_as_one_launch(sd, case):
+    """The same streams uploaded and run as ONE launch per piece (P stays in LDS across all steps of a piece), in pieces that
+    end on the steps the fixture kept a covariance for; against the golden vectors and against the general kernels."""
+    g = gu.load(case)
+    n = len(g["mean0"])
+    steps = len(g["lin"])
+    cuts = sorted(set(int(s) + 1 for s in g["out_cov_steps"]) | {steps})
+    kept = {int(s): i for i, s in enumerate(g["out_cov_steps"])}
+    out = {}
+    for small in (1, 0):
+        with sd.EkfSlam(n) as f:
+            f.set_option("small_state", small)
+            f.set_state_diag(g["mean0"], g["diag0"])
+            f.stream_upload(g["lin"], g["ang"], g["idx"], g["zr"], g["zb"])
+            at = 0
+            for c in cuts:
+                f.stream_run(at, c - at)
+                at = c
+                mu, P = f.state()
+                close(mu, g["out_mean"][c - 1])
+                if c - 1 in kept:
+                    close(P, g["out_cov"][kept[c - 1]])
+            assert f.flags() == 0
+            assert small_launches(sd, f) == (len(cuts) if small else 0)
+            out[small] = (mu, P)
+    close(out[1][0], out[0][0], 1e-10)
+    close(out[1][1], out[0][1], 1e-10)
+
+
+@pytest.mark.parametrize("case", gu.REPLAY_CASES)
+def test_drop_in_function_golden_on_the_small_path(sd, case, monkeypatch):
+    """`EKF_pose_estimation` (the reference's whole function: association, augmentation, step) on the replay fixtures the
+    reference itself produced, all flag variants, with the handle on the small-state path."""
+    from slam_duckietown_amd import ekf_bindings as eb
+    monkeypatch.setenv("EKFSLAM_HIP_SMALL_STATE", "1")
+    g = gu.load(case)
+    monkeypatch.setattr(eb, "DROP_IN_CONFIG", eb.EkfConfig(enable_measurement_model=bool(g["flag_measurement"]),
+                                                           enable_circular_interpolation=bool(g["flag_circular"]),
+                                                           disable_motion_model=bool(g["flag_no_motion"]),
+                                                           ignore_tags=gu.ignore_tags(g)))
+    if eb._drop.filt is not None:
+        eb._drop.filt.close()
+        eb._drop.filt = None
+    mean, cov, ti = np.zeros(3), np.eye(3) * 0.1, {}
+    try:
+        for k in range(len(g["lin"])):
+            mean, cov, tags = sd.EKF_pose_estimation(g["ang"][k], g["lin"][k], mean, cov, 0.7, gu.detections_for_step(g, k), ti)
+            n = int(g["out_size"][k])
+            assert len(mean) == n
+            close(mean, g["out_mean"][k, :n])
+            close(cov, g["out_cov"][k, :n, :n])
+            assert list(tags.keys()) == [i for i in g["out_obs_order"][k] if i >= 0]
+        assert small_launches(sd, eb._drop.filt) >= len(g["lin"]) - 2    # (the handle is re-created when the map outgrows it)
+    finally:
+        if eb._drop.filt is not None:
+            eb._drop.filt.close()
+            eb._drop.filt = None
+
+
+@pytest.mark.parametrize("case", gu.REPLAY_CASES)
+def test_device_side_association_golden_on_the_small_path(sd, case):
+    """The whole front end on the GPU (k_associate: association, gate, averaging, augmentation) feeding the small-state kernel."""
+    g = gu.load(case)
+    cfg = sd.EkfConfig(enable_measurement_model=bool(g["flag_measurement"]), enable_circular_interpolation=bool(g["flag_circular"]),
+                       disable_motion_model=bool(g["flag_no_motion"]))
+    with sd.EkfSlam(3 + 2 * 12, config=cfg) as f:
+        f.set_option("small_state", 1)
+        if gu.ignore_tags(g):
+            f.set_association(1.5, gu.ignore_tags(g))
+        for k in range(len(g["lin"])):
+            f.step_detections(g["lin"][k], g["ang"][k], gu.detections_for_step(g, k))
+            n = int(g["out_size"][k])
+            mu, P = f.state()
+            assert len(mu) == n
+            close(mu, g["out_mean"][k, :n])
+            close(P, g["out_cov"][k, :n, :n])
+        assert sorted(f.tag_index().items(), key=lambda kv: kv[1]) == [tuple(r) for r in g["out_tag_index"]]
+        assert f.flags() == 0 and small_launches(sd, f) == len(g["lin"])
+
+
+def test_bank_of_small_filters_of_different_size_against_the_oracle(sd):
+    """12 trajectories of 5 .. 64 landmarks in one handle (one workgroup each), dense starts, predictions and updates on their
+    own, 0 .. 20 observations per step (more than 16 are split into passes), an uploaded stream in the middle."""
+    rng = np.random.default_rng(7)
+    sizes = [5, 12, 12, 20, 31, 40, 47, 50, 58, 63, 64, 64]
+    B = len(sizes)
+    cfg = orc.EkfConfig()
+    means, covs = [], []
+    for b, N in enumerate(sizes):
+        n = 3 + 2 * N
+        A = rng.normal(size=(n, 5)) * 0.3
+        covs.append(A @ A.T + np.diag(rng.uniform(0.5, 2.0, n)))
+        means.append(np.concatenate([[0.0, 0.0, 0.1 * b], rng.uniform(-1.0, 1.0, 2 * N)]))
+
+    def observe(b, m):
+        N = sizes[b]
+        idx = rng.choice(N, size=min(m, N), replace=False).astype(np.int32)
+        dx, dy = means[b][3 + 2 * idx] - means[b][0], means[b][4 + 2 * idx] - means[b][1]
+        return idx, np.hypot(dx, dy) + rng.normal(0, 0.02, len(idx)), np.arctan2(dy, dx) - means[b][2] + rng.normal(0, 0.02, len(idx))
+
+    with sd.EkfSlam(131, batch=B) as f:
+        f.set_option("small_state", 1)
+        for b in range(B):
+            f.set_state(means[b], covs[b], b)
+        for it in range(12):
+            lin, ang = rng.uniform(0.002, 0.02, B), rng.uniform(-0.3, 0.3, B)
+            ang[rng.random(B) < 0.3] = 0.004
+            obs = [observe(b, int(rng.integers(0, 21))) for b in range(B)]
+            kind = it % 4
+            if kind == 0:
+                f.step(lin, ang, [o[0] for o in obs], [o[1] for o in obs], [o[2] for o in obs])
+                for b in range(B):
+                    means[b], covs[b] = orc.ekf_step_dense(means[b], covs[b], lin[b], ang[b], *obs[b], cfg)
+            elif kind == 1:
+                f.predict(lin, ang)
+                for b in range(B):
+                    means[b], covs[b] = orc.predict_dense(means[b], covs[b], lin[b], ang[b], cfg)
+            elif kind == 2:
+                f.update([o[0] for o in obs], [o[1] for o in obs], [o[2] for o in obs])
+                for b in range(B):
+                    means[b], covs[b] = orc.update_dense(means[b], covs[b], *obs[b], cfg)
+            else:
+                steps, mcap = 7, 4
+                idx = np.zeros((steps, B, mcap), dtype=np.int32)
+                zr, zb = np.zeros((steps, B, mcap)), np.zeros((steps, B, mcap))
+                ms = np.zeros((steps, B), dtype=np.int32)
+                lins, angs = rng.uniform(0.002, 0.02, (steps, B)), rng.uniform(-0.2, 0.2, (steps, B))
+                for k in range(steps):
+                    for b in range(B):
+                        o = observe(b, int(rng.integers(0, mcap + 1)))
+                        m = len(o[0])
+                        ms[k, b] = m
+                        idx[k, b, :m], zr[k, b, :m], zb[k, b, :m] = o
+                        means[b], covs[b] = orc.ekf_step_dense(means[b], covs[b], lins[k, b], angs[k, b], o[0], o[1], o[2], cfg)
+                f.run_stream(lins, angs, idx, zr, zb, ms)
+        assert small_launches(sd, f) > 0
+        for b in range(B):
+            mu, P = f.state(b)
+            assert f.flags(b) == 0 and len(mu) == 3 + 2 * sizes[b]
+            close(mu, means[b])
+            close(P, covs[b])
+            assert np.array_equal(P, P.T)
+
+
+def test_q_zero_and_growth_on_the_small_path(sd):
+    """q = 0 (a landmark exactly at the robot's position) propagates NaN like NumPy's 0/0 at :466-469 and raises the sticky
+    flag -- in its own trajectory only; augmentation between small-state steps."""
+    with sd.EkfSlam(3 + 2 * 10, batch=2) as f:
+        f.set_option("small_state", 1)
+        mu = np.array([0.2, -0.1, 0.3, 0.2, -0.1, 1.0, 0.5])
+        for b in range(2):
+            f.set_state(mu, np.eye(7) * 0.2, b)
+        f.add_landmarks(np.array([[0.4, 0.9]]), 1)
+        f.step([0.0, 0.004], [0.0, 0.02], [[0], [2]], [[0.3], [0.9]], [[0.1], [0.2]])
+        assert f.flags(0) & 1 and not np.isfinite(f.mean(0)).all()
+        assert f.flags(1) == 0
+        om, oP = np.concatenate([mu, [0.4, 0.9]]), np.zeros((9, 9))
+        oP[:7, :7] = np.eye(7) * 0.2
+        oP[7, 7] = oP[8, 8] = 1.0e4
+        om, oP = orc.ekf_step_dense(om, oP, 0.004, 0.02, [2], [0.9], [0.2], orc.EkfConfig())
+        m1, P1 = f.state(1)
+        close(m1, om)
+        close(P1, oP)
