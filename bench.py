@@ -27,7 +27,7 @@ The JSON line also carries
   steady_state  the headline workload timed behind a full sweep of the landmarks (dense covariance: fp64 MFMA power, and the
                 clock the part holds, depend on the operands -- ~9 % slower than the young filter the contract times)
   sclk_mhz      shader clock sampled during the headline's timed region
-  Every secondary leg runs in a child process of its own (allocation placement: see main).
+  `--leg NAME` runs one secondary leg alone and prints it.
   (rank 0, N = 1 only, except sclk_mhz and rank_dt_ms).
 """
 from __future__ import annotations
@@ -415,7 +415,7 @@ SECONDARY_LEGS = ["single_trajectory", "obs_1_per_step", "config5", "steady_stat
 
 
 def secondary_leg(name, args):
-    """One secondary leg of the JSON line -> {key: value}.  Runs in a child process of its own (see main)."""
+    """One secondary leg of the JSON line -> {key: value}."""
     import slam_duckietown_amd as sd
     import slam_duckietown_amd.sharding as shard
     import slam_duckietown_amd.synthetic as sd_syn
@@ -479,21 +479,6 @@ def secondary_leg(name, args):
     raise SystemExit(f"unknown leg {name}")
 
 
-def run_leg_in_child(name, args):
-    """`python bench.py --leg NAME ...` as a child process; its one JSON line is the leg.  A failed leg is reported, not hidden."""
-    import subprocess
-    cmd = [sys.executable, os.path.abspath(__file__), "--leg", name, "--steps", str(args.steps), "--warmup", str(args.warmup),
-           "--landmarks", str(args.landmarks), "--obs", str(args.obs), "--trajectories", str(args.trajectories)]
-    for o in args.option:
-        cmd += ["--option", o]
-    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
-    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, timeout=600)
-    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-    if r.returncode != 0 or not lines:
-        return {name: {"error": f"leg process exited with {r.returncode}", "stderr_tail": r.stderr[-400:]}}
-    return json.loads(lines[-1])
-
-
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -506,7 +491,7 @@ def main():
     ap.add_argument("--no-single", action="store_true")
     ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE",
                     help="ekf_set_option knob, e.g. flush_every=3 (default: library defaults)")
-    ap.add_argument("--leg", default=None, help="(internal) run ONE secondary leg and print it as a JSON line")
+    ap.add_argument("--leg", default=None, help="run ONE secondary leg (see SECONDARY_LEGS) and print it as a JSON line")
     args = ap.parse_args()
     if args.leg:
         if not any(o.startswith("active_bound=") for o in args.option):
@@ -605,13 +590,13 @@ def main():
         out["roofline"].update(pmc_traffic(f"N{args.landmarks}_B{B}", args.option))
     if world == 1 and rank == 0:
         if not args.no_single:
-            # Every secondary leg runs in a FRESH CHILD PROCESS (this one stays alive and idle, its handles closed): a process
-            # that has freed a large buffer gets worse-placed memory for the next one from the HIP allocator -- the N = 8000 pass
-            # reads 387 - 391 us behind the headline leg of the same process against 349 - 360 us in a process of its own, and the
-            # same handle allocated BEFORE the headline leg and timed after it reads 359 us (tools/leg_order_probe.py,
-            # profiles/r04_config5_pass.txt).  A user's program creates its filter bank once; a leg per process is that.
+            # Secondary legs, one handle after another in this process.  (Until round 4 the second handle of a process ran its
+            # look-ahead -- the pass on a second stream beside the next solve -- 10 % slower than the first: HIP's mapping of
+            # freshly created streams onto hardware queues after the first handle's streams had been destroyed.  The library now
+            # parks a destroyed handle's stream pair and hands it to the next handle: tools/leg_order_probe.py,
+            # profiles/r04_dense_operands.txt part 2.  `--leg NAME` runs one leg in a process of its own.)
             for name in SECONDARY_LEGS:
-                out.update(run_leg_in_child(name, args))
+                out.update(secondary_leg(name, args))
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.landmarks, args.obs)
     if rank == 0:

@@ -53,6 +53,35 @@ void launch_panels_cad(hipStream_t, int, double*, double*, double*, const double
 using namespace ekf;
 
 static thread_local std::string g_create_error;
+
+// Stream pairs outlive their handles.  A handle drives two HIP streams (its own and the one the look-ahead sends the covariance
+// pass to, beside the next cadence's solve).  HIP maps streams onto a few hardware queues as they are created; measured on this
+// pool: the second handle of a process -- created after the first one's streams had been destroyed -- ran its pass and the solve
+// beside it 10 % slower (N = 8000 x 1: 389 us against 355 us; 355 us again with lookahead = 0: the two streams no longer ran
+// side by side), whatever memory it was given (tools/leg_order_probe.py, profiles/r04_dense_operands.txt part 2).  So the pair
+// a destroyed handle leaves is parked here, per device, and the next handle on that device takes it over: the mapping the
+// first pair got in a fresh process is the one every later handle runs on.  (Streams are idle when parked: free_all
+// synchronises them.)
+#include <mutex>
+struct StreamPair { int device; hipStream_t stream, aux; };
+static std::mutex g_pairs_mu;
+static std::vector<StreamPair> g_pairs;
+static bool take_stream_pair(int device, hipStream_t* stream, hipStream_t* aux) {
+  std::lock_guard<std::mutex> lk(g_pairs_mu);
+  for (size_t i = 0; i < g_pairs.size(); ++i)
+    if (g_pairs[i].device == device) {
+      *stream = g_pairs[i].stream;
+      *aux = g_pairs[i].aux;
+      g_pairs.erase(g_pairs.begin() + (long)i);
+      return true;
+    }
+  return false;
+}
+static void park_stream_pair(int device, hipStream_t stream, hipStream_t aux) {
+  std::lock_guard<std::mutex> lk(g_pairs_mu);
+  g_pairs.push_back({device, stream, aux});
+}
+
 constexpr int RING = 16;
 constexpr int PACK_SMALL_N = 131;        // states up to 64 landmarks are downloaded by k_pack_small (137 KB of pinned memory)
 
@@ -202,11 +231,13 @@ static void free_all(ekf_handle* h) {
   if (h->t1) (void)hipEventDestroy(h->t1);
   if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
   if (h->ev_join) (void)hipEventDestroy(h->ev_join);
-  if (h->aux) {
-    (void)hipStreamSynchronize(h->aux);
-    (void)hipStreamDestroy(h->aux);
+  if (h->aux) (void)hipStreamSynchronize(h->aux);
+  if (h->stream && h->aux) {
+    park_stream_pair(h->device, h->stream, h->aux);    // (see g_pairs: the next handle on this device takes the pair over)
+  } else {
+    if (h->aux) (void)hipStreamDestroy(h->aux);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
   }
-  if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
 }
 
@@ -287,8 +318,10 @@ extern "C" int ekf_create(int device, int n_max, int batch, const ekf_config* cf
     }                                                                                     \
   } while (0)
   CREATE_TRY(hipSetDevice(device));
-  CREATE_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
-  CREATE_TRY(hipStreamCreateWithFlags(&h->aux, hipStreamNonBlocking));
+  if (!take_stream_pair(device, &h->stream, &h->aux)) {
+    CREATE_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    CREATE_TRY(hipStreamCreateWithFlags(&h->aux, hipStreamNonBlocking));
+  }
   CREATE_TRY(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
   CREATE_TRY(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
   const size_t ldz = (size_t)h->ld;

@@ -279,11 +279,14 @@ int launch_small_stream(hipStream_t st, double* P, const double* mu_in, double* 
   const int n = n_hi < SMALL_N_MAX ? n_hi : SMALL_N_MAX, ps = n | 1;
   const size_t bytes = sizeof(double) * ((size_t)n * ps + 5 * (size_t)n + 4) + 2 * sizeof(StepIn);
   const int full = (int)(sizeof(double) * ((size_t)SMALL_N_MAX * (SMALL_N_MAX | 1) + 5 * SMALL_N_MAX + 4) + 2 * sizeof(StepIn));
-  static bool raised = false;
-  if (!raised) {                                            // (more than 64 KB of dynamic LDS needs the attribute once)
+  // more than 64 KB of dynamic LDS needs the attribute -- once per DEVICE (a process may hold handles on several GPUs)
+  static bool raised[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return -1;
+  if (n > 80 && !raised[dev]) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_small_stream<256, 9>), hipFuncAttributeMaxDynamicSharedMemorySize, full) != hipSuccess)
       return -1;
-    raised = true;
+    raised[dev] = true;
   }
 #define EKF_SMALL(TM)                                                                                                        \
   hipLaunchKernelGGL((k_small_stream<256, TM>), dim3(batch), dim3(256), bytes, st, P, mu_in, mu_out, nact, in, batch, nsteps, \

@@ -54,6 +54,18 @@ elif mode == "hold_dummy":
     p = C.c_void_p()
     assert hip.hipMalloc(C.byref(p), C.c_size_t(6 << 30)) == 0
     leg("(6 GB held)")
+elif mode in ("after_headline_nolook", "first_nolook"):
+    if mode == "after_headline_nolook":
+        headline()
+    N = 8000
+    s = syn.synthetic_stream(N, 120, 8, 0)
+    f = sd.EkfSlam(3 + 2 * N)
+    f.set_option("active_bound", 0)
+    f.set_option("lookahead", 0)
+    f.set_state_diag(s[0], s[1])
+    f.stream_upload(*[np.stack([s[i]], 1) for i in (2, 3, 4, 5, 6)])
+    f.sync()
+    print(mode, "pass us", round(timed_handle(f, None), 1))
 elif mode == "prealloc":
     N = 8000
     s = syn.synthetic_stream(N, 120, 8, 0)
