@@ -139,6 +139,7 @@ struct ekf_handle : ekf::HostPlan {
   double* dgbuf = nullptr;        // per trajectory: the next cadence's block, gathered while this one's ranks are pending
   long lookaheads = 0;
   long small_launches = 0;        // statistics: launches of the small-state path (k_small_stream)
+  int opt_zero_copy_inputs = 1;   // small-state online steps read their records from the pinned ring (no staged copy)
   int last_kernel = -1, last_nkt = 0, last_streaming = 0;   // what the last covariance pass launched
   int last_shares = 0;            // ... and whether it ran on equal static shares (k_flush_rs, a few long trajectories)
   std::vector<unsigned> flags_host;
@@ -843,6 +844,15 @@ static int do_step(ekf_handle* h, int base_flags, const double* lin, const doubl
       m_pass_hi = std::max(m_pass_hi, hs[b].m);
       h->neff_enq[b] = h->opt_active_bound ? h->neff[b] : h->n[b];
     }
+    if (small_path(h) && h->opt_zero_copy_inputs) {
+      // small-state path: the one workgroup per trajectory fetches its 352-byte record straight from the pinned ring (one
+      // coalesced read over PCIe, ~1.5 us) -- a staged host-to-device copy in front of the kernel costs 5 - 10 us of latency
+      // per step, which at these sizes is a third of the step
+      if (int rc = enqueue_pass(h, hs, m_pass_hi)) return rc;
+      HIP_TRY(h, hipEventRecord(h->ring_ev[slot], h->stream));   // (the slot is free once the kernel has run)
+      h->ring_used[slot] = true;
+      continue;
+    }
     HIP_TRY(h, hipMemcpyAsync(ds, hs, sizeof(StepIn) * h->batch, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipEventRecord(h->ring_ev[slot], h->stream));
     h->ring_used[slot] = true;
@@ -1321,6 +1331,11 @@ extern "C" int ekf_set_option(ekf_handle* h, const char* name, int value) {
     HIP_TRY(h, hipSetDevice(h->device));
     if (int rc = flush_pending(h)) return rc;          // (the small-state path runs only with nothing pending)
     h->opt_small_state = value;
+    return EKF_OK;
+  }
+  if (std::strcmp(name, "zero_copy_inputs") == 0) {
+    if (value != 0 && value != 1) return fail(h, EKF_ERR_ARG, "zero_copy_inputs must be 0 or 1");
+    h->opt_zero_copy_inputs = value;
     return EKF_OK;
   }
   if (std::strcmp(name, "pass_share_order") == 0) {

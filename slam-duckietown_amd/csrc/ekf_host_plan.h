@@ -39,7 +39,7 @@ struct HostPlan {
   int opt_fused_step = 1;         // 1 = one launch per step where the launch is small (k_step_split), 0 = always two
   int opt_fused_cadence = 1;      // 1 = uploaded streams run whole cadences as one solve + one panel launch (ekf_cadence.hip)
   int opt_lookahead = 1;
-  int opt_small_state = 1;        // 1 = filters whose covariance fits a CU's LDS (n_max <= 131) run in ONE workgroup (ekf_small.hip)
+  int opt_small_state = 1;        // 1 = small filters (n_max <= 79: up to 38 landmarks) run in ONE workgroup, P in LDS (ekf_small.hip)
   int opt_rows_per_block = 0;     // 0 = auto (flush kernel: rows per workgroup, multiple of 16)
   int opt_pass_chunk = 0;         // 0 = auto (k_flush_rs: strips per unit)
   int opt_share_order = 1;        // 1 = static shares dealt to the XCDs by starting column (order_pass_shares), 0 = as built

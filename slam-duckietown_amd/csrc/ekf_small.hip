@@ -1,6 +1,8 @@
-// The SMALL-STATE path (gfx950, wave64): a filter whose whole covariance fits the LDS of one CU -- n <= SMALL_N_MAX = 131,
-// i.e. up to 64 landmarks: the reference's real map has 12 (src/replay_no_ros.py:26) -- runs every step, or a whole uploaded
-// stream of steps, inside ONE workgroup with P resident in LDS.
+// The SMALL-STATE path (gfx950, wave64): a small filter -- n <= SMALL_N_MAX = 79, i.e. up to 38 landmarks: the reference's real
+// map has 12 (src/replay_no_ros.py:26) -- runs every step, or a whole uploaded stream of steps, inside ONE workgroup with P
+// resident in LDS.  (The limit is where this path stops winning, not where LDS ends: tools/step_latency.py, N = 38: 25.7 us per
+// online step and 13.0 us per streamed step against 27.5 / 18.9 us on the general kernels; N = 45: 30.6 / 16.7 against 27.6 / 19.0;
+// N = 64: 44 / 25 against 28 / 19 -- the down-date and the per-launch load / store of the triangle grow with n^2.)
 //
 // The general kernels are built for covariances that live in HBM: a step appends ranks, the O(n^2) pass is deferred, and every
 // step pays a sequential "solve" chain of ~1.4 us per landmark on the compressed block plus two or three dependent launches.
@@ -13,14 +15,14 @@
 //     simple-form, sequentially re-linearised arithmetic as the reference, three workgroup barriers per landmark,
 //   * writes mean and upper triangle back.
 // One launch per online step (instead of solve + panels [+ pass]); ONE launch for a whole uploaded stream.  N = 20, m = 8, one
-// trajectory: ~3 us per step against 19 us on the general path; a bank of small filters is one workgroup each.
+// trajectory: 9.8 us per step against 18 - 19 us on the general path; a bank of small filters is one workgroup each.
 // No rank is ever pending on this path (pending_k stays 0), so every other entry point -- uploads, downloads, augmentation,
 // device-side association, the dense product -- works on P_base as it stands.
 #include "ekf_devfn.h"
 
 namespace ekf {
 
-constexpr int SMALL_N_MAX = 131;        // 3 + 2 * 64: the (n x (n | 1)) matrix + vectors stay below 160 KB of LDS
+constexpr int SMALL_N_MAX = 79;         // 3 + 2 * 38 (<= 5 column tiles of 16; 50 KB of LDS): beyond, the general kernels are faster
 
 // One step's landmark updates and prediction on the LDS-resident state.  `Pl` is n x ps (ps odd: row and column walks are
 // both conflict-free), `mu` the mean, `hp` / `kk` 2 x n scratch.
@@ -102,7 +104,7 @@ __device__ __forceinline__ void small_step(double* __restrict__ Pl, double* __re
   }
   // ---- the landmarks, in order (:436-480) ----
   // What one landmark costs is latency, so every phase is as parallel as its data allow: the columns of (H P) one per thread
-  // (n <= 131: waves 0 - 2), the innovation (atan2 + wrap: the longest scalar chain, needed by the mean only) on wave 3 beside
+  // (n <= 79: waves 0 - 1), the innovation (atan2 + wrap: the longest scalar chain, needed by the mean only) on wave 3 beside
   // them, the rank-2 down-date as 16 x 16 tiles of the upper triangle over all 256 threads (independent iterations: the
   // loads of the next tiles are in flight under this one's FMAs).
   const int ty = tid >> 4, tx = tid & 15;
@@ -168,7 +170,7 @@ __device__ __forceinline__ void small_step(double* __restrict__ Pl, double* __re
     //  stores are predicated -- with the loads under the `a <= b` branch each tile was its own trip to LDS: 8 of 16 us per step)
 #ifndef SM_SKIP_UPDATE                                   /* diagnostic build (timing only, wrong results): no covariance down-date */
     if constexpr (TM <= 5) {
-      // few tiles (n <= 80): ALL of them in flight at once -- one round trip to LDS for the whole down-date
+      // ALL tiles in flight at once -- one round trip to LDS for the whole down-date
       constexpr int NTILE = TM * (TM + 1) / 2;
       double pv[NTILE], h0[TM], h1[TM], k0[TM], k1[TM];
 #pragma unroll
@@ -244,9 +246,35 @@ __global__ __launch_bounds__(NT) void k_small_stream(double* __restrict__ P, con
   static_assert(sizeof(StepIn) % 8 == 0 && RW <= NT, "one 8-byte word of a record per thread");
   unsigned long long* recw = reinterpret_cast<unsigned long long*>(sc + 4);   // 2 x RW words
   double* Pb = P + (long)b * pstride;
-  for (int e = tid; e < n * n; e += NT) {
-    const int r = e / n, c = e - r * n;
-    Pl[r * ps + c] = Pb[p_index(ld, min(r, c), max(r, c))];
+  // the stored upper triangle, rows dealt to the waves, columns to the lanes (coalesced), four rows' loads in flight together;
+  // every entry is written to both places of the LDS matrix (n <= 79 < 2 x 64: at most two columns per lane and row)
+  {
+    const int w = tid >> 6, lane = tid & 63;
+    constexpr int NWV = NT / 64, U = 4;
+    for (int r0 = w; r0 < n; r0 += NWV * U) {
+      double v[U][3];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int r = min(r0 + NWV * u, n - 1);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const int c = min(max(lane + 64 * q, r), n - 1);          // (clamped into the row's stored part: no load under a branch)
+          v[u][q] = Pb[p_index(ld, r, c)];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int r = r0 + NWV * u;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const int c = lane + 64 * q;
+          if (r < n && c >= r && c < n) {
+            Pl[r * ps + c] = v[u][q];
+            Pl[c * ps + r] = v[u][q];
+          }
+        }
+      }
+    }
   }
   for (int c = tid; c < n; c += NT) mu[c] = mu_in[(long)b * ld + c];
   if (tid < RW) recw[tid] = reinterpret_cast<const unsigned long long*>(in + b)[tid];
@@ -266,9 +294,14 @@ __global__ __launch_bounds__(NT) void k_small_stream(double* __restrict__ P, con
     bad |= !(fabs(v) <= 1.79769313486231570815e308);
   }
   if (__syncthreads_or(bad) && tid == 0) atomicOr(flags + b, EKF_FLAG_NONFINITE);
-  for (int e = tid; e < n * n; e += NT) {
-    const int r = e / n, c = e - r * n;
-    if (r <= c) Pb[p_index(ld, r, c)] = Pl[r * ps + c];
+  {
+    const int w = tid >> 6, lane = tid & 63;
+    for (int r = w; r < n; r += NT / 64)
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int c = lane + 64 * q;
+        if (c >= r && c < n) Pb[p_index(ld, r, c)] = Pl[r * ps + c];
+      }
   }
 }
 
@@ -278,22 +311,11 @@ int launch_small_stream(hipStream_t st, double* P, const double* mu_in, double* 
                         int batch, int nsteps, unsigned* flags, const DeviceConfig& cfg, int ld, long pstride, int n_hi) {
   const int n = n_hi < SMALL_N_MAX ? n_hi : SMALL_N_MAX, ps = n | 1;
   const size_t bytes = sizeof(double) * ((size_t)n * ps + 5 * (size_t)n + 4) + 2 * sizeof(StepIn);
-  const int full = (int)(sizeof(double) * ((size_t)SMALL_N_MAX * (SMALL_N_MAX | 1) + 5 * SMALL_N_MAX + 4) + 2 * sizeof(StepIn));
-  // more than 64 KB of dynamic LDS needs the attribute -- once per DEVICE (a process may hold handles on several GPUs)
-  static bool raised[64] = {};
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return -1;
-  if (n > 80 && !raised[dev]) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_small_stream<256, 9>), hipFuncAttributeMaxDynamicSharedMemorySize, full) != hipSuccess)
-      return -1;
-    raised[dev] = true;
-  }
 #define EKF_SMALL(TM)                                                                                                        \
   hipLaunchKernelGGL((k_small_stream<256, TM>), dim3(batch), dim3(256), bytes, st, P, mu_in, mu_out, nact, in, batch, nsteps, \
                      flags, cfg, ld, pstride)
   if (n <= 48) EKF_SMALL(3);
-  else if (n <= 80) EKF_SMALL(5);
-  else EKF_SMALL(9);
+  else EKF_SMALL(5);
 #undef EKF_SMALL
   return 0;
 }

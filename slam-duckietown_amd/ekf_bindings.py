@@ -540,7 +540,7 @@ class _DropInState:
 _drop = _DropInState()
 DROP_IN_CONFIG = EkfConfig()      # edit like the reference's module constants
 DROP_IN_ALWAYS_UPLOAD = False     # True: never trust the records, upload mean and covariance every call
-DROP_IN_MIN_CAPACITY = 131        # n_max of the first handle (64 landmarks: the small-state path, P resident in LDS); grows by doubling
+DROP_IN_MIN_CAPACITY = 79         # n_max of the first handle (38 landmarks: the small-state path, P resident in LDS); grows by doubling
 
 
 def _cov_sums(cov: np.ndarray) -> np.ndarray:
