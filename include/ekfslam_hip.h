@@ -103,6 +103,14 @@ int ekf_update(ekf_handle *h, const int *idx, const double *range, const double 
 int ekf_step(ekf_handle *h, const double *lin, const double *ang, const int *idx,
              const double *range, const double *bearing, const int *m, int stride);
 
+/* ekf_step followed by ekf_download_state(h, b, mu, P, n), as ONE call: one iteration of the reference's loop
+ * (`mean, covariance, tags = EKF_pose_estimation(...)`, src/replay_no_ros.py:229-237; the return at :482 hands back the
+ * whole state every call).  Same results as the two calls.  On the small-state path (option "small_state") the step's
+ * own launch writes trajectory b's mean, mirrored covariance and flags into pinned host memory: one kernel launch and one
+ * synchronisation per call; otherwise the two calls are made for the caller.  Blocking; n must equal the state size. */
+int ekf_step_fetch(ekf_handle *h, const double *lin, const double *ang, const int *idx, const double *range,
+                   const double *bearing, const int *m, int stride, int b, double *mu, double *P, int n);
+
 /* Device-side front end (association, 1.5 m gate, per-tag averaging, augmentation: src/replay_no_ros.py:280-360)
  * followed by the fused step: one window of raw AprilTag detections per trajectory, frames concatenated in
  * order -- count[b] detections at tag_id / pose_t (x, y, z of tag.pose_t) / pose_err [b*stride + i].  The tag-id

@@ -36,7 +36,7 @@ void launch_mirror(hipStream_t, double*, const int*, int, long, int, int);
 void launch_pack_small(hipStream_t, const double*, const double*, const unsigned*, int, int, double*);
 int small_state_limit();
 int launch_small_stream(hipStream_t, double*, const double*, double*, const int*, const StepIn*, int, int, unsigned*,
-                        const DeviceConfig&, int, long, int);
+                        const DeviceConfig&, int, long, int, double*, int, unsigned long long*, unsigned long long);
 void launch_associate(hipStream_t, const DetIn*, int*, int*, int*, double*, double*, double*, double*, StepIn*,
                       AssocOut*, unsigned*, const AssocConfig&, int, long, int, int, int);
 void launch_fill_diag(hipStream_t, double*, int, int, const double*);
@@ -83,6 +83,8 @@ static void park_stream_pair(int device, hipStream_t stream, hipStream_t aux) {
 }
 
 constexpr int RING = 16;
+constexpr int RING_GROUP = 4;             // slots per completion event: an event record between two launches costs the
+                                          // stream a barrier packet, ~2 us per online step of a small filter
 constexpr int PACK_SMALL_N = 131;        // states up to 64 landmarks are downloaded by k_pack_small (137 KB of pinned memory)
 
 struct ekf_handle : ekf::HostPlan {
@@ -98,8 +100,9 @@ struct ekf_handle : ekf::HostPlan {
   SolveOut* dso = nullptr;
   double* dfac = nullptr;         // pending factors restricted to the gathered indices (k_solve -> k_panels)
   StepIn *d_ring = nullptr, *h_ring = nullptr;
-  hipEvent_t ring_ev[RING]{};
-  bool ring_used[RING]{};
+  hipEvent_t ring_ev[RING / RING_GROUP]{};   // one event per group of slots (see ring_take)
+  bool ring_used[RING / RING_GROUP]{};
+  bool ring_open[RING / RING_GROUP]{};
   int ring_pos = 0;
   StepIn* d_stream = nullptr;
   size_t stream_cap = 0;
@@ -139,6 +142,11 @@ struct ekf_handle : ekf::HostPlan {
   double* dgbuf = nullptr;        // per trajectory: the next cadence's block, gathered while this one's ranks are pending
   long lookaheads = 0;
   long small_launches = 0;        // statistics: launches of the small-state path (k_small_stream)
+  long fused_fetches = 0;         // statistics: ekf_step_fetch calls answered by the step's own launch
+  int fetch_b = -1;               // ekf_step_fetch: the trajectory whose state the next small-state launch leaves in h_pack
+  bool fetched = false;
+  unsigned long long fetch_seq = 0;   // ... and the sequence number that launch releases behind it (polled by the host)
+  int opt_fetch_spin = 1;
   int opt_zero_copy_inputs = 1;   // small-state online steps read their records from the pinned ring (no staged copy)
   int last_kernel = -1, last_nkt = 0, last_streaming = 0;   // what the last covariance pass launched
   int last_shares = 0;            // ... and whether it ran on equal static shares (k_flush_rs, a few long trajectories)
@@ -289,6 +297,7 @@ extern "C" int ekf_create(int device, int n_max, int batch, const ekf_config* cf
   h->pstride = p_alloc(h->rows, h->ld);                // (column panels of 4096 doubles beyond ld = 4096: ekf_device.h)
   if (cfg) h->cfg = *cfg; else ekf_config_default(&h->cfg);
   if (const char* e = std::getenv("EKFSLAM_HIP_SMALL_STATE")) h->opt_small_state = std::atoi(e) != 0;   // (tests pin the general kernels at small sizes)
+  if (const char* e = std::getenv("EKFSLAM_HIP_FETCH_SPIN")) h->opt_fetch_spin = std::atoi(e) != 0;
   const double s = h->cfg.motion_sigma, q = h->cfg.meas_sigma;
   h->dcfg.rd[0] = s * s;                        // src/replay_no_ros.py:421
   h->dcfg.rd[1] = s * s;
@@ -502,6 +511,16 @@ extern "C" int ekf_upload_state_diag(ekf_handle* h, int b, const double* mu, con
   return EKF_OK;
 }
 
+// The pinned buffer small states come back through (k_pack_small, k_small_stream's host_out): n x n covariance, mean, flags;
+// its last word is the sequence number ekf_step_fetch polls.
+constexpr size_t PACK_WORDS = (size_t)PACK_SMALL_N * PACK_SMALL_N + PACK_SMALL_N + 2;
+static int pack_buffer(ekf_handle* h) {
+  if (h->h_pack) return EKF_OK;
+  HIP_TRY(h, hipHostMalloc(&h->h_pack, sizeof(double) * PACK_WORDS, hipHostMallocCoherent));
+  std::memset(h->h_pack, 0, sizeof(double) * PACK_WORDS);
+  return EKF_OK;
+}
+
 // The step kernels keep only the upper triangle of P_base current.  Before the host (or the dense product)
 // looks at trajectory b: apply the pending ranks, then mirror the upper triangle into the lower one.
 static int materialize(ekf_handle* h, int b) {
@@ -522,7 +541,7 @@ extern "C" int ekf_download_state(ekf_handle* h, int b, double* mu, double* P, i
     // pinned host memory; one synchronisation for everything (see k_pack_small)
     if (h->host_bad[b]) return check_internal(h, b, "ekf_download_state");
     if (int rc = flush_pending(h)) return rc;
-    if (!h->h_pack) HIP_TRY(h, hipHostMalloc(&h->h_pack, sizeof(double) * ((size_t)PACK_SMALL_N * PACK_SMALL_N + PACK_SMALL_N + 1), hipHostMallocDefault));
+    if (int rc = pack_buffer(h)) return rc;
     launch_pack_small(h->stream, h->dP + (size_t)b * h->pstride, h->dmu2[h->cur] + (size_t)b * h->ld, h->dflags + b, h->ld, n, h->h_pack);
     HIP_TRY(h, hipGetLastError());
     HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -666,10 +685,15 @@ static bool small_path(const ekf_handle* h) {
 }
 static int enqueue_small(ekf_handle* h, const StepIn* d_in, int nsteps) {
   const int n_hi = h->sizes_dirty ? h->n_max : *std::max_element(h->n.begin(), h->n.end());
+  const int out_b = h->fetch_b;                        // (ekf_step_fetch, last pass of its step: see there)
+  h->fetch_b = -1;
   if (launch_small_stream(h->stream, h->dP, h->dmu2[h->cur], h->dmu2[h->cur ^ 1], h->dn, d_in, h->batch, nsteps, h->dflags,
-                          h->dcfg, h->ld, h->pstride, n_hi) != 0)
+                          h->dcfg, h->ld, h->pstride, n_hi, out_b >= 0 ? h->h_pack : nullptr, out_b,
+                          out_b >= 0 ? reinterpret_cast<unsigned long long*>(h->h_pack + PACK_WORDS - 1) : nullptr,
+                          out_b >= 0 ? ++h->fetch_seq : 0ull) != 0)
     return fail(h, EKF_ERR_HIP, "small-state launch: hipFuncSetAttribute failed");
   HIP_TRY(h, hipGetLastError());
+  h->fetched = out_b >= 0;
   h->cur ^= 1;
   h->small_launches += 1;
   return EKF_OK;
@@ -805,8 +829,31 @@ static int enqueue_cadence(ekf_handle* h, int k, int g, int end, bool presolved,
   return EKF_OK;
 }
 
+// The input rings (h_ring / d_ring, h_det / d_det): RING slots used in order.  A slot may be refilled by the host once the
+// work that read it has run; that is tracked per GROUP of slots -- the event of a group is recorded behind the launch that
+// read its last slot and waited for when the ring comes round to its first slot again.
+static int ring_take(ekf_handle* h, int* slot) {
+  const int s = h->ring_pos, g = s / RING_GROUP;
+  h->ring_pos = (s + 1) % RING;
+  if (s % RING_GROUP == 0) {
+    if (h->ring_open[g]) HIP_TRY(h, hipStreamSynchronize(h->stream));   // (a failed call left the group without its event)
+    else if (h->ring_used[g]) HIP_TRY(h, hipEventSynchronize(h->ring_ev[g]));
+  }
+  h->ring_open[g] = true;
+  *slot = s;
+  return EKF_OK;
+}
+static int ring_done(ekf_handle* h, int slot) {
+  if (slot % RING_GROUP != RING_GROUP - 1) return EKF_OK;
+  const int g = slot / RING_GROUP;
+  HIP_TRY(h, hipEventRecord(h->ring_ev[g], h->stream));
+  h->ring_used[g] = true;
+  h->ring_open[g] = false;
+  return EKF_OK;
+}
+
 static int do_step(ekf_handle* h, int base_flags, const double* lin, const double* ang, const int* idx,
-                   const double* range, const double* bearing, const int* m, int stride) {
+                   const double* range, const double* bearing, const int* m, int stride, int fetch_b = -1) {
   if (!h) return EKF_ERR_ARG;
   if (int rc = check_host_bad(h, "ekf_step")) return rc;
   if (int rc = refresh_sizes(h)) return rc;
@@ -829,9 +876,8 @@ static int do_step(ekf_handle* h, int base_flags, const double* lin, const doubl
   if (int rc = push_floor(h, false)) return rc;
   const int passes = std::max(1, (m_hi + MMAX - 1) / MMAX);
   for (int p = 0; p < passes; ++p) {
-    const int slot = h->ring_pos;
-    h->ring_pos = (h->ring_pos + 1) % RING;
-    if (h->ring_used[slot]) HIP_TRY(h, hipEventSynchronize(h->ring_ev[slot]));
+    int slot;
+    if (int rc = ring_take(h, &slot)) return rc;
     StepIn* hs = h->h_ring + (size_t)slot * h->batch;
     StepIn* ds = h->d_ring + (size_t)slot * h->batch;
     int flags = (upd ? FLAG_UPDATE : 0) | ((pred && p == 0) ? FLAG_PREDICT : 0);
@@ -844,20 +890,20 @@ static int do_step(ekf_handle* h, int base_flags, const double* lin, const doubl
       m_pass_hi = std::max(m_pass_hi, hs[b].m);
       h->neff_enq[b] = h->opt_active_bound ? h->neff[b] : h->n[b];
     }
+    h->fetch_b = p == passes - 1 ? fetch_b : -1;
     if (small_path(h) && h->opt_zero_copy_inputs) {
       // small-state path: the one workgroup per trajectory fetches its 352-byte record straight from the pinned ring (one
       // coalesced read over PCIe, ~1.5 us) -- a staged host-to-device copy in front of the kernel costs 5 - 10 us of latency
       // per step, which at these sizes is a third of the step
       if (int rc = enqueue_pass(h, hs, m_pass_hi)) return rc;
-      HIP_TRY(h, hipEventRecord(h->ring_ev[slot], h->stream));   // (the slot is free once the kernel has run)
-      h->ring_used[slot] = true;
+      if (int rc = ring_done(h, slot)) return rc;                // (the slot is free once the kernel has run)
       continue;
     }
     HIP_TRY(h, hipMemcpyAsync(ds, hs, sizeof(StepIn) * h->batch, hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(h, hipEventRecord(h->ring_ev[slot], h->stream));
-    h->ring_used[slot] = true;
+    if (int rc = ring_done(h, slot)) return rc;
     if (int rc = enqueue_pass(h, ds, m_pass_hi)) return rc;
   }
+  h->fetch_b = -1;
   return EKF_OK;
 }
 
@@ -896,9 +942,8 @@ extern "C" int ekf_step_detections(ekf_handle* h, const double* lin, const doubl
   if (int rc = push_floor(h, false)) return rc;
   // an upper bound of the landmarks observed this window (distinct tag ids) selects the kernel instantiation
   int m_hi = 0;
-  const int slot = h->ring_pos;
-  h->ring_pos = (h->ring_pos + 1) % RING;
-  if (h->ring_used[slot]) HIP_TRY(h, hipEventSynchronize(h->ring_ev[slot]));
+  int slot;
+  if (int rc = ring_take(h, &slot)) return rc;
   DetIn* hs = h->h_det + (size_t)slot * h->batch;
   DetIn* ds = h->d_det + (size_t)slot * h->batch;
   for (int b = 0; b < h->batch; ++b) {
@@ -929,8 +974,7 @@ extern "C" int ekf_step_detections(ekf_handle* h, const double* lin, const doubl
   if (!h->sizes_dirty)
     HIP_TRY(h, hipMemcpyAsync(h->dneff, h->neff.data(), sizeof(int) * h->batch, hipMemcpyHostToDevice, h->stream));
   HIP_TRY(h, hipMemcpyAsync(ds, hs, sizeof(DetIn) * h->batch, hipMemcpyHostToDevice, h->stream));
-  HIP_TRY(h, hipEventRecord(h->ring_ev[slot], h->stream));
-  h->ring_used[slot] = true;
+  if (int rc = ring_done(h, slot)) return rc;
   const int mcap = cap_for(m_hi);
   if (h->pending_k + ranks_for(mcap) > KTOT)
     if (int rc = flush_pending(h)) return rc;
@@ -1013,6 +1057,51 @@ extern "C" int ekf_update(ekf_handle* h, const int* idx, const double* range, co
 extern "C" int ekf_step(ekf_handle* h, const double* lin, const double* ang, const int* idx,
                         const double* range, const double* bearing, const int* m, int stride) {
   return do_step(h, FLAG_PREDICT | FLAG_UPDATE, lin, ang, idx, range, bearing, m, stride);
+}
+
+// ekf_step + ekf_download_state(b) in one call: what one iteration of the reference's loop is (EKF_pose_estimation returns
+// mean and covariance every call, src/replay_no_ros.py:229-237, :482).  On the small-state path the step's own launch
+// leaves trajectory b's state in pinned host memory (k_small_stream's host_out): one launch and one synchronisation per call.
+extern "C" int ekf_step_fetch(ekf_handle* h, const double* lin, const double* ang, const int* idx, const double* range,
+                              const double* bearing, const int* m, int stride, int b, double* mu, double* P, int n) {
+  if (int rc = check_b(h, b, "ekf_step_fetch")) return rc;
+  if (!mu || !P) return fail(h, EKF_ERR_ARG, "ekf_step_fetch: NULL output array");
+  if (n != h->n[b]) return fail(h, EKF_ERR_ARG, "ekf_step_fetch: n does not match the state size");
+  h->fetched = false;
+  int want = -1;
+  if (n <= PACK_SMALL_N && small_path(h) && h->opt_zero_copy_inputs) {
+    HIP_TRY(h, hipSetDevice(h->device));
+    if (int rc = pack_buffer(h)) return rc;
+    want = b;
+  }
+  const int rc_step = do_step(h, FLAG_PREDICT | FLAG_UPDATE, lin, ang, idx, range, bearing, m, stride, want);
+  h->fetch_b = -1;
+  if (rc_step) return rc_step;
+  if (!h->fetched) return ekf_download_state(h, b, mu, P, n);
+  h->fetched = false;
+  h->fused_fetches += 1;
+  if (h->opt_fetch_spin) {
+    // poll the sequence word the kernel releases behind its stores (pinned, coherent); every few microseconds make sure the
+    // stream is still busy -- a launch that failed would otherwise be waited for forever
+    const unsigned long long* word = reinterpret_cast<const unsigned long long*>(h->h_pack + PACK_WORDS - 1);
+    for (long spin = 1;; ++spin) {
+      if (__atomic_load_n(word, __ATOMIC_ACQUIRE) == h->fetch_seq) break;
+      if ((spin & 4095) == 0) {
+        const hipError_t q = hipStreamQuery(h->stream);
+        if (q == hipErrorNotReady) continue;
+        if (q != hipSuccess) return fail(h, EKF_ERR_HIP, std::string("ekf_step_fetch: ") + hipGetErrorString(q));
+        if (__atomic_load_n(word, __ATOMIC_ACQUIRE) == h->fetch_seq) break;
+        return fail(h, EKF_ERR_HIP, "ekf_step_fetch: the stream drained without the step's state having been written");
+      }
+      __builtin_ia32_pause();
+    }
+  } else {
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+  }
+  if ((unsigned)h->h_pack[(size_t)n * n + n] & EKF_FLAG_INTERNAL) return check_internal(h, b, "ekf_step_fetch");
+  std::memcpy(P, h->h_pack, sizeof(double) * (size_t)n * n);
+  std::memcpy(mu, h->h_pack + (size_t)n * n, sizeof(double) * n);
+  return EKF_OK;
 }
 
 extern "C" int ekf_stream_upload(ekf_handle* h, int steps, const double* lin, const double* ang, const int* idx,
@@ -1257,6 +1346,7 @@ extern "C" int ekf_debug_cadences(ekf_handle* h, long* cadences, long* steps) {
 extern "C" long ekf_debug_lookaheads(ekf_handle* h) { return h ? h->lookaheads : -1; }
 // (development aid, not declared in the header) launches of the small-state path so far
 extern "C" long ekf_debug_small_launches(ekf_handle* h) { return h ? h->small_launches : -1; }
+extern "C" long ekf_debug_fused_fetches(ekf_handle* h) { return h ? h->fused_fetches : -1; }
 
 // (development aid, not declared in the header) the fused cadence's record of trajectory b (head + per-landmark records)
 extern "C" long ekf_debug_cad(ekf_handle* h, int b, void* dst, long bytes) {
@@ -1336,6 +1426,11 @@ extern "C" int ekf_set_option(ekf_handle* h, const char* name, int value) {
   if (std::strcmp(name, "zero_copy_inputs") == 0) {
     if (value != 0 && value != 1) return fail(h, EKF_ERR_ARG, "zero_copy_inputs must be 0 or 1");
     h->opt_zero_copy_inputs = value;
+    return EKF_OK;
+  }
+  if (!std::strcmp(name, "fetch_spin")) {
+    if (value != 0 && value != 1) return fail(h, EKF_ERR_ARG, "fetch_spin must be 0 or 1");
+    h->opt_fetch_spin = value;
     return EKF_OK;
   }
   if (std::strcmp(name, "pass_share_order") == 0) {

@@ -230,7 +230,9 @@ template <int NT, int TM>
 __global__ __launch_bounds__(NT) void k_small_stream(double* __restrict__ P, const double* __restrict__ mu_in,
                                                      double* __restrict__ mu_out, const int* __restrict__ nact,
                                                      const StepIn* __restrict__ in, int batch, int nsteps,
-                                                     unsigned* __restrict__ flags, DeviceConfig cfg, int ld, long pstride) {
+                                                     unsigned* __restrict__ flags, DeviceConfig cfg, int ld, long pstride,
+                                                     double* __restrict__ host_out, int out_b,
+                                                     unsigned long long* __restrict__ host_seq, unsigned long long out_seq) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int b = blockIdx.x, tid = threadIdx.x;
   const int n = min(min(nact[b], SMALL_N_MAX), 16 * TM);
@@ -293,7 +295,24 @@ __global__ __launch_bounds__(NT) void k_small_stream(double* __restrict__ P, con
     mu_out[(long)b * ld + c] = v;
     bad |= !(fabs(v) <= 1.79769313486231570815e308);
   }
-  if (__syncthreads_or(bad) && tid == 0) atomicOr(flags + b, EKF_FLAG_NONFINITE);
+  const bool any_bad = __syncthreads_or(bad);
+  if (any_bad && tid == 0) atomicOr(flags + b, EKF_FLAG_NONFINITE);
+  if (host_out && b == out_b) {
+    // ekf_step_fetch: the state the caller asked for goes straight from LDS into pinned host memory, in k_pack_small's
+    // layout (dense mirrored n x n covariance, mean, sticky flags) -- no second launch between the step and the host
+    for (int e = tid; e < n * n; e += NT) {
+      const int r = e / n, c = e - r * n;
+      host_out[e] = Pl[r * ps + c];
+    }
+    for (int c = tid; c < n; c += NT) host_out[n * n + c] = mu[c];
+    if (tid == 0) host_out[n * n + n] = (double)(atomicOr(flags + b, 0u) | (any_bad ? EKF_FLAG_NONFINITE : 0u));
+    // the host does not wait for the launch to retire (completion signal, interrupt or poll of the runtime: 10 - 15 us) but
+    // polls this word: every thread's stores are fenced to system scope, then the call's sequence number is released
+    __threadfence_system();
+    __syncthreads();
+    if (tid == 0)
+      __hip_atomic_store(host_seq, out_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
   {
     const int w = tid >> 6, lane = tid & 63;
     for (int r = w; r < n; r += NT / 64)
@@ -308,12 +327,13 @@ __global__ __launch_bounds__(NT) void k_small_stream(double* __restrict__ P, con
 int small_state_limit() { return SMALL_N_MAX; }
 
 int launch_small_stream(hipStream_t st, double* P, const double* mu_in, double* mu_out, const int* nact, const StepIn* in,
-                        int batch, int nsteps, unsigned* flags, const DeviceConfig& cfg, int ld, long pstride, int n_hi) {
+                        int batch, int nsteps, unsigned* flags, const DeviceConfig& cfg, int ld, long pstride, int n_hi,
+                        double* host_out, int out_b, unsigned long long* host_seq, unsigned long long out_seq) {
   const int n = n_hi < SMALL_N_MAX ? n_hi : SMALL_N_MAX, ps = n | 1;
   const size_t bytes = sizeof(double) * ((size_t)n * ps + 5 * (size_t)n + 4) + 2 * sizeof(StepIn);
 #define EKF_SMALL(TM)                                                                                                        \
   hipLaunchKernelGGL((k_small_stream<256, TM>), dim3(batch), dim3(256), bytes, st, P, mu_in, mu_out, nact, in, batch, nsteps, \
-                     flags, cfg, ld, pstride)
+                     flags, cfg, ld, pstride, host_out, out_b, host_seq, out_seq)
   if (n <= 48) EKF_SMALL(3);
   else EKF_SMALL(5);
 #undef EKF_SMALL

@@ -111,6 +111,7 @@ ABI = {
     "ekf_predict": (C.c_int, [C.c_void_p, _dp, _dp]),
     "ekf_update": (C.c_int, [C.c_void_p, _ip, _dp, _dp, _ip, C.c_int]),
     "ekf_step": (C.c_int, [C.c_void_p, _dp, _dp, _ip, _dp, _dp, _ip, C.c_int]),
+    "ekf_step_fetch": (C.c_int, [C.c_void_p, _dp, _dp, _ip, _dp, _dp, _ip, C.c_int, C.c_int, _dp, _dp, C.c_int]),
     "ekf_set_association": (C.c_int, [C.c_void_p, C.c_double, _ip, C.c_int]),
     "ekf_step_detections": (C.c_int, [C.c_void_p, _dp, _dp, _ip, _ip, _dp, _dp, C.c_int]),
     "ekf_download_tags": (C.c_int, [C.c_void_p, C.c_int, _ip, _ip, _ip, _dp, _dp, _dp, _dp, _dp]),
@@ -176,6 +177,9 @@ def _p(a, typ=_dp):
     return a.ctypes.data_as(typ)
 
 
+_SMALL_OUT_N = 131        # (PACK_SMALL_N of csrc/ekf_api.hip: states the library hands over through one pinned buffer)
+
+
 class EkfSlam:
     """A bank of ``batch`` independent EKF-SLAM filters resident on one MI355X.
 
@@ -200,6 +204,14 @@ class EkfSlam:
         self._assoc_gate, self._assoc_ignore = self.config.gate_range, tuple(self.config.ignore_tags)
         self._host_index = {}
         self._host_tags = {}
+        # per-call staging arrays and their ctypes pointers, made once: `ndarray.ctypes.data_as` costs ~2 us per argument,
+        # seven of them were most of what an online step of a small filter cost on the host (the library copies everything
+        # it needs out of these arrays before the call returns)
+        self._lin, self._ang = np.zeros(self.batch), np.zeros(self.batch)
+        self._m = np.zeros(self.batch, dtype=np.int32)
+        self._plin, self._pang, self._pm = _p(self._lin), _p(self._ang), _p(self._m, _ip)
+        self._stages = {}
+        self._out = None
 
     # -- plumbing ------------------------------------------------------------------------------
     def _check(self, rc: int):
@@ -223,32 +235,42 @@ class EkfSlam:
     def __exit__(self, *exc):
         self.close()
 
-    def _per_traj(self, x, name):
-        a = np.atleast_1d(np.asarray(x, dtype=np.float64))
-        if a.shape == (1,) and self.batch > 1:
-            a = np.repeat(a, self.batch)
-        if a.shape != (self.batch,):
+    def _per_traj(self, x, name, out):
+        """One value per trajectory (a scalar or a one-element array is repeated) into the staging array `out`."""
+        if np.ndim(x) > 1 or (np.ndim(x) == 1 and len(x) not in (1, self.batch)):
             raise ValueError(f"{name}: expected {self.batch} values")
-        return np.ascontiguousarray(a)
+        out[:] = x
 
     def _obs(self, idx, ranges, bearings):
-        """Normalise observations to padded [batch, stride] arrays + m[batch]."""
-        if self.batch == 1 and (len(idx) == 0 or np.isscalar(idx[0]) or np.ndim(idx[0]) == 0):
-            idx, ranges, bearings = [idx], [ranges], [bearings]
+        """Observations into the padded [batch, stride] staging arrays + m[batch]; returns their pointers and the stride
+        (entries beyond m[b] are whatever an earlier call left there: the library reads m[b] of them)."""
+        if self.batch == 1 and (len(idx) == 0 or np.ndim(idx[0]) == 0):
+            idx, ranges, bearings = (idx,), (ranges,), (bearings,)
         if len(idx) != self.batch:
             raise ValueError("observations: one list per trajectory expected")
-        m = np.array([len(i) for i in idx], dtype=np.int32)
-        stride = max(1, int(m.max()) if len(m) else 1)
-        I = np.zeros((self.batch, stride), dtype=np.int32)
-        R = np.zeros((self.batch, stride))
-        B = np.zeros((self.batch, stride))
-        for b in range(self.batch):
-            if len(ranges[b]) != m[b] or len(bearings[b]) != m[b]:
+        lens = [len(i) for i in idx]
+        stride = max(1, max(lens))
+        st = self._stages.get(stride)
+        if st is None:
+            I = np.zeros((self.batch, stride), dtype=np.int32)
+            R, B = np.zeros((self.batch, stride)), np.zeros((self.batch, stride))
+            st = self._stages[stride] = (I, R, B, _p(I, _ip), _p(R), _p(B))
+        I, R, B, pI, pR, pB = st
+        for b, mb in enumerate(lens):
+            if len(ranges[b]) != mb or len(bearings[b]) != mb:
                 raise ValueError("idx / ranges / bearings lengths differ")
-            I[b, :m[b]] = idx[b]
-            R[b, :m[b]] = ranges[b]
-            B[b, :m[b]] = bearings[b]
-        return I, R, B, m, stride
+            I[b, :mb] = idx[b]
+            R[b, :mb] = ranges[b]
+            B[b, :mb] = bearings[b]
+        self._m[:] = lens
+        return pI, pR, pB, self._pm, stride
+
+    def _small_out(self):
+        """Output staging for small states (what the library packs into one pinned buffer anyway): pointers made once."""
+        if self._out is None:
+            mu, P = np.empty(_SMALL_OUT_N), np.empty(_SMALL_OUT_N * _SMALL_OUT_N)
+            self._out = (mu, P, _p(mu), _p(P))
+        return self._out
 
     # -- state ---------------------------------------------------------------------------------
     def size(self, b: int = 0) -> int:
@@ -291,6 +313,10 @@ class EkfSlam:
 
     def state(self, b: int = 0):
         n = self.size(b)
+        if n <= _SMALL_OUT_N:
+            mu, P, pmu, pP = self._small_out()
+            self._check(self._lib.ekf_download_state(self._h, b, pmu, pP, n))
+            return mu[:n].copy(), P[:n * n].reshape(n, n).copy()
         mu, P = np.empty(n), np.empty((n, n))
         self._check(self._lib.ekf_download_state(self._h, b, _p(mu), _p(P), n))
         return mu, P
@@ -316,19 +342,37 @@ class EkfSlam:
     # -- the EKF ---------------------------------------------------------------------------------
     def predict(self, lin, ang):
         """Motion model + P <- G_F P G_F^T + F^T R F  (src/replay_no_ros.py:368-430)."""
-        lin, ang = self._per_traj(lin, "lin"), self._per_traj(ang, "ang")
-        self._check(self._lib.ekf_predict(self._h, _p(lin), _p(ang)))
+        self._per_traj(lin, "lin", self._lin)
+        self._per_traj(ang, "ang", self._ang)
+        self._check(self._lib.ekf_predict(self._h, self._plin, self._pang))
 
     def update(self, idx, ranges, bearings):
         """Sequential range/bearing updates in the given order (src/replay_no_ros.py:436-480)."""
-        I, R, B, m, stride = self._obs(idx, ranges, bearings)
-        self._check(self._lib.ekf_update(self._h, _p(I, _ip), _p(R), _p(B), _p(m, _ip), stride))
+        pI, pR, pB, pm, stride = self._obs(idx, ranges, bearings)
+        self._check(self._lib.ekf_update(self._h, pI, pR, pB, pm, stride))
 
     def step(self, lin, ang, idx, ranges, bearings):
         """predict + update in one fused pass over P."""
-        lin, ang = self._per_traj(lin, "lin"), self._per_traj(ang, "ang")
-        I, R, B, m, stride = self._obs(idx, ranges, bearings)
-        self._check(self._lib.ekf_step(self._h, _p(lin), _p(ang), _p(I, _ip), _p(R), _p(B), _p(m, _ip), stride))
+        self._per_traj(lin, "lin", self._lin)
+        self._per_traj(ang, "ang", self._ang)
+        pI, pR, pB, pm, stride = self._obs(idx, ranges, bearings)
+        self._check(self._lib.ekf_step(self._h, self._plin, self._pang, pI, pR, pB, pm, stride))
+
+    def step_state(self, lin, ang, idx, ranges, bearings, b: int = 0):
+        """``step`` followed by ``state(b)`` as one library call (``ekf_step_fetch``): one iteration of the reference's
+        loop, which gets mean and covariance back from every call (src/replay_no_ros.py:229-237).  On the small-state
+        path that is one kernel launch and one synchronisation."""
+        self._per_traj(lin, "lin", self._lin)
+        self._per_traj(ang, "ang", self._ang)
+        pI, pR, pB, pm, stride = self._obs(idx, ranges, bearings)
+        n = self.size(b)
+        if n <= _SMALL_OUT_N:
+            mu, P, pmu, pP = self._small_out()
+            self._check(self._lib.ekf_step_fetch(self._h, self._plin, self._pang, pI, pR, pB, pm, stride, b, pmu, pP, n))
+            return mu[:n].copy(), P[:n * n].reshape(n, n).copy()
+        mu, P = np.empty(n), np.empty((n, n))
+        self._check(self._lib.ekf_step_fetch(self._h, self._plin, self._pang, pI, pR, pB, pm, stride, b, _p(mu), _p(P), n))
+        return mu, P
 
     # -- device-side front end (association, gate, averaging, augmentation on the GPU) -----------------
     def set_association(self, gate_range: float = 1.5, ignore_tags: Sequence[int] = ()):
@@ -363,7 +407,9 @@ class EkfSlam:
         through ``step`` (which splits lists of more than 16 landmarks), and the device's table follows the host's
         afterwards where its ids allow.  Same results either way (tests/test_gpu_api_regressions.py).  Only the capacity
         stays fixed: a map that would outgrow ``n_max`` raises ``EkfError`` before anything is enqueued."""
-        lin, ang = self._per_traj(lin, "lin"), self._per_traj(ang, "ang")
+        self._per_traj(lin, "lin", self._lin)
+        self._per_traj(ang, "ang", self._ang)
+        lin, ang = self._lin, self._ang
         if self.batch == 1 and (len(detections) == 0 or isinstance(detections[0], tuple)):
             detections = [detections]
         if len(detections) != self.batch:
@@ -382,7 +428,7 @@ class EkfSlam:
                 ids[b, i] = tag.tag_id
                 pt[b, i] = np.asarray(tag.pose_t, dtype=np.float64).ravel()[:3]
                 pe[b, i] = tag.pose_err
-        self._check(self._lib.ekf_step_detections(self._h, _p(lin), _p(ang), _p(count, _ip), _p(ids, _ip), _p(pt), _p(pe),
+        self._check(self._lib.ekf_step_detections(self._h, self._plin, self._pang, _p(count, _ip), _p(ids, _ip), _p(pt), _p(pe),
                                                   stride))
 
     def _step_detections_host(self, lin, ang, detections):
@@ -528,13 +574,13 @@ class _DropInState:
     """Device state kept between EKF_pose_estimation calls so the covariance need not be re-uploaded
     when the caller passes back exactly what the previous call returned (the reference loop does,
     src/replay_no_ros.py:229-237).  "Exactly" is checked against PRIVATE records of what was returned
-    (a copy of the mean, row and column sums of the covariance), never against the returned arrays
-    themselves: the caller owns those and may edit them in place."""
+    (a copy of the mean; of the covariance a byte-for-byte copy while it is small, its row and column sums beyond),
+    never against the returned arrays themselves: the caller owns those and may edit them in place."""
     filt: Optional[EkfSlam] = None
     mean_obj: Optional[np.ndarray] = None      # the objects handed to the caller (identity test only)
     cov_obj: Optional[np.ndarray] = None
-    mean_copy: Optional[np.ndarray] = None     # private records of their contents
-    cov_sums: Optional[np.ndarray] = None
+    mean_copy: Optional[bytes] = None          # private records of their contents
+    cov_record: object = None                  # (_cov_record)
 
 
 _drop = _DropInState()
@@ -547,6 +593,18 @@ def _cov_sums(cov: np.ndarray) -> np.ndarray:
     """Row sums and column sums: any edit of a single entry changes one of each, an edit of several entries
     goes unnoticed only if it cancels in every row and every column it touches."""
     return np.concatenate([cov.sum(axis=0), cov.sum(axis=1)])
+
+
+def _cov_record(cov: np.ndarray):
+    """What is remembered of a returned covariance: its bytes while that is cheap (up to 131 x 131: 0.3 us at the
+    reference's map size, and exact), row and column sums beyond (a private copy of a 128 MB matrix per call is not)."""
+    return cov.tobytes() if cov.size <= _SMALL_OUT_N * _SMALL_OUT_N else _cov_sums(cov)
+
+
+def _cov_matches(record, cov: np.ndarray) -> bool:
+    if isinstance(record, bytes):
+        return cov.size <= _SMALL_OUT_N * _SMALL_OUT_N and cov.tobytes() == record
+    return cov.size > _SMALL_OUT_N * _SMALL_OUT_N and np.array_equal(record, _cov_sums(cov))
 
 
 def EKF_pose_estimation(angular_displacement, linear_displacement, motion_model_mean, motion_model_covariance,
@@ -573,7 +631,7 @@ def EKF_pose_estimation(angular_displacement, linear_displacement, motion_model_
     resident = (not DROP_IN_ALWAYS_UPLOAD and d.filt is not None and d.mean_obj is motion_model_mean
                 and d.cov_obj is motion_model_covariance and d.filt.size() == n_old
                 and cov_in.shape == (n_old, n_old)
-                and np.array_equal(d.mean_copy, mean_in) and np.array_equal(d.cov_sums, _cov_sums(cov_in)))
+                and d.mean_copy == mean_in.tobytes() and _cov_matches(d.cov_record, cov_in))
     if d.filt is None or d.filt.n_max < n_new or d.filt.config != cfg:
         cap = max(DROP_IN_MIN_CAPACITY, n_new if d.filt is None else max(n_new, 2 * d.filt.n_max - 3))
         cap |= 1
@@ -587,15 +645,14 @@ def EKF_pose_estimation(angular_displacement, linear_displacement, motion_model_
     if new_xy:
         f.add_landmarks(np.array(new_xy))
     idx = list(tags_positions.keys())
-    f.step(linear_displacement, angular_displacement, idx,
-           [tags_positions[k][4] for k in idx], [tags_positions[k][5] for k in idx])
-    mean, cov = f.state()
+    mean, cov = f.step_state(linear_displacement, angular_displacement, idx,
+                             [tags_positions[k][4] for k in idx], [tags_positions[k][5] for k in idx])
     # (q == 0 or a singular S leave NaN in the mean, like NumPy's 0/0 at :466-469 -- the sticky device flag says the same,
     #  but asking for it costs a round trip per call)
     if not np.isfinite(mean).all():
         warnings.warn("EKF_pose_estimation: non-finite state (q == 0 or singular S)", RuntimeWarning)
     d.mean_obj, d.cov_obj = mean, cov
-    d.mean_copy, d.cov_sums = mean.copy(), _cov_sums(cov)
+    d.mean_copy, d.cov_record = mean.tobytes(), _cov_record(cov)
     return mean, cov, tags_positions
 
 

@@ -237,3 +237,83 @@ def test_q_zero_and_growth_on_the_small_path(sd):
         m1, P1 = f.state(1)
         close(m1, om)
         close(P1, oP)
+
+
+def fused_fetches(sd, f):
+    lib = sd.load_library()
+    lib.ekf_debug_fused_fetches.argtypes = [C.c_void_p]
+    lib.ekf_debug_fused_fetches.restype = C.c_long
+    return lib.ekf_debug_fused_fetches(f._h)
+
+
+@pytest.mark.parametrize("small,batch,which", [(1, 1, 0), (1, 3, 1), (0, 1, 0), (0, 2, 1)])
+def test_step_state_is_step_then_state(sd, small, batch, which):
+    """`ekf_step_fetch` (one iteration of the reference's loop: step, then mean and covariance back,
+    src/replay_no_ros.py:229-237): bit-identical to `step` + `state` on a twin filter, equal to the oracle, and on the
+    small-state path answered by the step's own launch -- also when a long observation list is split into two launches, when
+    nothing is observed, and for a trajectory that is not the first of its bank."""
+    rng = np.random.default_rng(77 + small + batch)
+    cfg = orc.EkfConfig()
+    N = 24
+    streams = [orc.synthetic_stream(N, 14, 8, 40 + t) for t in range(batch)]
+    means = [s[0].copy() for s in streams]
+    covs = [np.diag(s[1]) for s in streams]
+    with sd.EkfSlam(3 + 2 * N, batch=batch) as f, sd.EkfSlam(3 + 2 * N, batch=batch) as twin:
+        for g in (f, twin):
+            g.set_option("small_state", small)
+            for t, s in enumerate(streams):
+                g.set_state_diag(s[0], s[1], t)
+        for k in range(14):
+            m = [0, 1, 8, 20, 3][k % 5]                       # 20: more than one launch (16 landmarks per launch)
+            obs = []
+            for t in range(batch):
+                idx = rng.choice(N, size=m, replace=False).astype(np.int32)
+                lx, ly = means[t][3 + 2 * idx], means[t][4 + 2 * idx]
+                zr = np.hypot(lx - means[t][0], ly - means[t][1]) + rng.normal(0, 0.02, m)
+                zb = np.arctan2(ly - means[t][1], lx - means[t][0]) - means[t][2] + rng.normal(0, 0.02, m)
+                obs.append((idx, zr, zb))
+            lin = np.array([s[2][k] for s in streams])
+            ang = np.array([s[3][k] for s in streams])
+            args = (lin, ang, [o[0] for o in obs], [o[1] for o in obs], [o[2] for o in obs])
+            mu, P = f.step_state(*args, b=which)
+            twin.step(*args)
+            mu2, P2 = twin.state(which)
+            for t in range(batch):
+                means[t], covs[t] = orc.ekf_step_dense(means[t], covs[t], lin[t], ang[t], *obs[t], cfg)
+            assert np.array_equal(mu, mu2) and np.array_equal(P, P2), k
+            assert np.array_equal(P, P.T)
+            close(mu, means[which])
+            close(P, covs[which])
+        assert f.flags(which) == 0
+        assert fused_fetches(sd, f) == (14 if small else 0)
+        assert fused_fetches(sd, twin) == 0
+        # the state stayed resident: the other trajectories, and the same one read the ordinary way
+        for t in range(batch):
+            mu, P = f.state(t)
+            close(mu, means[t])
+            close(P, covs[t])
+
+
+def test_step_state_reports_what_the_two_calls_report(sd):
+    """q = 0 (a landmark at the robot's position: NaN like NumPy's 0/0, src/replay_no_ros.py:466-469) comes back through the
+    fused call with the sticky flag set; a wrong size is refused before anything is enqueued."""
+    mean = np.array([0.0, 0.0, 0.0, 0.0, 0.0, 1.0, 1.0])
+    with sd.EkfSlam(7) as f:
+        f.set_option("small_state", 1)
+        f.set_state(mean, np.eye(7))
+        lib = sd.load_library()
+        out_mu, out_P = np.empty(9), np.empty((9, 9))
+        one, z = np.zeros(1), np.zeros(1)
+        rc = lib.ekf_step_fetch(f._h, one.ctypes.data_as(C.POINTER(C.c_double)), z.ctypes.data_as(C.POINTER(C.c_double)),
+                                None, None, None, np.zeros(1, dtype=np.int32).ctypes.data_as(C.POINTER(C.c_int)), 0, 0,
+                                out_mu.ctypes.data_as(C.POINTER(C.c_double)), out_P.ctypes.data_as(C.POINTER(C.c_double)), 9)
+        assert rc != 0 and small_launches(sd, f) == 0
+        mu, P = f.step_state(0.0, 0.0, [], [], [])            # nothing observed, no motion: the pose stays where landmark 0 is
+        om, oP = orc.ekf_step_dense(mean, np.eye(7), 0.0, 0.0, [], [], [], orc.EkfConfig())
+        close(mu, om)
+        close(P, oP)
+        assert np.array_equal(mu[:2], mean[:2]) and f.flags() == 0
+        mu, P = f.step_state(0.0, 0.0, [0], [0.1], [0.0])     # the landmark coincides with the pose: q == 0
+        assert not np.isfinite(mu).all()
+        assert f.flags() & 1
+        assert fused_fetches(sd, f) == 2
