@@ -19,6 +19,8 @@
 #ifndef EKFSLAM_HIP_H
 #define EKFSLAM_HIP_H
 
+#include <stddef.h>
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -90,6 +92,13 @@ int ekf_state_size(ekf_handle *h, int b, int *n);
 /* State augmentation, src/replay_no_ros.py:341-360: append k landmarks (indices must continue the
  * current count), mean = xy[2*i..], variance = landmark_init_var, zero cross terms. */
 int ekf_add_landmarks(ekf_handle *h, int b, int first_index, const double *xy, int k);
+
+/* Pinned (page-locked, device-visible) host memory for the arrays a binding hands to its caller.  The reference's loop
+ * gets a fresh n x n covariance back from every call (src/replay_no_ros.py:229-237, :482): in freshly allocated pageable
+ * memory a 128 MB download first faults in and pins 32 768 pages (5 ms on top of 2.3 ms of PCIe time at N = 2000); the
+ * Python binding recycles buffers from these instead.  ekf_host_alloc returns NULL when the allocation fails. */
+void *ekf_host_alloc(size_t bytes);
+void ekf_host_free(void *p);
 
 /* predict(): src/replay_no_ros.py:368-430 for every trajectory (lin[b], ang[b]).  O(n) work. */
 int ekf_predict(ekf_handle *h, const double *lin, const double *ang);

@@ -216,6 +216,19 @@ extern "C" int ekf_device_count(int* count) {
   return EKF_OK;
 }
 
+// Pinned host memory for the arrays a binding hands to its caller (see include/ekfslam_hip.h).
+extern "C" void* ekf_host_alloc(size_t bytes) {
+  void* p = nullptr;
+  if (bytes == 0 || hipHostMalloc(&p, bytes, hipHostMallocPortable) != hipSuccess) {
+    (void)hipGetLastError();
+    return nullptr;
+  }
+  return p;
+}
+extern "C" void ekf_host_free(void* p) {
+  if (p) (void)hipHostFree(p);
+}
+
 extern "C" const char* ekf_last_error(ekf_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
 
 static void free_all(ekf_handle* h) {

@@ -21,6 +21,7 @@ import dataclasses
 import os
 import subprocess
 import warnings
+import weakref
 from typing import Optional, Sequence
 
 import numpy as np
@@ -111,6 +112,8 @@ ABI = {
     "ekf_predict": (C.c_int, [C.c_void_p, _dp, _dp]),
     "ekf_update": (C.c_int, [C.c_void_p, _ip, _dp, _dp, _ip, C.c_int]),
     "ekf_step": (C.c_int, [C.c_void_p, _dp, _dp, _ip, _dp, _dp, _ip, C.c_int]),
+    "ekf_host_alloc": (C.c_void_p, [C.c_size_t]),
+    "ekf_host_free": (None, [C.c_void_p]),
     "ekf_step_fetch": (C.c_int, [C.c_void_p, _dp, _dp, _ip, _dp, _dp, _ip, C.c_int, C.c_int, _dp, _dp, C.c_int]),
     "ekf_set_association": (C.c_int, [C.c_void_p, C.c_double, _ip, C.c_int]),
     "ekf_step_detections": (C.c_int, [C.c_void_p, _dp, _dp, _ip, _ip, _dp, _dp, C.c_int]),
@@ -178,6 +181,55 @@ def _p(a, typ=_dp):
 
 
 _SMALL_OUT_N = 131        # (PACK_SMALL_N of csrc/ekf_api.hip: states the library hands over through one pinned buffer)
+
+
+class _PinnedPool:
+    """Recycled pinned host buffers behind the LARGE arrays handed to the caller (covariances beyond 131 x 131).
+
+    The reference's loop gets a fresh covariance from every call (src/replay_no_ros.py:229-237).  A fresh ``np.empty`` of
+    128 MB (N = 2000) is 32 768 untouched pages: the download faults them in and pins them (5 ms on top of 2.3 ms of PCIe
+    time) and dropping the previous array unmaps as many (another 5 ms).  Here the array is a view of a buffer from
+    ``ekf_host_alloc``; the buffer comes back to the pool when the LAST view of it is gone (the ctypes object every view's
+    ``base`` chain ends in is what the finaliser watches), and is handed out again for the next array of that size.
+    Beyond ``LIMIT`` bytes of live buffers -- a caller that keeps every covariance -- arrays are ordinary ``np.empty``."""
+    LIMIT = 2 << 30
+    KEEP = 2                      # free buffers kept per size (the loop holds one array while the next is filled)
+
+    def __init__(self):
+        self.free = {}
+        self.live = 0
+
+    def empty(self, lib, shape):
+        count = int(np.prod(shape))
+        nbytes = 8 * count
+        ptr = None
+        if self.free.get(nbytes):
+            ptr = self.free[nbytes].pop()
+        else:
+            for other in [k for k in self.free if k != nbytes]:            # the map grew: the old size is not coming back
+                for q in self.free.pop(other):
+                    lib.ekf_host_free(q)
+                    self.live -= other
+            if self.live + nbytes <= self.LIMIT:
+                ptr = lib.ekf_host_alloc(nbytes)
+                if ptr:
+                    self.live += nbytes
+        if not ptr:
+            return np.empty(shape)
+        buf = (C.c_double * count).from_address(ptr)
+        weakref.finalize(buf, self._release, lib, ptr, nbytes).atexit = False
+        return np.frombuffer(buf, dtype=np.float64).reshape(shape)
+
+    def _release(self, lib, ptr, nbytes):
+        kept = self.free.setdefault(nbytes, [])
+        if len(kept) < self.KEEP:
+            kept.append(ptr)
+        else:
+            lib.ekf_host_free(ptr)
+            self.live -= nbytes
+
+
+_pinned = _PinnedPool()
 
 
 class EkfSlam:
@@ -301,7 +353,7 @@ class EkfSlam:
 
     def covariance(self, b: int = 0) -> np.ndarray:
         n = self.size(b)
-        out = np.empty((n, n))
+        out = _pinned.empty(self._lib, (n, n)) if n > _SMALL_OUT_N else np.empty((n, n))
         self._check(self._lib.ekf_download_state(self._h, b, None, _p(out), n))
         return out
 
@@ -317,7 +369,7 @@ class EkfSlam:
             mu, P, pmu, pP = self._small_out()
             self._check(self._lib.ekf_download_state(self._h, b, pmu, pP, n))
             return mu[:n].copy(), P[:n * n].reshape(n, n).copy()
-        mu, P = np.empty(n), np.empty((n, n))
+        mu, P = np.empty(n), _pinned.empty(self._lib, (n, n))
         self._check(self._lib.ekf_download_state(self._h, b, _p(mu), _p(P), n))
         return mu, P
 
@@ -370,7 +422,7 @@ class EkfSlam:
             mu, P, pmu, pP = self._small_out()
             self._check(self._lib.ekf_step_fetch(self._h, self._plin, self._pang, pI, pR, pB, pm, stride, b, pmu, pP, n))
             return mu[:n].copy(), P[:n * n].reshape(n, n).copy()
-        mu, P = np.empty(n), np.empty((n, n))
+        mu, P = np.empty(n), _pinned.empty(self._lib, (n, n))
         self._check(self._lib.ekf_step_fetch(self._h, self._plin, self._pang, pI, pR, pB, pm, stride, b, _p(mu), _p(P), n))
         return mu, P
 
@@ -571,40 +623,23 @@ class EkfSlam:
 # Drop-in for the reference function
 # ------------------------------------------------------------------------------------------------
 class _DropInState:
-    """Device state kept between EKF_pose_estimation calls so the covariance need not be re-uploaded
-    when the caller passes back exactly what the previous call returned (the reference loop does,
-    src/replay_no_ros.py:229-237).  "Exactly" is checked against PRIVATE records of what was returned
-    (a copy of the mean; of the covariance a byte-for-byte copy while it is small, its row and column sums beyond),
-    never against the returned arrays themselves: the caller owns those and may edit them in place."""
+    """Device state kept between EKF_pose_estimation calls so that a SMALL state need not be uploaded again when the
+    caller passes back exactly what the previous call returned (the reference loop does, src/replay_no_ros.py:229-237).
+    "Exactly" is checked against PRIVATE byte-for-byte records of what was returned, never against the returned arrays
+    themselves: the caller owns those and may edit them in place.  Beyond 131 x 131 nothing is remembered and every call
+    uploads: proving that a large covariance is unchanged means reading all of it (row and column sums of the 128 MB at
+    N = 2000 cost 19 ms per call), uploading it takes 2.3 ms."""
     filt: Optional[EkfSlam] = None
     mean_obj: Optional[np.ndarray] = None      # the objects handed to the caller (identity test only)
     cov_obj: Optional[np.ndarray] = None
-    mean_copy: Optional[bytes] = None          # private records of their contents
-    cov_record: object = None                  # (_cov_record)
+    mean_copy: Optional[bytes] = None          # private records of their contents (small states only)
+    cov_copy: Optional[bytes] = None
 
 
 _drop = _DropInState()
 DROP_IN_CONFIG = EkfConfig()      # edit like the reference's module constants
 DROP_IN_ALWAYS_UPLOAD = False     # True: never trust the records, upload mean and covariance every call
 DROP_IN_MIN_CAPACITY = 79         # n_max of the first handle (38 landmarks: the small-state path, P resident in LDS); grows by doubling
-
-
-def _cov_sums(cov: np.ndarray) -> np.ndarray:
-    """Row sums and column sums: any edit of a single entry changes one of each, an edit of several entries
-    goes unnoticed only if it cancels in every row and every column it touches."""
-    return np.concatenate([cov.sum(axis=0), cov.sum(axis=1)])
-
-
-def _cov_record(cov: np.ndarray):
-    """What is remembered of a returned covariance: its bytes while that is cheap (up to 131 x 131: 0.3 us at the
-    reference's map size, and exact), row and column sums beyond (a private copy of a 128 MB matrix per call is not)."""
-    return cov.tobytes() if cov.size <= _SMALL_OUT_N * _SMALL_OUT_N else _cov_sums(cov)
-
-
-def _cov_matches(record, cov: np.ndarray) -> bool:
-    if isinstance(record, bytes):
-        return cov.size <= _SMALL_OUT_N * _SMALL_OUT_N and cov.tobytes() == record
-    return cov.size > _SMALL_OUT_N * _SMALL_OUT_N and np.array_equal(record, _cov_sums(cov))
 
 
 def EKF_pose_estimation(angular_displacement, linear_displacement, motion_model_mean, motion_model_covariance,
@@ -628,10 +663,11 @@ def EKF_pose_estimation(angular_displacement, linear_displacement, motion_model_
         new_xy.append((tags_positions[j][0], tags_positions[j][1]))   # KeyError like the reference
 
     d = _drop
-    resident = (not DROP_IN_ALWAYS_UPLOAD and d.filt is not None and d.mean_obj is motion_model_mean
+    small = n_old <= _SMALL_OUT_N
+    resident = (not DROP_IN_ALWAYS_UPLOAD and small and d.filt is not None and d.mean_obj is motion_model_mean
                 and d.cov_obj is motion_model_covariance and d.filt.size() == n_old
                 and cov_in.shape == (n_old, n_old)
-                and d.mean_copy == mean_in.tobytes() and _cov_matches(d.cov_record, cov_in))
+                and d.mean_copy == mean_in.tobytes() and d.cov_copy == cov_in.tobytes())
     if d.filt is None or d.filt.n_max < n_new or d.filt.config != cfg:
         cap = max(DROP_IN_MIN_CAPACITY, n_new if d.filt is None else max(n_new, 2 * d.filt.n_max - 3))
         cap |= 1
@@ -652,7 +688,7 @@ def EKF_pose_estimation(angular_displacement, linear_displacement, motion_model_
     if not np.isfinite(mean).all():
         warnings.warn("EKF_pose_estimation: non-finite state (q == 0 or singular S)", RuntimeWarning)
     d.mean_obj, d.cov_obj = mean, cov
-    d.mean_copy, d.cov_record = mean.tobytes(), _cov_record(cov)
+    d.mean_copy, d.cov_copy = (mean.tobytes(), cov.tobytes()) if len(mean) <= _SMALL_OUT_N else (None, None)
     return mean, cov, tags_positions
 
 

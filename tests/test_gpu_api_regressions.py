@@ -61,6 +61,50 @@ def test_drop_in_sees_in_place_edits_of_returned_arrays(sd):
     assert edits >= 6
 
 
+def test_drop_in_beyond_the_small_records_uploads_and_recycles_buffers(sd):
+    """A state beyond 131 x 131: the drop-in keeps no record of what it returned and uploads every call (in-place edits of
+    the returned arrays are simply what gets uploaded), and the covariances it returns are views of recycled pinned
+    buffers (`ekf_host_alloc`): an array the caller still holds must never be handed out again, one the caller dropped is."""
+    import gc
+    from slam_duckietown_amd import ekf_bindings as eb
+    N, m, calls = 80, 6, 15                                 # (the last call is not one that is edited afterwards)
+    mean0, diag0, lin, ang, idx, zr, zb = orc.synthetic_stream(N, calls, m, 5)
+    ti, oti = {1000 + i: i for i in range(N)}, {1000 + i: i for i in range(N)}
+    ocfg = orc.EkfConfig()
+    mean, cov = mean0.copy(), np.diag(diag0)
+    omean, ocov = mean0.copy(), np.diag(diag0)
+    held = []
+    for k in range(calls):
+        xr, yr = zr[k] * np.cos(zb[k]), zr[k] * np.sin(zb[k])
+        det = [(float(k), [NS(tag_id=1000 + int(i), pose_R=np.eye(3), pose_t=np.array([[-y], [0.0], [x]]), pose_err=0.0)
+                           for i, x, y in zip(idx[k], xr, yr)])]
+        mean, cov, _ = eb.EKF_pose_estimation(ang[k], lin[k], mean, cov, 0.7, det, ti)
+        omean, ocov, _ = orc.ekf_pose_estimation_dense(ang[k], lin[k], omean, ocov, 0.7, det, oti, ocfg)
+        close(mean, omean)
+        close(cov, ocov)
+        assert cov.flags.writeable and np.array_equal(cov, cov.T)
+        if k % 4 == 1:                                      # in-place edits far from the pose block, and of the mean
+            cov[40, 40] *= 1.25
+            ocov[40, 40] *= 1.25
+            mean[2] += 0.01
+            omean[2] += 0.01
+        if k < 5:
+            held.append((cov, cov.copy()))                  # the caller keeps these: their buffers stay theirs
+    for arr, copy in held:
+        assert np.array_equal(arr, copy)
+    assert eb._drop.filt.size() == 3 + 2 * N and eb._drop.mean_copy is None
+    nbytes = 8 * (3 + 2 * N) ** 2
+    live_before = eb._pinned.live
+    assert live_before >= 6 * nbytes                        # five held + the current one, all backed by the pool
+    del held, arr, copy
+    gc.collect()
+    assert len(eb._pinned.free.get(nbytes, [])) == eb._pinned.KEEP and eb._pinned.live < live_before
+    kept = set(eb._pinned.free[nbytes])
+    P2 = eb._drop.filt.covariance()                         # the next large array comes out of the pool
+    assert len(eb._pinned.free[nbytes]) == eb._pinned.KEEP - 1 and P2.ctypes.data in kept
+    close(P2, ocov)
+
+
 def test_uploaded_stream_follows_later_state_changes(sd):
     """ekf_stream_upload bakes the active bound that follows from the stream's own observations; a dense upload, a
     second run of the same stream or a toggled option between upload and run must still give the dense reference

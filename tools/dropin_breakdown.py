@@ -11,7 +11,8 @@ import slam_duckietown_amd as sd
 import slam_duckietown_amd.synthetic as syn
 from slam_duckietown_amd import ekf_bindings as eb
 
-N, m, calls = int(sys.argv[1]) if len(sys.argv) > 1 else 12, int(sys.argv[2]) if len(sys.argv) > 2 else 3, 300
+N, m = int(sys.argv[1]) if len(sys.argv) > 1 else 12, int(sys.argv[2]) if len(sys.argv) > 2 else 3
+calls = 300 if N <= 100 else 60
 mean0, diag0, lin, ang, idx, zr, zb = syn.synthetic_stream(N, calls, m, 0)
 ti = {1000 + i: i for i in range(N)}
 T = {}
@@ -27,8 +28,7 @@ def timed(name, fn):
 
 
 eb.associate = timed("associate", eb.associate)
-eb._cov_record = timed("cov_record", eb._cov_record)
-eb._cov_matches = timed("cov_matches", eb._cov_matches)
+sd.EkfSlam.set_state = timed("set_state", sd.EkfSlam.set_state)
 sd.EkfSlam.step_state = timed("step_state", sd.EkfSlam.step_state)
 mean, cov = mean0.copy(), np.diag(diag0)
 total = []
@@ -38,6 +38,6 @@ for k in range(calls):
     t0 = time.perf_counter()
     mean, cov, _ = sd.EKF_pose_estimation(ang[k], lin[k], mean, cov, 0.7, [(0.0, tags)], ti)
     total.append(time.perf_counter() - t0)
-med = {k: np.median(v[40:]) * 1e6 * (len(v) / calls) for k, v in T.items()}
-print(f"N={N} m={m} fetch_spin={os.environ.get('EKFSLAM_HIP_FETCH_SPIN', 'default')}: total {np.median(total[20:]) * 1e6:6.1f} us = " +
-      "  ".join(f"{k} {v:5.1f}" for k, v in med.items()) + f"  rest {np.median(total[20:]) * 1e6 - sum(med.values()):5.1f}")
+med = {k: np.median(v[len(v) // 6:]) * 1e6 * (len(v) / calls) for k, v in T.items()}
+print(f"N={N} m={m} fetch_spin={os.environ.get('EKFSLAM_HIP_FETCH_SPIN', 'default')}: total {np.median(total[10:]) * 1e6:6.1f} us = " +
+      "  ".join(f"{k} {v:5.1f}" for k, v in med.items()) + f"  rest {np.median(total[10:]) * 1e6 - sum(med.values()):5.1f}")
