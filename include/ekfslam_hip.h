@@ -78,8 +78,9 @@ int ekf_destroy(ekf_handle *h);
 
 /* Whole state in / out for trajectory b (checkpoint, parity checks).  Blocking.
  * A covariance is symmetric: the device keeps its upper triangle only, so of an uploaded P the upper
- * triangle is authoritative, and a download returns that triangle mirrored (the reference's own Sigma is
- * symmetric to rounding). */
+ * triangle is authoritative (entries below the diagonal are not even sent: 56 % of the matrix crosses PCIe
+ * at n = 4003), and a download returns that triangle mirrored (the reference's own Sigma is symmetric to
+ * rounding). */
 int ekf_upload_state(ekf_handle *h, int b, const double *mu, const double *P, int n);
 int ekf_upload_state_diag(ekf_handle *h, int b, const double *mu, const double *diagP, int n);
 int ekf_download_state(ekf_handle *h, int b, double *mu, double *P, int n);

@@ -499,7 +499,11 @@ extern "C" int ekf_upload_state(ekf_handle* h, int b, const double* mu, const do
   HIP_TRY(h, hipSetDevice(h->device));
   if (int rc = flush_pending(h)) return rc;
   if (int rc = clear_internal(h, b)) return rc;
-  HIP_TRY(h, copy_cov(h, b, const_cast<double*>(P), n, 0, 0, n, n, true));
+  // the upper triangle is what the device keeps (and all it ever reads): blocks of rows, each from its first diagonal
+  // column on -- 56 % of the matrix at n = 4003 (1.3 instead of 2.3 ms over PCIe)
+  constexpr int UP_ROWS = 512;
+  for (int r0 = 0; r0 < n; r0 += UP_ROWS)
+    HIP_TRY(h, copy_cov(h, b, const_cast<double*>(P) + (size_t)r0 * n + r0, n, r0, r0, std::min(UP_ROWS, n - r0), n - r0, true));
   HIP_TRY(h, hipMemcpyAsync(h->dmu2[h->cur] + (size_t)b * h->ld, mu, sizeof(double) * n, hipMemcpyHostToDevice, h->stream));
   if (int rc = set_size(h, b, n)) return rc;
   h->neff[b] = n;                                      // arbitrary dense covariance: everything is active
