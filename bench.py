@@ -49,7 +49,11 @@ MFMA_F64_MEASURED_TF = 77.9    # sustained v_mfma_f64_16x16x4 on this part (accu
 
 
 def make_streams(sd_syn, traj_ids, n_landmarks, steps, m):
-    streams = [sd_syn.synthetic_stream(n_landmarks, steps, m, t) for t in traj_ids]
+    made = {}                          # (a bank may repeat trajectory ids: each stream is generated once)
+    for t in traj_ids:
+        if t not in made:
+            made[t] = sd_syn.synthetic_stream(n_landmarks, steps, m, t)
+    streams = [made[t] for t in traj_ids]
     lin = np.stack([s[2] for s in streams], axis=1)
     ang = np.stack([s[3] for s in streams], axis=1)
     idx = np.stack([s[4] for s in streams], axis=1)
@@ -466,6 +470,11 @@ def secondary_leg(name, args):
                                    options=args.option)
         leg["bank_of_256"] = {"workload": "N=20, m=8, 256 trajectories (one workgroup each), 500 steps", "value": 256 * 500 / dtb,
                               "unit": "steps/s"}
+        # three workgroups are resident per CU (148 VGPRs): the throughput of the path (tools/small_bank_sweep.py)
+        dtc, _, _, _ = time_filter(sd, sd_syn, shard, grp, dev, [t % 256 for t in range(768)], 20, args.obs, 500, 20,
+                                   profile_leg=False, options=args.option)
+        leg["bank_of_768"] = {"workload": "N=20, m=8, 768 trajectories (the 256 above, three times), 500 steps",
+                              "value": 768 * 500 / dtc, "unit": "steps/s"}
         return {name: leg}
     if name == "config2":
         return {name: stream_leg(sd, sd_syn, shard, grp, dev, 500, args.obs, 500, 20, args.option, "BASELINE config 2")}
