@@ -184,7 +184,10 @@ int ekf_profile_read(ekf_handle *h, double *pass_ms_total, long long *pass_launc
  * "pass_share_order" (row-slab pass on static shares: 1 = shares dealt to the XCDs by starting column, 0 = as cut; same
  * result bit for bit), "small_state" (1 = a handle with n_max <= 79 -- up to 38 landmarks -- runs every step, or a whole
  * uploaded stream, as ONE workgroup per trajectory with the covariance resident in LDS: nothing is ever pending; 0 = the
- * general kernels; the default can be set for new handles with the environment variable EKFSLAM_HIP_SMALL_STATE);
+ * general kernels; the default can be set for new handles with the environment variable EKFSLAM_HIP_SMALL_STATE),
+ * "zero_copy_inputs" (1 = the small-state kernel reads an online step's record straight from the pinned input ring, 0 = a
+ * staged copy first), "fetch_spin" (1 = ekf_step_fetch on the small-state path polls the sequence word its launch releases
+ * behind the state it wrote to pinned memory, 0 = it waits for the stream; same results);
  * unknown names fail.
  * "fused_cadence" and "lookahead" change the ORDER in which a step's pending ranks are summed (and whether the look-ahead
  * applies depends on the device's CU count and the size of the launch): results are equal to rounding across these
