@@ -413,3 +413,95 @@ def test_row_slab_pass_equal_shares_cover_every_strip_once(sd):
         for rb in range(nrb):
             assert (seen[:, rb, :s_last - 2 * rb + 1] == 1).all() and (seen[:, rb, s_last - 2 * rb + 1:] == 0).all()
         assert max(costs) - min(costs) <= 4, (batch, n, wgs, min(costs), max(costs))
+
+
+def test_pinned_pool_recycles_only_what_nobody_holds():
+    """The binding's pool of pinned buffers behind large returned covariances (ekf_bindings._PinnedPool), driven with malloc /
+    free in place of ekf_host_alloc / ekf_host_free: a buffer goes back to the pool when the LAST view of its array is gone
+    (sub-views keep it), at most KEEP free buffers per size are kept, a new size evicts the old ones, and beyond LIMIT the
+    arrays are ordinary ones."""
+    import ctypes as C
+    import gc
+    from slam_duckietown_amd import ekf_bindings as eb
+    libc = C.CDLL(None)
+    libc.malloc.restype, libc.malloc.argtypes, libc.free.argtypes = C.c_void_p, [C.c_size_t], [C.c_void_p]
+
+    class Lib:
+        allocated, freed = [], []
+
+        def ekf_host_alloc(self, nbytes):
+            p = libc.malloc(nbytes)
+            self.allocated.append(p)
+            return p
+
+        def ekf_host_free(self, p):
+            self.freed.append(p)
+            libc.free(p)
+
+    lib, pool = Lib(), eb._PinnedPool()
+    a = pool.empty(lib, (150, 150))
+    assert a.shape == (150, 150) and a.flags.writeable and a.flags.c_contiguous and a.ctypes.data == lib.allocated[0]
+    a[:] = 3.0
+    corner = a[:2, :2]
+    del a
+    gc.collect()
+    assert pool.free == {} and pool.live == 8 * 150 * 150           # the sub-view still owns the buffer
+    assert corner.sum() == 12.0
+    del corner
+    gc.collect()
+    assert pool.free == {8 * 150 * 150: [lib.allocated[0]]}
+    b = pool.empty(lib, (150, 150))
+    assert b.ctypes.data == lib.allocated[0] and len(lib.allocated) == 1       # handed out again, not allocated again
+    c, d, e = (pool.empty(lib, (150, 150)) for _ in range(3))
+    del b, c, d, e
+    gc.collect()
+    assert len(pool.free[8 * 150 * 150]) == pool.KEEP and len(lib.freed) == 4 - pool.KEEP
+    assert pool.live == pool.KEEP * 8 * 150 * 150
+    f = pool.empty(lib, (152, 152))                                  # the map grew: the old size is given back
+    assert pool.free == {} and pool.live == 8 * 152 * 152 and len(lib.freed) == 4
+    pool.LIMIT = pool.live                                           # (instance attribute: this pool only)
+    g = pool.empty(lib, (152, 152))
+    assert g.shape == (152, 152) and len(lib.allocated) == 5 and g.base is None and f.base is not None   # g: a plain np.empty
+    del f, g
+    gc.collect()
+    for p in pool.free.pop(8 * 152 * 152):
+        lib.ekf_host_free(p)
+
+
+def test_binding_stages_arguments_without_a_device():
+    """EkfSlam's per-call staging (padded [batch, stride] arrays with cached pointers, one value per trajectory): shapes,
+    padding, reuse and the errors, on an object that never touched the library."""
+    import ctypes as C
+    from slam_duckietown_amd import ekf_bindings as eb
+    f = eb.EkfSlam.__new__(eb.EkfSlam)
+    f.batch = 3
+    f._lin, f._ang, f._m = np.zeros(3), np.zeros(3), np.zeros(3, dtype=np.int32)
+    f._plin, f._pang, f._pm = eb._p(f._lin), eb._p(f._ang), eb._p(f._m, eb._ip)
+    f._stages, f._out, f._h = {}, None, C.c_void_p()
+    f._per_traj(0.25, "lin", f._lin)
+    assert f._lin.tolist() == [0.25] * 3
+    f._per_traj([1.0, 2.0, 3.0], "lin", f._lin)
+    assert f._lin.tolist() == [1.0, 2.0, 3.0]
+    f._per_traj(np.array([7.0]), "lin", f._lin)
+    assert f._lin.tolist() == [7.0] * 3
+    for wrong in ([1.0, 2.0], np.zeros((3, 1)), np.zeros(4)):
+        with pytest.raises(ValueError):
+            f._per_traj(wrong, "lin", f._lin)
+    pI, pR, pB, pm, stride = f._obs([[4, 2], [], [1, 0, 3]], [[1.0, 2.0], [], [3.0, 4.0, 5.0]], [[.1, .2], [], [.3, .4, .5]])
+    I, R, B = f._stages[3][:3]
+    assert stride == 3 and f._m.tolist() == [2, 0, 3] and I.shape == (3, 3) and I.dtype == np.int32
+    assert I[0, :2].tolist() == [4, 2] and I[2].tolist() == [1, 0, 3] and R[2].tolist() == [3.0, 4.0, 5.0] and B[0, 1] == .2
+    assert C.addressof(pI.contents) == I.ctypes.data and C.addressof(pm.contents) == f._m.ctypes.data
+    again = f._obs([[9], [8], [7]], [[1.0], [2.0], [3.0]], [[0.0], [0.0], [0.0]])
+    assert again[4] == 1 and f._stages[1][0][:, 0].tolist() == [9, 8, 7] and f._m.tolist() == [1, 1, 1]
+    assert f._obs([[4, 2], [], [1, 0, 3]], [[1.0, 2.0], [], [3.0, 4.0, 5.0]], [[.1, .2], [], [.3, .4, .5]])[0] is pI   # reused
+    with pytest.raises(ValueError):
+        f._obs([[1], [2]], [[1.0], [2.0]], [[0.0], [0.0]])            # two lists for three trajectories
+    with pytest.raises(ValueError):
+        f._obs([[1], [2], [3]], [[1.0], [2.0, 9.0], [3.0]], [[0.0], [0.0], [0.0]])
+    one = eb.EkfSlam.__new__(eb.EkfSlam)
+    one.batch = 1
+    one._m = np.zeros(1, dtype=np.int32)
+    one._pm, one._stages, one._h = eb._p(one._m, eb._ip), {}, C.c_void_p()
+    assert one._obs([5, 6], [1.0, 2.0], [0.1, 0.2])[4] == 2 and one._m[0] == 2          # a flat list is one trajectory's
+    assert one._obs([], [], [])[4] == 1 and one._m[0] == 0
