@@ -187,7 +187,9 @@ int ekf_profile_read(ekf_handle *h, double *pass_ms_total, long long *pass_launc
  * general kernels; the default can be set for new handles with the environment variable EKFSLAM_HIP_SMALL_STATE),
  * "zero_copy_inputs" (1 = the small-state kernel reads an online step's record straight from the pinned input ring, 0 = a
  * staged copy first), "fetch_spin" (1 = ekf_step_fetch on the small-state path polls the sequence word its launch releases
- * behind the state it wrote to pinned memory, 0 = it waits for the stream; same results);
+ * behind the state it wrote to pinned memory, 0 = it waits for the stream; same results), "pack_dense" (downloads of a whole
+ * state into PINNED host memory, e.g. from ekf_host_alloc: 1 = up to 40 MB a kernel mirrors the stored triangle straight into
+ * the destination, no mirror pass and no copy engine; 2 = at every size; 0 = never: mirror pass + rectangle copy; same bytes);
  * unknown names fail.
  * "fused_cadence" and "lookahead" change the ORDER in which a step's pending ranks are summed (and whether the look-ahead
  * applies depends on the device's CU count and the size of the launch): results are equal to rounding across these

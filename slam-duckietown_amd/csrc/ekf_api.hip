@@ -34,6 +34,7 @@ void launch_predict_rc(hipStream_t, double*, const double*, double*, const int*,
 void launch_add_landmarks(hipStream_t, double*, double*, int, int, int, double, const double*);
 void launch_mirror(hipStream_t, double*, const int*, int, long, int, int);
 void launch_pack_small(hipStream_t, const double*, const double*, const unsigned*, int, int, double*);
+void launch_pack_dense(hipStream_t, const double*, int, int, double*);
 int small_state_limit();
 int launch_small_stream(hipStream_t, double*, const double*, double*, const int*, const StepIn*, int, int, unsigned*,
                         const DeviceConfig&, int, long, int, double*, int, unsigned long long*, unsigned long long);
@@ -143,6 +144,8 @@ struct ekf_handle : ekf::HostPlan {
   long lookaheads = 0;
   long small_launches = 0;        // statistics: launches of the small-state path (k_small_stream)
   long fused_fetches = 0;         // statistics: ekf_step_fetch calls answered by the step's own launch
+  long dense_packs = 0;           // statistics: large downloads written by k_pack_dense (pinned destination)
+  int opt_pack_dense = 1;
   int fetch_b = -1;               // ekf_step_fetch: the trajectory whose state the next small-state launch leaves in h_pack
   bool fetched = false;
   unsigned long long fetch_seq = 0;   // ... and the sequence number that launch releases behind it (polled by the host)
@@ -569,10 +572,27 @@ extern "C" int ekf_download_state(ekf_handle* h, int b, double* mu, double* P, i
   }
   if (int rc = check_internal(h, b, "ekf_download_state")) return rc;
   if (P) {
-    if (int rc = materialize(h, b)) return rc;     // the covariance is P_base + pending ranks, upper triangle
+    // a destination in pinned host memory (what the Python binding hands out for large covariances: ekf_host_alloc) is
+    // written by a kernel -- mirrored on the way, no SDMA copy (k_pack_dense); anything else by the mirror pass + rectangle copy
+    hipPointerAttribute_t attr{};
+    double* dst = nullptr;
+    // (up to 40 MB -- N = 1100: there the kernel is as fast as the copy engine at its best, 38 - 47 GB/s, and does not have
+    //  the copy's bad days; beyond, the engine's larger PCIe payloads win: 54.6 against 49.8 GB/s at N = 2000.  tools/download_paths.py)
+    const bool pack = h->opt_pack_dense == 2 || (h->opt_pack_dense == 1 && (size_t)n * n * sizeof(double) <= (40u << 20));
+    if (pack && hipPointerGetAttributes(&attr, P) == hipSuccess && attr.type == hipMemoryTypeHost)
+      dst = static_cast<double*>(attr.devicePointer);
+    else
+      (void)hipGetLastError();                     // (an ordinary pointer is "invalid value" to the query)
+    if (dst) {
+      if (int rc = flush_pending(h)) return rc;    // the covariance is P_base + pending ranks, upper triangle
+      launch_pack_dense(h->stream, h->dP + (size_t)b * h->pstride, h->ld, n, dst);
+      HIP_TRY(h, hipGetLastError());
+      h->dense_packs += 1;
+    } else {
+      if (int rc = materialize(h, b)) return rc;
+      HIP_TRY(h, copy_cov(h, b, P, n, 0, 0, n, n, false));
+    }
   }
-  if (P)
-    HIP_TRY(h, copy_cov(h, b, P, n, 0, 0, n, n, false));
   if (mu)
     HIP_TRY(h, hipMemcpyAsync(mu, h->dmu2[h->cur] + (size_t)b * h->ld, sizeof(double) * n, hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -1364,6 +1384,7 @@ extern "C" long ekf_debug_lookaheads(ekf_handle* h) { return h ? h->lookaheads :
 // (development aid, not declared in the header) launches of the small-state path so far
 extern "C" long ekf_debug_small_launches(ekf_handle* h) { return h ? h->small_launches : -1; }
 extern "C" long ekf_debug_fused_fetches(ekf_handle* h) { return h ? h->fused_fetches : -1; }
+extern "C" long ekf_debug_dense_packs(ekf_handle* h) { return h ? h->dense_packs : -1; }
 
 // (development aid, not declared in the header) the fused cadence's record of trajectory b (head + per-landmark records)
 extern "C" long ekf_debug_cad(ekf_handle* h, int b, void* dst, long bytes) {
@@ -1443,6 +1464,11 @@ extern "C" int ekf_set_option(ekf_handle* h, const char* name, int value) {
   if (std::strcmp(name, "zero_copy_inputs") == 0) {
     if (value != 0 && value != 1) return fail(h, EKF_ERR_ARG, "zero_copy_inputs must be 0 or 1");
     h->opt_zero_copy_inputs = value;
+    return EKF_OK;
+  }
+  if (!std::strcmp(name, "pack_dense")) {
+    if (value < 0 || value > 2) return fail(h, EKF_ERR_ARG, "pack_dense must be 0, 1 or 2");
+    h->opt_pack_dense = value;
     return EKF_OK;
   }
   if (!std::strcmp(name, "fetch_spin")) {

@@ -2648,6 +2648,55 @@ void launch_pack_small(hipStream_t st, const double* Pb, const double* mub, cons
   hipLaunchKernelGGL(k_pack_small, dim3(blocks), dim3(256), 0, st, Pb, mub, flag_b, ld, n, host_out);
 }
 
+// ---------------------------------------------------------------------------------------------
+// k_pack_dense: the download of a LARGE state into pinned (device-visible) host memory as one kernel: every 64 x 64
+// tile of the stored upper triangle is read once and written twice -- as it stands and, through LDS, transposed --
+// straight into the caller's dense n x n array, 512-byte row segments both times.  No mirror pass over the device
+// copy, and no SDMA copy: the runtime's choice of copy engine halves the rate of an 8 MB rectangle copy once a
+// process has used more streams (profiles/r04_small_state.txt, part 3); stores from 2016 workgroups do not care.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_pack_dense(const double* __restrict__ Pb, int ld, int n, double* __restrict__ host_out) {
+  __shared__ double T[64][65];
+  // tile (ti, tj), ti <= tj, from the linear workgroup index (row ti holds nt - ti tiles)
+  const int nt = (n + 63) >> 6;
+  int ti = 0, rest = blockIdx.x;
+  while (rest >= nt - ti) {
+    rest -= nt - ti;
+    ++ti;
+  }
+  const int tj = ti + rest;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int r = ty; r < 64; r += 4) {
+    const int row = ti * 64 + r, col = tj * 64 + tx;
+    double v = 0.0;
+    if (row < n && col < n) v = Pb[p_index(ld, min(row, col), max(row, col))];     // (diagonal tile: its lower half mirrored)
+    T[r][tx] = v;
+  }
+  __syncthreads();
+  // over PCIe in 16-byte stores, two 512-byte row segments per wave instruction: lanes 0 - 31 one row, lanes 32 - 63 the next
+  const int half = tx >> 5, c2 = 2 * (tx & 31);
+#pragma unroll 2
+  for (int pass = 0; pass < 2; ++pass) {
+    if (pass == 1 && ti == tj) break;
+    for (int r = 2 * ty + half; r < 64; r += 8) {
+      const int row = (pass ? tj : ti) * 64 + r, col = (pass ? ti : tj) * 64 + c2;
+      if (row >= n || col >= n) continue;
+      const double v0 = pass ? T[c2][r] : T[r][c2], v1 = pass ? T[c2 + 1][r] : T[r][c2 + 1];
+      double* dst = host_out + (long)row * n + col;
+      if (col + 1 < n) {
+        typedef double d2 __attribute__((ext_vector_type(2), aligned(8)));
+        *reinterpret_cast<d2*>(dst) = d2{v0, v1};
+      } else {
+        *dst = v0;
+      }
+    }
+  }
+}
+void launch_pack_dense(hipStream_t st, const double* Pb, int ld, int n, double* host_out) {
+  const int nt = (n + 63) / 64;
+  hipLaunchKernelGGL(k_pack_dense, dim3(nt * (nt + 1) / 2), dim3(256), 0, st, Pb, ld, n, host_out);
+}
+
 void launch_mirror(hipStream_t st, double* P, const int* nact, int ld, long pstride, int batch, int n_hi) {
   const int t = (n_hi + 63) / 64;
   hipLaunchKernelGGL(k_mirror, dim3(t, t, batch), dim3(256), 0, st, P, nact, ld, pstride);

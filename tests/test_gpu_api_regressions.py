@@ -434,3 +434,46 @@ def test_single_launch_step_wait_is_bounded(sd):
             assert np.array_equal(a, b, equal_nan=True), f"{name} changed although the step timed out"
         with pytest.raises(sd.EkfError, match="trajectory 5"):
             f.mean(5)
+
+@pytest.mark.parametrize("n_lm,batch,which", [(70, 1, 0), (300, 2, 1), (2100, 1, 0)])
+def test_download_into_pinned_memory_by_kernel_equals_the_copy(sd, n_lm, batch, which):
+    """A whole state downloaded into pinned host memory is written by a kernel (k_pack_dense: mirrored on the way, no copy
+    engine) up to 40 MB, by the mirror pass + the runtime's rectangle copy beyond and into ordinary memory: the same bytes
+    either way -- with ranks pending (the download applies them first), for a trajectory that is not the first, for a size that
+    is no multiple of the 64 x 64 tile and on the column-panel layout (n = 4203 > 4096)."""
+    import ctypes as C
+    lib = sd.load_library()
+    lib.ekf_debug_dense_packs.argtypes, lib.ekf_debug_dense_packs.restype = [C.c_void_p], C.c_long
+    n = 3 + 2 * n_lm
+    streams = [orc.synthetic_stream(n_lm, 3, 8, 20 + t) for t in range(batch)]
+    with sd.EkfSlam(n, batch=batch) as f:
+        f.set_option("small_state", 0)
+        for t, s in enumerate(streams):
+            f.set_state_diag(s[0], s[1], t)
+        for k in range(3):                                   # three steps: 48 ranks pending, no pass yet
+            f.step([s[2][k] for s in streams], [s[3][k] for s in streams], [s[4][k] for s in streams],
+                   [s[5][k] for s in streams], [s[6][k] for s in streams])
+        out = {}
+        for mode in (2, 0, 1):
+            f.set_option("pack_dense", mode)
+            before = lib.ekf_debug_dense_packs(f._h)
+            mu, P = f.state(which)                           # (the binding's array: a recycled pinned buffer)
+            assert P.base is not None
+            took_kernel = lib.ekf_debug_dense_packs(f._h) - before
+            assert took_kernel == (1 if mode == 2 or (mode == 1 and 8 * n * n <= 40 << 20) else 0)
+            out[mode] = (mu, P)
+        plain_mu, plain_P = np.empty(n), np.empty((n, n))    # ordinary memory: never the kernel
+        f.set_option("pack_dense", 2)
+        before = lib.ekf_debug_dense_packs(f._h)
+        dp = C.POINTER(C.c_double)
+        assert lib.ekf_download_state(f._h, which, plain_mu.ctypes.data_as(dp), plain_P.ctypes.data_as(dp), n) == 0
+        assert lib.ekf_debug_dense_packs(f._h) == before
+        for mode in (2, 1):
+            assert np.array_equal(out[mode][0], out[0][0]) and np.array_equal(out[mode][1], out[0][1])
+        assert np.array_equal(plain_P, out[0][1]) and np.array_equal(plain_P, plain_P.T)
+        om, oP = streams[which][0].copy(), np.diag(streams[which][1])
+        for k in range(3):
+            s = streams[which]
+            om, oP = orc.ekf_step_structured(om, oP, s[2][k], s[3][k], s[4][k], s[5][k], s[6][k], orc.EkfConfig())
+        close(plain_mu, om)
+        close(plain_P, oP)

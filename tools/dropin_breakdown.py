@@ -11,6 +11,12 @@ import slam_duckietown_amd as sd
 import slam_duckietown_amd.synthetic as syn
 from slam_duckietown_amd import ekf_bindings as eb
 
+if "--after" in sys.argv:                      # run a secondary leg of bench.py in this process first (leg-order effects)
+    import argparse, bench
+    i = sys.argv.index("--after")
+    bench.secondary_leg(sys.argv[i + 1], argparse.Namespace(gpus=1, steps=200, warmup=20, landmarks=2000, obs=8, trajectories=32,
+                                                            option=[], leg=None, no_cpu_baseline=True, no_single=False))
+    del sys.argv[i:i + 2]
 N, m = int(sys.argv[1]) if len(sys.argv) > 1 else 12, int(sys.argv[2]) if len(sys.argv) > 2 else 3
 calls = 300 if N <= 100 else 60
 mean0, diag0, lin, ang, idx, zr, zb = syn.synthetic_stream(N, calls, m, 0)
