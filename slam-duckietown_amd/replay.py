@@ -50,8 +50,10 @@ class ReplayResult:
 class GpuBackend:
     """Runs association on the host and augmentation + predict + update on the MI355X."""
 
-    def __init__(self, config=None, capacity: int = 203, device: int = 0, device_association: bool = False):
-        """device_association=True: association / gate / averaging / augmentation run on the GPU too
+    def __init__(self, config=None, capacity: int = 79, device: int = 0, device_association: bool = False):
+        """capacity: n_max of the first handle (79 = 38 landmarks: the small-state path, one launch per window -- the
+        reference's map has 12, src/replay_no_ros.py:26); the handle is re-created with twice the room when the map outgrows it.
+        device_association=True: association / gate / averaging / augmentation run on the GPU too
         (`EkfSlam.step_detections`).  The device front end has limits the reference does not (16 distinct tags
         and 64 detections per window, tag ids below 1024, a fixed capacity): every window is checked against them
         on the host first; the state is regrown when the map would not fit, and a window beyond the per-window
@@ -61,10 +63,12 @@ class GpuBackend:
         self.device_association = device_association
         self._make = lambda cap: EkfSlam(cap | 1, 1, device, self.config)
         self.filt = self._make(capacity)
+        self._cache = None            # (mean, covariance) of the device state when the last step brought them back with it
         if device_association:
             self.filt.set_association(self.config.gate_range, self.config.ignore_tags)
 
     def set_state(self, mean, cov):
+        self._cache = None
         n = len(mean)
         if n > self.filt.n_max:
             self.filt.close()
@@ -74,6 +78,7 @@ class GpuBackend:
         self.filt.set_state(mean, cov)
 
     def _grow(self, n_needed):
+        self._cache = None
         mean, cov = self.filt.state()
         index = self.filt.tag_index() if self.device_association else None
         self.filt.close()
@@ -85,9 +90,13 @@ class GpuBackend:
                 self.filt.set_tag_index(index)
 
     def pose(self) -> np.ndarray:
+        if self._cache is not None:
+            return self._cache[0][:3].copy()
         return self.filt.mean()[:3]
 
     def state(self):
+        if self._cache is not None:
+            return self._cache[0].copy(), self._cache[1].copy()
         return self.filt.state()
 
     def _window_tags(self, detections):
@@ -106,6 +115,7 @@ class GpuBackend:
 
     def step(self, ang, lin, detections, tag_index) -> dict:
         from .ekf_bindings import EKF_DMAX, EKF_MMAX, EKF_TAGMAX
+        cached, self._cache = self._cache, None
         if self.device_association:
             dev_index = self.filt.tag_index()
             if tag_index and not dev_index:                       # a pre-filled TAG_INDEX (god mode) goes to the device
@@ -123,7 +133,7 @@ class GpuBackend:
                 return tags
             tag_index.clear()                                     # this window: host association, no limits
             tag_index.update(dev_index)
-        pose = self.pose()                                        # world guesses use the pre-step pose (:331-332)
+        pose = cached[0][:3] if cached is not None else self.pose()   # world guesses use the pre-step pose (:331-332)
         tags = associate(detections, tag_index, pose, self.config.gate_range, self.config.ignore_tags)
         n_old = self.filt.size()
         n_new = max(n_old, 3 + 2 * len(tag_index))
@@ -133,7 +143,12 @@ class GpuBackend:
         if new_xy:
             self.filt.add_landmarks(np.array(new_xy))
         idx = list(tags.keys())
-        self.filt.step(lin, ang, idx, [tags[k][4] for k in idx], [tags[k][5] for k in idx])
+        if self.filt.n_max <= 131:
+            # a small state comes back with the step (ekf_step_fetch: on the small-state path ONE launch, whose result the
+            # host polls for): the loop reads the pose after every window (:241) and the next window's association needs it
+            self._cache = self.filt.step_state(lin, ang, idx, [tags[k][4] for k in idx], [tags[k][5] for k in idx])
+        else:
+            self.filt.step(lin, ang, idx, [tags[k][4] for k in idx], [tags[k][5] for k in idx])
         if self.device_association and all(0 <= t < EKF_TAGMAX for t in tag_index):
             self.filt.set_tag_index(tag_index)                    # the device table follows the host's for the next window
         return tags

@@ -196,3 +196,34 @@ def test_replay_loop_with_device_association_gpu():
     finally:
         be.close()
     check_against_reference_loop(res, g, seen, 1e-9)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("device_association", [False, True])
+def test_replay_loop_on_the_small_state_path_gpu(device_association, monkeypatch):
+    """The reference's loop at its real map size on the path it takes by default outside this test suite (tests/conftest.py
+    pins the general kernels): GpuBackend's first handle holds 38 landmarks, so every window is ONE launch of the small-state
+    kernel, and with the host association the state comes back with the step (ekf_step_fetch: pose() and state() answer from
+    what it brought).  Same fixture -- the reference's own replay() -- same bar."""
+    import ctypes as C
+    import slam_duckietown_amd as sd
+    import slam_duckietown_amd.replay as rp
+    monkeypatch.setenv("EKFSLAM_HIP_SMALL_STATE", "1")
+    g = gu.load("replay_events")
+    detect, seen = fixture_detector(g)
+    be = rp.GpuBackend(device_association=device_association)
+    try:
+        assert be.filt.n_max == 79
+        res = rp.replay(str(g["events_csv"]).splitlines(), backend=be, detector=detect)
+        lib = sd.load_library()
+        for fn in (lib.ekf_debug_small_launches, lib.ekf_debug_fused_fetches):
+            fn.argtypes, fn.restype = [C.c_void_p], C.c_long
+        W = len(g["out_size"])
+        assert lib.ekf_debug_small_launches(be.filt._h) >= W
+        assert lib.ekf_debug_fused_fetches(be.filt._h) == (0 if device_association else W)
+        mean, cov = be.state()                               # (what the last step brought back) == the device's own copy
+        dm, dc = be.filt.state()
+        assert np.array_equal(mean, dm) and np.array_equal(cov, dc)
+    finally:
+        be.close()
+    check_against_reference_loop(res, g, seen, 1e-9)
