@@ -19,11 +19,13 @@ The JSON line also carries
   cpu_baseline  the oracle's reference-shaped dense NumPy step timed on this box's host cores (rank 0,
                 N = 1 only, a bounded sample) at N = 2000, with N = 500, N = 20 (500 steps) and N = 12 under
                 `by_config`
-  single_trajectory  BASELINE config 3 (B = 1) steps/s; config1 / config2: N = 20 x 1 (500 steps), N = 500 x 1
+  single_trajectory  BASELINE config 3 (B = 1) steps/s over >= 200 steps; config1 / config2: N = 20 x 1 (500 steps; plus banks
+                of 256 and 768 such filters on the small-state path), N = 500 x 1
   online_step   the host-driven call surface: one `EkfSlam.step` per call (indices not known in advance,
                 no fused cadence), N = 2000 x 32 and x 1
   drop_in       `EKF_pose_estimation` per call INCLUDING its 8 n^2-byte download (the reference's loop,
-                src/replay_no_ros.py:229-237), N = 12 (the reference's real map, :26), 500, 2000: ms per call
+                src/replay_no_ros.py:229-237) and, beyond 131 x 131, the upload of the upper triangle: N = 12 (the
+                reference's real map, :26), 20, 500, 2000: ms per call
   steady_state  the headline workload timed behind a full sweep of the landmarks (dense covariance: fp64 MFMA power, and the
                 clock the part holds, depend on the operands -- ~9 % slower than the young filter the contract times)
   sclk_mhz      shader clock sampled during the headline's timed region
