@@ -37,7 +37,7 @@ void launch_pack_small(hipStream_t, const double*, const double*, const unsigned
 void launch_pack_dense(hipStream_t, const double*, int, int, double*);
 int small_state_limit();
 int launch_small_stream(hipStream_t, double*, const double*, double*, const int*, const StepIn*, int, int, unsigned*,
-                        const DeviceConfig&, int, long, int, double*, int, unsigned long long*, unsigned long long);
+                        const DeviceConfig&, int, long, int, double*, int, unsigned long long*, unsigned long long, bool);
 void launch_associate(hipStream_t, const DetIn*, int*, int*, int*, double*, double*, double*, double*, StepIn*,
                       AssocOut*, unsigned*, const AssocConfig&, int, long, int, int, int);
 void launch_fill_diag(hipStream_t, double*, int, int, const double*);
@@ -727,7 +727,7 @@ static int enqueue_small(ekf_handle* h, const StepIn* d_in, int nsteps) {
   if (launch_small_stream(h->stream, h->dP, h->dmu2[h->cur], h->dmu2[h->cur ^ 1], h->dn, d_in, h->batch, nsteps, h->dflags,
                           h->dcfg, h->ld, h->pstride, n_hi, out_b >= 0 ? h->h_pack : nullptr, out_b,
                           out_b >= 0 ? reinterpret_cast<unsigned long long*>(h->h_pack + PACK_WORDS - 1) : nullptr,
-                          out_b >= 0 ? ++h->fetch_seq : 0ull) != 0)
+                          out_b >= 0 ? ++h->fetch_seq : 0ull, h->batch > 3 * h->cu_count) != 0)
     return fail(h, EKF_ERR_HIP, "small-state launch: hipFuncSetAttribute failed");
   HIP_TRY(h, hipGetLastError());
   h->fetched = out_b >= 0;

@@ -227,12 +227,12 @@ __device__ __forceinline__ void small_step(double* __restrict__ Pl, double* __re
 // One workgroup per trajectory runs `nsteps` steps: in[k * batch + b], k = 0 .. nsteps - 1.
 // TM: column tiles of 16 the state spans at most (n <= 16 TM): the down-date's loads are unrolled over them.
 template <int NT, int TM>
-__global__ __launch_bounds__(NT) void k_small_stream(double* __restrict__ P, const double* __restrict__ mu_in,
-                                                     double* __restrict__ mu_out, const int* __restrict__ nact,
-                                                     const StepIn* __restrict__ in, int batch, int nsteps,
-                                                     unsigned* __restrict__ flags, DeviceConfig cfg, int ld, long pstride,
-                                                     double* __restrict__ host_out, int out_b,
-                                                     unsigned long long* __restrict__ host_seq, unsigned long long out_seq) {
+__device__ __forceinline__ void small_stream_body(double* __restrict__ P, const double* __restrict__ mu_in,
+                                                  double* __restrict__ mu_out, const int* __restrict__ nact,
+                                                  const StepIn* __restrict__ in, int batch, int nsteps,
+                                                  unsigned* __restrict__ flags, const DeviceConfig& cfg, int ld, long pstride,
+                                                  double* __restrict__ host_out, int out_b,
+                                                  unsigned long long* __restrict__ host_seq, unsigned long long out_seq) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int b = blockIdx.x, tid = threadIdx.x;
   const int n = min(min(nact[b], SMALL_N_MAX), 16 * TM);
@@ -324,18 +324,38 @@ __global__ __launch_bounds__(NT) void k_small_stream(double* __restrict__ P, con
   }
 }
 
+#define SMALL_STREAM_ARGS                                                                                                  \
+  double *__restrict__ P, const double *__restrict__ mu_in, double *__restrict__ mu_out, const int *__restrict__ nact,      \
+      const StepIn *__restrict__ in, int batch, int nsteps, unsigned *__restrict__ flags, DeviceConfig cfg, int ld,        \
+      long pstride, double *__restrict__ host_out, int out_b, unsigned long long *__restrict__ host_seq,                   \
+      unsigned long long out_seq
+#define SMALL_STREAM_PASS P, mu_in, mu_out, nact, in, batch, nsteps, flags, cfg, ld, pstride, host_out, out_b, host_seq, out_seq
+// The latency form: whatever registers the compiler wants (148 / 203 VGPRs: three / two workgroups resident per CU) ...
+template <int NT, int TM>
+__global__ __launch_bounds__(NT) void k_small_stream(SMALL_STREAM_ARGS) {
+  small_stream_body<NT, TM>(SMALL_STREAM_PASS);
+}
+// ... and the throughput form for banks that more than fill the chip at that occupancy: the same code held to 128 VGPRs (a few
+// spilled registers: one trajectory alone is 10 % slower), four workgroups per CU -- banks of 1024 +34 %, of 4096 +14 %
+// (tools/small_bank_sweep.py).  Same instructions on the data: bit-identical results.
+template <int NT, int TM>
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_small_stream_occ(SMALL_STREAM_ARGS) {
+  small_stream_body<NT, TM>(SMALL_STREAM_PASS);
+}
+
 int small_state_limit() { return SMALL_N_MAX; }
 
 int launch_small_stream(hipStream_t st, double* P, const double* mu_in, double* mu_out, const int* nact, const StepIn* in,
                         int batch, int nsteps, unsigned* flags, const DeviceConfig& cfg, int ld, long pstride, int n_hi,
-                        double* host_out, int out_b, unsigned long long* host_seq, unsigned long long out_seq) {
+                        double* host_out, int out_b, unsigned long long* host_seq, unsigned long long out_seq, bool many) {
   const int n = n_hi < SMALL_N_MAX ? n_hi : SMALL_N_MAX, ps = n | 1;
   const size_t bytes = sizeof(double) * ((size_t)n * ps + 5 * (size_t)n + 4) + 2 * sizeof(StepIn);
-#define EKF_SMALL(TM)                                                                                                        \
-  hipLaunchKernelGGL((k_small_stream<256, TM>), dim3(batch), dim3(256), bytes, st, P, mu_in, mu_out, nact, in, batch, nsteps, \
-                     flags, cfg, ld, pstride, host_out, out_b, host_seq, out_seq)
-  if (n <= 48) EKF_SMALL(3);
-  else EKF_SMALL(5);
+#define EKF_SMALL(K, TM)                                                                                                 \
+  hipLaunchKernelGGL((K<256, TM>), dim3(batch), dim3(256), bytes, st, P, mu_in, mu_out, nact, in, batch, nsteps, flags, cfg, ld, \
+                     pstride, host_out, out_b, host_seq, out_seq)
+  if (many && n <= 48) EKF_SMALL(k_small_stream_occ, 3);
+  else if (n <= 48) EKF_SMALL(k_small_stream, 3);
+  else EKF_SMALL(k_small_stream, 5);
 #undef EKF_SMALL
   return 0;
 }

@@ -317,3 +317,39 @@ def test_step_state_reports_what_the_two_calls_report(sd):
         assert not np.isfinite(mu).all()
         assert f.flags() & 1
         assert fused_fetches(sd, f) == 2
+
+
+def test_a_bank_that_overfills_the_chip_takes_the_throughput_kernel_bit_identically(sd):
+    """More than three trajectories per CU: the small-state kernel runs in its 128-VGPR form, four workgroups resident per CU
+    (k_small_stream_occ) -- the same instructions on the data, so sampled trajectories equal, bit for bit, the same
+    trajectories run in a bank of two (the latency form), and the oracle."""
+    N, steps, B = 12, 6, 800
+    base = [orc.synthetic_stream(N, steps, 5, 60 + t) for t in range(8)]
+    cols = [np.ascontiguousarray(np.stack([base[b % 8][i] for b in range(B)], 1)) for i in (2, 3, 4, 5, 6)]
+    with sd.EkfSlam(3 + 2 * N, batch=B) as f:
+        f.set_option("small_state", 1)
+        for b in range(B):
+            f.set_state_diag(base[b % 8][0], base[b % 8][1], b)
+        f.stream_upload(*cols)
+        f.stream_run(0, 3)                                  # one launch for three steps ...
+        for k in range(3, steps):                           # ... then online steps
+            f.step(cols[0][k], cols[1][k], list(cols[2][k]), list(cols[3][k]), list(cols[4][k]))
+        big = {b: f.state(b) for b in (0, 5, 333, 799)}
+        assert small_launches(sd, f) == 1 + (steps - 3) and not any(f.flags(b) for b in big)
+    for b, (mu, P) in big.items():
+        s = base[b % 8]
+        with sd.EkfSlam(3 + 2 * N, batch=2) as g:
+            g.set_option("small_state", 1)
+            for t in range(2):
+                g.set_state_diag(s[0], s[1], t)
+            g.stream_upload(*[np.ascontiguousarray(np.stack([s[i], s[i]], 1)) for i in (2, 3, 4, 5, 6)])
+            g.stream_run(0, 3)
+            for k in range(3, steps):
+                g.step([s[2][k]] * 2, [s[3][k]] * 2, [s[4][k]] * 2, [s[5][k]] * 2, [s[6][k]] * 2)
+            mu2, P2 = g.state(1)
+        assert np.array_equal(mu, mu2) and np.array_equal(P, P2), b
+        om, oP = s[0].copy(), np.diag(s[1])
+        for k in range(steps):
+            om, oP = orc.ekf_step_dense(om, oP, s[2][k], s[3][k], s[4][k], s[5][k], s[6][k], orc.EkfConfig())
+        close(mu, om)
+        close(P, oP)
