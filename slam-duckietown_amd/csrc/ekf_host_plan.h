@@ -286,7 +286,13 @@ inline PassPlan plan_pass(const HostPlan* h) {
   // three per CU the slabs are cut into chunks of strips) or is a few long trajectories; measured at N=2000: 8
   // trajectories 256 us against 266 us with k_flush, 4 trajectories 166 / 164 us, 1 trajectory 97 / 52 us (pipeline
   // fills dominate)
-  if (p.kernel < 0) p.kernel = (p.streaming && ((long)h->batch * slabs >= (long)h->cu_count || p.long_few)) ? 2 : 0;
+  // SHORT slabs (n < 3000: fewer than 24 slabs of at most 47 strips) need more of them before the row-slab form's pipeline fills
+  // are paid for -- 2.35 slabs per CU up to n = 2048, one per CU from n = 3072 on (N = 500 x 32, 64: the column strips +10 %, +3 %,
+  // x 128: the row slabs +9 %; N = 1000 x 16, 32: strips +20 %, +7 %, x 64: slabs +2.5 %; N = 1500 x 16 and N = 2000 x 8: slabs
+  // +4 %, +12 %; tools/mid_size_probe.sh, profiles/r04_n_sweep.txt)
+  const double per_cu = slabs >= 24 ? 1.0 : slabs <= 16 ? 2.35 : 2.35 - (slabs - 16) * (1.35 / 8.0);
+  if (p.kernel < 0)
+    p.kernel = (p.streaming && ((double)h->batch * slabs >= per_cu * h->cu_count || p.long_few)) ? 2 : 0;
   // A few long trajectories on static shares: the pass leaves one CU per trajectory free, so that the next cadence's solve
   // (one workgroup per trajectory) can run beside it (the look-ahead of ekf_stream_run); always, not only when a solve
   // follows: the share table is built per workgroup count (N = 8000 x 1: 255 instead of 256 workgroups, 0.4 %).
