@@ -182,7 +182,8 @@ int ekf_profile_read(ekf_handle *h, double *pass_ms_total, long long *pass_launc
  * rounding (1e-10 relative guaranteed, 1e-13 .. 1e-12 measured; the tests assert 1e-11), not bit for bit; 0 = one step at a time), "lookahead" (1 = where the pass is a
  * small launch, the next cadence's solve runs beside it on the handle's second stream; 0 = strictly in sequence),
  * "pass_share_order" (row-slab pass on static shares: 1 = shares dealt to the XCDs by starting column, 0 = as cut; same
- * result bit for bit), "small_state" (1 = a handle with n_max <= 79 -- up to 38 landmarks -- runs every step, or a whole
+ * result bit for bit), "small_state" (1 = a handle with n_max <= 79 -- up to 38 landmarks; n_max <= 131, 64 landmarks, for a bank of at least 128
+ * trajectories -- runs every step, or a whole
  * uploaded stream, as ONE workgroup per trajectory with the covariance resident in LDS: nothing is ever pending; 0 = the
  * general kernels; the default can be set for new handles with the environment variable EKFSLAM_HIP_SMALL_STATE),
  * "zero_copy_inputs" (1 = the small-state kernel reads an online step's record straight from the pinned input ring, 0 = a

@@ -35,7 +35,7 @@ void launch_add_landmarks(hipStream_t, double*, double*, int, int, int, double, 
 void launch_mirror(hipStream_t, double*, const int*, int, long, int, int);
 void launch_pack_small(hipStream_t, const double*, const double*, const unsigned*, int, int, double*);
 void launch_pack_dense(hipStream_t, const double*, int, int, double*);
-int small_state_limit();
+int small_state_limit(int batch);
 int launch_small_stream(hipStream_t, double*, const double*, double*, const int*, const StepIn*, int, int, unsigned*,
                         const DeviceConfig&, int, long, int, double*, int, unsigned long long*, unsigned long long, bool);
 void launch_associate(hipStream_t, const DetIn*, int*, int*, int*, double*, double*, double*, double*, StepIn*,
@@ -718,7 +718,7 @@ static int flush_pending(ekf_handle* h) { return flush_pending(h, nullptr); }
 // The small-state path (ekf_small.hip): a filter bank whose covariances fit the LDS of a CU runs `nsteps` steps per trajectory
 // inside one workgroup, P resident in LDS; nothing is ever pending on it.
 static bool small_path(const ekf_handle* h) {
-  return h->opt_small_state && h->n_max <= small_state_limit() && h->pending_k == 0;
+  return h->opt_small_state && h->n_max <= small_state_limit(h->batch) && h->pending_k == 0;
 }
 static int enqueue_small(ekf_handle* h, const StepIn* d_in, int nsteps) {
   const int n_hi = h->sizes_dirty ? h->n_max : *std::max_element(h->n.begin(), h->n.end());

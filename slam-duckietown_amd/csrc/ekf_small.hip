@@ -1,5 +1,5 @@
-// The SMALL-STATE path (gfx950, wave64): a small filter -- n <= SMALL_N_MAX = 79, i.e. up to 38 landmarks: the reference's real
-// map has 12 (src/replay_no_ros.py:26) -- runs every step, or a whole uploaded stream of steps, inside ONE workgroup with P
+// The SMALL-STATE path (gfx950, wave64): a small filter -- n <= SMALL_N_MAX = 79, i.e. up to 38 landmarks (n <= 131, 64 landmarks,
+// in a bank of at least 128 trajectories): the reference's real map has 12 (src/replay_no_ros.py:26) -- runs every step, or a whole uploaded stream of steps, inside ONE workgroup with P
 // resident in LDS.  (The limit is where this path stops winning, not where LDS ends: tools/step_latency.py, N = 38: 25.7 us per
 // online step and 13.0 us per streamed step against 27.5 / 18.9 us on the general kernels; N = 45: 30.6 / 16.7 against 27.6 / 19.0;
 // N = 64: 44 / 25 against 28 / 19 -- the down-date and the per-launch load / store of the triangle grow with n^2.)
@@ -23,6 +23,9 @@
 namespace ekf {
 
 constexpr int SMALL_N_MAX = 79;         // 3 + 2 * 38 (<= 5 column tiles of 16; 50 KB of LDS): beyond, the general kernels are faster
+                                        // for ONE trajectory (latency) ...
+constexpr int SMALL_N_MAX_BANK = 131;   // ... but not for a bank that fills the chip (3 + 2 * 64; 9 column tiles, 137 KB of LDS: one
+constexpr int SMALL_BANK_MIN = 128;     // workgroup per CU): N = 64 x 256 10.4 M against 7.9 M steps/s, x 1024 against 5.4 M
 
 // One step's landmark updates and prediction on the LDS-resident state.  `Pl` is n x ps (ps odd: row and column walks are
 // both conflict-free), `mu` the mean, `hp` / `kk` 2 x n scratch.
@@ -108,7 +111,6 @@ __device__ __forceinline__ void small_step(double* __restrict__ Pl, double* __re
   // them, the rank-2 down-date as 16 x 16 tiles of the upper triangle over all 256 threads (independent iterations: the
   // loads of the next tiles are in flight under this one's FMAs).
   const int ty = tid >> 4, tx = tid & 15;
-  const int T = (n + 15) >> 4;
   for (int j = 0; j < m; ++j) {
     const int lm = s.idx[j];
     if (lm < 0 || lm >= n_lm) continue;                     // (uniform; validated on the host, and by k_associate)
@@ -169,7 +171,7 @@ __device__ __forceinline__ void small_step(double* __restrict__ Pl, double* __re
     // (every load of a row of tiles is unconditional, at clamped addresses, and in flight before the first FMA; only the
     //  stores are predicated -- with the loads under the `a <= b` branch each tile was its own trip to LDS: 8 of 16 us per step)
 #ifndef SM_SKIP_UPDATE                                   /* diagnostic build (timing only, wrong results): no covariance down-date */
-    if constexpr (TM <= 5) {
+    {
       // ALL tiles in flight at once -- one round trip to LDS for the whole down-date
       constexpr int NTILE = TM * (TM + 1) / 2;
       double pv[NTILE], h0[TM], h1[TM], k0[TM], k1[TM];
@@ -196,27 +198,6 @@ __device__ __forceinline__ void small_step(double* __restrict__ Pl, double* __re
             Pl[b * ps + a] = v;
           }
         }
-    } else
-    for (int i = 0; i < T; ++i) {
-      const int a = 16 * i + ty, ac = min(a, n - 1);
-      const double ka0 = kk[ac], ka1 = kk[n + ac];
-      double pv[TM], h0[TM], h1[TM];
-#pragma unroll
-      for (int u = 0; u < TM; ++u) {
-        const int bc = min(16 * (i + u) + tx, n - 1);
-        pv[u] = Pl[ac * ps + bc];
-        h0[u] = hp[bc];
-        h1[u] = hp[n + bc];
-      }
-#pragma unroll
-      for (int u = 0; u < TM; ++u) {
-        const int b = 16 * (i + u) + tx;
-        const double v = pv[u] - (ka0 * h0[u] + ka1 * h1[u]);
-        if (a <= b && b < n) {
-          Pl[a * ps + b] = v;
-          Pl[b * ps + a] = v;
-        }
-      }
     }
 #endif
     for (int c = tid; c < n; c += NT) mu[c] += kk[c] * y0 + kk[n + c] * y1;     // :476
@@ -235,7 +216,8 @@ __device__ __forceinline__ void small_stream_body(double* __restrict__ P, const 
                                                   unsigned long long* __restrict__ host_seq, unsigned long long out_seq) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int b = blockIdx.x, tid = threadIdx.x;
-  const int n = min(min(nact[b], SMALL_N_MAX), 16 * TM);
+  const int n = min(min(nact[b], SMALL_N_MAX_BANK), 16 * TM);
+  constexpr int NQ = (16 * TM + 63) / 64;                   // columns per lane and row of the triangle's load / store
   const int ps = n | 1;                                     // odd row stride
   double* Pl = lds;
   double* mu = Pl + n * ps;
@@ -259,7 +241,7 @@ __device__ __forceinline__ void small_stream_body(double* __restrict__ P, const 
       for (int u = 0; u < U; ++u) {
         const int r = min(r0 + NWV * u, n - 1);
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
+        for (int q = 0; q < NQ; ++q) {
           const int c = min(max(lane + 64 * q, r), n - 1);          // (clamped into the row's stored part: no load under a branch)
           v[u][q] = Pb[p_index(ld, r, c)];
         }
@@ -268,7 +250,7 @@ __device__ __forceinline__ void small_stream_body(double* __restrict__ P, const 
       for (int u = 0; u < U; ++u) {
         const int r = r0 + NWV * u;
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
+        for (int q = 0; q < NQ; ++q) {
           const int c = lane + 64 * q;
           if (r < n && c >= r && c < n) {
             Pl[r * ps + c] = v[u][q];
@@ -317,7 +299,7 @@ __device__ __forceinline__ void small_stream_body(double* __restrict__ P, const 
     const int w = tid >> 6, lane = tid & 63;
     for (int r = w; r < n; r += NT / 64)
 #pragma unroll
-      for (int q = 0; q < 2; ++q) {
+      for (int q = 0; q < NQ; ++q) {
         const int c = lane + 64 * q;
         if (c >= r && c < n) Pb[p_index(ld, r, c)] = Pl[r * ps + c];
       }
@@ -342,20 +324,43 @@ template <int NT, int TM>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_small_stream_occ(SMALL_STREAM_ARGS) {
   small_stream_body<NT, TM>(SMALL_STREAM_PASS);
 }
+// ... and the 7-tile form (81 <= n <= 112, banks only) held to 256 VGPRs instead of 266: two workgroups per CU where LDS allows
+// (n <= 93: 69 KB each).
+template <int NT, int TM>
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_small_stream_two(SMALL_STREAM_ARGS) {
+  small_stream_body<NT, TM>(SMALL_STREAM_PASS);
+}
 
-int small_state_limit() { return SMALL_N_MAX; }
+int small_state_limit(int batch) { return batch >= SMALL_BANK_MIN ? SMALL_N_MAX_BANK : SMALL_N_MAX; }
 
 int launch_small_stream(hipStream_t st, double* P, const double* mu_in, double* mu_out, const int* nact, const StepIn* in,
                         int batch, int nsteps, unsigned* flags, const DeviceConfig& cfg, int ld, long pstride, int n_hi,
                         double* host_out, int out_b, unsigned long long* host_seq, unsigned long long out_seq, bool many) {
-  const int n = n_hi < SMALL_N_MAX ? n_hi : SMALL_N_MAX, ps = n | 1;
+  const int n = n_hi < SMALL_N_MAX_BANK ? n_hi : SMALL_N_MAX_BANK, ps = n | 1;
   const size_t bytes = sizeof(double) * ((size_t)n * ps + 5 * (size_t)n + 4) + 2 * sizeof(StepIn);
 #define EKF_SMALL(K, TM)                                                                                                 \
   hipLaunchKernelGGL((K<256, TM>), dim3(batch), dim3(256), bytes, st, P, mu_in, mu_out, nact, in, batch, nsteps, flags, cfg, ld, \
                      pstride, host_out, out_b, host_seq, out_seq)
+  // (more than 64 KB of dynamic LDS has to be asked for, once per kernel)
+#define EKF_SMALL_BIG(K, TM)                                                                                             \
+  do {                                                                                                                   \
+    static bool asked = false;                                                                                           \
+    if (!asked) {                                                                                                        \
+      const size_t most = sizeof(double) * ((size_t)SMALL_N_MAX_BANK * (SMALL_N_MAX_BANK | 1) + 5 * SMALL_N_MAX_BANK + 4) + \
+                          2 * sizeof(StepIn);                                                                            \
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&K<256, TM>), hipFuncAttributeMaxDynamicSharedMemorySize,   \
+                              (int)most) != hipSuccess)                                                                  \
+        return 1;                                                                                                        \
+      asked = true;                                                                                                      \
+    }                                                                                                                    \
+    EKF_SMALL(K, TM);                                                                                                    \
+  } while (0)
   if (many && n <= 48) EKF_SMALL(k_small_stream_occ, 3);
   else if (n <= 48) EKF_SMALL(k_small_stream, 3);
-  else EKF_SMALL(k_small_stream, 5);
+  else if (n <= 80) EKF_SMALL(k_small_stream, 5);
+  else if (n <= 112) EKF_SMALL_BIG(k_small_stream_two, 7);
+  else EKF_SMALL_BIG(k_small_stream, 9);
+#undef EKF_SMALL_BIG
 #undef EKF_SMALL
   return 0;
 }

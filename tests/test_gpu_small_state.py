@@ -353,3 +353,61 @@ def test_a_bank_that_overfills_the_chip_takes_the_throughput_kernel_bit_identica
             om, oP = orc.ekf_step_dense(om, oP, s[2][k], s[3][k], s[4][k], s[5][k], s[6][k], orc.EkfConfig())
         close(mu, om)
         close(P, oP)
+
+
+@pytest.mark.parametrize("n_lm,n_cap", [(45, 45), (50, 64), (64, 64)])
+def test_banks_take_the_small_path_up_to_64_landmarks(sd, n_lm, n_cap):
+    """One trajectory of more than 38 landmarks is faster on the general kernels (latency); a bank that fills the chip is not:
+    from 128 trajectories on a handle of up to n_max = 131 (64 landmarks) runs the small-state kernel, one workgroup per
+    trajectory with up to 137 KB of LDS (7 or 9 column tiles).  Uploaded stream, online steps with 0 .. 20 observations, the
+    fused step + state, a dense start: sampled trajectories against the oracle and against the same bank on the general kernels."""
+    rng = np.random.default_rng(5 + n_lm)
+    B, steps = 130, 6
+    cfg = orc.EkfConfig()
+    base = [orc.synthetic_stream(n_lm, steps, 8, 80 + t) for t in range(6)]
+    n = 3 + 2 * n_lm
+    A = rng.normal(size=(n, 4)) * 0.2
+    dense0 = A @ A.T + np.diag(rng.uniform(0.5, 2.0, n))
+    cols = [np.ascontiguousarray(np.stack([base[b % 6][i] for b in range(B)], 1)) for i in (2, 3, 4, 5, 6)]
+    extra = []                                               # online steps behind the stream: 0, 3 and 20 observations
+    for m in (0, 3, 20):
+        idx = rng.choice(n_lm, size=m, replace=False).astype(np.int32)
+        extra.append((0.004, 0.03, idx, rng.uniform(0.4, 1.5, m), rng.uniform(-0.5, 0.5, m)))
+    out = {}
+    with sd.EkfSlam(3 + 2 * n_cap, batch=1) as one:
+        one.set_option("small_state", 1)
+        one.set_state_diag(base[0][0], base[0][1])
+        one.step(base[0][2][0], base[0][3][0], base[0][4][0], base[0][5][0], base[0][6][0])
+        assert small_launches(sd, one) == 0                  # a single trajectory of this size: the general kernels
+    for small in (1, 0):
+        with sd.EkfSlam(3 + 2 * n_cap, batch=B) as f:
+            f.set_option("small_state", small)
+            for b in range(B):
+                if b == 7:
+                    f.set_state(base[b % 6][0], dense0, b)
+                else:
+                    f.set_state_diag(base[b % 6][0], base[b % 6][1], b)
+            f.stream_upload(*cols)
+            f.stream_run(0, steps)
+            for k, (lin, ang, idx, zr, zb) in enumerate(extra):
+                args = ([lin] * B, [ang] * B, [idx] * B, [zr] * B, [zb] * B)
+                if k == 1:
+                    mu_f, P_f = f.step_state(*args, b=7)
+                else:
+                    f.step(*args)
+            out[small] = {b: f.state(b) for b in (0, 7, 64, 129)}
+            assert np.array_equal(out[small][7][0], mu_f) or k == 2          # (the fused fetch returned the state of step 1)
+            assert not any(f.flags(b) for b in out[small])
+            assert small_launches(sd, f) == (1 + 4 if small else 0)          # the stream, then 1 + 1 + 2 launches (20 > 16 landmarks)
+    for b in (0, 7, 64, 129):
+        s = base[b % 6]
+        om, oP = s[0].copy(), (dense0.copy() if b == 7 else np.diag(s[1]))
+        for k in range(steps):
+            om, oP = orc.ekf_step_dense(om, oP, s[2][k], s[3][k], s[4][k], s[5][k], s[6][k], cfg)
+        for lin, ang, idx, zr, zb in extra:
+            om, oP = orc.ekf_step_dense(om, oP, lin, ang, idx, zr, zb, cfg)
+        close(out[1][b][0], om)
+        close(out[1][b][1], oP)
+        close(out[1][b][0], out[0][b][0], 1e-10)
+        close(out[1][b][1], out[0][b][1], 1e-10)
+        assert np.array_equal(out[1][b][1], out[1][b][1].T)
