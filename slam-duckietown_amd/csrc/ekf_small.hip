@@ -341,17 +341,19 @@ int launch_small_stream(hipStream_t st, double* P, const double* mu_in, double* 
 #define EKF_SMALL(K, TM)                                                                                                 \
   hipLaunchKernelGGL((K<256, TM>), dim3(batch), dim3(256), bytes, st, P, mu_in, mu_out, nact, in, batch, nsteps, flags, cfg, ld, \
                      pstride, host_out, out_b, host_seq, out_seq)
-  // (more than 64 KB of dynamic LDS has to be asked for, once per kernel)
+  // (more than 64 KB of dynamic LDS has to be asked for, once per kernel and device)
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 1;
 #define EKF_SMALL_BIG(K, TM)                                                                                             \
   do {                                                                                                                   \
-    static bool asked = false;                                                                                           \
-    if (!asked) {                                                                                                        \
+    static unsigned long long asked = 0;                                                                                 \
+    if (!((asked >> dev) & 1ull)) {                                                                                      \
       const size_t most = sizeof(double) * ((size_t)SMALL_N_MAX_BANK * (SMALL_N_MAX_BANK | 1) + 5 * SMALL_N_MAX_BANK + 4) + \
                           2 * sizeof(StepIn);                                                                            \
       if (hipFuncSetAttribute(reinterpret_cast<const void*>(&K<256, TM>), hipFuncAttributeMaxDynamicSharedMemorySize,   \
                               (int)most) != hipSuccess)                                                                  \
         return 1;                                                                                                        \
-      asked = true;                                                                                                      \
+      asked |= 1ull << dev;                                                                                              \
     }                                                                                                                    \
     EKF_SMALL(K, TM);                                                                                                    \
   } while (0)
