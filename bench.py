@@ -301,7 +301,7 @@ def online_step_leg(sd, sd_syn, device, n_landmarks, batch, m, steps, warmup, op
         if batch == 1:
             f.step(cols[0][k][0], cols[1][k][0], cols[2][k][0], cols[3][k][0], cols[4][k][0])
         else:
-            f.step(cols[0][k], cols[1][k], list(cols[2][k]), list(cols[3][k]), list(cols[4][k]))
+            f.step(cols[0][k], cols[1][k], cols[2][k], cols[3][k], cols[4][k])        # [batch, m] arrays: one block copy each
 
     for k in range(warmup):
         one(k)

@@ -495,6 +495,13 @@ def test_binding_stages_arguments_without_a_device():
     again = f._obs([[9], [8], [7]], [[1.0], [2.0], [3.0]], [[0.0], [0.0], [0.0]])
     assert again[4] == 1 and f._stages[1][0][:, 0].tolist() == [9, 8, 7] and f._m.tolist() == [1, 1, 1]
     assert f._obs([[4, 2], [], [1, 0, 3]], [[1.0, 2.0], [], [3.0, 4.0, 5.0]], [[.1, .2], [], [.3, .4, .5]])[0] is pI   # reused
+    blk = f._obs(np.array([[1, 2], [3, 4], [5, 6]], dtype=np.int64), np.full((3, 2), 1.5), np.arange(6.0).reshape(3, 2))
+    assert blk[4] == 2 and f._m.tolist() == [2, 2, 2] and f._stages[2][0].tolist() == [[1, 2], [3, 4], [5, 6]]      # a bank at once
+    assert f._stages[2][2][2].tolist() == [4.0, 5.0] and f._stages[2][1][1, 0] == 1.5
+    with pytest.raises(ValueError):
+        f._obs(np.zeros((2, 2), dtype=np.int32), np.zeros((2, 2)), np.zeros((2, 2)))      # two rows for three trajectories
+    with pytest.raises(ValueError):
+        f._obs(np.zeros((3, 2), dtype=np.int32), np.zeros((3, 1)), np.zeros((3, 2)))
     with pytest.raises(ValueError):
         f._obs([[1], [2]], [[1.0], [2.0]], [[0.0], [0.0]])            # two lists for three trajectories
     with pytest.raises(ValueError):

@@ -477,3 +477,33 @@ def test_download_into_pinned_memory_by_kernel_equals_the_copy(sd, n_lm, batch, 
             om, oP = orc.ekf_step_structured(om, oP, s[2][k], s[3][k], s[4][k], s[5][k], s[6][k], orc.EkfConfig())
         close(plain_mu, om)
         close(plain_P, oP)
+
+
+def test_a_bank_s_observations_as_arrays_equal_the_lists(sd):
+    """`step` / `update` / `step_state` take a whole bank's observations as [batch, m] arrays (one block copy each instead of one
+    per trajectory): the same state, bit for bit, as the lists of per-trajectory lists."""
+    B, N = 5, 30
+    streams = [orc.synthetic_stream(N, 4, 6, 90 + t) for t in range(B)]
+    with sd.EkfSlam(3 + 2 * N, batch=B) as f, sd.EkfSlam(3 + 2 * N, batch=B) as g:
+        for h in (f, g):
+            for t, s in enumerate(streams):
+                h.set_state_diag(s[0], s[1], t)
+        for k in range(4):
+            lin, ang = np.array([s[2][k] for s in streams]), np.array([s[3][k] for s in streams])
+            idx, zr, zb = (np.stack([s[i][k] for s in streams]) for i in (4, 5, 6))
+            if k == 2:
+                f.update(idx, zr, zb)
+                g.update(list(idx), list(zr), list(zb))
+            elif k == 3:
+                mu, P = f.step_state(lin, ang, idx, zr, zb, b=3)
+                g.step(lin, ang, [list(r) for r in idx], [list(r) for r in zr], [list(r) for r in zb])
+                mu2, P2 = g.state(3)
+                assert np.array_equal(mu, mu2) and np.array_equal(P, P2)
+            else:
+                f.step(lin, ang, idx, zr, zb)
+                g.step(lin, ang, list(idx), list(zr), list(zb))
+        for t in range(B):
+            a, b = f.state(t), g.state(t)
+            assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+        with pytest.raises(ValueError):
+            f.step(lin, ang, idx[:3], zr[:3], zb[:3])
