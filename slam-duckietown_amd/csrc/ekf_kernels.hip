@@ -1588,6 +1588,9 @@ __global__ __launch_bounds__(256, 2) void k_flush(double* __restrict__ P, const 
     const int lin = blockIdx.x;
     const int q = total >> 3, r = total & 7, xcd = lin & 7, slot = lin >> 3;
     int rem = ((xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+#ifdef FLUSH_XCD_PROBE                                   /* probe builds: 1 = no remap (every 8th workgroup of the enumeration per XCD) */
+    if (FLUSH_XCD_PROBE == 1) rem = lin;
+#endif
     for (;; ++by) {
       const int cnt = gx - (by * rows_per_block) / 256;
       if (rem < cnt || cnt <= 0) break;
