@@ -64,11 +64,13 @@ class GpuBackend:
         self._make = lambda cap: EkfSlam(cap | 1, 1, device, self.config)
         self.filt = self._make(capacity)
         self._cache = None            # (mean, covariance) of the device state when the last step brought them back with it
+        self._dev_index = None        # device_association: the device's tag table as last downloaded (one download per window)
         if device_association:
             self.filt.set_association(self.config.gate_range, self.config.ignore_tags)
 
     def set_state(self, mean, cov):
         self._cache = None
+        self._dev_index = None
         n = len(mean)
         if n > self.filt.n_max:
             self.filt.close()
@@ -79,6 +81,7 @@ class GpuBackend:
 
     def _grow(self, n_needed):
         self._cache = None
+        self._dev_index = None
         mean, cov = self.filt.state()
         index = self.filt.tag_index() if self.device_association else None
         self.filt.close()
@@ -117,7 +120,7 @@ class GpuBackend:
         from .ekf_bindings import EKF_DMAX, EKF_MMAX, EKF_TAGMAX
         cached, self._cache = self._cache, None
         if self.device_association:
-            dev_index = self.filt.tag_index()
+            dev_index = dict(self._dev_index) if self._dev_index is not None else self.filt.tag_index()
             if tag_index and not dev_index:                       # a pre-filled TAG_INDEX (god mode) goes to the device
                 self.filt.set_tag_index(tag_index)
                 dev_index = dict(tag_index)
@@ -128,8 +131,9 @@ class GpuBackend:
             if len(ids) <= EKF_MMAX and count <= EKF_DMAX and all(0 <= t < EKF_TAGMAX for t in ids):
                 self.filt.step_detections(lin, ang, detections)
                 tags = self.filt.tags_positions()                 # raises if the device still had to drop something
+                self._dev_index = self.filt.tag_index()
                 tag_index.clear()
-                tag_index.update(self.filt.tag_index())
+                tag_index.update(self._dev_index)
                 return tags
             tag_index.clear()                                     # this window: host association, no limits
             tag_index.update(dev_index)
@@ -149,8 +153,10 @@ class GpuBackend:
             self._cache = self.filt.step_state(lin, ang, idx, [tags[k][4] for k in idx], [tags[k][5] for k in idx])
         else:
             self.filt.step(lin, ang, idx, [tags[k][4] for k in idx], [tags[k][5] for k in idx])
+        self._dev_index = None
         if self.device_association and all(0 <= t < EKF_TAGMAX for t in tag_index):
             self.filt.set_tag_index(tag_index)                    # the device table follows the host's for the next window
+            self._dev_index = dict(tag_index)
         return tags
 
     def close(self):
