@@ -20,6 +20,7 @@ import ctypes as C
 import dataclasses
 import os
 import subprocess
+import threading
 import warnings
 import weakref
 from typing import Optional, Sequence
@@ -198,22 +199,26 @@ class _PinnedPool:
     def __init__(self):
         self.free = {}
         self.live = 0
+        # handles may be driven from several host threads (one each); finalisers run wherever the last reference dies,
+        # possibly inside empty() of the same thread: a re-entrant lock
+        self.lock = threading.RLock()
 
     def empty(self, lib, shape):
         count = int(np.prod(shape))
         nbytes = 8 * count
         ptr = None
-        if self.free.get(nbytes):
-            ptr = self.free[nbytes].pop()
-        else:
-            for other in [k for k in self.free if k != nbytes]:            # the map grew: the old size is not coming back
-                for q in self.free.pop(other):
-                    lib.ekf_host_free(q)
-                    self.live -= other
-            if self.live + nbytes <= self.LIMIT:
-                ptr = lib.ekf_host_alloc(nbytes)
-                if ptr:
-                    self.live += nbytes
+        with self.lock:
+            if self.free.get(nbytes):
+                ptr = self.free[nbytes].pop()
+            else:
+                for other in [k for k in self.free if k != nbytes]:        # the map grew: the old size is not coming back
+                    for q in self.free.pop(other):
+                        lib.ekf_host_free(q)
+                        self.live -= other
+                if self.live + nbytes <= self.LIMIT:
+                    ptr = lib.ekf_host_alloc(nbytes)
+                    if ptr:
+                        self.live += nbytes
         if not ptr:
             return np.empty(shape)
         buf = (C.c_double * count).from_address(ptr)
@@ -221,12 +226,13 @@ class _PinnedPool:
         return np.frombuffer(buf, dtype=np.float64).reshape(shape)
 
     def _release(self, lib, ptr, nbytes):
-        kept = self.free.setdefault(nbytes, [])
-        if len(kept) < self.KEEP:
-            kept.append(ptr)
-        else:
-            lib.ekf_host_free(ptr)
-            self.live -= nbytes
+        with self.lock:
+            kept = self.free.setdefault(nbytes, [])
+            if len(kept) < self.KEEP:
+                kept.append(ptr)
+            else:
+                lib.ekf_host_free(ptr)
+                self.live -= nbytes
 
 
 _pinned = _PinnedPool()
