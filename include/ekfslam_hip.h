@@ -200,6 +200,32 @@ int ekf_set_option(ekf_handle *h, const char *name, int value);
  * MFMA k-tiles (4 pending ranks each) it applied, and whether it took the nontemporal (streaming) path. */
 int ekf_last_pass(ekf_handle *h, int *kernel, int *k_tiles, int *streaming);
 
+/* --- diagnostics (development hooks: counters and raw views the tests use to assert WHICH path ran; no reference
+ * interface stands behind them, they change nothing, and a production caller never needs them) --- */
+/* Fused cadences ekf_stream_run has launched so far and the steps (of the uploaded stream) they covered. */
+int ekf_debug_cadences(ekf_handle *h, long *cadences, long *steps);
+/* Cadences whose solve ran beside the previous covariance pass (look-ahead). */
+long ekf_debug_lookaheads(ekf_handle *h);
+/* Pieces of the longest static share the last row-slab pass used (0 = work queues / column strips; -1 = NULL handle). */
+int ekf_debug_last_pass_shares(ekf_handle *h);
+/* Launches of the small-state path; ekf_step_fetch calls served by the step's own launch; whole-state downloads written
+ * by k_pack_dense. */
+long ekf_debug_small_launches(ekf_handle *h);
+long ekf_debug_fused_fetches(ekf_handle *h);
+long ekf_debug_dense_packs(ekf_handle *h);
+/* Raw device views behind a stream synchronisation, no flush: the fused cadence's record of trajectory b (returns its
+ * size; copies min(bytes, size)); `which` = 0 P_base (allocated doubles), 1 V, 2 W, 3 the pending pose noise, 4 the mean the
+ * next step reads (dst == NULL: the count); the words behind the row-slab pass's queue heads
+ * (where a -DRS_STAMPS build leaves its time stamps). */
+long ekf_debug_cad(ekf_handle *h, int b, void *dst, long bytes);
+long ekf_debug_snapshot(ekf_handle *h, int b, int which, double *dst, long count);
+int ekf_debug_read(ekf_handle *h, void *dst, long bytes);
+/* The planning arithmetic of the row-slab pass, host side only (no handle, no device): every unit of the eight per-XCD
+ * work queues in hand-out order (returns their number), and the static shares (workgroups x 16 pieces x 4 ints; returns the
+ * pieces of the longest share, 0 if one would need more than 16). */
+int ekf_debug_pass_units(int batch, int nrb, int nch, int mode, int *out, int cap);
+int ekf_debug_pass_shares(int batch, int n_hi, int workgroups, int *out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1351,7 +1351,7 @@ extern "C" int ekf_profile_read(ekf_handle* h, double* pass_ms_total, long long*
   return EKF_OK;
 }
 
-// (development aid, not declared in the header: the words behind the queue heads, where a -DRS_STAMPS build of
+// (diagnostics section of the header: the words behind the queue heads, where a -DRS_STAMPS build of
 //  k_flush_rs leaves its time stamps)
 extern "C" int ekf_debug_read(ekf_handle* h, void* dst, long bytes) {
   if (!h || !dst) return EKF_ERR_ARG;
@@ -1362,7 +1362,7 @@ extern "C" int ekf_debug_read(ekf_handle* h, void* dst, long bytes) {
   return EKF_OK;
 }
 
-// (development aid, not declared in the header; no device needed) the equal static shares of the row-slab pass for a
+// (diagnostics section of the header; no device needed) the equal static shares of the row-slab pass for a
 // few long trajectories: out = workgroups x 16 pieces x (trajectory, slab, first strip, strips); returns the pieces of
 // the longest share (0: no table) -- tests/test_cpu_host.py checks that every strip of every slab is covered exactly once
 extern "C" int ekf_debug_pass_shares(int batch, int n_hi, int workgroups, int* out) {
@@ -1370,11 +1370,11 @@ extern "C" int ekf_debug_pass_shares(int batch, int n_hi, int workgroups, int* o
   return build_pass_shares(batch, n_hi, workgroups, out);
 }
 
-// (development aid, not declared in the header) pieces of the longest share if the last covariance pass ran on equal
+// (diagnostics section of the header) pieces of the longest share if the last covariance pass ran on equal
 // static shares, else 0
 extern "C" int ekf_debug_last_pass_shares(ekf_handle* h) { return h ? h->last_shares : -1; }
 
-// (development aid, not declared in the header) how many fused cadences ekf_stream_run has launched and how many steps
+// (diagnostics section of the header) how many fused cadences ekf_stream_run has launched and how many steps
 // they covered: tests assert that the path they mean to check is the one that ran
 extern "C" int ekf_debug_cadences(ekf_handle* h, long* cadences, long* steps) {
   if (!h) return EKF_ERR_ARG;
@@ -1382,14 +1382,14 @@ extern "C" int ekf_debug_cadences(ekf_handle* h, long* cadences, long* steps) {
   if (steps) *steps = h->cadence_steps;
   return EKF_OK;
 }
-// (development aid, not declared in the header) how many of them had their solve run beside the previous covariance pass
+// (diagnostics section of the header) how many of them had their solve run beside the previous covariance pass
 extern "C" long ekf_debug_lookaheads(ekf_handle* h) { return h ? h->lookaheads : -1; }
-// (development aid, not declared in the header) launches of the small-state path so far
+// (diagnostics section of the header) launches of the small-state path so far
 extern "C" long ekf_debug_small_launches(ekf_handle* h) { return h ? h->small_launches : -1; }
 extern "C" long ekf_debug_fused_fetches(ekf_handle* h) { return h ? h->fused_fetches : -1; }
 extern "C" long ekf_debug_dense_packs(ekf_handle* h) { return h ? h->dense_packs : -1; }
 
-// (development aid, not declared in the header) the fused cadence's record of trajectory b (head + per-landmark records)
+// (diagnostics section of the header) the fused cadence's record of trajectory b (head + per-landmark records)
 extern "C" long ekf_debug_cad(ekf_handle* h, int b, void* dst, long bytes) {
   if (!h || b < 0 || b >= h->batch || !h->dcad) return -1;
   if (hipSetDevice(h->device) != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess) return -1;
@@ -1398,7 +1398,7 @@ extern "C" long ekf_debug_cad(ekf_handle* h, int b, void* dst, long bytes) {
   return have;
 }
 
-// (development aid, not declared in the header) raw device buffers of trajectory b, exactly as they stand -- no flush,
+// (diagnostics section of the header) raw device buffers of trajectory b, exactly as they stand -- no flush,
 // no mirror, no status check: which = 0 P_base (device layout, ekf_device.h: rows x ld up to ld = 4096, column panels beyond), 1 V (80 x ld), 2 W (80 x ld, MFMA-tiled), 3 the mean buffer
 // the NEXT step reads, 4 the other mean buffer.  Returns the number of doubles the buffer holds (copies min(count, that)).
 extern "C" long ekf_debug_snapshot(ekf_handle* h, int b, int which, double* dst, long count) {
@@ -1419,7 +1419,7 @@ extern "C" long ekf_debug_snapshot(ekf_handle* h, int b, int which, double* dst,
   return have;
 }
 
-// (development aid, not declared in the header; no device needed) the units of the row-slab pass's work queues in
+// (diagnostics section of the header; no device needed) the units of the row-slab pass's work queues in
 // hand-out order for a batch of `batch` trajectories of `nrb` slabs: what tests/test_cpu_host.py checks for coverage
 extern "C" int ekf_debug_pass_units(int batch, int nrb, int nch, int mode, int* out, int cap) {
   if (batch < 1 || nrb < 1 || nch < 1 || mode < 0 || mode > 3 || (cap > 0 && !out)) return -1;

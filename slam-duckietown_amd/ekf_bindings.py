@@ -135,6 +135,18 @@ ABI = {
     "ekf_profile_read": (C.c_int, [C.c_void_p, _dp, C.POINTER(C.c_longlong)]),
     "ekf_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
     "ekf_last_pass": (C.c_int, [C.c_void_p, _ip, _ip, _ip]),
+    # diagnostics (the header's last section)
+    "ekf_debug_cadences": (C.c_int, [C.c_void_p, C.POINTER(C.c_long), C.POINTER(C.c_long)]),
+    "ekf_debug_lookaheads": (C.c_long, [C.c_void_p]),
+    "ekf_debug_last_pass_shares": (C.c_int, [C.c_void_p]),
+    "ekf_debug_small_launches": (C.c_long, [C.c_void_p]),
+    "ekf_debug_fused_fetches": (C.c_long, [C.c_void_p]),
+    "ekf_debug_dense_packs": (C.c_long, [C.c_void_p]),
+    "ekf_debug_cad": (C.c_long, [C.c_void_p, C.c_int, C.c_void_p, C.c_long]),
+    "ekf_debug_snapshot": (C.c_long, [C.c_void_p, C.c_int, C.c_int, _dp, C.c_long]),
+    "ekf_debug_read": (C.c_int, [C.c_void_p, C.c_void_p, C.c_long]),
+    "ekf_debug_pass_units": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _ip, C.c_int]),
+    "ekf_debug_pass_shares": (C.c_int, [C.c_int, C.c_int, C.c_int, _ip]),
 }
 
 

@@ -39,6 +39,11 @@ def test_library_exports_every_declared_symbol(sd):
         assert hasattr(lib, name), f"{name} declared in include/ekfslam_hip.h but not exported"
         assert name in eb.ABI, f"{name} has no ctypes signature"
     assert sorted(eb.ABI) == names
+    # ... and the other way round: nothing named ekf_* leaves the library without a declaration (diagnostics included)
+    import subprocess
+    nm = subprocess.run(["nm", "-D", "--defined-only", sd.library_path()], check=True, capture_output=True, text=True).stdout
+    exported = sorted({ln.split()[-1] for ln in nm.splitlines() if re.fullmatch(r"ekf_[a-z0-9_]+", ln.split()[-1])})
+    assert exported == names, sorted(set(exported) ^ set(names))
 
 
 def test_config_default_matches_reference_constants(sd):
@@ -276,12 +281,10 @@ def test_row_slab_pass_hands_out_every_unit_exactly_once(sd):
     3 the same in half slabs),
     the eight queues together hand out every (trajectory, slab) exactly once -- as one whole slab or as all of its
     chunks.  The integer functions are the ones the kernel calls (`__host__ __device__`), reached here through an
-    undeclared test hook of the library; no device needed."""
+    diagnostics section of the header (`ekf_debug_pass_units`); no device needed."""
     import ctypes as C
     lib = sd.load_library()
     fn = lib.ekf_debug_pass_units
-    fn.restype = C.c_int
-    fn.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int]
     buf = (C.c_int * 70000)()
     for batch in list(range(1, 42)) + [64, 100]:
         for nrb in (1, 2, 5, 7, 8, 9, 15, 16, 17, 32, 126):
@@ -390,7 +393,6 @@ def test_row_slab_pass_equal_shares_cover_every_strip_once(sd):
     shares of equal cost (strips + 2 per piece) to within a few strips."""
     import ctypes
     lib = sd.load_library()
-    lib.ekf_debug_pass_shares.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_int)]
     for batch, n, wgs in [(1, 16003, 256), (2, 16003, 256), (1, 16003, 240), (3, 12003, 256), (7, 16003, 256),
                           (1, 21823, 256), (3, 1403, 8), (3, 1403, 5), (1, 4003, 8)]:
         out = np.zeros(wgs * 16 * 4, dtype=np.int32)

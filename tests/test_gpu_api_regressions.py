@@ -357,8 +357,6 @@ def _snapshot(sd, f, b=0):
     """P_base, V, W and the mean the next step reads, raw (development hook ekf_debug_snapshot: no flush, no check)."""
     import ctypes as C
     lib = sd.load_library()
-    lib.ekf_debug_snapshot.restype = C.c_long
-    lib.ekf_debug_snapshot.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double), C.c_long]
     out = []
     for which in (0, 1, 2, 3):
         count = lib.ekf_debug_snapshot(f._h, b, which, None, 0)
@@ -443,7 +441,6 @@ def test_download_into_pinned_memory_by_kernel_equals_the_copy(sd, n_lm, batch, 
     is no multiple of the 64 x 64 tile and on the column-panel layout (n = 4203 > 4096)."""
     import ctypes as C
     lib = sd.load_library()
-    lib.ekf_debug_dense_packs.argtypes, lib.ekf_debug_dense_packs.restype = [C.c_void_p], C.c_long
     n = 3 + 2 * n_lm
     streams = [orc.synthetic_stream(n_lm, 3, 8, 20 + t) for t in range(batch)]
     with sd.EkfSlam(n, batch=batch) as f:

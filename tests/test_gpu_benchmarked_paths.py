@@ -42,10 +42,6 @@ def close(a, b, tol=TIGHT):
 def debug_counters(sd, f):
     """(fused cadences, steps they covered, look-aheads, pieces of the longest static share of the last pass or 0)."""
     lib = sd.load_library()
-    lib.ekf_debug_cadences.argtypes = [C.c_void_p, C.POINTER(C.c_long), C.POINTER(C.c_long)]
-    lib.ekf_debug_lookaheads.argtypes = [C.c_void_p]
-    lib.ekf_debug_lookaheads.restype = C.c_long
-    lib.ekf_debug_last_pass_shares.argtypes = [C.c_void_p]
     a, b = C.c_long(), C.c_long()
     assert lib.ekf_debug_cadences(f._h, C.byref(a), C.byref(b)) == 0
     return a.value, b.value, lib.ekf_debug_lookaheads(f._h), lib.ekf_debug_last_pass_shares(f._h)

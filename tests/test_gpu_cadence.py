@@ -33,7 +33,6 @@ def sd():
 
 def cadences(sd, f):
     lib = sd.load_library()
-    lib.ekf_debug_cadences.argtypes = [C.c_void_p, C.POINTER(C.c_long), C.POINTER(C.c_long)]
     a, b = C.c_long(), C.c_long()
     assert lib.ekf_debug_cadences(f._h, C.byref(a), C.byref(b)) == 0
     return a.value, b.value
@@ -257,8 +256,6 @@ def test_all_three_shapes_of_the_panel_launch_agree(sd):
 
 def lookaheads(sd, f):
     lib = sd.load_library()
-    lib.ekf_debug_lookaheads.restype = C.c_long
-    lib.ekf_debug_lookaheads.argtypes = [C.c_void_p]
     return lib.ekf_debug_lookaheads(f._h)
 
 
@@ -303,7 +300,6 @@ def test_lookahead_beside_the_row_slab_pass_on_static_shares(sd):
     handles, the shares forced through `pass_workgroups`: against `lookahead=0` to rounding, against the oracle, and the
     launches really took that road (look-aheads counted, the last pass on a share table)."""
     lib = sd.load_library()
-    lib.ekf_debug_last_pass_shares.argtypes = [C.c_void_p]
     N, B, m, steps = 700, 3, 8, 27
     n = 3 + 2 * N
     streams = [orc.synthetic_stream(N, steps, m, 2300 + t) for t in range(B)]

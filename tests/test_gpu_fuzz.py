@@ -171,6 +171,4 @@ def test_random_mixed_api_sequences_against_the_oracle(sd, seed, n_lm, batch, sm
         if small:                                             # (not vacuous: the small-state kernel is what ran)
             import ctypes as C
             lib = sd.load_library()
-            lib.ekf_debug_small_launches.argtypes = [C.c_void_p]
-            lib.ekf_debug_small_launches.restype = C.c_long
             assert lib.ekf_debug_small_launches(f._h) > 10

@@ -34,7 +34,6 @@ def sd():
 
 def cadences(sd, f):
     lib = sd.load_library()
-    lib.ekf_debug_cadences.argtypes = [C.c_void_p, C.POINTER(C.c_long), C.POINTER(C.c_long)]
     a, b = C.c_long(), C.c_long()
     assert lib.ekf_debug_cadences(f._h, C.byref(a), C.byref(b)) == 0
     return a.value, b.value

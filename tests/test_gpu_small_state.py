@@ -35,8 +35,6 @@ def close(a, b, tol=TIGHT):
 
 def small_launches(sd, f):
     lib = sd.load_library()
-    lib.ekf_debug_small_launches.argtypes = [C.c_void_p]
-    lib.ekf_debug_small_launches.restype = C.c_long
     return lib.ekf_debug_small_launches(f._h)
 
 
@@ -241,8 +239,6 @@ def test_q_zero_and_growth_on_the_small_path(sd):
 
 def fused_fetches(sd, f):
     lib = sd.load_library()
-    lib.ekf_debug_fused_fetches.argtypes = [C.c_void_p]
-    lib.ekf_debug_fused_fetches.restype = C.c_long
     return lib.ekf_debug_fused_fetches(f._h)
 
 

@@ -25,8 +25,6 @@ def main():
     import slam_duckietown_amd as sd
     import slam_duckietown_amd.synthetic as syn
     lib = sd.load_library()
-    lib.ekf_debug_cad.restype = C.c_long
-    lib.ekf_debug_cad.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_long]
     B, N = args.trajectories, args.landmarks
     streams = [syn.synthetic_stream(N, 30, 8, t) for t in range(B)]
     f = sd.EkfSlam(3 + 2 * N, batch=B)

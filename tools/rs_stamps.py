@@ -21,7 +21,6 @@ f.sync()
 words = 8 * 32 + 256 * 64 * 2
 buf = np.zeros(words, dtype=np.uint32)
 lib = f._lib
-lib.ekf_debug_read.argtypes = [C.c_void_p, C.c_void_p, C.c_long]
 assert lib.ekf_debug_read(f._h, buf.ctypes.data_as(C.c_void_p), C.c_long(buf.nbytes)) == 0
 st = buf[8 * 32:].view(np.uint64).reshape(256, 64).astype(np.int64)
 names = ["loop top", "barrier 1", "pop+barrier 2", "scalars", "loads landed+strip stored", "tile0->image", "tile0->acc, barrier",
