@@ -50,36 +50,42 @@ MFMA_F64_SPEC_TF = 78.6        # public datasheet figure (the local guide lists 
 MFMA_F64_MEASURED_TF = 77.9    # sustained v_mfma_f64_16x16x4 on this part (accumulators in VGPRs): profiles/mfma_probe.txt
 
 
-def make_streams(sd_syn, traj_ids, n_landmarks, steps, m):
+def make_streams(sd_syn, traj_ids, n_landmarks, steps, m, variable=None):
+    """`variable` = (m_lo, m_hi): per trajectory and step m ~ uniform{m_lo..m_hi} scattered landmarks (synthetic.variable_stream)
+    instead of m consecutive ones; -> ..., mm[steps, batch] (None for a constant m)."""
     made = {}                          # (a bank may repeat trajectory ids: each stream is generated once)
     for t in traj_ids:
         if t not in made:
-            made[t] = sd_syn.synthetic_stream(n_landmarks, steps, m, t)
+            made[t] = (sd_syn.variable_stream(n_landmarks, steps, variable[0], variable[1], t) if variable
+                       else sd_syn.synthetic_stream(n_landmarks, steps, m, t))
     streams = [made[t] for t in traj_ids]
     lin = np.stack([s[2] for s in streams], axis=1)
     ang = np.stack([s[3] for s in streams], axis=1)
     idx = np.stack([s[4] for s in streams], axis=1)
     zr = np.stack([s[5] for s in streams], axis=1)
     zb = np.stack([s[6] for s in streams], axis=1)
-    return streams, lin, ang, idx, zr, zb
+    mm = np.stack([s[7] for s in streams], axis=1) if variable else None
+    return streams, lin, ang, idx, zr, zb, mm
 
 
-def time_filter(sd, sd_syn, shard, grp, device, traj_ids, n_landmarks, m, steps, warmup, profile_leg=True, options=(), clock=None):
+def time_filter(sd, sd_syn, shard, grp, device, traj_ids, n_landmarks, m, steps, warmup, profile_leg=True, options=(), clock=None,
+                variable=None):
     """Returns (max-over-ranks seconds for `steps` steps, pass_ms_total, pass_launches, device_ms).
     The timed region is sharding.timed_region (device sync + barrier on both sides, max over ranks): the function
     the world_size-2 gloo test covers."""
     n = 3 + 2 * n_landmarks
     total = warmup + steps
-    streams, lin, ang, idx, zr, zb = make_streams(sd_syn, traj_ids, n_landmarks, total, m)
+    streams, lin, ang, idx, zr, zb, mm = make_streams(sd_syn, traj_ids, n_landmarks, total, m, variable)
     f = sd.EkfSlam(n, batch=len(traj_ids), device=device)
     for opt in options:
         name, value = opt.split("=")
         f.set_option(name, int(value))
     for b, s in enumerate(streams):
         f.set_state_diag(s[0], s[1], b)
-    f.stream_upload(lin, ang, idx, zr, zb)
+    f.stream_upload(lin, ang, idx, zr, zb, mm)
     f.stream_run(0, warmup)
     f.flush()
+    cad0 = f.cadence_counters()
     dev = {}
     # every launch of the covariance pass inside the timed region is bracketed by a HIP event pair on the handle's
     # stream (two event records per pass: no measurable effect on the region)
@@ -102,6 +108,10 @@ def time_filter(sd, sd_syn, shard, grp, device, traj_ids, n_landmarks, m, steps,
         pass_ms, launches = f.profile_read()
         f.profile_enable(False)
     time_filter.last_pass_kernel = f.last_pass()
+    cad1 = f.cadence_counters()
+    # which path the timed steps took: (fused cadences, steps they covered), and the landmark updates they held
+    time_filter.last_cadences = (cad1[0] - cad0[0], cad1[1] - cad0[1])
+    time_filter.last_updates = int(mm[warmup:].sum()) if mm is not None else len(traj_ids) * steps * m
     flags = [f.flags(b) for b in range(len(traj_ids))]
     mu = f.mean(0)
     assert not any(flags) and np.isfinite(mu).all(), "filter diverged during the benchmark"
@@ -282,6 +292,25 @@ def stream_leg(sd, sd_syn, shard, grp, device, n_landmarks, m, steps, warmup, op
             "pass_kernel": getattr(time_filter, "last_pass_kernel", "")}
 
 
+def observation_shape_leg(sd, sd_syn, shard, grp, device, traj_ids, n_landmarks, steps, warmup, options, m=None, variable=None):
+    """The shapes the reference's loop produces (src/replay_no_ros.py:280-301, :436-480: whatever tags the window saw): a
+    landmark count that is no power of two (`m`), or one that changes from step to step and from trajectory to trajectory
+    with indices in no order (`variable` = (m_lo, m_hi)).  steps/s, landmark updates/s, covariance passes per step and the
+    fraction of the timed steps that ran as fused cadences."""
+    B = len(traj_ids)
+    dt, pass_ms, launches, _ = time_filter(sd, sd_syn, shard, grp, device, traj_ids, n_landmarks, m or 0, steps, warmup,
+                                           options=options, variable=variable)
+    cads, cad_steps = time_filter.last_cadences
+    shape = (f"m ~ uniform{{{variable[0]}..{variable[1]}}} per trajectory and step, scattered indices" if variable
+             else f"m={m} obs/step, consecutive indices")
+    return {"workload": f"N={n_landmarks}, {shape}, {B} trajectories, {steps} steps behind {warmup}",
+            "value": B * steps / dt, "unit": "steps/s", "landmark_updates_per_s": time_filter.last_updates / dt,
+            "mean_obs_per_step": time_filter.last_updates / (B * steps),
+            "pass_launches": launches, "passes_per_step": launches / steps, "steps_per_pass": steps / max(launches, 1),
+            "pass_avg_launch_ms": pass_ms / max(launches, 1), "pass_kernel": getattr(time_filter, "last_pass_kernel", ""),
+            "fused_cadences": cads, "fused_fraction": cad_steps / steps}
+
+
 def online_step_leg(sd, sd_syn, device, n_landmarks, batch, m, steps, warmup, options):
     """The call surface north_star says "drops into the existing Duckietown loop": one host-driven `EkfSlam.step` per
     EKF step (src/replay_no_ros.py:229-237, histogram_lane_filter_node.py:197-199 call the filter once per window) --
@@ -416,7 +445,7 @@ def cpu_baseline(n_landmarks, m, budget_s=14.0):
             "by_config": by}
 
 
-SECONDARY_LEGS = ["single_trajectory", "obs_1_per_step", "config5", "steady_state", "config1", "config2", "online_step",
+SECONDARY_LEGS = ["single_trajectory", "obs_1_per_step", "obs_5", "obs_12", "variable_m", "constant_m4", "config5", "steady_state", "config1", "config2", "online_step",
                   "drop_in", "dense_propagate"]
 
 
@@ -447,6 +476,14 @@ def secondary_leg(name, args):
                                    profile_leg=False, options=args.option)
         return {name: {"workload": f"N={args.landmarks}, m=1 obs/step, {B} trajectories, {steps_m1} steps (whole 40-step pass "
                                    "cadences)", "value": B * steps_m1 / dtm, "unit": "steps/s"}}
+    if name in ("obs_5", "obs_12", "constant_m4"):
+        # 240 steps = whole cadences at every packing (m = 4: 10 steps per pass, m = 5: 8, m = 12: 3)
+        mo = {"obs_5": 5, "obs_12": 12, "constant_m4": 4}[name]
+        return {name: observation_shape_leg(sd, sd_syn, shard, grp, dev, traj_ids, args.landmarks, 240, 40, args.option, m=mo)}
+    if name == "variable_m":
+        # m ~ uniform{0..8}: mean 4 landmarks per step -- compare with `constant_m4` (the same mean rank count)
+        return {name: observation_shape_leg(sd, sd_syn, shard, grp, dev, traj_ids, args.landmarks, 240, 40, args.option,
+                                            variable=(0, 8))}
     if name == "config5":
         return {name: config5_leg(sd, sd_syn, shard, grp, dev, args.obs)}
     if name == "steady_state":

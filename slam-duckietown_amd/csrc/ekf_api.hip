@@ -42,13 +42,13 @@ void launch_associate(hipStream_t, const DetIn*, int*, int*, int*, double*, doub
                       AssocOut*, unsigned*, const AssocConfig&, int, long, int, int, int);
 void launch_fill_diag(hipStream_t, double*, int, int, const double*);
 int dense_propagate(hipStream_t, double* P, double* tmp, const double* F, const double* Q, int n, int ld);
-void launch_solve_cad(hipStream_t, int, const double*, const double*, double*, double*, const int*, const StepIn*, int, int,
-                      CadOut*, unsigned*, const int*, const DeviceConfig&, int, long, const double*, int);
-void launch_gather_cad(hipStream_t, int, const double*, const double*, const double*, const double*, const StepIn*, int, int,
+void launch_solve_cad(hipStream_t, const double*, const double*, double*, double*, const int*, const StepIn*, const CadPlan*, int,
+                      CadOut*, unsigned*, const DeviceConfig&, int, long, const double*, int);
+void launch_gather_cad(hipStream_t, const double*, const double*, const double*, const double*, const StepIn*, const CadPlan*, int,
                        int, const DeviceConfig&, int, long, double*);
 long cadence_gbuf_doubles();
-void launch_panels_cad(hipStream_t, int, double*, double*, double*, const double*, double*, const int*, const CadOut*,
-                       SolveOut*, unsigned*, int, long, int, int);
+void launch_panels_cad(hipStream_t, double*, double*, double*, const double*, double*, const int*, const CadOut*,
+                       SolveOut*, unsigned*, int, long, int, int, int);
 }  // namespace ekf
 
 using namespace ekf;
@@ -135,7 +135,17 @@ struct ekf_handle : ekf::HostPlan {
   SolveOut* dmbox = nullptr;      // per trajectory: that solve's header and records, written through (mailbox_publish)
   unsigned step_seq = 0;          // sequence number of the last single-launch step
   CadOut* dcad = nullptr;         // per trajectory: head + per-landmark records of the cadence in flight (allocated on first use)
-  long cadences = 0, cadence_steps = 0;   // statistics: fused cadences launched, steps they covered
+  long cadences = 0, cadence_traj_steps = 0;   // statistics: fused cadences launched, trajectory-steps they completed
+  // The packed cadences of the ekf_stream_run in flight (ekf_host_plan.h: plan_cadences): one CadPlan per (cadence,
+  // trajectory), planned on the host for the whole run and uploaded once, stream-ordered, out of pinned memory.  Two copies,
+  // used alternately: the host may plan the next run while the upload of this one has not executed yet.
+  RunPlan run_plan;
+  CadPlan* dplan2[2] = {nullptr, nullptr};
+  CadPlan* hplan2[2] = {nullptr, nullptr};
+  size_t plan_cap2[2] = {0, 0};
+  hipEvent_t plan_ev[2] = {nullptr, nullptr};     // the upload out of hplan2[i] has been executed
+  bool plan_ev_used[2] = {false, false};
+  int plan_cur = 0;
   // look-ahead (small launches): the solve of the next cadence runs on the handle's stream beside the covariance pass of
   // this one, which goes to a second stream between two events; see ekf_stream_run
   hipStream_t aux = nullptr;
@@ -240,13 +250,15 @@ static void free_all(ekf_handle* h) {
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   void* ptrs[] = {h->dP, h->dmu2[0], h->dmu2[1], h->dV, h->dW, h->ddacc2[0], h->ddacc2[1], h->dscratch, h->dn, h->dflags, h->dso, h->dfac,
                   h->d_ring, h->d_stream, h->dF, h->dQ, h->dTmp, h->dPlin, h->dtagmap, h->dneff, h->d_det, h->d_assoc_step, h->dfloor, h->dqueue, h->dready, h->dmbox,
-                  h->d_assoc_out, h->dcad, h->dshares2[0], h->dshares2[1], h->dgbuf};
+                  h->d_assoc_out, h->dcad, h->dshares2[0], h->dshares2[1], h->dgbuf, h->dplan2[0], h->dplan2[1]};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (h->h_ring) (void)hipHostFree(h->h_ring);
   if (h->h_det) (void)hipHostFree(h->h_det);
   for (int i = 0; i < 2; ++i) {
     if (h->hshares2[i]) (void)hipHostFree(h->hshares2[i]);
     if (h->shares_ev[i]) (void)hipEventDestroy(h->shares_ev[i]);
+    if (h->hplan2[i]) (void)hipHostFree(h->hplan2[i]);
+    if (h->plan_ev[i]) (void)hipEventDestroy(h->plan_ev[i]);
   }
   if (h->h_flags) (void)hipHostFree(h->h_flags);
   if (h->h_pack) (void)hipHostFree(h->h_pack);
@@ -792,42 +804,77 @@ static int enqueue_pass(ekf_handle* h, const StepIn* d_in, int m_hi) {
   return EKF_OK;
 }
 
-// Steps [k, k + g) of the uploaded stream as one cadence; the covariance pass follows when it is due.
+// The plan of a run's cadences (h->run_plan) to the device: stream-ordered out of pinned memory, no host synchronisation.
+static int upload_run_plan(ekf_handle* h) {
+  const size_t count = h->run_plan.entries.size();
+  const int nb = h->plan_cur ^ 1;
+  if (h->plan_cap2[nb] < count) {
+    const size_t cap = std::max(count, (size_t)64 * h->batch);
+    if (h->plan_ev_used[nb]) HIP_TRY(h, hipEventSynchronize(h->plan_ev[nb]));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));       // (kernels of an earlier run may still read the old device copy)
+    if (h->dplan2[nb]) HIP_TRY(h, hipFree(h->dplan2[nb]));
+    if (h->hplan2[nb]) HIP_TRY(h, hipHostFree(h->hplan2[nb]));
+    h->dplan2[nb] = nullptr;
+    h->hplan2[nb] = nullptr;
+    h->plan_cap2[nb] = 0;
+    HIP_TRY(h, hipMalloc(&h->dplan2[nb], sizeof(CadPlan) * cap));
+    HIP_TRY(h, hipHostMalloc(&h->hplan2[nb], sizeof(CadPlan) * cap, hipHostMallocDefault));
+    if (!h->plan_ev[nb]) HIP_TRY(h, hipEventCreateWithFlags(&h->plan_ev[nb], hipEventDisableTiming));
+    h->plan_cap2[nb] = cap;
+    h->plan_ev_used[nb] = false;
+  }
+  // (the pinned copy is free once its previous upload has been executed: two runs back)
+  if (h->plan_ev_used[nb]) HIP_TRY(h, hipEventSynchronize(h->plan_ev[nb]));
+  std::memcpy(h->hplan2[nb], h->run_plan.entries.data(), sizeof(CadPlan) * count);
+  HIP_TRY(h, hipMemcpyAsync(h->dplan2[nb], h->hplan2[nb], sizeof(CadPlan) * count, hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(h, hipEventRecord(h->plan_ev[nb], h->stream));
+  h->plan_ev_used[nb] = true;
+  h->plan_cur = nb;
+  return EKF_OK;
+}
+
+// Cadence c of the run in flight (h->run_plan, uploaded): one solve launch, one panel launch; the covariance pass follows
+// when it is due -- behind every cadence but the run's last, and behind that one when its slots are used up.
 // Look-ahead (small launches, where the covariance pass -- the column-strip kernel -- leaves CUs free): when the pass is
-// due and the steps behind it form a cadence too, that cadence's solve does not wait for the pass.  Its block
+// due and another cadence follows, that cadence's solve does not wait for the pass.  Its block
 // P[C_u, C_u] is gathered while this cadence's ranks are still pending (k_gather_cad: base entries + the ranks' product
 // at C_u), the pass goes to the handle's second stream between two events, and the solve -- which touches nothing the
 // pass uses -- runs on the handle's own stream beside it; the next cadence's panel launch waits for both.  `presolved`
 // says that this cadence's solve has already been enqueued that way; *next_presolved that the next one's now is.
-static int enqueue_cadence(ekf_handle* h, int k, int g, int end, bool presolved, bool* next_presolved) {
+static int enqueue_cadence(ekf_handle* h, int c, bool presolved, bool* next_presolved) {
   *next_presolved = false;
+  const RunPlan& rp = h->run_plan;
   const int n_hi = *std::max_element(h->n.begin(), h->n.end());
-  const int mcap = cap_for(h->stream_mhi[k]), ktp = ranks_for(mcap);
+  const CadPlan* dpl = h->dplan2[h->plan_cur] + (size_t)c * h->batch;
   if (!h->dcad) HIP_TRY(h, hipMalloc(&h->dcad, sizeof(CadOut) * h->batch));
-  for (int b = 0; b < h->batch; ++b)                   // the cadence's active bound is its last step's
-    h->neff_enq[b] = std::min(h->n[b], std::max(h->floor_host[b], h->stream_own[(size_t)(k + g - 1) * h->batch + b]));
+  for (int b = 0; b < h->batch; ++b) h->neff_enq[b] = rp.entries[(size_t)c * h->batch + b].neff;
   const double* mu_in = h->dmu2[h->cur];
   double* mu_out = h->dmu2[h->cur ^ 1];
   if (!presolved)
-    launch_solve_cad(h->stream, mcap, h->dP, mu_in, mu_out, h->ddacc2[h->dcur ^ 1], h->dn,
-                     h->d_stream + (size_t)k * h->batch, h->batch, g, h->dcad, h->dflags, h->dfloor, h->dcfg, h->ld,
-                     h->pstride, nullptr, 0);
-  launch_panels_cad(h->stream, mcap, h->dP, h->dV, h->dW, mu_in, mu_out, h->dn, h->dcad, h->dso, h->dqueue, h->ld,
-                    h->pstride, h->batch, n_hi);
+    launch_solve_cad(h->stream, h->dP, mu_in, mu_out, h->ddacc2[h->dcur ^ 1], h->dn, h->d_stream, dpl, h->batch, h->dcad,
+                     h->dflags, h->dcfg, h->ld, h->pstride, nullptr, 0);
+  const int ranks = 2 * rp.slots_hi[c], nrp = (ranks + 3) & ~3;   // every trajectory writes the busiest one's ranks (zeros beyond its own)
+  launch_panels_cad(h->stream, h->dP, h->dV, h->dW, mu_in, mu_out, h->dn, h->dcad, h->dso, h->dqueue, h->ld,
+                    h->pstride, h->batch, n_hi, nrp);
   HIP_TRY(h, hipGetLastError());
   h->dcur ^= 1;
   h->cur ^= 1;
-  h->pending_k += g * ktp;
-  h->pending_steps += g;
+  h->pending_k += ranks;
+  h->pending_steps += rp.steps_hi[c];
   h->cadences += 1;
-  h->cadence_steps += g;
-  const bool due = h->opt_flush_every > 0 ? h->pending_steps >= h->opt_flush_every : h->pending_k + ktp > h->opt_rank_limit;
-  if (!(due || h->pending_k + 2 > KTOT)) return EKF_OK;
+  h->cadence_traj_steps += rp.steps_sum[c];
+  if (h->pending_k == 0) {                             // nothing observed anywhere in the bank: the panel launch has applied the noise
+    h->pending_steps = 0;
+    return EKF_OK;
+  }
+  const bool more = c + 1 < rp.ncad;
+  const bool due = more || h->pending_k + 2 > std::min(KTOT, h->opt_rank_limit) ||
+                   (h->opt_flush_every > 0 && h->pending_steps >= h->opt_flush_every);
+  if (!due) return EKF_OK;
   // (worth it where the pass is the column-strip kernel -- the row-slab pass fills every CU by itself -- and long enough
   //  to pay for the gather and the two cross-stream hand-overs, ~25 us together: from ~48 MB of covariance.  N = 2000 x 1:
   //  38.7 k -> 45.1 k steps/s, x 2: 57.6 k -> 61.9 k, x 4: 89.5 k -> 92.1 k; N = 500 x 1 and N = 20 x 1 lose 4 - 9 %;
   //  N = 8000 x 1 on static shares, the pass on 255 workgroups: 9.35 - 9.58 k -> 9.82 - 10.2 k)
-  const int k2 = k + g, g2 = h->opt_lookahead ? cadence_length(h, k2, end, true) : 0;
   const PassPlan plan = plan_pass(h);
   // ... or the row-slab pass on static shares that leaves the solves their CUs (a few long trajectories: N = 8000 x 1)
   // ... and for banks of up to 40 trajectories: every solve workgroup has to find a CU beside the pass, and the gather grows with
@@ -836,20 +883,20 @@ static int enqueue_cadence(ekf_handle* h, int k, int g, int end, bool presolved,
   const bool small_pass = plan.kernel == 0 && h->batch <= 40 && (double)h->batch * 8.0 * plan.e_hi * plan.e_hi >= 48.0e6;
   const bool shares_pass = plan.kernel == 2 && (plan.beside || (plan.long_few && h->batch < 8 && h->opt_pass_workgroups > 0 &&
                                                                   h->opt_pass_workgroups + h->batch <= h->cu_count));
-  if (g2 < 2 || !(small_pass || shares_pass)) return flush_pending(h);
+  if (!more || !h->opt_lookahead || !(small_pass || shares_pass)) return flush_pending(h);
   // ---- look-ahead: gather (stream) -> { pass (second stream) | solve of the next cadence (stream) } -> join ----
-  const int mcap2 = cap_for(h->stream_mhi[k2]);
+  const CadPlan* dpl2 = dpl + h->batch;
+  const int kb = (h->pending_k + 3) & ~3;
   if (!h->dgbuf) HIP_TRY(h, hipMalloc(&h->dgbuf, sizeof(double) * cadence_gbuf_doubles() * h->batch));
-  launch_gather_cad(h->stream, mcap2, h->dP, h->dV, h->dW, h->ddacc2[h->dcur], h->d_stream + (size_t)k2 * h->batch, h->batch,
-                    g2, (h->pending_k + 3) & ~3, h->dcfg, h->ld, h->pstride, h->dgbuf);
+  launch_gather_cad(h->stream, h->dP, h->dV, h->dW, h->ddacc2[h->dcur], h->d_stream, dpl2, h->batch, kb, h->dcfg, h->ld,
+                    h->pstride, h->dgbuf);
   HIP_TRY(h, hipGetLastError());
   HIP_TRY(h, hipEventRecord(h->ev_fork, h->stream));
   HIP_TRY(h, hipStreamWaitEvent(h->aux, h->ev_fork, 0));
   // (the solve first: it is ready to go the moment the gather ends, the pass has an event to wait for -- the one
   //  workgroup per trajectory finds its CU before the pass fills the chip)
-  launch_solve_cad(h->stream, mcap2, h->dP, h->dmu2[h->cur], h->dmu2[h->cur ^ 1], h->ddacc2[h->dcur ^ 1], h->dn,
-                   h->d_stream + (size_t)k2 * h->batch, h->batch, g2, h->dcad, h->dflags, h->dfloor, h->dcfg, h->ld,
-                   h->pstride, h->dgbuf, (((h->pending_k + 3) & ~3) + 7) / 8);
+  launch_solve_cad(h->stream, h->dP, h->dmu2[h->cur], h->dmu2[h->cur ^ 1], h->ddacc2[h->dcur ^ 1], h->dn, h->d_stream, dpl2,
+                   h->batch, h->dcad, h->dflags, h->dcfg, h->ld, h->pstride, h->dgbuf, (kb + 7) / 8);
   // From here on the next cadence's solve has overwritten dcad, the pose mean and the pending-noise buffer: a failure
   // below cannot be undone.  Whatever happens the two streams are joined again, and a failure marks every trajectory
   // undefined (EKF_ERR_STATE from then on, until it is uploaded again).
@@ -1165,6 +1212,7 @@ extern "C" int ekf_stream_upload(ekf_handle* h, int steps, const double* lin, co
     }
   std::vector<StepIn> host(count);
   h->stream_mhi.assign(steps, 0);
+  h->stream_m.assign(count, 0);
   h->stream_own.assign(count, 3);
   h->stream_maxlm.assign(h->batch, 0);
   h->stream_steps = 0;
@@ -1178,6 +1226,7 @@ extern "C" int ekf_stream_upload(ekf_handle* h, int steps, const double* lin, co
       fill_step(host[e], h->n[b], own[b], lin[e], ang[e], FLAG_PREDICT | FLAG_UPDATE, idx ? idx + e * stride : nullptr,
                 range ? range + e * stride : nullptr, bearing ? bearing + e * stride : nullptr, mb, 0);
       h->stream_mhi[k] = std::max(h->stream_mhi[k], mb);
+      h->stream_m[e] = (unsigned char)host[e].m;
       h->stream_own[e] = own[b];
       for (int i = 0; i < mb; ++i) h->stream_maxlm[b] = std::max(h->stream_maxlm[b], host[e].idx[i] + 1);
     }
@@ -1216,16 +1265,18 @@ extern "C" int ekf_stream_run(ekf_handle* h, int first, int count) {
     h->neff_enq = h->neff;
     return EKF_OK;
   }
-  bool presolved = false;                              // the cadence that starts at k has its solve enqueued already (look-ahead)
   for (int k = first; k < first + count;) {
-    // A whole cadence at once where nothing is pending: the steps up to the next covariance pass as one solve launch
-    // and one panel launch (ekf_cadence.hip).  It takes steps of one rank-slot size (1, 2, 4, 8 or 16 landmarks), all
-    // with something observed, as many as the pass cadence allows -- at least two, or the per-step path is as good.
-    const int g = cadence_length(h, k, first + count);
-    if (g >= 2) {
-      if (int rc = enqueue_cadence(h, k, g, first + count, presolved, &presolved)) return rc;
-      k += g;
-      continue;
+    // Where nothing is pending the rest of the range runs as packed cadences (ekf_cadence.hip): per cadence one solve launch
+    // and one panel launch for a trajectory's next 40 landmark updates and every prediction in between, each trajectory on
+    // its own cursor, a covariance pass between two cadences.  While ranks are pending (steps enqueued before this call) the
+    // per-step kernels append to them until their pass is due.
+    if (cadences_possible(h)) {
+      plan_cadences(h, k, first + count, h->run_plan);
+      if (int rc = upload_run_plan(h)) return rc;
+      bool presolved = false;                          // the next cadence's solve has been enqueued already (look-ahead)
+      for (int c = 0; c < h->run_plan.ncad; ++c)
+        if (int rc = enqueue_cadence(h, c, presolved, &presolved)) return rc;
+      break;
     }
     for (int b = 0; b < h->batch; ++b)
       h->neff_enq[b] = std::min(h->n[b], std::max(h->floor_host[b], h->stream_own[(size_t)k * h->batch + b]));
@@ -1379,7 +1430,7 @@ extern "C" int ekf_debug_last_pass_shares(ekf_handle* h) { return h ? h->last_sh
 extern "C" int ekf_debug_cadences(ekf_handle* h, long* cadences, long* steps) {
   if (!h) return EKF_ERR_ARG;
   if (cadences) *cadences = h->cadences;
-  if (steps) *steps = h->cadence_steps;
+  if (steps) *steps = h->cadence_traj_steps / std::max(h->batch, 1);
   return EKF_OK;
 }
 // (diagnostics section of the header) how many of them had their solve run beside the previous covariance pass

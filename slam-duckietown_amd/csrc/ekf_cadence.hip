@@ -22,6 +22,9 @@
 // lets the solve of the NEXT cadence run beside the pass of this one (ekf_api.hip: look-ahead).
 // Slot layout of C_u (CadGeom, ekf_device.h): later landmarks at LOWER positions, so what is still needed is always a
 // prefix of the positions: compile-time bounds for the panel's register array X, a shrinking prefix of lanes here.
+// Round 5: the cadence is PACKED (ekf_device.h: CadPlan): a trajectory's next <= 40 landmark updates, whatever steps they
+// belong to and however many each step holds, with every prediction in between; every trajectory of the bank walks its own
+// sequence.  One instantiation of each kernel serves every landmark count (rounds 3 - 4 had one per slot size 1/2/4/8/16).
 // Same algebra as the per-step path in a different summation order: results agree to rounding (1e-10 relative guaranteed, 1e-13 .. 1e-12 measured,
 // tests/test_gpu_cadence.py), not bit for bit.
 #include <type_traits>
@@ -64,22 +67,64 @@ constexpr int CAD_DW = CAD_NW - 2;      // waves that share a down-date by rows 
 constexpr int CAD_DCH = 7;              // rows of a down-date chunk (all reads of a chunk in flight together)
 constexpr int CAD_DQ = (CAD_CU - 2 + CAD_DCH * CAD_DW - 1) / (CAD_DCH * CAD_DW) * CAD_DCH;   // rows per down-date wave
 
-template <int MCAP>
+// The positions C_u of a trajectory's cadence, formed the same way by the solve and by the look-ahead gather: thread p <
+// CAD_SLOTS takes touched step p of the plan -- its landmark range [lo, hi), the slots in front of it (a 40-entry prefix sum
+// through LDS) -- and writes its landmarks' positions; `per_slot(s, step record, j)` lets the solve pick up the measurements.
+// Returns (to every thread) the number of slots.  cntS / firstS: CAD_SLOTS + 1 ints of LDS each.
+template <class PerSlot>
+__device__ __forceinline__ int cad_positions(const CadPlan& pl, const StepIn* __restrict__ in, int batch, int b, const DeviceConfig& cfg,
+                                             int tid, int* Cs, int* cntS, int* firstS, PerSlot per_slot) {
+  using G = CadGeom;
+  if (tid < 128) Cs[tid] = tid < 3 ? tid : 0;
+  int cnt = 0, lo = 0;
+  const StepIn* st = nullptr;
+  if (tid < pl.ns) {
+    st = in + ((long)(pl.t0 + tid) * batch + b);
+    const int m = ((st->flags & FLAG_UPDATE) && cfg.enable_measurement_model) ? min(st->m, MMAX) : 0;
+    lo = tid == 0 ? pl.j0 : 0;
+    const int hi = tid == pl.ns - 1 ? min(pl.jend, m) : m;
+    cnt = max(hi - lo, 0);
+  }
+  if (tid <= CAD_SLOTS) cntS[tid] = tid < CAD_SLOTS ? cnt : 0;
+  __syncthreads();
+  if (tid <= CAD_SLOTS) {
+    int f = 0;
+    for (int u = 0; u < tid; ++u) f += cntS[u];
+    firstS[tid] = f;
+  }
+  __syncthreads();
+  const int nslots = min(firstS[CAD_SLOTS], CAD_SLOTS);
+  const int s0 = G::GM - nslots;
+  if (tid < pl.ns) {
+    const int f = firstS[tid];
+    for (int j = 0; j < cnt; ++j) {
+      const int s = s0 + f + j;
+      if (s < G::GM) {                                 // (a plan that disagrees with the records cannot write outside)
+        const int idx = st->idx[lo + j], p = G::pa(s);
+        Cs[p] = 3 + 2 * idx;
+        Cs[p + 1] = 4 + 2 * idx;
+        per_slot(s, st, lo + j);
+      }
+    }
+  }
+  return nslots;
+}
+
 __global__ __launch_bounds__(64 * CAD_NW) void k_solve_cad(const double* __restrict__ P,
                                                     const double* __restrict__ mu_in, double* __restrict__ mu_out,
                                                     double* __restrict__ dacc_out, const int* __restrict__ nact,
-                                                    const StepIn* __restrict__ in, int batch, int nsteps,
+                                                    const StepIn* __restrict__ in, const CadPlan* __restrict__ plan, int batch,
                                                     CadOut* __restrict__ out, unsigned* __restrict__ flags,
-                                                    const int* __restrict__ neff_floor, DeviceConfig cfg, int ld,
+                                                    DeviceConfig cfg, int ld,
                                                     long pstride, const double* __restrict__ gbuf, int gparts) {
-  using G = CadGeom<MCAP>;
+  using G = CadGeom;
   constexpr int GM = G::GM, CU = G::CU;
   __shared__ __attribute__((aligned(16))) double Pc[CAD_ROWS][CAD_CS];
   __shared__ double2 hpS[128], kcS[128];
   __shared__ int Cs[128];
   __shared__ double2 zS[CAD_SLOTS];                    // (range, bearing) of slot s
-  __shared__ double2 laS[CAD_SLOTS];                   // (lin, ang) of step t
-  __shared__ int mS[CAD_SLOTS], fS[CAD_SLOTS];
+  __shared__ double2 laS[CAD_SLOTS];                   // (lin, ang) of touched step p
+  __shared__ int mS[CAD_SLOTS + 1], firstS[CAD_SLOTS + 1], fS[CAD_SLOTS];
   __shared__ double mot[4];                            // G[0,2], G[1,2] of the step being predicted
   __shared__ double2 hS[2][6];                         // linearisation of slot s in hS[s & 1]: {h[0][k], h[1][k]}, k < 5
   __shared__ double2 siS[2];                           // S^-1 of the slot in flight
@@ -89,43 +134,39 @@ __global__ __launch_bounds__(64 * CAD_NW) void k_solve_cad(const double* __restr
   const double* Pb = P + (long)b * pstride;
   const double* mu_in_b = mu_in + (long)b * ld;
   CadOut& o = out[b];
+  const CadPlan pl = plan[b];
+  const int nsteps = pl.ns;                            // touched steps
 
-  // ---- inputs: slot s = t * MCAP + j of the cadence (thread s), its two positions, the steps' scalars ----
-  if (tid < 128) Cs[tid] = tid < 3 ? tid : 0;
-  __syncthreads();
-  if (tid < GM) {
-    const int s = tid, t = s / MCAP, j = s - t * MCAP;
-    int m = 0, idx = 0;
-    double zr = 0.0, zb = 0.0;
-    if (t < nsteps) {
-      const StepIn& st = in[(long)t * batch + b];
-      m = ((st.flags & FLAG_UPDATE) && cfg.enable_measurement_model) ? min(st.m, MCAP) : 0;
-      if (j < m) {
-        idx = st.idx[j];
-        zr = st.range[j];
-        zb = st.bearing[j];
-      }
-      if (j == 0) {
-        mS[t] = m;
-        fS[t] = st.flags;
-        laS[t] = make_double2(st.lin, st.ang);
-      }
+  // ---- inputs: the plan's steps (thread p: touched step p), their landmarks' slots and positions ----
+  if (tid < CAD_SLOTS) {
+    int fl = 0;
+    double2 la = make_double2(0.0, 0.0);
+    if (tid < nsteps) {
+      const StepIn& st = in[(long)(pl.t0 + tid) * batch + b];
+      fl = st.flags;
+      if (tid == 0 && pl.j0 > 0) fl &= ~FLAG_PREDICT;   // a step cut by the previous cadence: its prediction has happened
+      la = make_double2(st.lin, st.ang);
     }
-    const int p = G::pa(s);
-    const bool valid = t < nsteps && j < m;
-    Cs[p] = valid ? 3 + 2 * idx : 0;
-    Cs[p + 1] = valid ? 4 + 2 * idx : 0;
-    zS[s] = make_double2(zr, zb);
+    fS[tid] = fl;
+    laS[tid] = la;
   }
-  const int neff_eff = min(nact[b], max(in[(long)(nsteps - 1) * batch + b].neff, neff_floor[b]));
+  const int nslots = cad_positions(pl, in, batch, b, cfg, tid, Cs, mS, firstS,
+                                   [&](int s, const StepIn* st, int j) { zS[s] = make_double2(st->range[j], st->bearing[j]); });
+  const int s0 = GM - nslots;
+  const int cu = 3 + 2 * nslots;                       // positions in use
+  const int neff_eff = min(nact[b], pl.neff);
   __syncthreads();
   const int Cl0 = Cs[lane], Cl1 = Cs[64 + lane];       // positions lane and 64 + lane
   if (tid <= CU) o.C[tid] = tid < CU ? Cs[tid] : 0;
-  if (tid < CAD_SLOTS) o.m[tid] = tid < nsteps ? mS[tid] : 0;
+  if (tid < CAD_SLOTS) {
+    // slot of touched step p's first landmark -- or of the next step's that has one: the panel launch applies a step's
+    // prediction when it reaches that slot
+    o.sfirst[tid] = tid < nsteps ? s0 + firstS[tid] : GM;
+  }
   if (tid == 0) {
-    o.nsteps = nsteps;
+    o.nslots = nslots;
     o.neff = neff_eff;
-    o.nranks = 2 * MCAP * nsteps;
+    o.npred = nsteps;
     o.pad0 = 0;
   }
 
@@ -204,7 +245,7 @@ __global__ __launch_bounds__(64 * CAD_NW) void k_solve_cad(const double* __restr
           double t0[RQ], t1[RQ];
 #pragma unroll
           for (int q = 0; q < RQ; ++q) {
-            const int r = min(wave + CAD_NW * q, CU - 1);
+            const int r = min(wave + CAD_NW * q, max(cu - 1, 0));
             const double* gb = gbuf + (((long)gp * batch + b) * CAD_ROWS + r) * CAD_CS;
             t0[q] = gb[lane];
             t1[q] = gb[lane_b];
@@ -220,10 +261,10 @@ __global__ __launch_bounds__(64 * CAD_NW) void k_solve_cad(const double* __restr
 #pragma unroll
       for (int q = 0; q < RQ; ++q) {
         const int r = wave + CAD_NW * q;
-        if (r < CU) {                                  // (wave-uniform)
+        if (r < cu) {                                  // (wave-uniform)
           const int Cr = Cs[r];
           gv0[q] = Pb[p_index(ld, min(Cr, Cl0), max(Cr, Cl0))];     // the upper triangle is authoritative
-          if (CU > 64) gv1[q] = Pb[p_index(ld, min(Cr, Cl1), max(Cr, Cl1))];
+          if (cu > 64) gv1[q] = Pb[p_index(ld, min(Cr, Cl1), max(Cr, Cl1))];
         }
       }
     }
@@ -234,7 +275,7 @@ __global__ __launch_bounds__(64 * CAD_NW) void k_solve_cad(const double* __restr
 #pragma unroll
     for (int q = 0; q < RQ; ++q) {
       const int r = wave + CAD_NW * q;
-      if (r < CU) {
+      if (r < cu) {
         Pc[r][lane] = gv0[q];
         if (64 + lane < CAD_CS) Pc[r][64 + lane] = gv1[q];
       }
@@ -262,8 +303,8 @@ __global__ __launch_bounds__(64 * CAD_NW) void k_solve_cad(const double* __restr
   const int ds = wave == 0 ? 0 : wave - 1;             // down-date slot of this wave (waves 0, 2 .. CAD_NW - 2)
   for (int t = 0; t < nsteps; ++t) {
     const int m = __builtin_amdgcn_readfirstlane(mS[t]);
-    const int s_first = t * MCAP;
-    const int ca = G::pa(s_first) + 2;                 // positions in use during this step: [0, ca)
+    const int s_first = s0 + __builtin_amdgcn_readfirstlane(firstS[t]);   // (a step without landmarks: the next step's first slot)
+    const int ca = G::pa(s_first) + 2;                 // positions in use from this step on: [0, ca)  (s_first == GM: the pose)
     const bool two = ca > 64;                          // (uniform) the second half of the columns is live
     // ---- prediction of step t on the block: P' = G P G^T + R restricted to C_u (:428-430).  Only rows / columns 0, 1
     // change, and the block is exactly symmetric: lane r holds P[0..2][r] = P[r][0..2] and produces P'[r][0], P'[r][1],
@@ -502,6 +543,10 @@ __global__ __launch_bounds__(64 * CAD_NW) void k_solve_cad(const double* __restr
       dacc_out[4 * b + 0] = rdsum0;
       dacc_out[4 * b + 1] = rdsum1;
       dacc_out[4 * b + 2] = rdsum2;
+      o.rdsum[0] = rdsum0;                             // (for a cadence that appends no rank anywhere in the bank: see pose_epilogue)
+      o.rdsum[1] = rdsum1;
+      o.rdsum[2] = rdsum2;
+      o.rdsum[3] = 0.0;
     }
   }
   if (wave == 0 && lane < 3) {
@@ -511,31 +556,38 @@ __global__ __launch_bounds__(64 * CAD_NW) void k_solve_cad(const double* __restr
 }
 
 // What the solve leaves to the panel launch (its workgroup 0 of every trajectory, lanes 0..2 of wave 0): the new ranks'
-// entries at the pose's state indices, zero ranks for the slots a step leaves empty, the k-tile pad, the pose block's
-// share of the in-place prediction, the active bound the next covariance pass reads, and (trajectory 0) the work-queue
-// heads of the row-slab pass, which start every pass at zero.
-template <int MCAP>
+// entries at the pose's state indices, zero ranks up to the bank's rank count `nrp` (a multiple of 4: the busiest
+// trajectory's ranks, padded to a whole k-tile), the pose block's share of the in-place prediction, the active bound the
+// next covariance pass reads, and (trajectory 0) the work-queue heads of the row-slab pass, which start every pass at zero.
+// nrp == 0 -- no trajectory of the bank observed anything in this cadence, no pass will follow for it -- : the predictions'
+// noise goes to the pose diagonal here (what k_predict_rc does for a single prediction-only step).
 __device__ __forceinline__ void pose_epilogue(const CadOut& o, double* Pb, double* Vb, double* Wb, SolveOut* so, unsigned* queue,
-                                              int b, int ld, int lane) {
+                                              int b, int ld, int lane, int nrp) {
   const int ld16 = ld >> 4;
+  const int s0 = CAD_SLOTS - o.nslots;
   // one (slot, pose index) pair per lane and round: the loads of a round are in flight together
-  const int pairs = 3 * MCAP * o.nsteps;
+  const int pairs = 3 * o.nslots;
   for (int e = lane; e < pairs; e += 64) {
-    const int s = e / 3, l = e - 3 * s, t = s / MCAP, j = s - t * MCAP;
-    double4_t vw = {0.0, 0.0, 0.0, 0.0};
-    if (j < o.m[t]) vw = *reinterpret_cast<const double4_t*>(o.posevw[s][l]);
-    Vb[(long)(2 * s) * ld + l] = vw[0];
-    Vb[(long)(2 * s + 1) * ld + l] = vw[1];
-    Wb[wm_index(ld16, 2 * s, l)] = vw[2];
-    Wb[wm_index(ld16, 2 * s + 1, l)] = vw[3];
+    const int q = e / 3, l = e - 3 * q;
+    const double4_t vw = *reinterpret_cast<const double4_t*>(o.posevw[s0 + q][l]);
+    Vb[(long)(2 * q) * ld + l] = vw[0];
+    Vb[(long)(2 * q + 1) * ld + l] = vw[1];
+    Wb[wm_index(ld16, 2 * q, l)] = vw[2];
+    Wb[wm_index(ld16, 2 * q + 1, l)] = vw[3];
   }
   if (lane < 3) {
-    for (int k = o.nranks; k < ((o.nranks + 3) & ~3); ++k) {   // k-tile pad
+    for (int k = 2 * o.nslots; k < nrp; ++k) {         // this trajectory used fewer ranks than the bank's busiest: zeros
       Vb[(long)k * ld + lane] = 0.0;
       Wb[wm_index(ld16, k, lane)] = 0.0;
     }
-    Pb[lane] += o.ddpose[0][lane];                     // entry (0, l)
-    if (lane >= 1) Pb[p_lds(ld) + lane] += o.ddpose[1][lane];   // entry (1, l); (1, 0) lies below the diagonal
+    double d0 = o.ddpose[0][lane], d1 = o.ddpose[1][lane];
+    if (nrp == 0) {                                    // (uniform) no pass follows: the noise of the predictions, now
+      if (lane == 0) d0 += o.rdsum[0];
+      if (lane == 1) d1 += o.rdsum[1];
+      if (lane == 2) Pb[2 * p_lds(ld) + 2] += o.rdsum[2];
+    }
+    Pb[lane] += d0;                                    // entry (0, l)
+    if (lane >= 1) Pb[p_lds(ld) + lane] += d1;         // entry (1, l); (1, 0) lies below the diagonal
   }
   if (lane == 0) so[b].neff = o.neff;                  // what the covariance pass reads as this trajectory's bound
   if (b == 0 && lane < 8) queue[lane * RS_QSTRIDE] = 0u;
@@ -557,18 +609,19 @@ constexpr int CAD_GP = KTOT / 8;        // parts (workgroups per trajectory): 8 
 constexpr int CAD_GW = 8;               // waves of a gather workgroup
 constexpr int CAD_VS = 96 + 1;          // row stride of Vc and of M
 
-template <int MCAP>
 __global__ __launch_bounds__(64 * CAD_GW) void k_gather_cad(const double* __restrict__ P, const double* __restrict__ V,
                                                             const double* __restrict__ W, const double* __restrict__ dacc,
-                                                            const StepIn* __restrict__ in, int batch, int nsteps, int kb,
+                                                            const StepIn* __restrict__ in, const CadPlan* __restrict__ plan,
+                                                            int batch, int kb,
                                                             DeviceConfig cfg, int ld, long pstride,
                                                             double* __restrict__ gbuf) {
-  using G = CadGeom<MCAP>;
-  constexpr int GM = G::GM, CU = G::CU;
+  using G = CadGeom;
+  constexpr int CU = G::CU;
   __shared__ __attribute__((aligned(16))) double Wc[96][9];          // [a][k], 8 ranks (stride 9: rows on different banks)
   __shared__ __attribute__((aligned(16))) double Vc[8][CAD_VS];      // [k][a]
   __shared__ __attribute__((aligned(16))) double Ms[96][CAD_VS];     // this part's share of M
   __shared__ int Cs[128];
+  __shared__ int cntS[CAD_SLOTS + 1], firstS[CAD_SLOTS + 1];
   const int part = blockIdx.x, b = blockIdx.y;
   const int k0 = 8 * part;                             // this workgroup's ranks: k0 .. k0 + 7
   const int tid = threadIdx.x, lane = tid & 63;
@@ -577,21 +630,8 @@ __global__ __launch_bounds__(64 * CAD_GW) void k_gather_cad(const double* __rest
   const double* Vb = V + (long)b * KTOT * ld;
   const double* Wb = W + (long)b * KTOT * ld;
   const int ld16 = ld >> 4;
-  if (tid < 128) Cs[tid] = tid < 3 ? tid : 0;
-  __syncthreads();
-  if (tid < GM) {                                      // (as in k_solve_cad)
-    const int s = tid, t = s / MCAP, j = s - t * MCAP;
-    int m = 0, idx = 0;
-    if (t < nsteps) {
-      const StepIn& st = in[(long)t * batch + b];
-      m = ((st.flags & FLAG_UPDATE) && cfg.enable_measurement_model) ? min(st.m, MCAP) : 0;
-      if (j < m) idx = st.idx[j];
-    }
-    const int p = G::pa(s);
-    const bool valid = t < nsteps && j < m;
-    Cs[p] = valid ? 3 + 2 * idx : 0;
-    Cs[p + 1] = valid ? 4 + 2 * idx : 0;
-  }
+  const CadPlan pl = plan[b];
+  cad_positions(pl, in, batch, b, cfg, tid, Cs, cntS, firstS, [](int, const StepIn*, int) {});   // (as in k_solve_cad)
   __syncthreads();
   const int Cl0 = Cs[lane], Cl1 = Cs[64 + lane];
   // (part 0) the base entries first: their latency hides under the staging and the product
@@ -676,17 +716,17 @@ __global__ __launch_bounds__(64 * CAD_GW) void k_gather_cad(const double* __rest
 // NW waves of 64 state indices per workgroup share one staging of the records (LDS, 16-byte broadcast reads at
 // compile-time offsets); after the single barrier the waves never synchronise again.
 // ---------------------------------------------------------------------------------------------
-template <int MCAP, int NW>
+template <int NW>
 __global__ __launch_bounds__(64 * NW) void k_panels_cad(double* __restrict__ P, double* __restrict__ V,
                                                         double* __restrict__ W, const double* __restrict__ mu_in,
                                                         double* __restrict__ mu_out, const int* __restrict__ nact,
                                                         const CadOut* __restrict__ co, SolveOut* __restrict__ so,
-                                                        unsigned* __restrict__ queue, int ld, long pstride) {
-  using G = CadGeom<MCAP>;
-  constexpr int CU = G::CU, GMAX = G::GMAX, NT = 64 * NW;
+                                                        unsigned* __restrict__ queue, int ld, long pstride, int nrp) {
+  using G = CadGeom;
+  constexpr int CU = G::CU, GM = G::GM, NT = 64 * NW;
   __shared__ __attribute__((aligned(16))) double sRec[G::REC];
   __shared__ double2 sG[CAD_SLOTS];
-  __shared__ int sM[CAD_SLOTS];
+  __shared__ int sF[CAD_SLOTS];
   const int b = blockIdx.y;
   const int n = nact[b];
   const int w0 = blockIdx.x * NT;
@@ -694,7 +734,8 @@ __global__ __launch_bounds__(64 * NW) void k_panels_cad(double* __restrict__ P, 
   const CadOut& o = co[b];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int nsteps = o.nsteps, neff = o.neff, nranks = o.nranks;
+  const int nslots = o.nslots, npred = o.npred, neff = o.neff;
+  const int s0 = GM - nslots;                          // slots in use: s0 .. GM - 1
   const int ld16 = ld >> 4;
   double* Pb = P + (long)b * pstride;
   double* Vb = V + (long)b * KTOT * ld;
@@ -703,7 +744,8 @@ __global__ __launch_bounds__(64 * NW) void k_panels_cad(double* __restrict__ P, 
   const bool act = i < n;
   const int ii = act ? i : n - 1;                      // idle lanes shadow the last state index (no stores)
   const bool actw = act && i >= 3;                     // the pose's state indices are the solve's
-  const bool live = i0 < neff && i0 < n;               // (uniform) this wave replays
+  const bool busy = nslots > 0 || npred > 0;           // (uniform) this trajectory does something in this cadence
+  const bool live = i0 < neff && i0 < n && busy;       // (uniform) this wave replays
   // the gather does not depend on the staged records: all of it is issued before the barrier
   double X[CU];
   if (live) {
@@ -713,7 +755,8 @@ __global__ __launch_bounds__(64 * NW) void k_panels_cad(double* __restrict__ P, 
     // P(c, i), P(c + 1, i) are stored mirrored, as P_base(i, c), P_base(i, c + 1): side by side in row i.  Those column-
     // direction gathers touch a different cache line per lane (a CU takes about a cycle per line: 42 of this kernel's 92 us
     // at N = 2000 x 32 when every entry was its own 8-byte load), so a wave that lies entirely at or above the pair takes
-    // both with ONE 16-byte load per lane (8-byte aligned: column 3 + 2 idx is odd).
+    // both with ONE 16-byte load per lane (8-byte aligned: column 3 + 2 idx is odd).  (Positions beyond the cadence's
+    // carry index 0: a coalesced read of row 0 that nothing uses.)
 #pragma unroll
     for (int a = 3; a < CU; a += 2) {
       const int c0 = o.C[a], c1 = o.C[a + 1];
@@ -735,22 +778,20 @@ __global__ __launch_bounds__(64 * NW) void k_panels_cad(double* __restrict__ P, 
 #pragma unroll
     for (int a = 0; a < CU; ++a) X[a] = 0.0;
   }
-  if (w0 < neff) {                                     // (uniform) some wave of this workgroup replays: stage the records
-    const int cnt = G::rec_off(nsteps * MCAP) / 2;     // double2 units
+  if (w0 < neff && busy) {                             // (uniform) some wave of this workgroup replays: stage the records
     const double2* src = reinterpret_cast<const double2*>(o.rec);
     double2* dst = reinterpret_cast<double2*>(sRec);
-    for (int e = tid; e < cnt; e += NT) dst[e] = src[e];
+    for (int e = G::rec_off(s0) / 2 + tid; e < G::REC / 2; e += NT) dst[e] = src[e];
     if (tid < CAD_SLOTS) {
-      sM[tid] = o.m[tid];
+      sF[tid] = o.sfirst[tid];
       sG[tid] = *reinterpret_cast<const double2*>(o.g[tid]);
     }
   }
   __syncthreads();
   if (i0 >= n) return;
-  const int nrp = (nranks + 3) & ~3;                   // ranks written: whole k-tiles
-  if (i0 >= neff) {
-    // beyond the active bound the rows and columns of P are exactly zero off the diagonal: the cadence's ranks are
-    // zero there and the mean is carried over
+  if (!live) {
+    // beyond the active bound the rows and columns of P are exactly zero off the diagonal (and an idle trajectory appends
+    // nothing): the cadence's ranks are zero there and the mean is carried over
     if (actw) {
       for (int k = 0; k < nrp; ++k) {
         Vb[(long)k * ld + i] = 0.0;
@@ -758,74 +799,72 @@ __global__ __launch_bounds__(64 * NW) void k_panels_cad(double* __restrict__ P, 
       }
       mu_out[(long)b * ld + i] = mu_in[(long)b * ld + i];
     }
+    if (blockIdx.x == 0 && wave == 0) pose_epilogue(o, Pb, Vb, Wb, so, queue, b, ld, lane, nrp);
     return;
   }
   double d0 = 0.0, d1 = 0.0, dm = 0.0;
-#pragma unroll
-  for (int t = 0; t < GMAX; ++t) {
-    if (t < nsteps) {                                  // (uniform)
-      // prediction (:430): of the stored triangle it changes rows 0, 1 only; thread i adds its two entries to P_base at
-      // the end (the ranks are unaffected), the pose diagonal's noise never meets a state index >= 3
-      const double2 g = sG[t];
+  int tp = 0;                                          // (uniform) next touched step whose prediction is due
+  // prediction (:430): of the stored triangle it changes rows 0, 1 only; thread i adds its two entries to P_base at the end
+  // (the ranks are unaffected), the pose diagonal's noise never meets a state index >= 3
+  auto predictions_before = [&](int s) {
+    while (tp < npred && sF[tp] <= s) {
+      const double2 g = sG[tp];
       const double t0 = g.x * X[2], t1 = g.y * X[2];
       X[0] += t0;
       X[1] += t1;
       d0 += t0;
       d1 += t1;
-      const int mt = sM[t];
+      ++tp;
+    }
+  };
 #pragma unroll
-      for (int j = 0; j < MCAP; ++j) {
-        const int s = t * MCAP + j;                    // (compile-time after unrolling)
-        const int pa = G::pa(s), kr = 2 * s, off = G::rec_off(s);
-        if (j < mt) {                                  // (uniform)
-          const double2* R = reinterpret_cast<const double2*>(__builtin_assume_aligned(sRec + off, 16));
-          double2 hk[5];
+  for (int s = 0; s < GM; ++s) {                       // (s, and with it every index of X and of the records, is compile-time)
+    if (s >= s0) {                                     // (uniform)
+      predictions_before(s);
+      const int pa = G::pa(s), off = G::rec_off(s);
+      const int kr = 2 * (s - s0);
+      const double2* R = reinterpret_cast<const double2*>(__builtin_assume_aligned(sRec + off, 16));
+      double2 hk[5];
 #pragma unroll
-          for (int k = 0; k < 5; ++k) hk[k] = R[k];
-          const double2 s01 = R[5], s23 = R[6], yy = R[7];
-          double e0 = hk[0].x * X[0], e1 = hk[0].y * X[0];      // (H_s P_s)[:, i] = h5 . x[sel]
+      for (int k = 0; k < 5; ++k) hk[k] = R[k];
+      const double2 s01 = R[5], s23 = R[6], yy = R[7];
+      double e0 = hk[0].x * X[0], e1 = hk[0].y * X[0];      // (H_s P_s)[:, i] = h5 . x[sel]
 #pragma unroll
-          for (int k = 1; k < 5; ++k) {
-            const double xv = (k < 3) ? X[k] : X[pa + (k - 3)];
-            e0 = fma(hk[k].x, xv, e0);
-            e1 = fma(hk[k].y, xv, e1);
-          }
-          const double f0 = e0 * s01.x + e1 * s23.x;   // K_s[i, :] = (H_s P_s)[:, i]^T S^-1  (P symmetric)
-          const double f1 = e0 * s01.y + e1 * s23.y;
-          dm += f0 * yy.x + f1 * yy.y;                 // :476
+      for (int k = 1; k < 5; ++k) {
+        const double xv = (k < 3) ? X[k] : X[pa + (k - 3)];
+        e0 = fma(hk[k].x, xv, e0);
+        e1 = fma(hk[k].y, xv, e1);
+      }
+      const double f0 = e0 * s01.x + e1 * s23.x;       // K_s[i, :] = (H_s P_s)[:, i]^T S^-1  (P symmetric)
+      const double f1 = e0 * s01.y + e1 * s23.y;
+      dm += f0 * yy.x + f1 * yy.y;                     // :476
 #ifdef CADP_SKIP_STORE                                  /* diagnostic build: no rank stores (a value that is never -7 keeps e, f alive) */
-          if (actw && e0 == -7.0 && f0 == -7.0) {
+      if (actw && e0 == -7.0 && f0 == -7.0) {
 #else
-          if (actw) {
+      if (actw) {
 #endif
-            Vb[(long)kr * ld + i] = e0;
-            Vb[(long)(kr + 1) * ld + i] = e1;
-            Wb[wm_index(ld16, kr, i)] = -f0;
-            Wb[wm_index(ld16, kr + 1, i)] = -f1;
-          }
-          if (!(t + 1 == nsteps && j + 1 == mt)) {     // (uniform) x[a] -= K_s[C_u[a], :] . (H_s P_s)[:, i], what lives on
+        Vb[(long)kr * ld + i] = e0;
+        Vb[(long)(kr + 1) * ld + i] = e1;
+        Wb[wm_index(ld16, kr, i)] = -f0;
+        Wb[wm_index(ld16, kr + 1, i)] = -f1;
+      }
+      // x[a] -= K_s[C_u[a], :] . (H_s P_s)[:, i], what lives on (behind the last slot: the pose rows, for the predictions of
+      // steps that observe nothing)
 #pragma unroll
 #ifdef CADP_SKIP_DD                                     /* diagnostic build: only the rows the next landmark reads are down-dated */
-            for (int a = 0; a < (pa < 5 ? pa : 5); ++a) {
+      for (int a = 0; a < (pa < 5 ? pa : 5); ++a) {
 #else
-            for (int a = 0; a < pa; ++a) {
+      for (int a = 0; a < pa; ++a) {
 #endif
-              const double2 kc = R[8 + a];
-              X[a] = fma(-kc.x, e0, X[a]);
-              X[a] = fma(-kc.y, e1, X[a]);
-            }
-          }
-        } else if (actw) {
-          Vb[(long)kr * ld + i] = 0.0;
-          Vb[(long)(kr + 1) * ld + i] = 0.0;
-          Wb[wm_index(ld16, kr, i)] = 0.0;
-          Wb[wm_index(ld16, kr + 1, i)] = 0.0;
-        }
+        const double2 kc = R[8 + a];
+        X[a] = fma(-kc.x, e0, X[a]);
+        X[a] = fma(-kc.y, e1, X[a]);
       }
     }
   }
+  predictions_before(GM);                              // steps behind the last landmark
   if (actw) {
-    for (int k = nranks; k < nrp; ++k) {               // k-tile pad
+    for (int k = 2 * nslots; k < nrp; ++k) {           // fewer ranks than the bank's busiest trajectory (and the k-tile pad): zeros
       Vb[(long)k * ld + i] = 0.0;
       Wb[wm_index(ld16, k, i)] = 0.0;
     }
@@ -833,7 +872,7 @@ __global__ __launch_bounds__(64 * NW) void k_panels_cad(double* __restrict__ P, 
     Pb[p_col(ld, i) + p_lds(ld)] += d1;                // entry (1, i)
     mu_out[(long)b * ld + i] = mu_in[(long)b * ld + i] + dm;
   }
-  if (blockIdx.x == 0 && wave == 0) pose_epilogue<MCAP>(o, Pb, Vb, Wb, so, queue, b, ld, lane);
+  if (blockIdx.x == 0 && wave == 0) pose_epilogue(o, Pb, Vb, Wb, so, queue, b, ld, lane, nrp);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -845,18 +884,17 @@ __global__ __launch_bounds__(64 * NW) void k_panels_cad(double* __restrict__ P, 
 // (double-buffered by landmark parity: one barrier per landmark); each wave then down-dates its own rows (<= 23 instead
 // of 83).  Rows of a wave sit at position 3 + 8p + 2 wave + e: one base address per wave, compile-time offsets.
 // ---------------------------------------------------------------------------------------------
-template <int MCAP>
 __global__ __launch_bounds__(256) void k_panels_cad_ks(double* __restrict__ P, double* __restrict__ V,
                                                        double* __restrict__ W, const double* __restrict__ mu_in,
                                                        double* __restrict__ mu_out, const int* __restrict__ nact,
                                                        const CadOut* __restrict__ co, SolveOut* __restrict__ so,
-                                                       unsigned* __restrict__ queue, int ld, long pstride) {
-  using G = CadGeom<MCAP>;
-  constexpr int GM = G::GM, CU = G::CU, GMAX = G::GMAX;
+                                                       unsigned* __restrict__ queue, int ld, long pstride, int nrp) {
+  using G = CadGeom;
+  constexpr int GM = G::GM, CU = G::CU;
   constexpr int LP = (GM + 3) / 4;                     // landmark position-slots per wave
   __shared__ __attribute__((aligned(16))) double sRec[G::REC + 32];   // (+ what the last record's K reads may overshoot)
   __shared__ double2 sG[CAD_SLOTS];
-  __shared__ int sM[CAD_SLOTS];
+  __shared__ int sF[CAD_SLOTS];
   __shared__ double2 sE[2][64];
   const int b = blockIdx.y;
   const int n = nact[b];
@@ -865,7 +903,8 @@ __global__ __launch_bounds__(256) void k_panels_cad_ks(double* __restrict__ P, d
   const CadOut& o = co[b];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int nsteps = o.nsteps, neff = o.neff, nranks = o.nranks;
+  const int nslots = o.nslots, npred = o.npred, neff = o.neff;
+  const int s0 = GM - nslots;                          // slots in use: s0 .. GM - 1
   const int ld16 = ld >> 4;
   double* Pb = P + (long)b * pstride;
   double* Vb = V + (long)b * KTOT * ld;
@@ -874,7 +913,7 @@ __global__ __launch_bounds__(256) void k_panels_cad_ks(double* __restrict__ P, d
   const bool act = i < n;
   const int ii = act ? i : n - 1;                      // idle lanes shadow the last state index (no stores)
   const bool actw = act && i >= 3;                     // the pose's state indices are the solve's
-  const bool live = i0 < neff;                         // (uniform) this workgroup replays
+  const bool live = i0 < neff && (nslots > 0 || npred > 0);   // (uniform) this workgroup replays
   double XP[3], XL[2 * LP];
   if (live) {
 #pragma unroll
@@ -892,21 +931,19 @@ __global__ __launch_bounds__(256) void k_panels_cad_ks(double* __restrict__ P, d
         XL[2 * pp + 1] = Pb[p_index(ld, min(c1, ii), max(c1, ii))];
       }
     }
-    const int cnt = G::rec_off(nsteps * MCAP) / 2;     // double2 units
     const double2* src = reinterpret_cast<const double2*>(o.rec);
     double2* dst = reinterpret_cast<double2*>(sRec);
-    for (int e = tid; e < cnt; e += 256) dst[e] = src[e];
-    if (tid < 16) dst[cnt + tid] = make_double2(0.0, 0.0);
+    for (int e = G::rec_off(s0) / 2 + tid; e < G::REC / 2; e += 256) dst[e] = src[e];
+    if (tid < 16) dst[G::REC / 2 + tid] = make_double2(0.0, 0.0);
     if (tid < CAD_SLOTS) {
-      sM[tid] = o.m[tid];
+      sF[tid] = o.sfirst[tid];
       sG[tid] = *reinterpret_cast<const double2*>(o.g[tid]);
     }
   }
   __syncthreads();
-  const int nrp = (nranks + 3) & ~3;                   // ranks written: whole k-tiles
   if (!live) {
-    // beyond the active bound the rows and columns of P are exactly zero off the diagonal: the cadence's ranks are
-    // zero there and the mean is carried over
+    // beyond the active bound the rows and columns of P are exactly zero off the diagonal (and an idle trajectory appends
+    // nothing): the cadence's ranks are zero there and the mean is carried over
     if (actw && wave == 0) {
       for (int k = 0; k < nrp; ++k) {
         Vb[(long)k * ld + i] = 0.0;
@@ -914,88 +951,85 @@ __global__ __launch_bounds__(256) void k_panels_cad_ks(double* __restrict__ P, d
       }
       mu_out[(long)b * ld + i] = mu_in[(long)b * ld + i];
     }
+    if (blockIdx.x == 0 && wave == 0) pose_epilogue(o, Pb, Vb, Wb, so, queue, b, ld, lane, nrp);
     return;
   }
   const double* recw = sRec + 4 * wave;                // K of this wave's rows: + compile-time offsets
   double d0 = 0.0, d1 = 0.0, dm = 0.0;
   int par = 0;                                         // (uniform) hand-over buffer: alternates with every landmark processed
-#pragma unroll
-  for (int t = 0; t < GMAX; ++t) {
-    if (t < nsteps) {                                  // (uniform)
-      const double2 g = sG[t];
-      const double t0 = g.x * XP[2], t1 = g.y * XP[2]; // prediction (:430): rows 0, 1 (see k_panels_cad)
+  int tp = 0;                                          // (uniform) next touched step whose prediction is due
+  auto predictions_before = [&](int s) {               // prediction (:430): rows 0, 1 (see k_panels_cad)
+    while (tp < npred && sF[tp] <= s) {
+      const double2 g = sG[tp];
+      const double t0 = g.x * XP[2], t1 = g.y * XP[2];
       XP[0] += t0;
       XP[1] += t1;
       d0 += t0;
       d1 += t1;
-      const int mt = sM[t];
+      ++tp;
+    }
+  };
 #pragma unroll
-      for (int j = 0; j < MCAP; ++j) {
-        const int s = t * MCAP + j;                    // (compile-time after unrolling)
-        const int pa = G::pa(s), kr = 2 * s, off = G::rec_off(s);
-        const int q = GM - 1 - s, OW = q & 3, PL = q >> 2;   // the landmark's position-slot: owner wave, its local pair
-        if (j < mt) {                                  // (uniform)
-          const double2* R = reinterpret_cast<const double2*>(__builtin_assume_aligned(sRec + off, 16));
-          if (wave == OW) {                            // (uniform) e = (H_s P_s)[:, i] = h5 . x[sel], finished by the rows' owner
-            double2 hk[5];
+  for (int s = 0; s < GM; ++s) {                       // (compile-time after unrolling)
+    if (s >= s0) {                                     // (uniform)
+      predictions_before(s);
+      const int pa = G::pa(s), off = G::rec_off(s);
+      const int kr = 2 * (s - s0);
+      const int q = GM - 1 - s, OW = q & 3, PL = q >> 2;   // the landmark's position-slot: owner wave, its local pair
+      const double2* R = reinterpret_cast<const double2*>(__builtin_assume_aligned(sRec + off, 16));
+      if (wave == OW) {                                // (uniform) e = (H_s P_s)[:, i] = h5 . x[sel], finished by the rows' owner
+        double2 hk[5];
 #pragma unroll
-            for (int k = 0; k < 5; ++k) hk[k] = R[k];
-            double e0 = hk[0].x * XP[0], e1 = hk[0].y * XP[0];
+        for (int k = 0; k < 5; ++k) hk[k] = R[k];
+        double e0 = hk[0].x * XP[0], e1 = hk[0].y * XP[0];
 #pragma unroll
-            for (int k = 1; k < 5; ++k) {
-              const double xv = (k < 3) ? XP[k] : XL[2 * PL + (k - 3)];
-              e0 = fma(hk[k].x, xv, e0);
-              e1 = fma(hk[k].y, xv, e1);
-            }
-            sE[par][lane] = make_double2(e0, e1);
+        for (int k = 1; k < 5; ++k) {
+          const double xv = (k < 3) ? XP[k] : XL[2 * PL + (k - 3)];
+          e0 = fma(hk[k].x, xv, e0);
+          e1 = fma(hk[k].y, xv, e1);
+        }
+        sE[par][lane] = make_double2(e0, e1);
+      }
+      WG_LDS_BARRIER();
+      const double2 ee = sE[par][lane];
+      par ^= 1;
+      const double e0 = ee.x, e1 = ee.y;
+      const double2 s01 = R[5], s23 = R[6], yy = R[7];
+      const double f0 = e0 * s01.x + e1 * s23.x;       // K_s[i, :] = (H_s P_s)[:, i]^T S^-1  (P symmetric)
+      const double f1 = e0 * s01.y + e1 * s23.y;
+      dm += f0 * yy.x + f1 * yy.y;                     // :476
+      if (actw && wave == (s & 3)) {                   // (the ranks' stores dealt over the waves)
+        Vb[(long)kr * ld + i] = e0;
+        Vb[(long)(kr + 1) * ld + i] = e1;
+        Wb[wm_index(ld16, kr, i)] = -f0;
+        Wb[wm_index(ld16, kr + 1, i)] = -f1;
+      }
+      // x[a] -= K_s[C_u[a], :] . (H_s P_s)[:, i], what lives on (behind the last slot: the pose rows only)
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const double2 kc = R[8 + k];
+        XP[k] = fma(-kc.x, e0, XP[k]);
+        XP[k] = fma(-kc.y, e1, XP[k]);
+      }
+      // own landmark rows at positions 3 + 8p + 2 wave + e < pa; the pair at the boundary may already be dead for
+      // this wave: what lands in a dead row does not matter
+      const double2* Rw = reinterpret_cast<const double2*>(__builtin_assume_aligned(recw + off + 16, 16));
+#pragma unroll
+      for (int pp = 0; pp < LP; ++pp) {
+        if (3 + 8 * pp < pa) {                         // (compile-time) some wave's rows of this pair are live
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            const double2 kc = Rw[3 + 8 * pp + e];
+            XL[2 * pp + e] = fma(-kc.x, e0, XL[2 * pp + e]);
+            XL[2 * pp + e] = fma(-kc.y, e1, XL[2 * pp + e]);
           }
-          WG_LDS_BARRIER();
-          const double2 ee = sE[par][lane];
-          par ^= 1;
-          const double e0 = ee.x, e1 = ee.y;
-          const double2 s01 = R[5], s23 = R[6], yy = R[7];
-          const double f0 = e0 * s01.x + e1 * s23.x;   // K_s[i, :] = (H_s P_s)[:, i]^T S^-1  (P symmetric)
-          const double f1 = e0 * s01.y + e1 * s23.y;
-          dm += f0 * yy.x + f1 * yy.y;                 // :476
-          if (actw && wave == (s & 3)) {               // (the ranks' stores dealt over the waves)
-            Vb[(long)kr * ld + i] = e0;
-            Vb[(long)(kr + 1) * ld + i] = e1;
-            Wb[wm_index(ld16, kr, i)] = -f0;
-            Wb[wm_index(ld16, kr + 1, i)] = -f1;
-          }
-          if (!(t + 1 == nsteps && j + 1 == mt)) {     // (uniform) x[a] -= K_s[C_u[a], :] . (H_s P_s)[:, i], what lives on
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-              const double2 kc = R[8 + k];
-              XP[k] = fma(-kc.x, e0, XP[k]);
-              XP[k] = fma(-kc.y, e1, XP[k]);
-            }
-            // own landmark rows at positions 3 + 8p + 2 wave + e < pa; the pair at the boundary may already be dead for
-            // this wave: what lands in a dead row does not matter
-            const double2* Rw = reinterpret_cast<const double2*>(__builtin_assume_aligned(recw + off + 16, 16));
-#pragma unroll
-            for (int pp = 0; pp < LP; ++pp) {
-              if (3 + 8 * pp < pa) {                   // (compile-time) some wave's rows of this pair are live
-#pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                  const double2 kc = Rw[3 + 8 * pp + e];
-                  XL[2 * pp + e] = fma(-kc.x, e0, XL[2 * pp + e]);
-                  XL[2 * pp + e] = fma(-kc.y, e1, XL[2 * pp + e]);
-                }
-              }
-            }
-          }
-        } else if (actw && wave == (s & 3)) {
-          Vb[(long)kr * ld + i] = 0.0;
-          Vb[(long)(kr + 1) * ld + i] = 0.0;
-          Wb[wm_index(ld16, kr, i)] = 0.0;
-          Wb[wm_index(ld16, kr + 1, i)] = 0.0;
         }
       }
     }
   }
+  predictions_before(GM);                              // steps behind the last landmark
   if (actw && wave == 0) {
-    for (int k = nranks; k < nrp; ++k) {               // k-tile pad
+    for (int k = 2 * nslots; k < nrp; ++k) {           // fewer ranks than the bank's busiest trajectory (and the k-tile pad): zeros
       Vb[(long)k * ld + i] = 0.0;
       Wb[wm_index(ld16, k, i)] = 0.0;
     }
@@ -1003,7 +1037,7 @@ __global__ __launch_bounds__(256) void k_panels_cad_ks(double* __restrict__ P, d
     Pb[p_col(ld, i) + p_lds(ld)] += d1;                // entry (1, i)
     mu_out[(long)b * ld + i] = mu_in[(long)b * ld + i] + dm;
   }
-  if (blockIdx.x == 0 && wave == 0) pose_epilogue<MCAP>(o, Pb, Vb, Wb, so, queue, b, ld, lane);
+  if (blockIdx.x == 0 && wave == 0) pose_epilogue(o, Pb, Vb, Wb, so, queue, b, ld, lane, nrp);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1013,64 +1047,35 @@ __global__ __launch_bounds__(256) void k_panels_cad_ks(double* __restrict__ P, d
 long cadence_gbuf_doubles() { return (long)CAD_GP * CAD_ROWS * CAD_CS; }   // per trajectory: CAD_GP parts
 
 // (look-ahead) the next cadence's block while `kb` ranks are pending -> gbuf
-void launch_gather_cad(hipStream_t st, int mcap, const double* P, const double* V, const double* W, const double* dacc,
-                       const StepIn* in, int batch, int nsteps, int kb, const DeviceConfig& cfg, int ld, long pstride,
+void launch_gather_cad(hipStream_t st, const double* P, const double* V, const double* W, const double* dacc,
+                       const StepIn* in, const CadPlan* plan, int batch, int kb, const DeviceConfig& cfg, int ld, long pstride,
                        double* gbuf) {
-#define EKF_GATHER_CAD(M)                                                                                             \
-  hipLaunchKernelGGL((k_gather_cad<M>), dim3((kb + 7) / 8, batch), dim3(64 * CAD_GW), 0, st, P, V, W, dacc, in, batch, nsteps, \
-                     kb, cfg, ld, pstride, gbuf)
-  switch (mcap) {
-    case 1: EKF_GATHER_CAD(1); break;
-    case 2: EKF_GATHER_CAD(2); break;
-    case 4: EKF_GATHER_CAD(4); break;
-    case 8: EKF_GATHER_CAD(8); break;
-    default: EKF_GATHER_CAD(16); break;
-  }
-#undef EKF_GATHER_CAD
+  hipLaunchKernelGGL(k_gather_cad, dim3((kb + 7) / 8, batch), dim3(64 * CAD_GW), 0, st, P, V, W, dacc, in, plan, batch, kb, cfg,
+                     ld, pstride, gbuf);
 }
 
-void launch_solve_cad(hipStream_t st, int mcap, const double* P, const double* mu_in, double* mu_out, double* dacc_out,
-                      const int* nact, const StepIn* in, int batch, int nsteps, CadOut* out, unsigned* flags,
-                      const int* neff_floor, const DeviceConfig& cfg, int ld, long pstride, const double* gbuf, int gparts) {
-#define EKF_SOLVE_CAD(M)                                                                                              \
-  hipLaunchKernelGGL((k_solve_cad<M>), dim3(batch), dim3(64 * CAD_NW), 0, st, P, mu_in, mu_out, dacc_out, nact, in, batch, \
-                     nsteps, out, flags, neff_floor, cfg, ld, pstride, gbuf, gparts)
-  switch (mcap) {
-    case 1: EKF_SOLVE_CAD(1); break;
-    case 2: EKF_SOLVE_CAD(2); break;
-    case 4: EKF_SOLVE_CAD(4); break;
-    case 8: EKF_SOLVE_CAD(8); break;
-    default: EKF_SOLVE_CAD(16); break;
-  }
-#undef EKF_SOLVE_CAD
+void launch_solve_cad(hipStream_t st, const double* P, const double* mu_in, double* mu_out, double* dacc_out,
+                      const int* nact, const StepIn* in, const CadPlan* plan, int batch, CadOut* out, unsigned* flags,
+                      const DeviceConfig& cfg, int ld, long pstride, const double* gbuf, int gparts) {
+  hipLaunchKernelGGL(k_solve_cad, dim3(batch), dim3(64 * CAD_NW), 0, st, P, mu_in, mu_out, dacc_out, nact, in, plan, batch, out,
+                     flags, cfg, ld, pstride, gbuf, gparts);
 }
 
-template <int MCAP>
-static void launch_panels_cad_t(hipStream_t st, double* P, double* V, double* W, const double* mu_in, double* mu_out,
-                                const int* nact, const CadOut* co, SolveOut* so, unsigned* queue, int ld, long pstride,
-                                int batch, int n_hi) {
+// `nrp`: the ranks the bank's busiest trajectory appends, padded to a whole k-tile (every trajectory writes that many)
+void launch_panels_cad(hipStream_t st, double* P, double* V, double* W, const double* mu_in, double* mu_out,
+                       const int* nact, const CadOut* co, SolveOut* so, unsigned* queue, int ld, long pstride, int batch,
+                       int n_hi, int nrp) {
   // few state indices (the latency regime): four waves split the rows of the panel of 64 state indices (k_panels_cad_ks);
   // up to one wave per SIMD: one wave per workgroup
   if ((long)((n_hi + 63) / 64) * batch <= CAD_KS_WAVES)
-    hipLaunchKernelGGL((k_panels_cad_ks<MCAP>), dim3((n_hi + 63) / 64, batch), dim3(256), 0, st, P, V, W, mu_in, mu_out,
-                       nact, co, so, queue, ld, pstride);
+    hipLaunchKernelGGL(k_panels_cad_ks, dim3((n_hi + 63) / 64, batch), dim3(256), 0, st, P, V, W, mu_in, mu_out,
+                       nact, co, so, queue, ld, pstride, nrp);
   else if ((long)((n_hi + 63) / 64) * batch <= 1024)
-    hipLaunchKernelGGL((k_panels_cad<MCAP, 1>), dim3((n_hi + 63) / 64, batch), dim3(64), 0, st, P, V, W, mu_in, mu_out,
-                       nact, co, so, queue, ld, pstride);
+    hipLaunchKernelGGL((k_panels_cad<1>), dim3((n_hi + 63) / 64, batch), dim3(64), 0, st, P, V, W, mu_in, mu_out,
+                       nact, co, so, queue, ld, pstride, nrp);
   else
-    hipLaunchKernelGGL((k_panels_cad<MCAP, 4>), dim3((n_hi + 255) / 256, batch), dim3(256), 0, st, P, V, W, mu_in,
-                       mu_out, nact, co, so, queue, ld, pstride);
-}
-void launch_panels_cad(hipStream_t st, int mcap, double* P, double* V, double* W, const double* mu_in, double* mu_out,
-                       const int* nact, const CadOut* co, SolveOut* so, unsigned* queue, int ld, long pstride, int batch,
-                       int n_hi) {
-  switch (mcap) {
-    case 1: launch_panels_cad_t<1>(st, P, V, W, mu_in, mu_out, nact, co, so, queue, ld, pstride, batch, n_hi); break;
-    case 2: launch_panels_cad_t<2>(st, P, V, W, mu_in, mu_out, nact, co, so, queue, ld, pstride, batch, n_hi); break;
-    case 4: launch_panels_cad_t<4>(st, P, V, W, mu_in, mu_out, nact, co, so, queue, ld, pstride, batch, n_hi); break;
-    case 8: launch_panels_cad_t<8>(st, P, V, W, mu_in, mu_out, nact, co, so, queue, ld, pstride, batch, n_hi); break;
-    default: launch_panels_cad_t<16>(st, P, V, W, mu_in, mu_out, nact, co, so, queue, ld, pstride, batch, n_hi); break;
-  }
+    hipLaunchKernelGGL((k_panels_cad<4>), dim3((n_hi + 255) / 256, batch), dim3(256), 0, st, P, V, W, mu_in,
+                       mu_out, nact, co, so, queue, ld, pstride, nrp);
 }
 
 }  // namespace ekf

@@ -104,47 +104,66 @@ struct alignas(16) SolveOut : SolveHead {
 static_assert(sizeof(SolveHead) % 16 == 0, "SolveHead must stay 16-byte granular");
 // (SolveOut = head, then the records: `it` starts at sizeof(SolveHead))
 
-// ---- fused cadence (ekf_cadence.hip): the steps between two covariance passes of an uploaded stream as ONE solve launch
-// and ONE panel launch.  Right after a pass nothing is pending and the stream knows the next steps' landmark indices: the
-// union panel P(C_u, i), C_u = {0,1,2} + the landmark indices of all steps of the cadence, is gathered from P_base once,
-// the predictions and the sequential landmark updates of src/replay_no_ros.py:368-480 are replayed on it, and all ranks
-// are appended at once.  Landmark slot s = t * MCAP + j (step t of the cadence, j-th observation, in processing order)
-// sits at positions pa(s), pa(s) + 1 of C_u with pa(s) = 3 + 2 (GM - 1 - s): later slots at LOWER positions, so that
-// "everything a later update still needs" is always the prefix [0, pa(s)) of the positions -- compile-time bounds for the
-// panel's register array, a shrinking prefix of lanes for the solve.  A landmark observed in two steps simply has two
-// slots (duplicate positions carry identical values); unused slots (m_t < MCAP, fewer steps than GMAX) gather index 0.
+// ---- fused cadence (ekf_cadence.hip): everything between two covariance passes of an uploaded stream as ONE solve launch
+// and ONE panel launch.  Right after a pass nothing is pending and the stream knows the next landmark indices: the union
+// panel P(C_u, i), C_u = {0,1,2} + the landmark indices of all updates up to the next pass, is gathered from P_base once, the
+// predictions and the sequential landmark updates of src/replay_no_ros.py:368-480 are replayed on it, and all ranks are
+// appended at once.
+// Round 5: the cadence is PACKED.  A trajectory's stream is the flat sequence  P_t, L_t,0 .. L_t,m_t-1, P_t+1, ...  (P = the
+// prediction of step t, L = one landmark update); a cadence takes the next <= CAD_SLOTS landmark updates of that sequence,
+// whatever steps they belong to (a step may be cut: its remaining landmarks open the next cadence, without a second
+// prediction), plus every prediction in between -- exactly 2 ranks per landmark update, no rounding of a step's landmark
+// count to a slot size, steps that observe nothing ride along for free.  Every trajectory of a bank walks its OWN sequence
+// (trajectories are closed systems, src/replay_no_ros.py:269-482 couples nothing): after a pass each one has used its 40
+// slots, however its landmark counts wander (CadPlan, planned on the host: ekf_host_plan.h).
+// Slots are RIGHT-ALIGNED: a cadence of `nslots` updates uses the slots s0 = CAD_SLOTS - nslots .. CAD_SLOTS - 1; slot s sits
+// at positions pa(s), pa(s) + 1 of C_u with pa(s) = 3 + 2 (CAD_SLOTS - 1 - s): later slots at LOWER positions, the last one
+// always at 3, 4 -- "everything a later update still needs" is always the prefix [0, pa(s)) of the positions: compile-time
+// bounds for the panel's register array, a shrinking prefix of lanes for the solve, and a short cadence costs what its
+// slots cost.  A landmark observed twice has two slots (duplicate positions carry identical values); positions beyond
+// 3 + 2 nslots gather index 0 and are never read.
 constexpr int CAD_SLOTS = KTOT / 2;                  // landmark slots of a cadence (2 ranks each)
 constexpr int CAD_CU = 3 + 2 * CAD_SLOTS;            // gathered positions at most (83)
-template <int MCAP>
+__host__ __device__ constexpr int cad_pa(int s) { return 3 + 2 * (CAD_SLOTS - 1 - s); }
+// record of slot s (doubles): h5t[5][2], si[4], y[2], then K_s[C_u[a], :] for the positions a < pa(s) a later slot or
+// step still reads; records are packed back to back
+__host__ __device__ constexpr int cad_rec_off(int s) { return 16 * s + 2 * (s * (3 + 2 * (CAD_SLOTS - 1)) - s * (s - 1)); }
 struct CadGeom {
-  static constexpr int GMAX = CAD_SLOTS / MCAP;      // steps of a full cadence (40, 20, 10, 5, 2)
-  static constexpr int GM = GMAX * MCAP;             // landmark slots (40; 32 at MCAP = 16)
-  static constexpr int CU = 3 + 2 * GM;              // gathered positions
-  __host__ __device__ static constexpr int pa(int s) { return 3 + 2 * (GM - 1 - s); }
-  // record of slot s (doubles): h5t[5][2], si[4], y[2], then K_s[C_u[a], :] for the positions a < pa(s) a later slot or
-  // step still reads; records are packed back to back
-  __host__ __device__ static constexpr int rec_off(int s) { return 16 * s + 2 * (s * (3 + 2 * (GM - 1)) - s * (s - 1)); }
-  static constexpr int REC = rec_off(GM);
+  static constexpr int GM = CAD_SLOTS;               // landmark slots
+  static constexpr int CU = CAD_CU;                  // gathered positions
+  __host__ __device__ static constexpr int pa(int s) { return cad_pa(s); }
+  __host__ __device__ static constexpr int rec_off(int s) { return cad_rec_off(s); }
+  static constexpr int REC = cad_rec_off(CAD_SLOTS);
 };
-constexpr int CAD_REC_MAX = CadGeom<8>::REC;         // 4000 doubles (the same for MCAP = 1, 2, 4, 8; less at 16)
-static_assert(CadGeom<1>::REC == CAD_REC_MAX && CadGeom<2>::REC == CAD_REC_MAX && CadGeom<4>::REC == CAD_REC_MAX &&
-              CadGeom<16>::REC <= CAD_REC_MAX, "record area");
+constexpr int CAD_REC_MAX = CadGeom::REC;            // 4000 doubles
+// What one trajectory does in one cadence (host -> device, 32 B): the steps t0 .. t0 + ns - 1 of the uploaded stream; of the
+// first one the landmarks from j0 on (j0 > 0: the step was cut by the previous cadence, its prediction has happened), of
+// the last one the landmarks up to jend (exclusive; the rest open the next cadence).  ns == 0: nothing (the trajectory has
+// reached the end of the range; its ranks of this cadence are zero).
+struct CadPlan {
+  int t0, j0, ns, jend;
+  int nslots;                 // landmark updates (<= CAD_SLOTS)
+  int neff;                   // active bound of the cadence (its last step's, raised to the handle's floor)
+  int pad[2];
+};
 struct alignas(16) CadHead {
-  int nsteps;                 // steps of this cadence (<= GMAX)
-  int neff;                   // active bound of the cadence (its last step's)
-  int nranks;                 // ranks appended: 2 * MCAP * nsteps
+  int nslots;                 // landmark slots in use: CAD_SLOTS - nslots .. CAD_SLOTS - 1
+  int neff;                   // active bound of the cadence
+  int npred;                  // steps touched (a prediction each, except a first step cut by the previous cadence)
   int pad0;
-  int m[CAD_SLOTS];           // observations of step t (0 when the measurement model is off)
+  int sfirst[CAD_SLOTS];      // slot of the first landmark of touched step p, or of the next one that has any (CAD_SLOTS: none)
   int C[CAD_CU + 1];          // gathered state indices by position
-  double g[CAD_SLOTS][2];     // G[0,2], G[1,2] of step t's motion Jacobian
+  double g[CAD_SLOTS][2];     // G[0,2], G[1,2] of touched step p's motion Jacobian (0 when it predicts nothing)
   double prow[2][CAD_CU + 1]; // (diagnostic) P(0, C_u[a]), P(1, C_u[a]) before the cadence
   double ddpose[2][4];        // what the cadence's predictions add to P_base(0, l), P_base(1, l), l < 3 (the pose block)
+  double rdsum[4];            // pose-block noise of the cadence's predictions (applied by the panel launch when no rank is pending)
 };
 struct alignas(16) CadOut : CadHead {
   double rec[CAD_REC_MAX];
   double posevw[CAD_SLOTS][3][4];   // the new ranks' entries at the pose's state indices l < 3: V[2s][l], V[2s+1][l], W[l][2s], W[l][2s+1]
 };
 static_assert(sizeof(CadHead) % 16 == 0, "CadHead must stay 16-byte granular");
+static_assert(sizeof(CadPlan) == 32, "CadPlan is 32 bytes");
 
 // Device-side association: one window of raw AprilTag detections per trajectory.
 constexpr int DMAX = 64;                // detections per window

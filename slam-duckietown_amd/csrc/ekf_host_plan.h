@@ -15,7 +15,6 @@
 namespace ekf {
 
 constexpr int RS_ROWS = 128;            // rows of a slab of the row-slab pass = 8 waves x 16
-inline int cadence_steps_max(int mcap) { return CAD_SLOTS / mcap; }
 
 // What the planning functions read of a handle (ekf_handle derives from this).
 struct HostPlan {
@@ -31,6 +30,7 @@ struct HostPlan {
   bool sizes_dirty = false;       // the device grew the state: n / neff must be read back before use
   int stream_steps = 0;
   std::vector<int> stream_mhi;    // per step: most observations of any trajectory
+  std::vector<unsigned char> stream_m;   // per (step, trajectory): observations the kernels will process (0 with the measurement model off)
   std::vector<int> stream_own;    // per (step, trajectory): active bound from the stream's OWN observations up to that step
   std::vector<int> stream_maxlm;  // per trajectory: landmarks the stream needs in the state (largest index + 1)
   int opt_active_bound = 1;       // 0 = always treat the whole state as active
@@ -325,17 +325,87 @@ inline void order_pass_shares(int workgroups, int pieces, int* table_ptr, size_t
   std::copy(out.begin(), out.end(), table_ptr);
 }
 
-// How many steps of the uploaded stream, starting at step k, can run as one fused cadence (0 = none).
-inline int cadence_length(const HostPlan* h, int k, int end, bool after_pass = false) {
-  if (!h->opt_fused_cadence || (h->pending_k != 0 && !after_pass) || h->sizes_dirty || k >= end) return 0;
-  const int m0 = h->stream_mhi[k];
-  if (m0 < 1) return 0;
-  const int mcap = cap_for(m0), ktp = ranks_for(mcap);
-  int g = std::min(end - k, cadence_steps_max(mcap));
-  g = std::min(g, h->opt_flush_every > 0 ? h->opt_flush_every : h->opt_rank_limit / ktp);   // the pass cadence
-  for (int t = 1; t < g; ++t)
-    if (h->stream_mhi[k + t] < 1 || cap_for(h->stream_mhi[k + t]) != mcap) g = t;
-  return g;
+// ---- the packed cadences of ekf_stream_run (ekf_device.h: CadPlan) ----
+// Steps [k, end) of the uploaded stream as a sequence of fused cadences, planned in one go.  Every trajectory walks its own
+// flat sequence of predictions and landmark updates; a cadence gives it
+//   * whole steps while their landmarks fit the slots that are left (steps that observe nothing are free),
+//   * then, if slots are left and the next step does not fit, that step's prediction and as many of its landmarks as do fit
+//     (the rest open the trajectory's next cadence -- no second prediction),
+// within `slot_limit` landmark updates ("rank_limit" / 2, at most CAD_SLOTS) and `step_limit` touched steps ("flush_every",
+// at most CAD_SLOTS: the kernels' per-step arrays).  The covariance pass follows every cadence but possibly the last, with
+// as many ranks as the busiest trajectory appended (the others zero-fill): the number of passes of a run is what the
+// trajectory with the most landmark updates needs at 40 per pass, however the counts are spread over steps and trajectories.
+// A trajectory that has reached `end` idles (ns = 0).  The plan of a trajectory depends on its own observations only.
+struct RunPlan {
+  int ncad = 0;
+  std::vector<CadPlan> entries;          // ncad x batch
+  std::vector<int> slots_hi;             // per cadence: most landmark updates of any trajectory
+  std::vector<int> steps_hi;             // per cadence: most steps completed by any trajectory
+  std::vector<long> steps_sum;           // per cadence: steps completed, summed over the trajectories
+};
+inline int cadence_slot_limit(const HostPlan* h) { return std::max(1, std::min(CAD_SLOTS, h->opt_rank_limit / 2)); }
+inline int cadence_step_limit(const HostPlan* h) { return h->opt_flush_every > 0 ? std::min(CAD_SLOTS, h->opt_flush_every) : CAD_SLOTS; }
+inline bool cadences_possible(const HostPlan* h) {
+  return h->opt_fused_cadence && h->pending_k == 0 && !h->sizes_dirty && (int)h->stream_m.size() == h->stream_steps * h->batch;
+}
+inline void plan_cadences(const HostPlan* h, int k, int end, RunPlan& rp) {
+  const int B = h->batch, slot_limit = cadence_slot_limit(h), step_limit = cadence_step_limit(h);
+  rp.ncad = 0;
+  rp.entries.clear();
+  rp.slots_hi.clear();
+  rp.steps_hi.clear();
+  rp.steps_sum.clear();
+  std::vector<int> ct(B, k), cj(B, 0);   // cursor per trajectory: next step, next landmark of it (> 0: the step is cut)
+  for (;;) {
+    bool any = false;
+    for (int b = 0; b < B; ++b) any = any || ct[b] < end;
+    if (!any) break;
+    const size_t base = rp.entries.size();
+    rp.entries.resize(base + B);
+    int slots_hi = 0, steps_hi = 0;
+    long steps_sum = 0;
+    for (int b = 0; b < B; ++b) {
+      CadPlan& e = rp.entries[base + b];
+      e = CadPlan{};
+      e.t0 = ct[b];
+      e.j0 = cj[b];
+      int t = ct[b], j = cj[b], slots = 0, ns = 0, done = 0;
+      e.jend = 0;
+      while (t < end && ns < step_limit) {
+        const int m = h->stream_m[(size_t)t * B + b], left = m - j;
+        if (slots + left <= slot_limit) {              // the whole (rest of the) step
+          slots += left;
+          e.jend = m;
+          ++ns;
+          ++done;
+          ++t;
+          j = 0;
+          continue;
+        }
+        const int room = slot_limit - slots;
+        if (room > 0) {                                // cut: its prediction (if not yet done) and `room` landmarks
+          slots += room;
+          j += room;
+          e.jend = j;
+          ++ns;
+        }
+        break;
+      }
+      e.ns = ns;
+      e.nslots = slots;
+      const int t_last = ns > 0 ? e.t0 + ns - 1 : std::max(e.t0 - 1, 0);   // (an idle trajectory keeps its last step's bound)
+      e.neff = std::min(h->n[b], std::max(h->floor_host[b], h->stream_own[(size_t)t_last * B + b]));
+      ct[b] = t;
+      cj[b] = j;
+      slots_hi = std::max(slots_hi, slots);
+      steps_hi = std::max(steps_hi, done);
+      steps_sum += done;
+    }
+    rp.slots_hi.push_back(slots_hi);
+    rp.steps_hi.push_back(steps_hi);
+    rp.steps_sum.push_back(steps_sum);
+    rp.ncad += 1;
+  }
 }
 
 // Validate one trajectory's whole observation list (all device passes of it) before any handle state changes:

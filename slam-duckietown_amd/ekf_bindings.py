@@ -647,6 +647,12 @@ class EkfSlam:
         regs = {4: (4, 0), 8: (8, 0), 12: (12, 0), 16: (16, 0), 20: (15, 5)}[tiles]
         return f"ekf::k_flush<{regs[0]}, {regs[1]}, {nt}>"
 
+    def cadence_counters(self):
+        """(fused cadences launched by stream_run so far, steps of the uploaded stream they covered): which path ran."""
+        a, b = C.c_long(), C.c_long()
+        self._check(self._lib.ekf_debug_cadences(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
     def set_option(self, name: str, value: int):
         self._check(self._lib.ekf_set_option(self._h, name.encode(), int(value)))
 

@@ -32,6 +32,48 @@ def true_poses(steps: int) -> np.ndarray:
     return out
 
 
+def _world(n_landmarks: int, trajectory_id: int):
+    rng = np.random.default_rng(1234 + trajectory_id)
+    u = rng.random(n_landmarks)
+    phi = rng.random(n_landmarks) * 2 * np.pi
+    r = 1.2 * np.sqrt(u)
+    lm = np.stack([r * np.cos(phi), 0.2 + r * np.sin(phi)], axis=1)
+    mean0 = np.zeros(3 + 2 * n_landmarks)
+    mean0[3:] = (lm + rng.normal(0.0, 0.05, lm.shape)).ravel()
+    diag0 = np.full(3 + 2 * n_landmarks, 10000.0)
+    diag0[0:3] = 0.1
+    return rng, lm, mean0, diag0
+
+
+def variable_stream(n_landmarks: int, steps: int, m_lo: int = 0, m_hi: int = 8, trajectory_id: int = 0):
+    """The shapes the reference's loop produces (src/replay_no_ros.py:280-301, :436: whatever tags the window saw): per
+    step m ~ uniform{m_lo..m_hi} landmarks drawn WITHOUT order or locality (``rng.choice(N, m, replace=False)``).
+    Same world, kinematics and noise as synthetic_stream.
+    -> mean0, diagP0, lin[steps], ang[steps], idx[steps, m_hi] (entries beyond m[k] are 0), range, bearing, m[steps] int32."""
+    rng, lm, mean0, diag0 = _world(n_landmarks, trajectory_id)
+    lin = np.full(steps, 0.004)
+    ang = np.full(steps, 0.02)
+    ang[9::10] = 0.005
+    stride = max(1, m_hi)
+    idx = np.zeros((steps, stride), dtype=np.int32)
+    zr = np.zeros((steps, stride))
+    zb = np.zeros((steps, stride))
+    mk = rng.integers(m_lo, m_hi + 1, size=steps).astype(np.int32)
+    pose = np.zeros(3)
+    for k in range(steps):
+        pose = _advance(pose, lin[k], ang[k])
+        m = int(mk[k])
+        vis = rng.choice(n_landmarks, m, replace=False)
+        d = lm[vis] - pose[0:2]
+        c, s = np.cos(pose[2]), np.sin(pose[2])
+        xr = c * d[:, 0] + s * d[:, 1] + rng.normal(0.0, 0.01, m)
+        yr = -s * d[:, 0] + c * d[:, 1] + rng.normal(0.0, 0.01, m)
+        idx[k, :m] = vis
+        zr[k, :m] = np.sqrt(xr ** 2 + yr ** 2)
+        zb[k, :m] = np.arctan2(yr, xr)
+    return mean0, diag0, lin, ang, idx, zr, zb, mk
+
+
 def synthetic_stream(n_landmarks: int, steps: int, m: int = 8, trajectory_id: int = 0):
     """-> mean0 (n,), diagP0 (n,), lin[steps], ang[steps], idx[steps,m] int32, range[steps,m], bearing[steps,m]."""
     rng = np.random.default_rng(1234 + trajectory_id)

@@ -192,32 +192,85 @@ static void check_planning(std::mt19937& rng) {
       CHECK(longest >= 0 && longest <= pass_share_pieces(), "shares %d", longest);
       if (longest > 0) order_pass_shares(p.rs_workgroups, pass_share_pieces(), table.data(), table.size());
     }
-    // cadences of a random uploaded stream
-    const int steps = 1 + rng() % 120;
-    h.stream_mhi.resize(steps);
+    // the packed cadences of a random uploaded stream (plan_cadences): every trajectory's flat sequence of predictions and
+    // landmark updates is covered exactly once, in order, within the slot and step limits
+    const int steps = 1 + rng() % 120, B = h.batch;
+    h.stream_steps = steps;
+    h.stream_m.assign((size_t)steps * B, 0);
+    h.stream_own.assign((size_t)steps * B, 3);
+    h.stream_mhi.assign(steps, 0);
+    const int shape = rng() % 4;                       // constant m / runs of a size / anything / mostly nothing
     int run_m = 1 + rng() % 16;
     for (int k = 0; k < steps; ++k) {
       if (rng() % 7 == 0) run_m = (int)(rng() % 17);
-      h.stream_mhi[k] = run_m;
-    }
-    h.stream_steps = steps;
-    const int pend = h.pending_k;
-    for (int k = 0; k < steps;) {
-      h.pending_k = rng() % 3 == 0 ? pend : 0;
-      const int end = k + 1 + (int)(rng() % (steps - k));
-      const int g = cadence_length(&h, k, end);
-      CHECK(g >= 0 && g <= end - k, "cadence %d of %d", g, end - k);
-      if (g > 0) {
-        const int mcap = cap_for(h.stream_mhi[k]);
-        CHECK(h.opt_fused_cadence && h.pending_k == 0 && !h.sizes_dirty, "a cadence where none may start");
-        CHECK(g <= cadence_steps_max(mcap), "cadence %d beyond %d slots", g, cadence_steps_max(mcap));
-        CHECK(g * ranks_for(mcap) <= KTOT, "cadence of %d ranks", g * ranks_for(mcap));
-        if (h.opt_flush_every > 0) CHECK(g <= h.opt_flush_every, "cadence %d beyond flush_every %d", g, h.opt_flush_every);
-        else CHECK(g * ranks_for(mcap) <= std::max(h.opt_rank_limit, ranks_for(mcap)), "cadence beyond the rank limit");
-        for (int t = 0; t < g; ++t) CHECK(h.stream_mhi[k + t] >= 1 && cap_for(h.stream_mhi[k + t]) == mcap, "mixed slot sizes in a cadence");
+      for (int b = 0; b < B; ++b) {
+        int m = run_m;
+        if (shape == 2) m = (int)(rng() % 17);
+        if (shape == 3) m = rng() % 5 == 0 ? (int)(rng() % 4) : 0;
+        if (shape == 1 && b > 0) m = (int)(rng() % (run_m + 1));
+        h.stream_m[(size_t)k * B + b] = (unsigned char)m;
+        h.stream_own[(size_t)k * B + b] = std::min(h.n[b], 3 + 2 * (int)(rng() % ((h.n_max - 3) / 2 + 1)));
+        h.stream_mhi[k] = std::max(h.stream_mhi[k], m);
       }
-      k += std::max(g, 1);
     }
+    const int pend = h.pending_k;
+    h.pending_k = 0;
+    const bool dirty = h.sizes_dirty;
+    h.sizes_dirty = false;
+    CHECK(cadences_possible(&h) == (h.opt_fused_cadence != 0), "cadences_possible");
+    const int k0 = (int)(rng() % steps), end = k0 + 1 + (int)(rng() % (steps - k0));
+    RunPlan rp;
+    plan_cadences(&h, k0, end, rp);
+    const int slot_limit = cadence_slot_limit(&h), step_limit = cadence_step_limit(&h);
+    CHECK(slot_limit >= 1 && slot_limit <= CAD_SLOTS && step_limit >= 1 && step_limit <= CAD_SLOTS, "limits %d %d", slot_limit, step_limit);
+    CHECK(rp.ncad >= 1 && rp.entries.size() == (size_t)rp.ncad * B && (int)rp.slots_hi.size() == rp.ncad, "plan shape");
+    long most = 0;
+    for (int b = 0; b < B; ++b) {
+      int t = k0, j = 0;                               // the trajectory's cursor
+      long total = 0, done = 0;
+      for (int c = 0; c < rp.ncad; ++c) {
+        const CadPlan& e = rp.entries[(size_t)c * B + b];
+        CHECK(e.t0 == t && e.j0 == j, "cadence %d of trajectory %d starts at (%d, %d), cursor (%d, %d)", c, b, e.t0, e.j0, t, j);
+        CHECK(e.ns >= 0 && e.ns <= step_limit && e.nslots >= 0 && e.nslots <= slot_limit, "cadence of %d steps, %d slots", e.ns, e.nslots);
+        CHECK(e.nslots <= rp.slots_hi[c], "slots_hi");
+        CHECK(e.neff >= 3 && e.neff <= h.n[b], "bound %d of %d", e.neff, h.n[b]);
+        if (e.ns == 0) {
+          CHECK(t == end && e.nslots == 0, "an idle trajectory that is not at the end");
+          continue;
+        }
+        CHECK(t < end, "work behind the end");
+        int slots = 0;
+        for (int p = 0; p < e.ns; ++p) {
+          const int m = h.stream_m[(size_t)(e.t0 + p) * B + b];
+          const int lo = p == 0 ? e.j0 : 0, hi = p == e.ns - 1 ? std::min(e.jend, m) : m;
+          CHECK(e.t0 + p < end && lo <= hi && hi <= m, "step %d of a cadence: landmarks [%d, %d) of %d", p, lo, hi, m);
+          if (p < e.ns - 1) CHECK(hi == m, "a step in the middle of a cadence is cut");
+          slots += hi - lo;
+        }
+        CHECK(slots == e.nslots, "slots %d against %d", slots, e.nslots);
+        const int m_last = h.stream_m[(size_t)(e.t0 + e.ns - 1) * B + b];
+        const bool cut = e.jend < m_last;
+        if (cut) CHECK(e.nslots == slot_limit, "a step is cut although %d of %d slots are free", slot_limit - e.nslots, slot_limit);
+        // greedy: the cadence stops because a limit is reached or the range ends
+        if (!cut && e.t0 + e.ns < end && e.ns < step_limit)
+          CHECK(e.nslots == slot_limit, "cadence stops early: %d of %d slots, %d of %d steps", e.nslots, slot_limit, e.ns, step_limit);
+        done += e.ns - (cut ? 1 : 0);
+        t = e.t0 + e.ns - (cut ? 1 : 0);
+        j = cut ? e.jend : 0;
+        total += slots;
+      }
+      CHECK(t == end && j == 0, "trajectory %d ends at (%d, %d), not at %d", b, t, j, end);
+      long want = 0;
+      for (int k = k0; k < end; ++k) want += h.stream_m[(size_t)k * B + b];
+      CHECK(total == want, "landmark updates %ld of %ld", total, want);
+      most = std::max(most, want);
+    }
+    // as many cadences as the busiest trajectory needs, when only the slots limit them
+    if (step_limit == CAD_SLOTS && most > 0) {
+      long steps_bound = (end - k0 + CAD_SLOTS - 1) / CAD_SLOTS;
+      CHECK(rp.ncad <= std::max((most + slot_limit - 1) / slot_limit, 1L) + steps_bound, "%d cadences for %ld updates", rp.ncad, most);
+    }
+    h.sizes_dirty = dirty;
     h.pending_k = pend;
   }
 }

@@ -335,7 +335,7 @@ def test_host_planning_logic_under_the_sanitizers(tmp_path):
     # the library itself is built from the same header (a stale copy would make this test vacuous)
     api = open(os.path.join(ROOT, "slam-duckietown_amd", "csrc", "ekf_api.hip")).read()
     assert '#include "ekf_host_plan.h"' in api and "struct ekf_handle : ekf::HostPlan" in api
-    for fn in ("plan_pass", "cadence_length", "fill_step", "validate_obs", "build_pass_shares", "order_pass_shares"):
+    for fn in ("plan_pass", "plan_cadences", "cadences_possible", "fill_step", "validate_obs", "build_pass_shares", "order_pass_shares"):
         assert re.search(r"\b%s\(" % fn, api), fn                      # called from the API ...
         assert not re.search(r"^(static|inline)[^\n;]*\b%s\(" % fn, api, flags=re.M), fn   # ... and defined only in the header
 

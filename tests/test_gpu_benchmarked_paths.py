@@ -1,7 +1,7 @@
 """GPU parity of the EXACT kernel instantiations and sizes bench.py runs (BASELINE configs 3, 4, 5), with the path
 asserted (a regression in the cadence / pass planning that silently fell back to other kernels must turn these red):
 
-* N=2000 x 32 trajectories, default options as bench.py sets them: two fused cadences of 5 steps (`k_solve_cad<8>` +
+* N=2000 x 32 trajectories, default options as bench.py sets them: two full fused cadences of 5 steps (`k_solve_cad` +
   `k_panels_cad<8,4>`), each followed by the streaming 80-rank row-slab pass `k_flush_rs<20,true>`, plus a one-step
   tail; dense covariances, against `oracle.ekf_step_structured`;
 * the streaming 80-rank column-strip instantiation `k_flush<15,5,true>` forced at N=300 against the reference-shaped
@@ -58,7 +58,7 @@ def dense_start(n, seed):
 
 def test_config4_shard_n2000_x32_default_cadence(sd):
     """BASELINE config 4's per-GPU shard exactly as bench.py runs it (N=2000, m=8, 32 trajectories, active bound
-    off, default cadence = 5 steps per 80-rank streaming pass): 11 steps = two fused cadences of 5 steps, each with its
+    off, default cadence = 5 steps per 80-rank streaming pass): 11 steps = two full fused cadences of 5 steps, each with its
     `k_flush_rs<20,true>` launch, plus a one-step tail -- asserted, not assumed.  Trajectories 0-2 start from three
     different dense covariances and are compared with the O(n^2) oracle; trajectory b > 2 repeats trajectory b % 3, so
     all 32 are checked -- bit for bit -- against an oracle-checked one, wherever they sit in the launch."""
@@ -82,10 +82,10 @@ def test_config4_shard_n2000_x32_default_cadence(sd):
         f.run_stream(np.stack([s[2] for s in pick], 1), np.stack([s[3] for s in pick], 1),
                      np.stack([s[4] for s in pick], 1), np.stack([s[5] for s in pick], 1),
                      np.stack([s[6] for s in pick], 1))
-        # the path bench.py times: two fused cadences covering 10 steps, the last full pass the row-slab kernel at 20 k-tiles
-        # (the one-step tail is still pending here: its pass runs with the first download below)
+        # the path bench.py times: two full fused cadences covering 10 steps, the last full pass the row-slab kernel at 20
+        # k-tiles (the third cadence -- the one-step tail -- is still pending here: its pass runs with the first download below)
         cad, covered, _, shares = debug_counters(sd, f)
-        assert (cad, covered) == (2, 10)
+        assert (cad, covered) == (3, 11)
         assert f.last_pass() == "ekf::k_flush_rs<20, true, false>" and shares == 0
         got = {}
         for b in range(B):

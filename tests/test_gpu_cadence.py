@@ -1,5 +1,6 @@
-"""GPU parity of the fused cadence (slam-duckietown_amd/csrc/ekf_cadence.hip): uploaded streams run the steps between
-two covariance passes as one solve launch + one panel launch.
+"""GPU parity of the fused cadence (slam-duckietown_amd/csrc/ekf_cadence.hip): uploaded streams run everything between
+two covariance passes as one solve launch + one panel launch.  Round 5: cadences are PACKED -- a trajectory's next 40
+landmark updates whatever steps they belong to (a step may be cut by a pass), every trajectory on its own cursor.
 
 The recurrences are those of the per-step kernels (src/replay_no_ros.py:368-480: motion model, P <- G P G^T + R, per
 landmark H, S, K, mean and covariance update) in a different summation order -- the effect of the cadence's earlier
@@ -38,6 +39,24 @@ def cadences(sd, f):
     return a.value, b.value
 
 
+def cadences_needed(m_col, slots=40, steps_cap=40):
+    """Cadences one trajectory's landmark counts need (the greedy of csrc/ekf_host_plan.h::plan_cadences, restated): whole
+    steps while they fit the slots left, then a cut step fills them."""
+    t, j, c = 0, 0, 0
+    while t < len(m_col):
+        c += 1
+        used = ns = 0
+        while t < len(m_col) and ns < steps_cap:
+            left = int(m_col[t]) - j
+            if used + left <= slots:
+                used, ns, t, j = used + left, ns + 1, t + 1, 0
+                continue
+            if slots - used > 0:
+                j += slots - used
+            break
+    return c
+
+
 def dense_start(n, seed, rank=6):
     rng = np.random.default_rng(seed)
     A = rng.normal(size=(n, rank)) * 0.3
@@ -68,9 +87,12 @@ def stack(streams, i):
 
 
 @pytest.mark.parametrize("N,B,m,steps", [(60, 1, 8, 12), (300, 3, 8, 11), (300, 2, 1, 85), (200, 2, 2, 43),
-                                         (257, 2, 4, 23), (120, 2, 16, 5), (700, 9, 8, 10)])
+                                         (257, 2, 4, 23), (120, 2, 16, 5), (700, 9, 8, 10),
+                                         (150, 2, 3, 30), (150, 2, 5, 17), (100, 2, 6, 14), (100, 1, 7, 12), (120, 2, 9, 9),
+                                         (150, 2, 10, 9), (150, 2, 11, 8), (150, 2, 12, 7), (130, 3, 13, 7), (130, 1, 15, 6)])
 def test_fused_cadence_equals_the_per_step_path_and_the_oracle(sd, N, B, m, steps):
-    """Every rank-slot size (1, 2, 4, 8, 16 landmarks per step), whole cadences plus a tail, dense starting
+    """Every landmark count per step from 1 to 16 that matters (powers of two -- the round-3 slot sizes -- and the counts
+    between them, where 40 slots end inside a step and the pass cuts it), whole cadences plus a tail, dense starting
     covariances, latency and throughput shapes of the panel launch: fused == per-step to PATH_TOL (1e-10 guaranteed by the header, 1e-13 .. 1e-12 measured), == oracle to 1e-9."""
     n = 3 + 2 * N
     streams = [orc.synthetic_stream(N, steps, m, 300 + t) for t in range(B)]
@@ -79,8 +101,7 @@ def test_fused_cadence_equals_the_per_step_path_and_the_oracle(sd, N, B, m, step
     args = (stack(streams, 2), stack(streams, 3), stack(streams, 4), stack(streams, 5), stack(streams, 6))
     fused, (nc, ns) = run_stream(sd, n, B, starts, means, *args, options=[("active_bound", 0)])
     plain, (pc, _) = run_stream(sd, n, B, starts, means, *args, options=[("active_bound", 0), ("fused_cadence", 0)])
-    g = 40 // {1: 1, 2: 2, 4: 4, 8: 8, 16: 16}[m]
-    assert pc == 0 and nc == steps // g + (1 if steps % g >= 2 else 0) and ns >= steps - 1
+    assert pc == 0 and nc == -(-steps * m // 40) and ns == steps      # exactly 2 ranks per landmark update: 40 updates per pass
     for b in range(B):
         assert orc.rel_fro(fused[b][0], plain[b][0]) < PATH_TOL
         assert orc.rel_fro(fused[b][1], plain[b][1]) < PATH_TOL
@@ -142,7 +163,7 @@ def test_ragged_observations_repeated_landmarks_and_empty_steps(sd):
     fused, (nc, ns) = run_stream(sd, n, B, starts, means, lin, ang, idx, zr, zb, m, options=[("active_bound", 0)])
     plain, _ = run_stream(sd, n, B, starts, means, lin, ang, idx, zr, zb, m,
                           options=[("active_bound", 0), ("fused_cadence", 0)])
-    assert nc == 4 and ns == 17                           # 5 + 5 + 5 + 2
+    assert nc == max(cadences_needed(m[:, b]) for b in range(B)) and ns == 17   # every trajectory on its own cursor
     for b in range(B):
         assert orc.rel_fro(fused[b][0], plain[b][0]) < PATH_TOL and orc.rel_fro(fused[b][1], plain[b][1]) < PATH_TOL
         om, oP = means[b].copy(), starts[b].copy()
@@ -187,11 +208,12 @@ def test_block_diagonal_start_with_the_active_bound(sd):
     assert orc.rel_fro(fused[1][0], om) < TIGHT and orc.rel_fro(fused[1][1], oP) < TIGHT
 
 
-@pytest.mark.parametrize("options,expect", [([("rank_limit", 48)], (4, 12)), ([("flush_every", 2)], (6, 12)),
-                                            ([("flush_every", 1)], (0, 0)), ([("rank_limit", 16)], (0, 0))])
+@pytest.mark.parametrize("options,expect", [([("rank_limit", 48)], (5, 13)), ([("flush_every", 2)], (7, 13)),
+                                            ([("flush_every", 1)], (13, 13)), ([("rank_limit", 16)], (13, 13)),
+                                            ([("rank_limit", 22)], (10, 13))])
 def test_cadence_follows_the_pass_cadence_options(sd, options, expect):
-    """`rank_limit` / `flush_every` shorten the cadence (3 and 2 steps here; a one-step cadence is the per-step path);
-    the result does not depend on it beyond rounding."""
+    """`rank_limit` / `flush_every` shorten the cadence (24, 8 or 11 landmark updates -- the last cuts every step --, 2 steps
+    or 1 step here); the result does not depend on it beyond rounding."""
     N, B, steps, m = 150, 2, 13, 8
     n = 3 + 2 * N
     streams = [orc.synthetic_stream(N, steps, m, 700 + t) for t in range(B)]
@@ -209,7 +231,8 @@ def test_cadence_follows_the_pass_cadence_options(sd, options, expect):
                                    dict(enable_measurement_model=False)])
 def test_config_flags_through_the_cadence(sd, flags):
     """The reference's module flags (src/replay_no_ros.py:18-19, :28) through the fused path; with the measurement
-    model off a step observes nothing and no cadence forms (prediction-only steps touch O(n) entries anyway)."""
+    model off a step observes nothing: the 11 predictions are ONE cadence that appends no rank and needs no pass (the
+    panel launch applies the motion noise itself)."""
     N, B, steps, m = 80, 2, 11, 8
     n = 3 + 2 * N
     streams = [orc.synthetic_stream(N, steps, m, 900 + t) for t in range(B)]
@@ -217,7 +240,7 @@ def test_config_flags_through_the_cadence(sd, flags):
     means = [s[0] for s in streams]
     args = (stack(streams, 2), stack(streams, 3), stack(streams, 4), stack(streams, 5), stack(streams, 6))
     got, (nc, _) = run_stream(sd, n, B, starts, means, *args, options=[("active_bound", 0)], cfg=sd.EkfConfig(**flags))
-    assert nc == (0 if "enable_measurement_model" in flags else 2)
+    assert nc == (1 if "enable_measurement_model" in flags else 3)
     ocfg = orc.EkfConfig(**flags)
     for b in range(B):
         s = streams[b]
@@ -280,9 +303,7 @@ def test_lookahead_solve_beside_the_pass(sd, N, B, m, steps):
             f.run_stream(*args)
             res[la] = [f.state(b) for b in range(B)]
             assert [f.flags(b) for b in range(B)] == [0] * B
-            g = 40 // {1: 1, 8: 8, 16: 16}[m]
-            full = steps // g
-            want = (full - 1 + (1 if steps % g >= 2 else 0)) if la else 0      # every cadence but the first is looked ahead
+            want = (-(-steps * m // 40) - 1) if la else 0                     # every cadence but the first is looked ahead
             assert lookaheads(sd, f) == want, (lookaheads(sd, f), want)
     for b in range(B):
         assert orc.rel_fro(res[1][b][0], res[0][b][0]) < PATH_TOL and orc.rel_fro(res[1][b][1], res[0][b][1]) < PATH_TOL
@@ -340,7 +361,7 @@ def test_stream_run_in_pieces_with_flushes_and_downloads_in_between(sd):
     start = dense_start(n, 1501)
     args = (s[2][:, None], s[3][:, None], s[4][:, None], s[5][:, None], s[6][:, None])
     whole, (nc, _) = run_stream(sd, n, B, [start], [s[0]], *args, options=[("active_bound", 0)])
-    assert nc == 8
+    assert nc == 9                                        # 41 steps x 8 landmarks = 8 x 40 + 8
     with sd.EkfSlam(n) as f:
         f.set_option("active_bound", 0)
         f.set_state(s[0], start)
@@ -362,9 +383,9 @@ def test_stream_run_in_pieces_with_flushes_and_downloads_in_between(sd):
 
 
 def test_slot_size_changes_along_the_stream(sd):
-    """The number of observations per step wanders between the rank-slot sizes (1, 2, 4, 8, 16 landmarks): a cadence only
-    takes steps of one size, so fused cadences, per-step kernels on top of pending ranks and passes at odd ranks
-    alternate along the stream.  Against the per-step path and the oracle."""
+    """The number of observations per step wanders (runs of 8, 3, 1, 16, 8, 2, 5 landmarks; the second trajectory anything
+    up to that): until round 4 a cadence only took steps of one rank-slot size and the stream alternated between fused
+    cadences and per-step kernels; packed cadences take everything.  Against the per-step path and the oracle."""
     N, B, steps = 200, 2, 46
     n = 3 + 2 * N
     rng = np.random.default_rng(77)
@@ -398,7 +419,7 @@ def test_slot_size_changes_along_the_stream(sd):
     fused, (nc, ns) = run_stream(sd, n, B, starts, means, lin, ang, idx, zr, zb, m, options=[("active_bound", 0)])
     plain, _ = run_stream(sd, n, B, starts, means, lin, ang, idx, zr, zb, m,
                           options=[("active_bound", 0), ("fused_cadence", 0)])
-    assert nc >= 5 and 10 <= ns < steps                   # cadences formed, and not everywhere
+    assert nc == max(cadences_needed(m[:, b]) for b in range(B)) and ns == steps   # all of it fused, 40 updates per pass
     for b in range(B):
         assert orc.rel_fro(fused[b][0], plain[b][0]) < PATH_TOL and orc.rel_fro(fused[b][1], plain[b][1]) < PATH_TOL
         om, oP = means[b].copy(), starts[b].copy()
@@ -406,6 +427,86 @@ def test_slot_size_changes_along_the_stream(sd):
             mb = m[k, b]
             om, oP = orc.ekf_step_dense(om, oP, lin[k, b], ang[k, b], idx[k, b, :mb], zr[k, b, :mb], zb[k, b, :mb], cfg)
         assert orc.rel_fro(fused[b][0], om) < TIGHT and orc.rel_fro(fused[b][1], oP) < TIGHT
+
+
+def wandering_stream(N, B, steps, counts, seed):
+    """Streams whose landmark count per step and trajectory is counts(k, b, rng), indices scattered (no order, no locality)."""
+    rng = np.random.default_rng(seed)
+    world = [orc.synthetic_world(N, seed + 1 + t) for t in range(B)]
+    cfg = orc.EkfConfig()
+    M = 16
+    lin = np.full((steps, B), 0.004)
+    ang = np.where(np.arange(steps)[:, None] % 7 == 6, 0.005, 0.02) * np.ones((1, B))
+    idx = np.zeros((steps, B, M), dtype=np.int32)
+    zr = np.zeros((steps, B, M))
+    zb = np.zeros((steps, B, M))
+    m = np.zeros((steps, B), dtype=np.int32)
+    pose = [np.zeros(3) for _ in range(B)]
+    for k in range(steps):
+        for b in range(B):
+            pose[b], _ = orc.motion_model(pose[b], lin[k, b], ang[k, b], cfg)
+            mb = int(counts(k, b, rng))
+            vis = rng.choice(N, size=mb, replace=False)
+            d = world[b][1][vis] - pose[b][0:2]
+            cth, sth = np.cos(pose[b][2]), np.sin(pose[b][2])
+            xr = cth * d[:, 0] + sth * d[:, 1] + rng.normal(0, 0.01, mb)
+            yr = -sth * d[:, 0] + cth * d[:, 1] + rng.normal(0, 0.01, mb)
+            m[k, b] = mb
+            idx[k, b, :mb] = vis
+            zr[k, b, :mb] = np.sqrt(xr ** 2 + yr ** 2)
+            zb[k, b, :mb] = np.arctan2(yr, xr)
+    return [w[2] for w in world], lin, ang, idx, zr, zb, m
+
+
+def check_against_per_step_and_oracle(sd, n, B, starts, means, lin, ang, idx, zr, zb, m, fused):
+    plain, _ = run_stream(sd, n, B, starts, means, lin, ang, idx, zr, zb, m, options=[("active_bound", 0), ("fused_cadence", 0)])
+    cfg = orc.EkfConfig()
+    for b in range(B):
+        assert orc.rel_fro(fused[b][0], plain[b][0]) < PATH_TOL and orc.rel_fro(fused[b][1], plain[b][1]) < PATH_TOL
+        assert np.array_equal(fused[b][1], fused[b][1].T)
+        om, oP = means[b].copy(), starts[b].copy()
+        for k in range(len(lin)):
+            mb = m[k, b]
+            om, oP = orc.ekf_step_dense(om, oP, lin[k, b], ang[k, b], idx[k, b, :mb], zr[k, b, :mb], zb[k, b, :mb], cfg)
+        assert orc.rel_fro(fused[b][0], om) < TIGHT and orc.rel_fro(fused[b][1], oP) < TIGHT
+
+
+@pytest.mark.parametrize("N,B,steps,hi", [(150, 4, 60, 8), (150, 3, 40, 16), (90, 1, 70, 3), (600, 12, 30, 8)])
+def test_packed_cadences_with_wandering_landmark_counts(sd, N, B, steps, hi):
+    """What the reference's loop produces (src/replay_no_ros.py:280-301, :436: whatever tags the window saw): per trajectory
+    and step m ~ uniform{0..hi} landmarks at scattered indices.  Every trajectory walks its own packed sequence -- steps cut
+    by a pass, steps that see nothing riding along, trajectories that finish a cadence early idling in the last one -- and
+    the bank needs as many passes as its busiest trajectory at 40 landmark updates per pass.  Against the per-step path
+    and the oracle; all steps fused."""
+    n = 3 + 2 * N
+    means, lin, ang, idx, zr, zb, m = wandering_stream(N, B, steps, lambda k, b, rng: rng.integers(0, hi + 1), 4200 + hi)
+    starts = [dense_start(n, 4300 + t) for t in range(B)]
+    fused, (nc, ns) = run_stream(sd, n, B, starts, means, lin, ang, idx, zr, zb, m, options=[("active_bound", 0)])
+    need = [cadences_needed(m[:, b]) for b in range(B)]
+    assert nc == max(need) and ns == steps
+    assert max(need) <= -(-int(m.sum(axis=0).max()) // 40) + 1     # what the busiest trajectory needs at 40 per pass (+ the tail)
+    check_against_per_step_and_oracle(sd, n, B, starts, means, lin, ang, idx, zr, zb, m, fused)
+
+
+def test_long_runs_without_observations_inside_a_fused_run(sd):
+    """Windows in which no tag is seen (the reference's loop then only predicts, src/replay_no_ros.py:435): 45 such steps at
+    the head of the stream are one cadence of 40 predictions that appends no rank anywhere in the bank -- no pass follows,
+    the panel launch puts the motion noise on the pose diagonal itself -- then observations resume, stop again for 50
+    steps in one trajectory only, and the stream ends on steps that see nothing."""
+    N, B, steps = 80, 2, 130
+
+    def counts(k, b, rng):
+        if k < 45 or k >= 122:
+            return 0
+        if b == 1 and 60 <= k < 110:
+            return 0
+        return rng.integers(1, 6)
+    n = 3 + 2 * N
+    means, lin, ang, idx, zr, zb, m = wandering_stream(N, B, steps, counts, 4400)
+    starts = [dense_start(n, 4500 + t) for t in range(B)]
+    fused, (nc, ns) = run_stream(sd, n, B, starts, means, lin, ang, idx, zr, zb, m, options=[("active_bound", 0)])
+    assert nc == max(cadences_needed(m[:, b]) for b in range(B)) and ns == steps
+    check_against_per_step_and_oracle(sd, n, B, starts, means, lin, ang, idx, zr, zb, m, fused)
 
 
 def test_golden_stream_through_the_cadence(sd):
@@ -424,7 +525,7 @@ def test_golden_stream_through_the_cadence(sd):
 
 def test_config4_shape_n2000_x32_fused_against_per_step(sd):
     """The benchmarked shape (N = 2000, m = 8, 32 trajectories: the throughput form of the panel launch, the row-slab
-    pass behind every cadence): two cadences + a tail against the per-step path."""
+    pass behind every full cadence): two full cadences + one of a single step against the per-step path."""
     N, B, steps, m, K = 2000, 32, 11, 8, 2
     n = 3 + 2 * N
     streams = [orc.synthetic_stream(N, steps, m, 40 + t) for t in range(K)]
@@ -441,7 +542,7 @@ def test_config4_shape_n2000_x32_fused_against_per_step(sd):
             f.run_stream(*args)
             res[fused] = [f.state(b) for b in (0, 1, 30, 31)]
             assert [f.flags(b) for b in range(B)] == [0] * B
-            assert cadences(sd, f) == ((2, 10) if fused else (0, 0))
+            assert cadences(sd, f) == ((3, 11) if fused else (0, 0))
     for a, b in zip(res[1], res[0]):
         assert orc.rel_fro(a[0], b[0]) < PATH_TOL and orc.rel_fro(a[1], b[1]) < PATH_TOL
     assert np.array_equal(res[1][0][1], res[1][2][1]) and np.array_equal(res[1][1][0], res[1][3][0])   # replicas agree bit for bit
