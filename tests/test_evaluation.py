@@ -6,6 +6,8 @@ import pytest
 
 from oracle import ekf_oracle as orc
 
+from tests.conftest import path_ran
+
 
 def test_vicon_alignment_matches_reference_formula():
     """align_vicon == the per-point rotate_around + normalise of scripts/decode_bag_file.py:176-178."""
@@ -110,14 +112,14 @@ def test_nees_statistics():
 
 
 @pytest.mark.gpu
-def test_block_download_and_monte_carlo_nees():
+def test_block_download_and_monte_carlo_nees(both_paths):
     """Pose NEES over a Monte-Carlo bank of 24 trajectories (different noise and maps per trajectory).
     With perfect odometry in the stream and the reference's generous noise constants the filter must
     come out conservative: average NEES below the upper chi-square bound."""
     import slam_duckietown_amd as sd
     import slam_duckietown_amd.evaluation as ev
     import slam_duckietown_amd.synthetic as syn
-    N, steps, B = 40, 30, 24
+    N, steps, B = 36, 30, 24            # (36 landmarks: n = 75, the small-state path by default)
     streams = [syn.synthetic_stream(N, steps, 8, t) for t in range(B)]
     with sd.EkfSlam(3 + 2 * N, batch=B) as f:
         for b, s in enumerate(streams):
@@ -134,16 +136,17 @@ def test_block_download_and_monte_carlo_nees():
         assert avg < hi
         path_err = ev.ate_rmse([f.mean(b)[:2] for b in range(B)], np.tile(truth[:2], (B, 1)))
         assert path_err < 0.05
+        assert path_ran(f, both_paths)
 
 
 @pytest.mark.gpu
-def test_monte_carlo_nees_and_ate_equal_the_oracle_bank():
+def test_monte_carlo_nees_and_ate_equal_the_oracle_bank(both_paths):
     """The same Monte-Carlo bank through the HIP path and through the oracle: per-trajectory NEES, their average and
     the ATE are the oracle's numbers (not merely inside a bound)."""
     import slam_duckietown_amd as sd
     import slam_duckietown_amd.evaluation as ev
     import slam_duckietown_amd.synthetic as syn
-    N, steps, B = 40, 30, 16
+    N, steps, B = 36, 30, 16            # (n = 75: the small-state path by default)
     streams = [syn.synthetic_stream(N, steps, 8, 100 + t) for t in range(B)]
     truth = syn.true_poses(steps)[-1]
     cfg = orc.EkfConfig()
@@ -166,6 +169,7 @@ def test_monte_carlo_nees_and_ate_equal_the_oracle_bank():
                      np.stack([s[6] for s in streams], 1))
         vals, avg, (lo, hi) = ev.pose_nees(f, np.tile(truth, (B, 1)))
         g_xy = [f.mean(b)[:2] for b in range(B)]
+        assert path_ran(f, both_paths)
     assert np.allclose(vals, o_nees, rtol=1e-7, atol=1e-12)
     assert abs(avg - o_nees.mean()) <= 1e-7 * o_nees.mean()
     ate_g, ate_o = ev.ate_rmse(g_xy, np.tile(truth[:2], (B, 1))), ev.ate_rmse(o_xy, np.tile(truth[:2], (B, 1)))
@@ -174,7 +178,7 @@ def test_monte_carlo_nees_and_ate_equal_the_oracle_bank():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("device_association", [False, True])
-def test_vicon_track_ate_on_the_gpu(device_association):
+def test_vicon_track_ate_on_the_gpu(device_association, both_paths):
     """The recorded Vicon track through the shipped GpuBackend (host and device front end): state equal to the
     oracle's on the same windows, ATE against the Vicon truth equal to the oracle's and within a few centimetres."""
     import slam_duckietown_amd.evaluation as ev
@@ -194,6 +198,7 @@ def test_vicon_track_ate_on_the_gpu(device_association):
             be.step(ang, lin, det, ti)
             path.append(np.array(be.pose()[:2]))
         mu, P = be.state()
+        assert path_ran(be.filt, both_paths)
     finally:
         be.close()
     assert ti == oti

@@ -28,7 +28,7 @@ def close(a, b, tol=TIGHT):
     assert r < tol, f"rel Frobenius {r:.3e} exceeds the expected {tol:g}"
 
 
-def test_drop_in_sees_in_place_edits_of_returned_arrays(sd):
+def test_drop_in_sees_in_place_edits_of_returned_arrays(sd, both_paths):
     """The caller owns the arrays EKF_pose_estimation returned and may edit them IN PLACE (a pose reset, a wrapped
     angle, an inflated landmark-landmark entry far from the pose block): the next call must start from the edited
     values like the reference does (src/replay_no_ros.py:229-237 passes them straight back in)."""
@@ -320,7 +320,7 @@ def test_step_detections_beyond_the_device_limits(sd):
         close(P, oP)
 
 
-def test_gpu_backend_device_association_beyond_the_device_limits(sd):
+def test_gpu_backend_device_association_beyond_the_device_limits(sd, both_paths):
     """replay.GpuBackend(device_association=True) against the host-association backend on windows the device
     front end cannot take alone: more than 16 distinct tags in a window, and a map that outgrows the capacity."""
     from slam_duckietown_amd.replay import GpuBackend

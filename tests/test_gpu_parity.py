@@ -9,6 +9,7 @@ import pytest
 
 from oracle import ekf_oracle as orc
 from tests import golden_util as gu
+from tests.conftest import path_ran
 
 pytestmark = pytest.mark.gpu
 
@@ -33,7 +34,7 @@ def close(a, b, tol=TIGHT):
 # golden vectors produced by the reference itself
 # ---------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("case", ["stream_n20_m8", "stream_n20_m1", "stream_n50_m8"])
-def test_stream_golden_every_step(sd, case):
+def test_stream_golden_every_step(sd, case, both_paths):
     g = gu.load(case)
     n = len(g["mean0"])
     kept = {int(s): i for i, s in enumerate(g["out_cov_steps"])}
@@ -44,7 +45,7 @@ def test_stream_golden_every_step(sd, case):
             close(f.mean(), g["out_mean"][k])
             if k in kept:
                 close(f.covariance(), g["out_cov"][kept[k]])
-        assert f.flags() == 0
+        assert f.flags() == 0 and path_ran(f, both_paths)
 
 
 def test_stream_golden_n500(sd):
@@ -67,7 +68,7 @@ def test_stream_golden_n500(sd):
 
 
 @pytest.mark.parametrize("case", gu.REPLAY_CASES)
-def test_drop_in_function_golden(sd, case):
+def test_drop_in_function_golden(sd, case, both_paths):
     """EKF_pose_estimation drop-in: association, gate, averaging, augmentation, flags, wraps."""
     from slam_duckietown_amd import ekf_bindings as eb
     g = gu.load(case)
@@ -87,11 +88,12 @@ def test_drop_in_function_golden(sd, case):
             close(mean, g["out_mean"][k, :n])
             close(cov, g["out_cov"][k, :n, :n])
         assert sorted(tag_index.items(), key=lambda kv: kv[1]) == [tuple(r) for r in g["out_tag_index"]]
+        assert path_ran(eb._drop.filt, both_paths)
     finally:
         eb.DROP_IN_CONFIG = sd.EkfConfig()
 
 
-def test_drop_in_fresh_arrays_are_uploaded(sd):
+def test_drop_in_fresh_arrays_are_uploaded(sd, both_paths):
     """A caller that passes arrays we did not return (or edits them) must not hit the resident state."""
     from slam_duckietown_amd import ekf_bindings as eb
     g = gu.load("replay_default")
@@ -111,9 +113,10 @@ def test_drop_in_fresh_arrays_are_uploaded(sd):
             ocov[0, 0] *= 1.5
         close(mean, omean)
         close(cov, ocov)
+    assert path_ran(eb._drop.filt, both_paths)
 
 
-def test_drop_in_keyerror_like_reference(sd):
+def test_drop_in_keyerror_like_reference(sd, both_paths):
     """A TAG_INDEX larger than the state with no measurement for the new index: KeyError (:359)."""
     from types import SimpleNamespace
     from slam_duckietown_amd import ekf_bindings as eb
@@ -240,7 +243,7 @@ def test_more_than_sixteen_landmarks_in_one_step(sd):
 @pytest.mark.parametrize("flags", [dict(enable_measurement_model=False), dict(disable_motion_model=True),
                                    dict(enable_circular_interpolation=False),
                                    dict(motion_sigma=0.03, meas_sigma=0.2)])
-def test_config_flags(sd, flags):
+def test_config_flags(sd, flags, both_paths):
     N = 30
     mean0, diag0, lin, ang, idx, zr, zb = orc.synthetic_stream(N, 25, 5, 7)
     ang = ang * 30.0            # theta crosses +-pi: wrap (:397) on, no wrap in the linear mode
@@ -252,11 +255,12 @@ def test_config_flags(sd, flags):
             f.step(lin[k], ang[k], idx[k], zr[k], zb[k])
             om, oP = orc.ekf_step_dense(om, oP, lin[k], ang[k], idx[k], zr[k], zb[k], ocfg)
         mu, P = f.state()
+        assert path_ran(f, both_paths)
     close(mu, om)
     close(P, oP)
 
 
-def test_augmentation_matches_reference_growth(sd):
+def test_augmentation_matches_reference_growth(sd, both_paths):
     """add_landmarks == the zero-pad + 1e4 diagonal of :341-360, including cross terms staying zero."""
     rng = np.random.default_rng(3)
     n0 = 3 + 2 * 4
@@ -268,6 +272,8 @@ def test_augmentation_matches_reference_growth(sd):
         f.set_state(mu0, P0)
         f.add_landmarks(xy)
         mu, P = f.state()
+        f.step(0.0, 0.0, [], [], [])                    # (one launch, so that the path shows; the state was read before it)
+        assert path_ran(f, both_paths)
     tp = {4 + i: [xy[i, 0], xy[i, 1]] for i in range(3)}
     om, oP = orc.augment(mu0, P0, 7, tp, orc.EkfConfig())
     assert np.array_equal(mu, om) and np.array_equal(P, oP)
@@ -307,7 +313,7 @@ def test_predict_dense_mfma(sd, n):
     close(P, F @ P0 @ F.T + Q, 1e-12)
 
 
-def test_proto3_surface(sd):
+def test_proto3_surface(sd, both_paths):
     """predict()/update() of src/EKF-SLAM.py:29-84 against vectors from the reference itself."""
     g = gu.load("proto3")
     state = np.array([0.0, 0.0, 0.0])
@@ -319,9 +325,11 @@ def test_proto3_surface(sd):
         state, cov = sd.update(state, cov, tuple(g["observation"][k]), g["landmark"][k])
         assert np.allclose(state, g["upd_state"][k], rtol=1e-9, atol=1e-12)
         close(cov, g["upd_cov"][k])
+    from slam_duckietown_amd import ekf_bindings as eb
+    assert path_ran(eb._proto["update"], both_paths)      # (`predict` is the dense product: no step kernel on either path)
 
 
-def test_q_zero_propagates_nan_and_sets_flag(sd):
+def test_q_zero_propagates_nan_and_sets_flag(sd, both_paths):
     """Landmark exactly at the robot: q = 0 -> NaN like NumPy (:466-469), no trap, sticky flag."""
     mu = np.array([0.0, 0.0, 0.0, 0.0, 0.0])
     with sd.EkfSlam(5) as f:
@@ -329,10 +337,10 @@ def test_q_zero_propagates_nan_and_sets_flag(sd):
         f.update([0], [0.5], [0.1])
         out = f.mean()
         assert not np.isfinite(out).all()
-        assert f.flags() & 1
+        assert f.flags() & 1 and path_ran(f, both_paths)
 
 
-def test_argument_errors(sd):
+def test_argument_errors(sd, both_paths):
     with sd.EkfSlam(3 + 2 * 5) as f:
         f.set_state_diag(np.zeros(13), np.ones(13))
         with pytest.raises(sd.EkfError):
@@ -466,7 +474,7 @@ def test_max_size_n8000_three_steps(sd):
 
 
 @pytest.mark.parametrize("case", gu.REPLAY_CASES)
-def test_device_side_association_golden(sd, case):
+def test_device_side_association_golden(sd, case, both_paths):
     """association, gate, averaging and augmentation on the GPU (`step_detections`)
     against the reference's own outputs: state size, update order, TAG_INDEX, mean and covariance."""
     g = gu.load(case)
@@ -488,10 +496,10 @@ def test_device_side_association_golden(sd, case):
                 close(mu, g["out_mean"][k, :n])
                 close(P, g["out_cov"][k, :n, :n])
         assert sorted(f.tag_index().items(), key=lambda kv: kv[1]) == [tuple(r) for r in g["out_tag_index"]]
-        assert f.flags() == 0
+        assert f.flags() == 0 and path_ran(f, both_paths)
 
 
-def test_device_association_matches_host_association(sd):
+def test_device_association_matches_host_association(sd, both_paths):
     """tags_positions from the device equal the host front end's (ulp-level differences only)."""
     g = gu.load("replay_default")
     ti = {}
@@ -507,16 +515,17 @@ def test_device_association_matches_host_association(sd):
                 assert dev[key][3] == host[key][3]
                 assert np.allclose([dev[key][i] for i in (0, 1, 2, 4, 5)], [host[key][i] for i in (0, 1, 2, 4, 5)],
                                    rtol=1e-13, atol=1e-15)
-        assert f.tag_index() == ti
+        assert f.tag_index() == ti and path_ran(f, both_paths)
 
 
-def test_device_association_overflow_flag(sd):
+def test_device_association_overflow_flag(sd, both_paths):
     from types import SimpleNamespace as NS
     mk = lambda i, x, z: NS(tag_id=i, pose_R=np.eye(3), pose_t=np.array([[x], [0.0], [z]]), pose_err=0.0)
     with sd.EkfSlam(3 + 2 * 2) as f:                    # room for two landmarks only
         f.step_detections(0.01, 0.0, [(0.0, [mk(5, 0.1, 0.5), mk(6, -0.1, 0.6), mk(7, 0.0, 0.7)])])
         assert f.size() == 7 and f.tag_index() == {5: 0, 6: 1}
         assert f.flags() & 2                              # EKF_FLAG_ASSOC: the third tag did not fit
+        assert path_ran(f, both_paths)
 
 
 def test_scattered_landmarks_varying_m(sd):

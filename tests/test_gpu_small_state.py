@@ -2,9 +2,10 @@
 (n_max <= 79: up to 38 landmarks; the reference's real map has 12, src/replay_no_ros.py:26) run every step -- or a whole
 uploaded stream -- inside one workgroup with P resident in LDS.  Same arithmetic as the reference (simple-form update,
 sequential re-linearisation, src/replay_no_ros.py:368-480), so the cases are the reference's own golden vectors: the N = 20
-streams (BASELINE config 1), the whole-function replay fixtures through the drop-in and through the device-side association, the flag
-variants, q = 0, augmentation, banks of trajectories of different size -- each asserted to have taken the small-state kernel.
-(tests/conftest.py pins every OTHER test module to the general kernels.)
+streams (BASELINE config 1) step by step and as one launch, q = 0, augmentation, banks of trajectories of different size,
+the step-and-fetch entry point -- each asserted to have taken the small-state kernel.  (The whole-function replay fixtures
+through the drop-in and through the device-side association, the flag variants, the 3-state surface, the replay driver, the
+node adapter and the Monte-Carlo evaluation run on BOTH paths where they live: the `both_paths` fixture of tests/conftest.py.)
 """
 import ctypes as C
 
@@ -99,57 +100,6 @@ def test_golden_streams_as_one_launch(sd, case):
             out[small] = (mu, P)
     close(out[1][0], out[0][0], 1e-10)
     close(out[1][1], out[0][1], 1e-10)
-
-
-@pytest.mark.parametrize("case", gu.REPLAY_CASES)
-def test_drop_in_function_golden_on_the_small_path(sd, case, monkeypatch):
-    """`EKF_pose_estimation` (the reference's whole function: association, augmentation, step) on the replay fixtures the
-    reference itself produced, all flag variants, with the handle on the small-state path."""
-    from slam_duckietown_amd import ekf_bindings as eb
-    monkeypatch.setenv("EKFSLAM_HIP_SMALL_STATE", "1")
-    g = gu.load(case)
-    monkeypatch.setattr(eb, "DROP_IN_CONFIG", eb.EkfConfig(enable_measurement_model=bool(g["flag_measurement"]),
-                                                           enable_circular_interpolation=bool(g["flag_circular"]),
-                                                           disable_motion_model=bool(g["flag_no_motion"]),
-                                                           ignore_tags=gu.ignore_tags(g)))
-    if eb._drop.filt is not None:
-        eb._drop.filt.close()
-        eb._drop.filt = None
-    mean, cov, ti = np.zeros(3), np.eye(3) * 0.1, {}
-    try:
-        for k in range(len(g["lin"])):
-            mean, cov, tags = sd.EKF_pose_estimation(g["ang"][k], g["lin"][k], mean, cov, 0.7, gu.detections_for_step(g, k), ti)
-            n = int(g["out_size"][k])
-            assert len(mean) == n
-            close(mean, g["out_mean"][k, :n])
-            close(cov, g["out_cov"][k, :n, :n])
-            assert list(tags.keys()) == [i for i in g["out_obs_order"][k] if i >= 0]
-        assert small_launches(sd, eb._drop.filt) >= len(g["lin"]) - 2    # (the handle is re-created when the map outgrows it)
-    finally:
-        if eb._drop.filt is not None:
-            eb._drop.filt.close()
-            eb._drop.filt = None
-
-
-@pytest.mark.parametrize("case", gu.REPLAY_CASES)
-def test_device_side_association_golden_on_the_small_path(sd, case):
-    """The whole front end on the GPU (k_associate: association, gate, averaging, augmentation) feeding the small-state kernel."""
-    g = gu.load(case)
-    cfg = sd.EkfConfig(enable_measurement_model=bool(g["flag_measurement"]), enable_circular_interpolation=bool(g["flag_circular"]),
-                       disable_motion_model=bool(g["flag_no_motion"]))
-    with sd.EkfSlam(3 + 2 * 12, config=cfg) as f:
-        f.set_option("small_state", 1)
-        if gu.ignore_tags(g):
-            f.set_association(1.5, gu.ignore_tags(g))
-        for k in range(len(g["lin"])):
-            f.step_detections(g["lin"][k], g["ang"][k], gu.detections_for_step(g, k))
-            n = int(g["out_size"][k])
-            mu, P = f.state()
-            assert len(mu) == n
-            close(mu, g["out_mean"][k, :n])
-            close(P, g["out_cov"][k, :n, :n])
-        assert sorted(f.tag_index().items(), key=lambda kv: kv[1]) == [tuple(r) for r in g["out_tag_index"]]
-        assert f.flags() == 0 and small_launches(sd, f) == len(g["lin"])
 
 
 def test_bank_of_small_filters_of_different_size_against_the_oracle(sd):

@@ -86,7 +86,7 @@ def test_adapter_sequencing_cpu(persistent):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("device_association", [False, True])
-def test_adapter_on_gpu(device_association):
+def test_adapter_on_gpu(device_association, both_paths):
     from slam_duckietown_amd.node_adapter import EkfNodeAdapter
     msgs = script(seed=5)
     ref_poses, ref_mu, ref_S = restated_node(msgs, True)
@@ -94,6 +94,8 @@ def test_adapter_on_gpu(device_association):
     try:
         poses = drive(ad, msgs)
         mu, S = ad.state()
+        from tests.conftest import path_ran
+        assert path_ran(ad.backend.filt, both_paths)
     finally:
         ad.close()
     for p, r in zip(poses, ref_poses):

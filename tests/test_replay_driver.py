@@ -9,6 +9,7 @@ from types import SimpleNamespace
 
 from oracle import ekf_oracle as orc
 from tests import golden_util as gu
+from tests.conftest import path_ran
 
 
 class OracleBackend:
@@ -150,7 +151,7 @@ def test_god_mode_matches_reference_cpu():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("device_association", [False, True])
-def test_god_mode_matches_reference_gpu(device_association):
+def test_god_mode_matches_reference_gpu(device_association, both_paths):
     """The god-mode log through the shipped GpuBackend: host association, and the whole front end on the GPU (the
     pre-filled TAG_INDEX goes to the device table)."""
     import slam_duckietown_amd.replay as rp
@@ -159,13 +160,14 @@ def test_god_mode_matches_reference_gpu(device_association):
     be = rp.GpuBackend(capacity=3 + 2 * 16, device_association=device_association)
     try:
         res = rp.replay(str(g["events_csv"]).splitlines(), backend=be, detector=detect, god_key=key)
+        assert path_ran(be.filt, both_paths)
     finally:
         be.close()
     check_against_reference_loop(res, merged, seen, 1e-9)
 
 
 @pytest.mark.gpu
-def test_replay_loop_matches_reference_gpu():
+def test_replay_loop_matches_reference_gpu(both_paths):
     import slam_duckietown_amd.replay as rp
     g = gu.load("replay_events")
     detect, seen = fixture_detector(g)
@@ -174,7 +176,7 @@ def test_replay_loop_matches_reference_gpu():
 
 
 @pytest.mark.gpu
-def test_fast_mode_matches_reference_gpu():
+def test_fast_mode_matches_reference_gpu(both_paths):
     import slam_duckietown_amd.replay as rp
     g, gf = gu.load("replay_events"), gu.load("replay_events_fast")
     detect, seen = fixture_detector(g)
@@ -185,7 +187,7 @@ def test_fast_mode_matches_reference_gpu():
 
 
 @pytest.mark.gpu
-def test_replay_loop_with_device_association_gpu():
+def test_replay_loop_with_device_association_gpu(both_paths):
     """The same log with the whole front end on the GPU (GpuBackend(device_association=True))."""
     import slam_duckietown_amd.replay as rp
     g = gu.load("replay_events")
@@ -193,6 +195,7 @@ def test_replay_loop_with_device_association_gpu():
     be = rp.GpuBackend(capacity=3 + 2 * 16, device_association=True)
     try:
         res = rp.replay(str(g["events_csv"]).splitlines(), backend=be, detector=detect)
+        assert path_ran(be.filt, both_paths)
     finally:
         be.close()
     check_against_reference_loop(res, g, seen, 1e-9)
@@ -201,11 +204,10 @@ def test_replay_loop_with_device_association_gpu():
 @pytest.mark.gpu
 @pytest.mark.parametrize("device_association", [False, True])
 def test_replay_loop_on_the_small_state_path_gpu(device_association, monkeypatch):
-    """The reference's loop at its real map size on the path it takes by default outside this test suite (tests/conftest.py
-    pins the general kernels): GpuBackend's first handle holds 38 landmarks, so every window is ONE launch of the small-state
-    kernel, and with the host association the state comes back with the step (ekf_step_fetch: pose() and state() answer from
-    what it brought).  Same fixture -- the reference's own replay() -- same bar."""
-    import ctypes as C
+    """The reference's loop at its real map size on the path it takes by default: GpuBackend's first handle holds 38
+    landmarks, so every window is ONE launch of the small-state kernel, and with the host association the state comes back
+    with the step (ekf_step_fetch: pose() and state() answer from what it brought) -- launches and fetches counted.  Same
+    fixture -- the reference's own replay() -- same bar."""
     import slam_duckietown_amd as sd
     import slam_duckietown_amd.replay as rp
     monkeypatch.setenv("EKFSLAM_HIP_SMALL_STATE", "1")
@@ -216,8 +218,6 @@ def test_replay_loop_on_the_small_state_path_gpu(device_association, monkeypatch
         assert be.filt.n_max == 79
         res = rp.replay(str(g["events_csv"]).splitlines(), backend=be, detector=detect)
         lib = sd.load_library()
-        for fn in (lib.ekf_debug_small_launches, lib.ekf_debug_fused_fetches):
-            fn.argtypes, fn.restype = [C.c_void_p], C.c_long
         W = len(g["out_size"])
         assert lib.ekf_debug_small_launches(be.filt._h) >= W
         assert lib.ekf_debug_fused_fetches(be.filt._h) == (0 if device_association else W)
