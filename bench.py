@@ -27,7 +27,11 @@ The JSON line also carries
                 src/replay_no_ros.py:229-237) and, beyond 131 x 131, the upload of the upper triangle: N = 12 (the
                 reference's real map, :26), 20, 500, 2000: ms per call
   steady_state  the headline workload timed behind a full sweep of the landmarks (dense covariance: fp64 MFMA power, and the
-                clock the part holds, depend on the operands -- ~9 % slower than the young filter the contract times)
+                clock the part holds, depend on the operands -- ~9 % slower than the young filter the contract times);
+                `roofline.frac_steady_state` / `avg_launch_ms_steady_state` / `value_steady_state` repeat it beside the headline
+  obs_5, obs_12, variable_m, constant_m4   the shapes the reference's loop produces (src/replay_no_ros.py:280-301, :436): landmark
+                counts that are no power of two, and m ~ uniform{0..8} per trajectory and step at scattered indices (beside a
+                constant m = 4, the same mean): steps/s, landmark updates/s, passes per step, fused fraction
   sclk_mhz      shader clock sampled during the headline's timed region
   `--leg NAME` runs one secondary leg alone and prints it.
   (rank 0, N = 1 only, except sclk_mhz and rank_dt_ms).
@@ -482,8 +486,12 @@ def secondary_leg(name, args):
         return {name: observation_shape_leg(sd, sd_syn, shard, grp, dev, traj_ids, args.landmarks, 240, 40, args.option, m=mo)}
     if name == "variable_m":
         # m ~ uniform{0..8}: mean 4 landmarks per step -- compare with `constant_m4` (the same mean rank count)
-        return {name: observation_shape_leg(sd, sd_syn, shard, grp, dev, traj_ids, args.landmarks, 240, 40, args.option,
-                                            variable=(0, 8))}
+        leg = observation_shape_leg(sd, sd_syn, shard, grp, dev, traj_ids, args.landmarks, 240, 40, args.option, variable=(0, 8))
+        # ... and what SURVEY 8 calls the real data's shape, 0 - 3 tags per window, one trajectory (until round 4 such a stream
+        # never formed a fused cadence)
+        leg["x1_m0to3"] = observation_shape_leg(sd, sd_syn, shard, grp, dev, [0], args.landmarks, 600, 60, args.option,
+                                                variable=(0, 3))
+        return {name: leg}
     if name == "config5":
         return {name: config5_leg(sd, sd_syn, shard, grp, dev, args.obs)}
     if name == "steady_state":
@@ -588,6 +596,7 @@ def main():
                                                 args.steps, args.warmup, options=args.option, clock=clk)
     value = shard.aggregate_steps_per_second(len(traj_ids) * args.steps, grp, dt)
     rank_dts = grp.gather_over_ranks(getattr(shard.timed_region, "last_local_seconds", dt))
+    rank_dev_ms = grp.gather_over_ranks(dev_ms / args.steps)
 
     out = None
     if rank == 0:
@@ -598,8 +607,7 @@ def main():
         avg_s = (pass_ms / max(launches, 1)) * 1e-3
         achieved = alg_bytes / avg_s / 1e9 if avg_s > 0 else 0.0
         steps_per_launch = args.steps / max(launches, 1)
-        mcap = next(c for c in (1, 2, 4, 8, 16) if c >= min(args.obs, 16))   # rank slots a step takes: 2 per landmark,
-        ranks = steps_per_launch * 2 * mcap                                   # landmark count rounded up to 1/2/4/8/16
+        ranks = steps_per_launch * 2 * args.obs                               # exactly 2 ranks per landmark update (packed cadences)
         out = {
             "metric": "EKF update steps/sec", "value": value, "unit": "steps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -630,8 +638,10 @@ def main():
                                  "(0.65 ms alone) and the memory side (0.68 ms alone, 6.05 TB/s) of the row-slab pass are balanced "
                                  "(DESIGN.md section 4), see `mfma`"},
             "device_ms_per_step": dev_ms / args.steps,
-            # every rank's own elapsed time of the timed region (value uses their maximum): dispatch skew is visible
+            # every rank's own elapsed time of the timed region (value uses their maximum) beside its own DEVICE time per step
+            # (HIP events on the handle's stream): host dispatch skew and device time can be told apart from one line
             "rank_dt_ms": [x * 1e3 for x in rank_dts],
+            "rank_device_ms_per_step": list(rank_dev_ms),
             # the shader clock while the timed region ran (sampled every 2 ms from a host thread)
             "sclk_mhz": clk.summary(),
         }
@@ -647,6 +657,14 @@ def main():
             # profiles/r04_dense_operands.txt part 2.  `--leg NAME` runs one leg in a process of its own.)
             for name in SECONDARY_LEGS:
                 out.update(secondary_leg(name, args))
+            # the same pass on a dense covariance (the `steady_state` leg): what a long-running filter sees; `frac` above is the
+            # young filter the contract's protocol times (most of V / W still exact zeros)
+            ss = out.get("steady_state", {})
+            if ss.get("pass_avg_launch_ms"):
+                out["roofline"]["avg_launch_ms_steady_state"] = ss["pass_avg_launch_ms"]
+                out["roofline"]["frac_steady_state"] = ss["pass_frac_of_hbm_peak"]
+                out["roofline"]["achieved_steady_state"] = ss["pass_frac_of_hbm_peak"] * HBM_PEAK_GBS
+                out["value_steady_state"] = ss["value"]
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.landmarks, args.obs)
     if rank == 0:

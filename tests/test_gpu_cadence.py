@@ -475,13 +475,13 @@ def check_against_per_step_and_oracle(sd, n, B, starts, means, lin, ang, idx, zr
         assert orc.rel_fro(fused[b][0], om) < TIGHT and orc.rel_fro(fused[b][1], oP) < TIGHT
 
 
-@pytest.mark.parametrize("N,B,steps,hi", [(150, 4, 60, 8), (150, 3, 40, 16), (90, 1, 70, 3), (600, 12, 30, 8), (1400, 24, 14, 8)])
+@pytest.mark.parametrize("N,B,steps,hi", [(150, 4, 60, 8), (150, 3, 40, 16), (90, 1, 70, 3), (600, 30, 20, 8), (1400, 24, 14, 8)])
 def test_packed_cadences_with_wandering_landmark_counts(sd, N, B, steps, hi):
     """What the reference's loop produces (src/replay_no_ros.py:280-301, :436: whatever tags the window saw): per trajectory
     and step m ~ uniform{0..hi} landmarks at scattered indices.  Every trajectory walks its own packed sequence -- steps cut
     by a pass, steps that see nothing riding along, trajectories that finish a cadence early idling in the last one -- and
     the bank needs as many passes as its busiest trajectory at 40 landmark updates per pass.  Against the per-step path
-    and the oracle; all steps fused.  (N = 600 x 12 and N = 1400 x 24: the one-wave and the throughput shape of the panel
+    and the oracle; all steps fused.  (N = 600 x 30 and N = 1400 x 24: the one-wave and the throughput shape of the panel
     launch; there the oracle checks two trajectories, the per-step path all.)"""
     n = 3 + 2 * N
     means, lin, ang, idx, zr, zb, m = wandering_stream(N, B, steps, lambda k, b, rng: rng.integers(0, hi + 1), 4200 + hi)
