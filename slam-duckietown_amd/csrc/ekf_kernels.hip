@@ -1588,9 +1588,6 @@ __global__ __launch_bounds__(256, 2) void k_flush(double* __restrict__ P, const 
     const int lin = blockIdx.x;
     const int q = total >> 3, r = total & 7, xcd = lin & 7, slot = lin >> 3;
     int rem = ((xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
-#ifdef FLUSH_XCD_PROBE                                   /* probe builds: 1 = no remap (every 8th workgroup of the enumeration per XCD) */
-    if (FLUSH_XCD_PROBE == 1) rem = lin;
-#endif
     for (;; ++by) {
       const int cnt = gx - (by * rows_per_block) / 256;
       if (rem < cnt || cnt <= 0) break;
@@ -1808,11 +1805,7 @@ __global__ __launch_bounds__(512, 2) void k_flush_rs(double* __restrict__ P, con
                                                      const int* __restrict__ nact,
                                                      const SolveOut* __restrict__ so, int ld, long pstride,
                                                      int nkt, int batch, int nrb, int nch, int cs_arg, int mode,
-                                                     unsigned* __restrict__ queue, const int* __restrict__ shares
-#ifdef RS_COLBUF                                         /* experiment: RS_COLBUF columns of every tile copied out coalesced */
-                                                     , double* __restrict__ colbuf
-#endif
-                                                     ) {
+                                                     unsigned* __restrict__ queue, const int* __restrict__ shares) {
   constexpr int RPW = NKT / 2;                         // ranks of a V strip each of the 8 waves stages
   __shared__ __attribute__((aligned(16))) double vbuf[2][NKT * 256];   // V strip as B fragments: [k-tile][col tile][lane]
   __shared__ __attribute__((aligned(16))) double img[8][16 * 64];      // per wave: 16 x 64 tile image (swizzled)
@@ -2035,13 +2028,8 @@ __global__ __launch_bounds__(512, 2) void k_flush_rs(double* __restrict__ P, con
       constexpr int OVA = 0, OW0 = OVA + NV, OE1A = OW0 + NE, OE2A = OE1A + NE, OE1B = OE2A + NE, OE2B = OE1B + NE,
                     OVB = OE2B + NE, ON1 = OVB + NV, ON2 = ON1 + 8, OWB = ON2 + 16, ON3 = OWB + NV, NSIDE = ON3 + 8;
 #else
-#ifdef RS_COLBUF
-      constexpr int NC = FIRST ? 0 : RS_COLBUF;
-#else
-      constexpr int NC = 0;
-#endif
       constexpr int OVA = 0, OW0 = OVA + NV, OE1A = OW0 + NE, OE2A = OE1A + NE, OE1B = OE2A + NE, OE2B = OE1B + NE,
-                    OC = OE2B + NE, OVB = OC + NC, ON1 = OVB + NV, ON3 = ON1 + 8, ON2 = ON3 + 8, OWB = ON2 + 16, NSIDE = OWB + NV;
+                    OC = OE2B + NE, OVB = OC, ON1 = OVB + NV, ON3 = ON1 + 8, ON2 = ON3 + 8, OWB = ON2 + 16, NSIDE = OWB + NV;
 #endif
       const __amdgpu_buffer_rsrc_t rsP = rs_rsrc(Pb);
       const unsigned off_prev = tile_off(t - 1);       // tile t-1 (FIRST: unused)
@@ -2074,19 +2062,6 @@ __global__ __launch_bounds__(512, 2) void k_flush_rs(double* __restrict__ P, con
           if (o >= OE2A && o < OE1B) stb16<NT>(rsP, loff, off_prev + (unsigned)(o - OE2A) * 2u * pl8, r[o - OE2A]);
           if (o >= OE1B && o < OE2B) r[o - OE1B] = *reinterpret_cast<const double2*>(&T[rm_base + 128 * (o - OE1B + 4)]);
           if (o >= OE2B && o < OC) stb16<NT>(rsP, loff, off_prev + (unsigned)(o - OE2B + 4) * 2u * pl8, r[o - OE2B]);
-#ifdef RS_COLBUF
-          if (o >= OC && o < OC + NC) {                // experiment: one column of the tile (still in the image) -> colbuf, 16 lanes x 8 bytes
-            const int sl = o - OC;
-            const int sidx = (j_last - 64 * (t - 1)) >> 6;                // (uniform) the strip of tile t-1
-            const bool want = sl == 0 || (sidx % 3) == 0;                  // synthetic plan: 1.33 wanted columns per strip
-            const int col = (sidx * 7 + 13 * sl) & 63, slot = (sidx * 2 + sl) % 80;
-            const double v = T[(lane & 15) * 64 + (col ^ ((lane & 1) << 4))];
-            const unsigned vo = (want && lane < 16) ? (unsigned)(i0w + lane) * 8u : 0xfffffff0u;
-            const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc(colbuf + (long)b * 84 * ld, 0, 84 * ld * 8, 0x00020000);
-            const uint2v_t d = __builtin_bit_cast(uint2v_t, v);
-            __builtin_amdgcn_raw_buffer_store_b64(d, rsC, (int)vo, (int)((unsigned)slot * ld8), 0);
-          }
-#endif
         }
         if (o >= ON1 && o < ON1 + 8) {                 // tile t+1: row-major registers -> image
           const int q = o - ON1;
@@ -2537,17 +2512,10 @@ template <int NKT, bool NT, bool PAN>
 static void launch_flush_rs_t(hipStream_t st, double* P, const double* V, const double* W, const double* dacc,
                               const int* nact, const SolveOut* so, int ld, long pstride, int batch, int n_hi, int nkt,
                               int workgroups, unsigned* queue, int chunk, const int* shares) {
-#ifdef RS_COLBUF
-  static double* colbuf = nullptr;                     // (experiment only: one scratch buffer for the process)
-  if (!colbuf) (void)hipMalloc(&colbuf, sizeof(double) * 84 * (size_t)ld * batch);
-#define RS_CB_ARG , colbuf
-#else
-#define RS_CB_ARG
-#endif
   const int nrb = (n_hi + RS_ROWS - 1) / RS_ROWS;
   if (shares) {                                        // equal static shares (mode 4): one per workgroup
     hipLaunchKernelGGL((k_flush_rs<NKT, NT, PAN>), dim3((unsigned)workgroups), dim3(512), 0, st, P, V, W, dacc, nact, so, ld,
-                       pstride, nkt, batch, nrb, 1, 0, 4, queue, shares RS_CB_ARG);
+                       pstride, nkt, batch, nrb, 1, 0, 4, queue, shares);
     return;
   }
   // Units (see the three modes at k_flush_rs's `pop`).  With an even number of trajectories per queue whole slabs taken
@@ -2588,8 +2556,7 @@ static void launch_flush_rs_t(hipStream_t st, double* P, const double* V, const 
   }
   const long units = (long)nrb * (mode == 0 ? nch : mode == 3 ? 2 : 1) * batch;   // (modes 1, 2: at least; only the grid size depends on it)
   hipLaunchKernelGGL((k_flush_rs<NKT, NT, PAN>), dim3((unsigned)std::min<long>(workgroups, units)), dim3(512), 0, st, P, V, W,
-                     dacc, nact, so, ld, pstride, nkt, batch, nrb, nch, cs, mode, queue, nullptr RS_CB_ARG);
-#undef RS_CB_ARG
+                     dacc, nact, so, ld, pstride, nkt, batch, nrb, nch, cs, mode, queue, nullptr);
 }
 
 void launch_flush_rs(hipStream_t st, bool streaming, double* P, const double* V, const double* W, const double* dacc,
