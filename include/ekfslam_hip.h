@@ -188,7 +188,11 @@ int ekf_profile_read(ekf_handle *h, double *pass_ms_total, long long *pass_launc
  * general kernels; the default can be set for new handles with the environment variable EKFSLAM_HIP_SMALL_STATE),
  * "zero_copy_inputs" (1 = the small-state kernel reads an online step's record straight from the pinned input ring, 0 = a
  * staged copy first), "fetch_spin" (1 = ekf_step_fetch on the small-state path polls the sequence word its launch releases
- * behind the state it wrote to pinned memory, 0 = it waits for the stream; same results), "pack_dense" (downloads of a whole
+ * behind the state it wrote to pinned memory, 0 = it waits for the stream; same results.  The polled hand-over assumes that
+ * the kernel's posted writes to coherent pinned memory become visible in fence -> release order -- validated on MI355X;
+ * every hand-over carries a second copy of its sequence number written by another wave, compared before the data is
+ * trusted, and "fetch_verify" = 1 also compares an XOR checksum of the whole payload; a mismatch waits for the stream
+ * instead and is counted, ekf_debug_fetch_retries), "pack_dense" (downloads of a whole
  * state into PINNED host memory, e.g. from ekf_host_alloc: 1 = up to 40 MB a kernel mirrors the stored triangle straight into
  * the destination, no mirror pass and no copy engine; 2 = at every size; 0 = never: mirror pass + rectangle copy; same bytes);
  * unknown names fail.
@@ -213,6 +217,9 @@ int ekf_debug_last_pass_shares(ekf_handle *h);
 long ekf_debug_small_launches(ekf_handle *h);
 long ekf_debug_fused_fetches(ekf_handle *h);
 long ekf_debug_dense_packs(ekf_handle *h);
+/* ekf_step_fetch hand-overs whose integrity trailer did not match what the host polled (answered after a stream
+ * synchronisation instead): 0 on a platform where the ordering assumption of the polled hand-over holds. */
+long ekf_debug_fetch_retries(ekf_handle *h);
 /* Raw device views behind a stream synchronisation, no flush: the fused cadence's record of trajectory b (returns its
  * size; copies min(bytes, size)); `which` = 0 P_base (allocated doubles), 1 V, 2 W, 3 the pending pose noise, 4 the mean the
  * next step reads (dst == NULL: the count); the words behind the row-slab pass's queue heads

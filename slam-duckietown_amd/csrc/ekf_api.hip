@@ -160,6 +160,8 @@ struct ekf_handle : ekf::HostPlan {
   bool fetched = false;
   unsigned long long fetch_seq = 0;   // ... and the sequence number that launch releases behind it (polled by the host)
   int opt_fetch_spin = 1;
+  int opt_fetch_verify = 0;       // 1 = ekf_step_fetch also checks the payload's XOR checksum before it trusts a polled hand-over
+  long fetch_retries = 0;         // statistics: hand-overs whose integrity trailer did not match (answered after a stream sync)
   int opt_zero_copy_inputs = 1;   // small-state online steps read their records from the pinned ring (no staged copy)
   int last_kernel = -1, last_nkt = 0, last_streaming = 0;   // what the last covariance pass launched
   int last_shares = 0;            // ... and whether it ran on equal static shares (k_flush_rs, a few long trajectories)
@@ -545,7 +547,9 @@ extern "C" int ekf_upload_state_diag(ekf_handle* h, int b, const double* mu, con
 
 // The pinned buffer small states come back through (k_pack_small, k_small_stream's host_out): n x n covariance, mean, flags;
 // its last word is the sequence number ekf_step_fetch polls.
-constexpr size_t PACK_WORDS = (size_t)PACK_SMALL_N * PACK_SMALL_N + PACK_SMALL_N + 2;
+// (covariance, mean, flags word; behind them the integrity trailer of ekf_step_fetch -- sequence number, XOR checksum --
+//  and, at a fixed place at the end, the sequence word the host polls)
+constexpr size_t PACK_WORDS = (size_t)PACK_SMALL_N * PACK_SMALL_N + PACK_SMALL_N + 4;
 static int pack_buffer(ekf_handle* h) {
   if (h->h_pack) return EKF_OK;
   HIP_TRY(h, hipHostMalloc(&h->h_pack, sizeof(double) * PACK_WORDS, hipHostMallocCoherent));
@@ -1182,6 +1186,22 @@ extern "C" int ekf_step_fetch(ekf_handle* h, const double* lin, const double* an
       }
       __builtin_ia32_pause();
     }
+    // Integrity: the host has seen the flag word while the launch is still running; that the payload is complete
+    // rests on the ordering of the kernel's posted writes (see k_small_stream).  Tripwire: the trailer's copy of the sequence
+    // number, written by another wave; with "fetch_verify" also the XOR checksum over the whole payload.  A mismatch falls
+    // back to waiting for the launch -- after which every write is visible -- and is counted.
+    const unsigned long long* trailer = reinterpret_cast<const unsigned long long*>(h->h_pack) + (size_t)n * n + n + 1;
+    bool good = __atomic_load_n(trailer, __ATOMIC_ACQUIRE) == h->fetch_seq;
+    if (good && h->opt_fetch_verify) {
+      const unsigned long long* w = reinterpret_cast<const unsigned long long*>(h->h_pack);
+      unsigned long long x = 0ull;
+      for (size_t i = 0; i < (size_t)n * n + n + 1; ++i) x ^= w[i];
+      good = x == trailer[1];
+    }
+    if (!good) {
+      h->fetch_retries += 1;
+      HIP_TRY(h, hipStreamSynchronize(h->stream));
+    }
   } else {
     HIP_TRY(h, hipStreamSynchronize(h->stream));
   }
@@ -1439,6 +1459,7 @@ extern "C" long ekf_debug_lookaheads(ekf_handle* h) { return h ? h->lookaheads :
 extern "C" long ekf_debug_small_launches(ekf_handle* h) { return h ? h->small_launches : -1; }
 extern "C" long ekf_debug_fused_fetches(ekf_handle* h) { return h ? h->fused_fetches : -1; }
 extern "C" long ekf_debug_dense_packs(ekf_handle* h) { return h ? h->dense_packs : -1; }
+extern "C" long ekf_debug_fetch_retries(ekf_handle* h) { return h ? h->fetch_retries : -1; }
 
 // (diagnostics section of the header) the fused cadence's record of trajectory b (head + per-landmark records)
 extern "C" long ekf_debug_cad(ekf_handle* h, int b, void* dst, long bytes) {
@@ -1523,6 +1544,11 @@ extern "C" int ekf_set_option(ekf_handle* h, const char* name, int value) {
   if (!std::strcmp(name, "pack_dense")) {
     if (value < 0 || value > 2) return fail(h, EKF_ERR_ARG, "pack_dense must be 0, 1 or 2");
     h->opt_pack_dense = value;
+    return EKF_OK;
+  }
+  if (!std::strcmp(name, "fetch_verify")) {
+    if (value != 0 && value != 1) return fail(h, EKF_ERR_ARG, "fetch_verify must be 0 or 1");
+    h->opt_fetch_verify = value;
     return EKF_OK;
   }
   if (!std::strcmp(name, "fetch_spin")) {

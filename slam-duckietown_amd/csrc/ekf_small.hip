@@ -18,6 +18,7 @@
 // trajectory: 9.8 us per step against 18 - 19 us on the general path; a bank of small filters is one workgroup each.
 // No rank is ever pending on this path (pending_k stays 0), so every other entry point -- uploads, downloads, augmentation,
 // device-side association, the dense product -- works on P_base as it stands.
+#include <atomic>
 #include "ekf_devfn.h"
 
 namespace ekf {
@@ -282,14 +283,41 @@ __device__ __forceinline__ void small_stream_body(double* __restrict__ P, const 
   if (host_out && b == out_b) {
     // ekf_step_fetch: the state the caller asked for goes straight from LDS into pinned host memory, in k_pack_small's
     // layout (dense mirrored n x n covariance, mean, sticky flags) -- no second launch between the step and the host
+    unsigned long long sum = 0ull;                      // XOR of the bit patterns this thread hands over
     for (int e = tid; e < n * n; e += NT) {
       const int r = e / n, c = e - r * n;
-      host_out[e] = Pl[r * ps + c];
+      const double v = Pl[r * ps + c];
+      host_out[e] = v;
+      sum ^= __builtin_bit_cast(unsigned long long, v);
     }
-    for (int c = tid; c < n; c += NT) host_out[n * n + c] = mu[c];
-    if (tid == 0) host_out[n * n + n] = (double)(atomicOr(flags + b, 0u) | (any_bad ? EKF_FLAG_NONFINITE : 0u));
+    for (int c = tid; c < n; c += NT) {
+      host_out[n * n + c] = mu[c];
+      sum ^= __builtin_bit_cast(unsigned long long, mu[c]);
+    }
+    if (tid == 0) {
+      const double fl = (double)(atomicOr(flags + b, 0u) | (any_bad ? EKF_FLAG_NONFINITE : 0u));
+      host_out[n * n + n] = fl;
+      sum ^= __builtin_bit_cast(unsigned long long, fl);
+    }
+    // Integrity trailer behind the payload: the call's sequence number, written by the LAST thread (another wave than the
+    // one that releases the flag word), and the XOR of every word of the payload (wave reduction, then one atomic per wave
+    // into LDS).  The host compares the first always and the second when asked to ("fetch_verify"): see ekf_step_fetch.
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum ^= __shfl_xor(sum, o);
+    __shared__ unsigned long long xsum;
+    if (tid == 0) xsum = 0ull;
+    __syncthreads();
+    if ((tid & 63) == 0) atomicXor(&xsum, sum);
+    __syncthreads();
+    if (tid == NT - 1) {
+      reinterpret_cast<unsigned long long*>(host_out)[n * n + n + 1] = out_seq;
+      reinterpret_cast<unsigned long long*>(host_out)[n * n + n + 2] = xsum;
+    }
     // the host does not wait for the launch to retire (completion signal, interrupt or poll of the runtime: 10 - 15 us) but
-    // polls this word: every thread's stores are fenced to system scope, then the call's sequence number is released
+    // polls this word: every thread's stores are fenced to system scope, then the call's sequence number is released.
+    // ASSUMPTION (validated on the MI355X boxes of this pool): posted writes of one kernel to
+    // coherent pinned host memory become visible in the order fence -> release, i.e. PCIe relaxed ordering does not let the
+    // flag word overtake the payload.  The trailer above is the tripwire for a platform where that does not hold.
     __threadfence_system();
     __syncthreads();
     if (tid == 0)
@@ -346,14 +374,14 @@ int launch_small_stream(hipStream_t st, double* P, const double* mu_in, double* 
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 1;
 #define EKF_SMALL_BIG(K, TM)                                                                                             \
   do {                                                                                                                   \
-    static unsigned long long asked = 0;                                                                                 \
-    if (!((asked >> dev) & 1ull)) {                                                                                      \
+    static std::atomic<unsigned long long> asked{0};   /* (handles on several host threads: a lost bit would only repeat the call) */ \
+    if (!((asked.load(std::memory_order_relaxed) >> dev) & 1ull)) {                                                      \
       const size_t most = sizeof(double) * ((size_t)SMALL_N_MAX_BANK * (SMALL_N_MAX_BANK | 1) + 5 * SMALL_N_MAX_BANK + 4) + \
                           2 * sizeof(StepIn);                                                                            \
       if (hipFuncSetAttribute(reinterpret_cast<const void*>(&K<256, TM>), hipFuncAttributeMaxDynamicSharedMemorySize,   \
                               (int)most) != hipSuccess)                                                                  \
         return 1;                                                                                                        \
-      asked |= 1ull << dev;                                                                                              \
+      asked.fetch_or(1ull << dev, std::memory_order_relaxed);                                                            \
     }                                                                                                                    \
     EKF_SMALL(K, TM);                                                                                                    \
   } while (0)

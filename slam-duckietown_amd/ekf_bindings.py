@@ -16,6 +16,7 @@ There is NO CPU fallback: if the shared library or a gfx950 device is missing, c
 """
 from __future__ import annotations
 
+import collections
 import ctypes as C
 import dataclasses
 import os
@@ -142,6 +143,7 @@ ABI = {
     "ekf_debug_small_launches": (C.c_long, [C.c_void_p]),
     "ekf_debug_fused_fetches": (C.c_long, [C.c_void_p]),
     "ekf_debug_dense_packs": (C.c_long, [C.c_void_p]),
+    "ekf_debug_fetch_retries": (C.c_long, [C.c_void_p]),
     "ekf_debug_cad": (C.c_long, [C.c_void_p, C.c_int, C.c_void_p, C.c_long]),
     "ekf_debug_snapshot": (C.c_long, [C.c_void_p, C.c_int, C.c_int, _dp, C.c_long]),
     "ekf_debug_read": (C.c_int, [C.c_void_p, C.c_void_p, C.c_long]),
@@ -209,28 +211,50 @@ class _PinnedPool:
     KEEP = 2                      # free buffers kept per size (the loop holds one array while the next is filled)
 
     def __init__(self):
-        self.free = {}
-        self.live = 0
+        self.free = collections.OrderedDict()      # size -> free buffers of that size, least recently used size first
+        self.live = 0                              # bytes allocated (handed out + free)
         # handles may be driven from several host threads (one each); finalisers run wherever the last reference dies,
         # possibly inside empty() of the same thread: a re-entrant lock
         self.lock = threading.RLock()
 
+    def _evict(self, need):
+        """(under the lock) Free buffers, least recently used size first, until `need` more bytes fit LIMIT; returns the
+        pointers to free -- outside the lock: hipHostFree synchronises the device."""
+        out = []
+        for size in list(self.free):
+            while self.free[size] and self.live + need > self.LIMIT:
+                out.append(self.free[size].pop())
+                self.live -= size
+            if not self.free[size]:
+                del self.free[size]
+            if self.live + need <= self.LIMIT:
+                break
+        return out
+
     def empty(self, lib, shape):
         count = int(np.prod(shape))
         nbytes = 8 * count
-        ptr = None
+        ptr, evicted = None, []
         with self.lock:
-            if self.free.get(nbytes):
-                ptr = self.free[nbytes].pop()
+            kept = self.free.get(nbytes)
+            if kept:
+                ptr = kept.pop()
+                self.free.move_to_end(nbytes)
             else:
-                for other in [k for k in self.free if k != nbytes]:        # the map grew: the old size is not coming back
-                    for q in self.free.pop(other):
-                        lib.ekf_host_free(q)
-                        self.live -= other
+                # buffers of OTHER sizes stay (two handles of different size, a map that grows a landmark at a time): they
+                # go only when this allocation would not fit LIMIT otherwise
+                if self.live + nbytes > self.LIMIT:
+                    evicted = self._evict(nbytes)
                 if self.live + nbytes <= self.LIMIT:
-                    ptr = lib.ekf_host_alloc(nbytes)
-                    if ptr:
-                        self.live += nbytes
+                    self.live += nbytes                # (reserved; the allocation itself happens outside the lock)
+                    ptr = -1
+        for q in evicted:
+            lib.ekf_host_free(q)
+        if ptr == -1:
+            ptr = lib.ekf_host_alloc(nbytes)
+            if not ptr:
+                with self.lock:
+                    self.live -= nbytes
         if not ptr:
             return np.empty(shape)
         buf = (C.c_double * count).from_address(ptr)
@@ -238,13 +262,17 @@ class _PinnedPool:
         return np.frombuffer(buf, dtype=np.float64).reshape(shape)
 
     def _release(self, lib, ptr, nbytes):
+        drop = False
         with self.lock:
             kept = self.free.setdefault(nbytes, [])
+            self.free.move_to_end(nbytes)
             if len(kept) < self.KEEP:
                 kept.append(ptr)
             else:
-                lib.ekf_host_free(ptr)
+                drop = True
                 self.live -= nbytes
+        if drop:
+            lib.ekf_host_free(ptr)
 
 
 _pinned = _PinnedPool()

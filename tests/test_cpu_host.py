@@ -420,8 +420,9 @@ def test_row_slab_pass_equal_shares_cover_every_strip_once(sd):
 def test_pinned_pool_recycles_only_what_nobody_holds():
     """The binding's pool of pinned buffers behind large returned covariances (ekf_bindings._PinnedPool), driven with malloc /
     free in place of ekf_host_alloc / ekf_host_free: a buffer goes back to the pool when the LAST view of its array is gone
-    (sub-views keep it), at most KEEP free buffers per size are kept, a new size evicts the old ones, and beyond LIMIT the
-    arrays are ordinary ones."""
+    (sub-views keep it), at most KEEP free buffers per size are kept, buffers of OTHER sizes stay (two handles of different size,
+    a map that grows a landmark at a time: ADVICE r04) until LIMIT forces the least recently used size out, and beyond LIMIT
+    the arrays are ordinary ones."""
     import ctypes as C
     import gc
     from slam_duckietown_amd import ekf_bindings as eb
@@ -459,15 +460,25 @@ def test_pinned_pool_recycles_only_what_nobody_holds():
     gc.collect()
     assert len(pool.free[8 * 150 * 150]) == pool.KEEP and len(lib.freed) == 4 - pool.KEEP
     assert pool.live == pool.KEEP * 8 * 150 * 150
-    f = pool.empty(lib, (152, 152))                                  # the map grew: the old size is given back
-    assert pool.free == {} and pool.live == 8 * 152 * 152 and len(lib.freed) == 4
-    pool.LIMIT = pool.live                                           # (instance attribute: this pool only)
-    g = pool.empty(lib, (152, 152))
-    assert g.shape == (152, 152) and len(lib.allocated) == 5 and g.base is None and f.base is not None   # g: a plain np.empty
-    del f, g
+    s150, s152 = 8 * 150 * 150, 8 * 152 * 152
+    f = pool.empty(lib, (152, 152))                                  # another size: the free buffers of the first one stay
+    assert len(pool.free[s150]) == pool.KEEP and pool.live == pool.KEEP * s150 + s152 and len(lib.freed) == 4 - pool.KEEP
+    b2 = pool.empty(lib, (150, 150))                                 # ... and are handed out again (a second handle's size)
+    assert b2.ctypes.data in lib.allocated[:4] and len(lib.allocated) == 5
+    del b2
     gc.collect()
-    for p in pool.free.pop(8 * 152 * 152):
-        lib.ekf_host_free(p)
+    pool.LIMIT = pool.live + s152 - s150                             # (instance attribute: this pool only) room for ONE more 152 x 152
+    g = pool.empty(lib, (152, 152))                                  # ... if a free buffer of the least recently used size goes
+    assert g.base is not None and len(pool.free[s150]) == pool.KEEP - 1 and len(lib.freed) == 4 - pool.KEEP + 1
+    assert pool.live == (pool.KEEP - 1) * s150 + 2 * s152
+    pool.LIMIT = pool.live - (pool.KEEP - 1) * s150                  # nothing fits any more, whatever is evicted
+    k = pool.empty(lib, (152, 152))
+    assert k.shape == (152, 152) and k.base is None and f.base is not None   # k: a plain np.empty
+    del f, g, k
+    gc.collect()
+    for size in list(pool.free):
+        for p in pool.free.pop(size):
+            lib.ekf_host_free(p)
 
 
 def test_binding_stages_arguments_without_a_device():

@@ -265,6 +265,30 @@ def test_step_state_reports_what_the_two_calls_report(sd):
         assert fused_fetches(sd, f) == 2
 
 
+@pytest.mark.parametrize("N,m", [(12, 3), (38, 8)])
+def test_polled_hand_over_carries_an_integrity_trailer(sd, N, m):
+    """ekf_step_fetch trusts the state it finds in pinned memory as soon as the sequence word arrives, while the launch is
+    still running (that rests on the ordering of the kernel's posted writes).  Every hand-over therefore carries a
+    second copy of the sequence number written by another wave and an XOR checksum of the payload; with `fetch_verify` the
+    host checks both.  200 calls: every one answered by the step's own launch, none retried, each equal to a plain download."""
+    lib = sd.load_library()
+    s = orc.synthetic_stream(N, 200, m, 70)
+    with sd.EkfSlam(3 + 2 * N) as f:
+        f.set_option("fetch_verify", 1)
+        f.set_state_diag(s[0], s[1])
+        for k in range(200):
+            mu, P = f.step_state(s[2][k], s[3][k], s[4][k], s[5][k], s[6][k])
+            if k % 20 == 0:
+                dm, dP = f.state()
+                assert np.array_equal(mu, dm) and np.array_equal(P, dP)
+        assert fused_fetches(sd, f) == 200 and lib.ekf_debug_fetch_retries(f._h) == 0 and f.flags() == 0
+    om, oP = s[0].copy(), np.diag(s[1])
+    for k in range(200):
+        om, oP = orc.ekf_step_dense(om, oP, s[2][k], s[3][k], s[4][k], s[5][k], s[6][k], orc.EkfConfig())
+    close(mu, om)
+    close(P, oP)
+
+
 def test_a_bank_that_overfills_the_chip_takes_the_throughput_kernel_bit_identically(sd):
     """More than three trajectories per CU: the small-state kernel runs in its 128-VGPR form, four workgroups resident per CU
     (k_small_stream_occ) -- the same instructions on the data, so sampled trajectories equal, bit for bit, the same
