@@ -57,6 +57,19 @@ __device__ __forceinline__ double wrap_pi(double a) {
   return r - M_PI;
 }
 
+// 1 / x from the hardware estimate (v_rcp_f64: ~1e-8 relative... in fact 2^-26) and two Newton steps -- each squares the error:
+// <= 1 ulp for finite non-zero x, inf / NaN / 0 behave like the IEEE division (1/0 = inf, 1/inf = 0, NaN through).  The IEEE
+// division behind `1.0 / x` is a v_div_scale / v_div_fmas / v_div_fixup sequence of ~250 dependent cycles on the solve's chain.
+__device__ __forceinline__ double fast_recip(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  const double e0 = fma(-x, r, 1.0);
+  const double r1 = fma(r, e0, r);
+  const double e1 = fma(-x, r1, 1.0);
+  const double r2 = fma(r1, e1, r1);
+  // (x = 0 or inf: the estimate is already exact -- inf or 0 -- and the Newton terms would make NaN of it)
+  return (x == 0.0 || fabs(x) == __builtin_inf()) ? r : r2;
+}
+
 // Innovation and 2x5 Jacobian of one range/bearing observation (src/replay_no_ros.py:443-469), in two parts: the
 // Jacobian (needed first, by the covariance chain) and the innovation (atan2: twice as long, needed only by the mean).
 // h[r][k] = row r, column k on {x, y, theta, lx, ly}.  q == 0 gives NaN rows like NumPy's 0/0.
