@@ -42,7 +42,7 @@ void launch_associate(hipStream_t, const DetIn*, int*, int*, int*, double*, doub
                       AssocOut*, unsigned*, const AssocConfig&, int, long, int, int, int);
 void launch_fill_diag(hipStream_t, double*, int, int, const double*);
 int dense_propagate(hipStream_t, double* P, double* tmp, const double* F, const double* Q, int n, int ld);
-void launch_solve_cad(hipStream_t, int, const double*, const double*, double*, double*, const int*, const StepIn*, const CadPlan*, int,
+void launch_solve_cad(hipStream_t, const double*, const double*, double*, double*, const int*, const StepIn*, const CadPlan*, int,
                       CadOut*, unsigned*, const DeviceConfig&, int, long, const double*, int);
 void launch_gather_cad(hipStream_t, const double*, const double*, const double*, const double*, const StepIn*, const CadPlan*, int,
                        int, const DeviceConfig&, int, long, double*);
@@ -159,7 +159,6 @@ struct ekf_handle : ekf::HostPlan {
   int fetch_b = -1;               // ekf_step_fetch: the trajectory whose state the next small-state launch leaves in h_pack
   bool fetched = false;
   unsigned long long fetch_seq = 0;   // ... and the sequence number that launch releases behind it (polled by the host)
-  int opt_solve_form = 0;         // fused cadence: 1 = the solve keeps the block in registers (k_solve_cad_r), 0 = in LDS (k_solve_cad)
   int opt_fetch_spin = 1;
   int opt_fetch_verify = 0;       // 1 = ekf_step_fetch also checks the payload's XOR checksum before it trusts a polled hand-over
   long fetch_retries = 0;         // statistics: hand-overs whose integrity trailer did not match (answered after a stream sync)
@@ -856,7 +855,7 @@ static int enqueue_cadence(ekf_handle* h, int c, bool presolved, bool* next_pres
   const double* mu_in = h->dmu2[h->cur];
   double* mu_out = h->dmu2[h->cur ^ 1];
   if (!presolved)
-    launch_solve_cad(h->stream, h->opt_solve_form, h->dP, mu_in, mu_out, h->ddacc2[h->dcur ^ 1], h->dn, h->d_stream, dpl, h->batch, h->dcad,
+    launch_solve_cad(h->stream, h->dP, mu_in, mu_out, h->ddacc2[h->dcur ^ 1], h->dn, h->d_stream, dpl, h->batch, h->dcad,
                      h->dflags, h->dcfg, h->ld, h->pstride, nullptr, 0);
   const int ranks = 2 * rp.slots_hi[c], nrp = (ranks + 3) & ~3;   // every trajectory writes the busiest one's ranks (zeros beyond its own)
   launch_panels_cad(h->stream, h->dP, h->dV, h->dW, mu_in, mu_out, h->dn, h->dcad, h->dso, h->dqueue, h->ld,
@@ -900,7 +899,7 @@ static int enqueue_cadence(ekf_handle* h, int c, bool presolved, bool* next_pres
   HIP_TRY(h, hipStreamWaitEvent(h->aux, h->ev_fork, 0));
   // (the solve first: it is ready to go the moment the gather ends, the pass has an event to wait for -- the one
   //  workgroup per trajectory finds its CU before the pass fills the chip)
-  launch_solve_cad(h->stream, h->opt_solve_form, h->dP, h->dmu2[h->cur], h->dmu2[h->cur ^ 1], h->ddacc2[h->dcur ^ 1], h->dn, h->d_stream, dpl2,
+  launch_solve_cad(h->stream, h->dP, h->dmu2[h->cur], h->dmu2[h->cur ^ 1], h->ddacc2[h->dcur ^ 1], h->dn, h->d_stream, dpl2,
                    h->batch, h->dcad, h->dflags, h->dcfg, h->ld, h->pstride, h->dgbuf, (kb + 7) / 8);
   // From here on the next cadence's solve has overwritten dcad, the pose mean and the pending-noise buffer: a failure
   // below cannot be undone.  Whatever happens the two streams are joined again, and a failure marks every trajectory
@@ -1545,11 +1544,6 @@ extern "C" int ekf_set_option(ekf_handle* h, const char* name, int value) {
   if (!std::strcmp(name, "pack_dense")) {
     if (value < 0 || value > 2) return fail(h, EKF_ERR_ARG, "pack_dense must be 0, 1 or 2");
     h->opt_pack_dense = value;
-    return EKF_OK;
-  }
-  if (!std::strcmp(name, "solve_form")) {
-    if (value != 0 && value != 1) return fail(h, EKF_ERR_ARG, "solve_form must be 0 or 1");
-    h->opt_solve_form = value;
     return EKF_OK;
   }
   if (!std::strcmp(name, "fetch_verify")) {

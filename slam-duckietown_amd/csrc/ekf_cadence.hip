@@ -128,6 +128,7 @@ __global__ __launch_bounds__(64 * CAD_NW) void k_solve_cad(const double* __restr
   __shared__ double mot[4];                            // G[0,2], G[1,2] of the step being predicted
   __shared__ double2 hS[2][6];                         // linearisation of slot s in hS[s & 1]: {h[0][k], h[1][k]}, k < 5
   __shared__ double2 siS[2];                           // S^-1 of the slot in flight
+  __shared__ double2 yS[2];                            // innovation of slot s in yS[s & 1] (for its record)
   const int b = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -352,15 +353,7 @@ __global__ __launch_bounds__(64 * CAD_NW) void k_solve_cad(const double* __restr
     if (wave == 1 && m > 0) {
       const double2 z = zS[s_first];
       innovation(lg, z.x, z.y, y0, y1);
-    }
-    double h[2][5];
-    if (wave == 0 && m > 0) {
-#pragma unroll
-      for (int k = 0; k < 5; ++k) {
-        const double2 tt = hS[s_first & 1][k];
-        h[0][k] = tt.x;
-        h[1][k] = tt.y;
-      }
+      if (lane == 0) yS[s_first & 1] = make_double2(y0, y1);
     }
     // ---- the step's landmarks, sequentially (:436-480) ----
     for (int j = 0; j < m; ++j) {
@@ -373,8 +366,17 @@ __global__ __launch_bounds__(64 * CAD_NW) void k_solve_cad(const double* __restr
       if (wave == 0) {
         // phase A: rows sel = {0, 1, 2, pa, pa + 1} of P at column l give (H P)[:, l]; P is symmetric, so P H^T is the
         // transpose and the gain needs no second product
+        // (the landmark's linearisation -- published by the mean wave before the barrier -- is read with the rows: one LDS
+        //  round trip for both)
         const int la = min(lane, pa + 1), lb = min(64 + lane, CAD_CS - 1);
+        double h[2][5];
         double pra[5], prb[5];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+          const double2 tt = hS[s & 1][k];
+          h[0][k] = tt.x;
+          h[1][k] = tt.y;
+        }
 #pragma unroll
         for (int k = 0; k < 5; ++k) {
           const int r = k < 3 ? k : pa + (k - 3);
@@ -415,7 +417,7 @@ __global__ __launch_bounds__(64 * CAD_NW) void k_solve_cad(const double* __restr
           S10 = fma(hv[k].y, h[0][k], S10);
           S11 = fma(hv[k].y, h[1][k], S11);
         }
-        const double rdet = 1.0 / (S00 * S11 - S01 * S10);
+        const double rdet = fast_recip(S00 * S11 - S01 * S10);   // (<= 1 ulp; the IEEE division is ~250 dependent cycles of this chain)
         const double i00 = S11 * rdet, i01 = -S01 * rdet, i10 = -S10 * rdet, i11 = S00 * rdet;
         const double2 ka = make_double2(hpa.x * i00 + hpa.y * i10, hpa.x * i01 + hpa.y * i11);   // K[C_u[l], :]
         kcS[lane] = ka;
@@ -437,8 +439,6 @@ __global__ __launch_bounds__(64 * CAD_NW) void k_solve_cad(const double* __restr
         if (lane < pa + 2) mu0 += k0.x * y0 + k0.y * y1;
         if (64 + lane < pa + 2) mu1 += k1.x * y0 + k1.y * y1;
         CSTAMP(1, s, 13);
-        if (lane == 0) *reinterpret_cast<double2*>(o.rec + G::rec_off(s) + 14) = make_double2(y0, y1);
-        CSTAMP(1, s, 14);
 #ifndef CADS_SKIP_JAC                                    /* diagnostic build: no re-linearisation (wrong results) */
         if (j + 1 < m) jacobian_at_mean(pa - 2, (s + 1) & 1);
         else if (t + 1 < nsteps) motion(t + 1);
@@ -451,6 +451,7 @@ __global__ __launch_bounds__(64 * CAD_NW) void k_solve_cad(const double* __restr
         if (two_j && 64 + lane < pa) rec2[8 + 64 + lane] = kb;
         if (lane < 5) rec2[lane] = hS[s & 1][lane];
         if (lane == 5 || lane == 6) rec2[lane] = siS[lane - 5];
+        if (lane == 7) rec2[7] = yS[s & 1];
         if (lane < 3) {
           const double2 hp = hpS[lane];
           double2* vw = reinterpret_cast<double2*>(o.posevw[s][lane]);
@@ -514,16 +515,9 @@ __global__ __launch_bounds__(64 * CAD_NW) void k_solve_cad(const double* __restr
       if (wave == 1 && j + 1 < m) {
         const double2 z = zS[s + 1];
         innovation(lg, z.x, z.y, y0, y1);
+        if (lane == 0) yS[(s + 1) & 1] = make_double2(y0, y1);
       }
       CSTAMP(1, s, 12);
-      if (wave == 0 && j + 1 < m) {
-#pragma unroll
-        for (int k = 0; k < 5; ++k) {
-          const double2 tt = hS[(s + 1) & 1][k];
-          h[0][k] = tt.x;
-          h[1][k] = tt.y;
-        }
-      }
       CSTAMP(0, s, 7);
     }
     if (m == 0) {                                      // (uniform) no landmark whose tail could carry the next motion model
@@ -550,499 +544,6 @@ __global__ __launch_bounds__(64 * CAD_NW) void k_solve_cad(const double* __restr
     }
   }
   if (wave == 0 && lane < 3) {
-    o.ddpose[0][lane] = dd0;                           // entry (0, l)
-    o.ddpose[1][lane] = dd1;                           // entry (1, l)
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
-// k_solve_cad_r (round 5): the same chain with the block P[C_u, C_u] held in REGISTERS.
-// The timeline of k_solve_cad (profiles/r05_solve_cad_timeline.txt) has two long stretches per landmark: the window between
-// its two barriers, where six waves read, down-date and write back the whole live block through LDS (55 KB each way: the LDS
-// pipe, ~1300 cycles) while the mean wave updates the mean and linearises the next landmark (~1300 as well), and ~900
-// cycles of hand-overs around the second barrier (its release, the chain wave's read of the next Jacobian, the loop).
-// Here
-//   * waves 2 .. 7 OWN the rows of the block: the pose rows 0..2 belong to wave 2, landmark pair u (positions 3 + 2u,
-//     4 + 2u) to wave 2 + u % 6, pair-slot u / 6 -- lane l holds columns l and 64 + l of each of its rows (56 - 68
-//     VGPRs).  The down-date P[r][l] -= K[r, :] . (H P)[:, l] is register arithmetic: a wave reads K of its rows (uniform
-//     16-byte LDS reads) and (H P) of its two columns; the block itself never travels.  Afterwards the owners of the five rows
-//     the NEXT landmark reads (0, 1, 2 and its own pair) publish them (5 x 88 doubles).  The prediction of a step
-//     (:428-430: rows / columns 0, 1) is applied by every owner to its own rows.
-//   * wave 0 is the whole sequential chain: (H P) from the published rows, S, the 2 x 2 inverse, K -- and, in the window, the
-//     mean update (it owns the mean), the next landmark's Jacobian at the new mean, or the next step's motion model: the
-//     Jacobian never crosses a wave boundary on its way into the next (H P).
-//   * wave 1 computes innovations (atan2: needed by the mean only, one landmark ahead of the chain) and writes the records.
-// Same arithmetic per element as k_solve_cad except where a row owner takes P[r][2], P[r][0] from its own row instead of
-// the mirrored entries of rows 0, 2 in the prediction (equal up to the rounding-level asymmetry of the block); the two
-// kernels agree to ~1e-15 relative (tests/test_gpu_cadence.py::test_both_solve_kernels_agree).
-// ---------------------------------------------------------------------------------------------
-constexpr int CAD_OW = 6;                                  // waves that own rows: 2 .. 7
-constexpr int CAD_PP = (CAD_SLOTS + CAD_OW - 1) / CAD_OW;  // pair-slots per owner (7)
-
-__global__ __launch_bounds__(64 * CAD_NW) void k_solve_cad_r(const double* __restrict__ P,
-                                                    const double* __restrict__ mu_in, double* __restrict__ mu_out,
-                                                    double* __restrict__ dacc_out, const int* __restrict__ nact,
-                                                    const StepIn* __restrict__ in, const CadPlan* __restrict__ plan, int batch,
-                                                    CadOut* __restrict__ out, unsigned* __restrict__ flags,
-                                                    DeviceConfig cfg, int ld,
-                                                    long pstride, const double* __restrict__ gbuf, int gparts) {
-  using G = CadGeom;
-  constexpr int GM = G::GM, CU = G::CU;
-  __shared__ __attribute__((aligned(16))) double rowS[5][CAD_CS];   // rows 0, 1, 2, pa, pa + 1 of the block for the landmark at pa
-  __shared__ double2 hpS[128], kcS[128];
-  __shared__ int Cs[128];
-  __shared__ double2 zS[CAD_SLOTS];                    // (range, bearing) of slot s
-  __shared__ double2 laS[CAD_SLOTS];                   // (lin, ang) of touched step p
-  __shared__ int mS[CAD_SLOTS + 1], firstS[CAD_SLOTS + 1], fS[CAD_SLOTS];
-  __shared__ double mot[4];                            // G[0,2], G[1,2] of the step being predicted
-  __shared__ double2 hS[2][6];                         // linearisation of slot s in hS[s & 1] (for its record)
-  __shared__ double2 siS[2];                           // S^-1 of the slot in flight
-  __shared__ double2 yS;                               // innovation of the slot in flight (wave 1 -> wave 0)
-  __shared__ double lgS[4];                            // dx, dy, theta, sqrt(q) of the NEXT slot's linearisation (wave 0 -> wave 1)
-  const int b = blockIdx.x;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const double* Pb = P + (long)b * pstride;
-  const double* mu_in_b = mu_in + (long)b * ld;
-  CadOut& o = out[b];
-  const CadPlan pl = plan[b];
-  const int nsteps = pl.ns;                            // touched steps
-
-  // ---- inputs: the plan's steps (thread p: touched step p), their landmarks' slots and positions ----
-  if (tid < CAD_SLOTS) {
-    int fl = 0;
-    double2 la = make_double2(0.0, 0.0);
-    if (tid < nsteps) {
-      const StepIn& st = in[(long)(pl.t0 + tid) * batch + b];
-      fl = st.flags;
-      if (tid == 0 && pl.j0 > 0) fl &= ~FLAG_PREDICT;   // a step cut by the previous cadence: its prediction has happened
-      la = make_double2(st.lin, st.ang);
-    }
-    fS[tid] = fl;
-    laS[tid] = la;
-  }
-  const int nslots = cad_positions(pl, in, batch, b, cfg, tid, Cs, mS, firstS,
-                                   [&](int s, const StepIn* st, int j) { zS[s] = make_double2(st->range[j], st->bearing[j]); });
-  const int s0 = GM - nslots;
-  const int cu = 3 + 2 * nslots;                       // positions in use
-  const int neff_eff = min(nact[b], pl.neff);
-  __syncthreads();
-  const int Cl0 = Cs[lane], Cl1 = Cs[64 + lane];       // positions lane and 64 + lane
-  if (tid <= CU) o.C[tid] = tid < CU ? Cs[tid] : 0;
-  if (tid < CAD_SLOTS) o.sfirst[tid] = tid < nsteps ? s0 + firstS[tid] : GM;
-  if (tid == 0) {
-    o.nslots = nslots;
-    o.neff = neff_eff;
-    o.npred = nsteps;
-    o.pad0 = 0;
-  }
-  const bool owner = wave >= 2;
-  const int wo = wave - 2;                             // (owners) pairs u = CAD_OW * pp + wo
-  const bool lane_b = 64 + lane < CAD_CS;              // columns 64 .. CAD_CS - 1 exist
-  const int lb = lane_b ? 64 + lane : 64;
-
-  // ---- wave 0: the mean (lane l holds positions l and 64 + l), the linearisation in flight ----
-  double mu0 = 0.0, mu1 = 0.0;
-  double rdsum0 = 0.0, rdsum1 = 0.0, rdsum2 = 0.0;     // pose-block noise of the whole cadence
-  double h[2][5];
-#pragma unroll
-  for (int k = 0; k < 5; ++k) h[0][k] = h[1][k] = 0.0;
-  auto mean_at = [&](int p) __attribute__((always_inline)) -> double {                // p wave-uniform
-    return p < 64 ? read_lane(mu0, p) : read_lane(mu1, p - 64);
-  };
-  // motion model of step t (src/replay_no_ros.py:368-417) at the current pose mean; publishes G[0,2], G[1,2]
-  auto motion = [&](int t) __attribute__((always_inline)) {
-    const double2 la = laS[t];
-    const bool do_pred = (fS[t] & FLAG_PREDICT) != 0;
-    const double th = read_lane(mu0, 2);
-    double g0 = 0.0, g1 = 0.0, nx = read_lane(mu0, 0), ny = read_lane(mu0, 1), nth = th;
-    if (do_pred && !cfg.disable_motion_model) {
-      const double lin = la.x, ang = la.y;
-      double sn0, c0;
-      sincos(th, &sn0, &c0);
-      if (cfg.enable_circular_interpolation && fabs(ang) > cfg.arc_threshold) {   // :390 arc
-        double sn1, c1;
-        sincos(th + ang, &sn1, &c1);
-        const double r = lin / ang;
-        nx += -r * sn0 + r * sn1;
-        ny += r * c0 - r * c1;
-        nth = wrap_pi(th + ang);                       // :397
-        g0 = -r * c0 + r * c1;                         // :401
-        g1 = -r * sn0 + r * sn1;                       // :402
-      } else {                                         // :376 straight / :405-417 linear mode
-        nx += lin * c0;
-        ny += lin * sn0;
-        if (!cfg.enable_circular_interpolation) nth = th + ang;   // no wrap (:409); :381 keeps theta
-        g0 = -lin * sn0;
-        g1 = lin * c0;
-      }
-    }
-    if (lane < 3) mu0 = lane == 0 ? nx : (lane == 1 ? ny : nth);
-    if (do_pred) {
-      rdsum0 += cfg.rd[0];
-      rdsum1 += cfg.rd[1];
-      rdsum2 += cfg.rd[2];
-    }
-    if (lane == 0) {
-      mot[0] = g0;
-      mot[1] = g1;
-      *reinterpret_cast<double2*>(o.g[t]) = make_double2(g0, g1);
-    }
-  };
-  // landmark at positions p, p + 1, linearised at the current mean: h stays in this wave's registers (its next (H P));
-  // hS[par] is for the record, lgS for the innovation (wave 1)
-  auto jacobian_at_mean = [&](int p, int par) __attribute__((always_inline)) {
-    const LinGeom lg = linearize_h(read_lane(mu0, 0), read_lane(mu0, 1), read_lane(mu0, 2), mean_at(p), mean_at(p + 1), h);
-    if (lane == 0) {
-#pragma unroll
-      for (int k = 0; k < 5; ++k) hS[par][k] = make_double2(h[0][k], h[1][k]);
-      *reinterpret_cast<double2*>(&lgS[0]) = make_double2(lg.dx, lg.dy);
-      *reinterpret_cast<double2*>(&lgS[2]) = make_double2(lg.th, lg.sq);
-    }
-  };
-
-  // ---- owners: their rows of P[C_u, C_u] (nothing is pending: P = P_base -- or the look-ahead gather's copy) ----
-  double Q[3][2], R[CAD_PP][2][2];
-#pragma unroll
-  for (int k = 0; k < 3; ++k) Q[k][0] = Q[k][1] = 0.0;
-#pragma unroll
-  for (int pp = 0; pp < CAD_PP; ++pp)
-#pragma unroll
-    for (int e = 0; e < 2; ++e) R[pp][e][0] = R[pp][e][1] = 0.0;
-  if (owner) {
-    auto fetch = [&](int r, double& v0, double& v1) __attribute__((always_inline)) {  // row at position r (uniform), columns lane and 64 + lane
-      if (gbuf) {
-        // look-ahead: the block was gathered (base + the ranks still pending then) by k_gather_cad, in `gparts` parts,
-        // added here in a fixed order
-        double a0 = 0.0, a1 = 0.0;
-        for (int gp = 0; gp < gparts; ++gp) {
-          const double* gb = gbuf + (((long)gp * batch + b) * CAD_ROWS + r) * CAD_CS;
-          a0 += gb[lane];
-          a1 += gb[lb];
-        }
-        v0 = a0;
-        v1 = a1;
-      } else {
-        const int Cr = Cs[r];
-        v0 = Pb[p_index(ld, min(Cr, Cl0), max(Cr, Cl0))];     // the upper triangle is authoritative
-        v1 = cu > 64 ? Pb[p_index(ld, min(Cr, Cl1), max(Cr, Cl1))] : 0.0;
-      }
-    };
-    if (wave == 2) {
-#pragma unroll
-      for (int k = 0; k < 3; ++k) fetch(k, Q[k][0], Q[k][1]);
-    }
-#pragma unroll
-    for (int pp = 0; pp < CAD_PP; ++pp) {
-      const int u = CAD_OW * pp + wo;
-      if (u < nslots) {                                // (uniform)
-#pragma unroll
-        for (int e = 0; e < 2; ++e) fetch(3 + 2 * u + e, R[pp][e][0], R[pp][e][1]);
-      }
-    }
-  }
-  if (wave == 0) {
-    mu0 = mu_in_b[Cl0];
-    mu1 = mu_in_b[Cl1];
-    motion(0);
-  }
-#ifndef CAD_STAMPS
-  if (wave == 2) {                                     // (diagnostic record) rows 0, 1 of the block before the cadence
-    if (lane < CU) {
-      o.prow[0][lane] = Q[0][0];
-      o.prow[1][lane] = Q[1][0];
-    }
-    if (64 + lane <= CU) {
-      o.prow[0][64 + lane] = 64 + lane < CU ? Q[0][1] : 0.0;
-      o.prow[1][64 + lane] = 64 + lane < CU ? Q[1][1] : 0.0;
-    }
-  }
-#endif
-  WG_LDS_BARRIER();                                    // mot of step 0 published
-
-  // (owners) the five rows the landmark at positions pa, pa + 1 reads -> rowS
-  auto publish_rows = [&](int pa) __attribute__((always_inline)) {
-    if (wave == 2) {
-#pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        rowS[k][lane] = Q[k][0];
-        if (lane_b) rowS[k][64 + lane] = Q[k][1];
-      }
-    }
-    const int u = (pa - 3) >> 1;
-    if (wo == u % CAD_OW) {                            // (uniform) this wave owns the pair
-      const int pu = u / CAD_OW;
-#pragma unroll
-      for (int pp = 0; pp < CAD_PP; ++pp) {
-        if (pp == pu) {                                // (uniform)
-#pragma unroll
-          for (int e = 0; e < 2; ++e) {
-            rowS[3 + e][lane] = R[pp][e][0];
-            if (lane_b) rowS[3 + e][64 + lane] = R[pp][e][1];
-          }
-        }
-      }
-    }
-  };
-
-  double dd0 = 0.0, dd1 = 0.0;                         // (wave 2, lanes 0..2) in-place change of P_base(0, l), P_base(1, l)
-  for (int t = 0; t < nsteps; ++t) {
-    const int m = __builtin_amdgcn_readfirstlane(mS[t]);
-    const int s_first = s0 + __builtin_amdgcn_readfirstlane(firstS[t]);   // (a step without landmarks: the next step's first slot)
-    // ---- prediction of step t on the block: P' = G P G^T + R restricted to C_u (:428-430).  Only rows / columns 0, 1
-    // change; every owner applies it to its own rows (lane l = column l).  Wave 0 linearises the step's first landmark.
-    if (owner) {
-      const bool do_pred = (fS[t] & FLAG_PREDICT) != 0;
-      const double g0 = mot[0], g1 = mot[1];
-      const int u_live = GM - s_first;                 // pairs u < u_live are still in use
-#pragma unroll
-      for (int pp = 0; pp < CAD_PP; ++pp) {
-        if (CAD_OW * pp + wo < u_live) {               // (uniform) columns 0, 1 of a landmark row: P'[r][c] = P[r][c] + g_c P[r][2]
-#pragma unroll
-          for (int e = 0; e < 2; ++e) {
-            const double x2 = read_lane(R[pp][e][0], 2);
-            const double v = R[pp][e][0];
-            if (lane == 0) R[pp][e][0] = fma(g0, x2, v);
-            if (lane == 1) R[pp][e][0] = fma(g1, x2, v);
-          }
-        }
-      }
-      if (wave == 2) {
-        // lane r holds P[0..2][r] = P[r][0..2] (the block is symmetric to rounding) and produces P'[r][0], P'[r][1], which
-        // for r >= 2 are also P'[0][r], P'[1][r]; the 2 x 2 corner travels between lanes 0, 1
-        const double rd0 = do_pred ? cfg.rd[0] : 0.0, rd1 = do_pred ? cfg.rd[1] : 0.0, rd2 = do_pred ? cfg.rd[2] : 0.0;
-        const double s20 = read_lane(Q[2][0], 0), s21 = read_lane(Q[2][0], 1), p22 = read_lane(Q[2][0], 2);
-        const double p0 = Q[0][0], p1 = Q[1][0], p2 = Q[2][0];
-        const double gr = lane == 0 ? g0 : (lane == 1 ? g1 : 0.0);
-        double x0 = p0, x1 = p1, x2 = p2;              // row r of G P, columns 0..2 (rows 0, 1 take g_r x row 2)
-        if (lane < 2) {
-          x0 = fma(gr, s20, p0);
-          x1 = fma(gr, s21, p1);
-          x2 = fma(gr, p22, p2);
-        }
-        double c0n = fma(g0, x2, x0), c1n = fma(g1, x2, x1);
-        dd0 += fma(g0, x2, lane < 2 ? gr * s20 : 0.0);   // P'(0, l) - P(0, l) and P'(1, l) - P(1, l) without the noise
-        dd1 += fma(g1, x2, lane < 2 ? gr * s21 : 0.0);
-        if (lane == 0) c0n += rd0;
-        if (lane == 1) c1n += rd1;
-        // lane r: c0n = P'[r][0], c1n = P'[r][1].  Row k's register holds P'[k][lane]:
-        const double c0_l0 = read_lane(c0n, 0), c1_l0 = read_lane(c1n, 0);   // P'[0][0], P'[0][1]
-        const double c0_l1 = read_lane(c0n, 1), c1_l1 = read_lane(c1n, 1);   // P'[1][0], P'[1][1]
-        const double c0_l2 = read_lane(c0n, 2), c1_l2 = read_lane(c1n, 2);   // P'[2][0], P'[2][1]
-        double q0 = c0n, q1 = c1n, q2 = p2;             // lanes >= 2: P'[0][l] = c0n, P'[1][l] = c1n, row 2 unchanged
-        if (lane == 0) { q0 = c0_l0; q1 = c0_l1; q2 = c0_l2; }
-        if (lane == 1) { q0 = c1_l0; q1 = c1_l1; q2 = c1_l2; }
-        if (lane == 2) q2 = p2 + rd2;
-        Q[0][0] = q0;
-        Q[1][0] = q1;
-        Q[2][0] = q2;
-        Q[0][1] = fma(g0, Q[2][1], Q[0][1]);            // columns 64 ..: plain entries of rows 0, 1
-        Q[1][1] = fma(g1, Q[2][1], Q[1][1]);
-      }
-      if (m > 0) publish_rows(G::pa(s_first));
-    } else if (wave == 0) {
-      if (m > 0) jacobian_at_mean(G::pa(s_first), s_first & 1);
-    }
-    WG_LDS_BARRIER();                                  // S0(t): the first landmark's rows and linearisation are published
-    double y0 = 0.0, y1 = 0.0;
-    if (wave == 1 && m > 0) {                          // its innovation, beside the chain's (H P), S, K
-      const double2 z = zS[s_first];
-      LinGeom lg;
-      lg.dx = lgS[0];
-      lg.dy = lgS[1];
-      lg.th = lgS[2];
-      lg.sq = lgS[3];
-      innovation(lg, z.x, z.y, y0, y1);
-      if (lane == 0) yS = make_double2(y0, y1);
-    }
-    // ---- the step's landmarks, sequentially (:436-480) ----
-    for (int j = 0; j < m; ++j) {
-      const int s = s_first + j, pa = G::pa(s);        // this landmark sits at positions pa, pa + 1; [0, pa) lives on
-      const bool two_j = pa + 2 > 64;                  // columns 64.. still in use
-      const bool last = j + 1 == m && t + 1 == nsteps; // nothing reads the block after this landmark
-      double2 ka = make_double2(0.0, 0.0), kb = make_double2(0.0, 0.0);
-      CSTAMP(0, s, 0);
-      if (wave == 0) {
-        // phase A: rows sel = {0, 1, 2, pa, pa + 1} of P at column l give (H P)[:, l]; P is symmetric, so P H^T is the
-        // transpose and the gain needs no second product
-        const int la = min(lane, pa + 1);
-        double pra[5], prb[5];
-#pragma unroll
-        for (int k = 0; k < 5; ++k) {
-          pra[k] = rowS[k][la];
-          prb[k] = 0.0;
-        }
-        if (two_j) {                                   // (uniform)
-#pragma unroll
-          for (int k = 0; k < 5; ++k) prb[k] = rowS[k][lb];
-        }
-        double2 hpa = make_double2(h[0][0] * pra[0], h[1][0] * pra[0]), hpb = make_double2(0.0, 0.0);
-#pragma unroll
-        for (int k = 1; k < 5; ++k) {
-          hpa.x = fma(h[0][k], pra[k], hpa.x);
-          hpa.y = fma(h[1][k], pra[k], hpa.y);
-        }
-        hpS[lane] = hpa;
-        if (two_j) {
-          hpb = make_double2(h[0][0] * prb[0], h[1][0] * prb[0]);
-#pragma unroll
-          for (int k = 1; k < 5; ++k) {
-            hpb.x = fma(h[0][k], prb[k], hpb.x);
-            hpb.y = fma(h[1][k], prb[k], hpb.y);
-          }
-          hpS[64 + lane] = hpb;
-        }
-        CSTAMP(0, s, 1);
-        // phase B: S = H P H^T + Q (:473) from the five pairs at sel -- out of this wave's own registers (v_readlane: the
-        // positions are wave-uniform), every lane redundantly
-        double2 hv[5];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) hv[k] = make_double2(read_lane(hpa.x, k), read_lane(hpa.y, k));
-#pragma unroll
-        for (int k = 3; k < 5; ++k) {
-          const int pk = pa + (k - 3);
-          hv[k] = pk < 64 ? make_double2(read_lane(hpa.x, pk), read_lane(hpa.y, pk))
-                          : make_double2(read_lane(hpb.x, pk - 64), read_lane(hpb.y, pk - 64));
-        }
-        double S00 = cfg.qd[0], S01 = 0.0, S10 = 0.0, S11 = cfg.qd[1];
-#pragma unroll
-        for (int k = 0; k < 5; ++k) {
-          S00 = fma(hv[k].x, h[0][k], S00);
-          S01 = fma(hv[k].x, h[1][k], S01);
-          S10 = fma(hv[k].y, h[0][k], S10);
-          S11 = fma(hv[k].y, h[1][k], S11);
-        }
-        const double rdet = fast_recip(S00 * S11 - S01 * S10);
-        const double i00 = S11 * rdet, i01 = -S01 * rdet, i10 = -S10 * rdet, i11 = S00 * rdet;
-        ka = make_double2(hpa.x * i00 + hpa.y * i10, hpa.x * i01 + hpa.y * i11);   // K[C_u[l], :]
-        kcS[lane] = ka;
-        if (two_j) {
-          kb = make_double2(hpb.x * i00 + hpb.y * i10, hpb.x * i01 + hpb.y * i11);
-          kcS[64 + lane] = kb;
-        }
-        if (lane == 0) {
-          siS[0] = make_double2(i00, i01);
-          siS[1] = make_double2(i10, i11);
-        }
-        CSTAMP(0, s, 2);
-      }
-      WG_LDS_BARRIER();                                // b1: K, (H P), S^-1 and the innovation of this landmark are in LDS
-      CSTAMP(0, s, 4);
-      CSTAMP(2, s, 8);
-      CSTAMP(1, s, 11);
-      if (wave == 0) {
-        // the mean (:476); then the next landmark's Jacobian at the new mean, or the next step's motion model
-        const double2 yy = yS;
-        if (lane < pa + 2) mu0 += ka.x * yy.x + ka.y * yy.y;
-        if (64 + lane < pa + 2) mu1 += kb.x * yy.x + kb.y * yy.y;
-        if (j + 1 < m) jacobian_at_mean(pa - 2, (s + 1) & 1);
-        else if (t + 1 < nsteps) motion(t + 1);
-      } else if (wave == 1) {
-        // the record of this landmark for the panel kernel, and the pose's own entries of the new ranks
-        double2* rec2 = reinterpret_cast<double2*>(o.rec + G::rec_off(s));
-        const double2 k0 = kcS[lane], k1 = kcS[64 + lane];
-        if (lane < pa) rec2[8 + lane] = k0;
-        if (two_j && 64 + lane < pa) rec2[8 + 64 + lane] = k1;
-        if (lane < 5) rec2[lane] = hS[s & 1][lane];
-        if (lane == 5 || lane == 6) rec2[lane] = siS[lane - 5];
-        if (lane == 7) rec2[7] = make_double2(y0, y1);
-        if (lane < 3) {
-          const double2 hp = hpS[lane];
-          double2* vw = reinterpret_cast<double2*>(o.posevw[s][lane]);
-          vw[0] = hp;
-          vw[1] = make_double2(-k0.x, -k0.y);
-        }
-      } else if (!last) {
-        // down-date (:480) of what lives on: P[r][l] -= K[r, :] . (H P)[:, l] for r, l < pa -- this wave's rows, in registers
-        // K of this wave's rows comes out of two per-lane reads of kcS through v_readlane (K[r] is uniform over the wave): a
-        // uniform 16-byte LDS read costs the LDS pipe what a full-width one does, and 6 waves x 17 of them were the window
-        const double2 hpa = hpS[lane];
-        double2 hpb = make_double2(0.0, 0.0);
-        if (two_j) hpb = hpS[lb];
-        const double2 kl0 = kcS[lane], kl1 = kcS[64 + lane];
-        auto k_of = [&](int r, double& kx, double& ky) __attribute__((always_inline)) {   // r wave-uniform
-          if (r < 64) {
-            kx = read_lane(kl0.x, r);
-            ky = read_lane(kl0.y, r);
-          } else {
-            kx = read_lane(kl1.x, r - 64);
-            ky = read_lane(kl1.y, r - 64);
-          }
-        };
-        const int u_cur = (pa - 3) >> 1;               // pairs u < u_cur live on
-        if (wave == 2) {
-#pragma unroll
-          for (int k = 0; k < 3; ++k) {
-            const double kx = read_lane(kl0.x, k), ky = read_lane(kl0.y, k);
-            Q[k][0] = fma(-kx, hpa.x, Q[k][0]);
-            Q[k][0] = fma(-ky, hpa.y, Q[k][0]);
-            if (two_j) {
-              Q[k][1] = fma(-kx, hpb.x, Q[k][1]);
-              Q[k][1] = fma(-ky, hpb.y, Q[k][1]);
-            }
-          }
-        }
-#pragma unroll
-        for (int pp = 0; pp < CAD_PP; ++pp) {
-          const int u = CAD_OW * pp + wo;
-          if (u < u_cur) {                             // (uniform)
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-              double kx, ky;
-              k_of(3 + 2 * u + e, kx, ky);
-              R[pp][e][0] = fma(-kx, hpa.x, R[pp][e][0]);
-              R[pp][e][0] = fma(-ky, hpa.y, R[pp][e][0]);
-              if (two_j) {
-                R[pp][e][1] = fma(-kx, hpb.x, R[pp][e][1]);
-                R[pp][e][1] = fma(-ky, hpb.y, R[pp][e][1]);
-              }
-            }
-          }
-        }
-        CSTAMP(2, s, 9);
-        if (j + 1 < m) publish_rows(pa - 2);           // the next landmark of this step (a new step predicts first)
-      }
-      CSTAMP(0, s, 5);
-      CSTAMP(2, s, 10);
-      CSTAMP(1, s, 12);
-      WG_LDS_BARRIER();                                // b2: rows and linearisation of the next landmark (or the next step's G) published
-      CSTAMP(0, s, 6);
-      if (wave == 1 && j + 1 < m) {
-        const double2 z = zS[s + 1];
-        LinGeom lg;
-        lg.dx = lgS[0];
-        lg.dy = lgS[1];
-        lg.th = lgS[2];
-        lg.sq = lgS[3];
-        innovation(lg, z.x, z.y, y0, y1);
-        if (lane == 0) yS = make_double2(y0, y1);
-        CSTAMP(1, s, 13);
-      }
-    }
-    if (m == 0) {                                      // (uniform) no landmark whose tail could carry the next motion model
-      if (wave == 0 && t + 1 < nsteps) motion(t + 1);
-      WG_LDS_BARRIER();
-    }
-  }
-
-  // ---- results the solve owns: the pose mean, the pose block of P_base's rows 0, 1, the pending pose noise ----
-  if (wave == 0) {
-    double* mu_out_b = mu_out + (long)b * ld;
-    bool bad = false;
-    if (lane < 3) mu_out_b[lane] = mu0;
-    bad = !(fabs(mu0) <= 1.79769313486231570815e308) || (64 + lane < CU && !(fabs(mu1) <= 1.79769313486231570815e308));
-    if (__any(bad) && lane == 0) atomicOr(flags + b, EKF_FLAG_NONFINITE);
-    if (lane == 0) {
-      dacc_out[4 * b + 0] = rdsum0;
-      dacc_out[4 * b + 1] = rdsum1;
-      dacc_out[4 * b + 2] = rdsum2;
-      o.rdsum[0] = rdsum0;                             // (for a cadence that appends no rank anywhere in the bank: see pose_epilogue)
-      o.rdsum[1] = rdsum1;
-      o.rdsum[2] = rdsum2;
-      o.rdsum[3] = 0.0;
-    }
-  }
-  if (wave == 2 && lane < 3) {
     o.ddpose[0][lane] = dd0;                           // entry (0, l)
     o.ddpose[1][lane] = dd1;                           // entry (1, l)
   }
@@ -1547,16 +1048,11 @@ void launch_gather_cad(hipStream_t st, const double* P, const double* V, const d
                      ld, pstride, gbuf);
 }
 
-// `form`: 1 = the block in registers (k_solve_cad_r, round 5), 0 = the block in LDS (k_solve_cad, rounds 3 - 4)
-void launch_solve_cad(hipStream_t st, int form, const double* P, const double* mu_in, double* mu_out, double* dacc_out,
+void launch_solve_cad(hipStream_t st, const double* P, const double* mu_in, double* mu_out, double* dacc_out,
                       const int* nact, const StepIn* in, const CadPlan* plan, int batch, CadOut* out, unsigned* flags,
                       const DeviceConfig& cfg, int ld, long pstride, const double* gbuf, int gparts) {
-  if (form)
-    hipLaunchKernelGGL(k_solve_cad_r, dim3(batch), dim3(64 * CAD_NW), 0, st, P, mu_in, mu_out, dacc_out, nact, in, plan, batch,
-                       out, flags, cfg, ld, pstride, gbuf, gparts);
-  else
-    hipLaunchKernelGGL(k_solve_cad, dim3(batch), dim3(64 * CAD_NW), 0, st, P, mu_in, mu_out, dacc_out, nact, in, plan, batch, out,
-                       flags, cfg, ld, pstride, gbuf, gparts);
+  hipLaunchKernelGGL(k_solve_cad, dim3(batch), dim3(64 * CAD_NW), 0, st, P, mu_in, mu_out, dacc_out, nact, in, plan, batch, out,
+                     flags, cfg, ld, pstride, gbuf, gparts);
 }
 
 // `nrp`: the ranks the bank's busiest trajectory appends, padded to a whole k-tile (every trajectory writes that many)

@@ -515,23 +515,6 @@ def test_long_runs_without_observations_inside_a_fused_run(sd):
     check_against_per_step_and_oracle(sd, n, B, starts, means, lin, ang, idx, zr, zb, m, fused)
 
 
-@pytest.mark.parametrize("N,B,hi,steps", [(120, 2, 8, 40), (700, 3, 16, 25), (60, 1, 1, 90)])
-def test_both_solve_kernels_agree(sd, N, B, hi, steps):
-    """The solve of a cadence in its two forms -- the block P[C_u, C_u] in LDS, down-dated through LDS by six waves
-    (`solve_form` = 0: rounds 3 - 4), and the block in the registers of its row owners (`solve_form` = 1: round 5, the
-    default) -- perform the same operations per entry except in the prediction of a landmark row's first two columns (own
-    row against the mirrored entries): equal to rounding, and each equal to the oracle."""
-    n = 3 + 2 * N
-    means, lin, ang, idx, zr, zb, m = wandering_stream(N, B, steps, lambda k, b, rng: rng.integers(0 if hi > 1 else 1, hi + 1), 5100 + hi)
-    starts = [dense_start(n, 5200 + t) for t in range(B)]
-    reg, (nc, ns) = run_stream(sd, n, B, starts, means, lin, ang, idx, zr, zb, m, options=[("active_bound", 0), ("solve_form", 1)])
-    lds, (nc0, _) = run_stream(sd, n, B, starts, means, lin, ang, idx, zr, zb, m, options=[("active_bound", 0), ("solve_form", 0)])
-    assert nc == nc0 and ns == steps
-    for b in range(B):
-        assert orc.rel_fro(reg[b][0], lds[b][0]) < 1e-12 and orc.rel_fro(reg[b][1], lds[b][1]) < 1e-12
-    check_against_per_step_and_oracle(sd, n, B, starts, means, lin, ang, idx, zr, zb, m, reg, oracle_for=(0,))
-
-
 def test_golden_stream_through_the_cadence(sd):
     """BASELINE config 1 (N = 20, 500 steps, the reference's own outputs in tests/golden/stream_n20_m8.npz) as ONE
     uploaded stream: 100 fused cadences back to back, final mean and covariance against the reference."""

@@ -11,9 +11,6 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
-NAMES_R = {0: "w0 start", 1: "w0 (H P) published", 2: "w0 S, K published", 4: "w0 past b1", 5: "w0 mean + next Jacobian done / at b2",
-           6: "w0 past b2", 8: "w2 past b1", 9: "w2 down-date done", 10: "w2 rows published / at b2", 11: "w1 past b1",
-           12: "w1 records issued / at b2", 13: "w1 next innovation done"}      # k_solve_cad_r (solve_form = 1, the default)
 NAMES = {0: "w0 start", 1: "w0 (H P) published", 2: "w0 S, K published", 3: "w0 records issued / at b1", 4: "w0 past b1",
          5: "w0 down-date done / at b2", 6: "w0 past b2", 7: "w0 next H read", 8: "w1 start", 9: "w1 at b1", 10: "w1 past b1",
          11: "w1 mean + next Jacobian done / at b2", 12: "w1 innovation done", 13: "w1 mean updated", 14: "w1 y record issued",
@@ -24,7 +21,6 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--landmarks", type=int, default=2000)
     ap.add_argument("--trajectories", type=int, default=32)
-    ap.add_argument("--solve-form", type=int, default=1, help="1 = k_solve_cad_r (block in registers), 0 = k_solve_cad (block in LDS)")
     args = ap.parse_args()
     import slam_duckietown_amd as sd
     import slam_duckietown_amd.synthetic as syn
@@ -33,7 +29,6 @@ def main():
     streams = [syn.synthetic_stream(N, 30, 8, t) for t in range(B)]
     f = sd.EkfSlam(3 + 2 * N, batch=B)
     f.set_option("active_bound", 0)
-    f.set_option("solve_form", args.solve_form)
     for b, s in enumerate(streams):
         f.set_state_diag(s[0], s[1], b)
     f.stream_upload(*[np.stack([s[i] for s in streams], 1) for i in (2, 3, 4, 5, 6)])
@@ -46,7 +41,7 @@ def main():
     off = (4 + 40 + 84) * 4 // 8 + 80
     st = buf[off:off + 48].astype(np.int64).reshape(3, 16)
     t0 = st[0, 0]
-    names = NAMES_R if args.solve_form else NAMES
+    names = NAMES
     for s in range(3):
         print(f"-- slot {s} (relative to slot 0's start, cycles)")
         for k in np.argsort(st[s]):
