@@ -772,7 +772,11 @@ static int enqueue_pass(ekf_handle* h, const StepIn* d_in, int m_hi) {
     h->cur ^= 1;
     return EKF_OK;
   }
-  if (h->pending_k + ktp > KTOT)
+  // The kernels WRITE the rank slots of `mcap` landmarks behind the pending ones (zeros where a trajectory observes fewer) plus
+  // the k-tile pad; the step is CHARGED the ranks of the busiest trajectory only (round 5: 2 per landmark, as the packed
+  // cadences do) -- the next step starts right behind them and overwrites the zeros.  m = 5: 7 steps per pass (until round 4:
+  // 5, the count rounded up to 8 landmarks), m = 12: 3 (2).
+  if (((h->pending_k + ktp + 3) & ~3) > KTOT)
     if (int rc = flush_pending(h)) return rc;
   dacc_in = h->ddacc2[h->dcur];
   dacc_out = h->ddacc2[h->dcur ^ 1];
@@ -798,11 +802,12 @@ static int enqueue_pass(ekf_handle* h, const StepIn* d_in, int m_hi) {
   HIP_TRY(h, hipGetLastError());
   h->dcur ^= 1;
   h->cur ^= 1;
-  h->pending_k += ktp;
+  h->pending_k += 2 * m_hi;
   h->pending_steps += 1;
   // cadence of the covariance pass: a fixed number of steps if asked for, otherwise as many steps as fit
   // `rank_limit` pending ranks (default 80) -- 5 steps at m = 8, 10 at m = 4, 40 at m = 1
-  const bool due = h->opt_flush_every > 0 ? h->pending_steps >= h->opt_flush_every : h->pending_k + ktp > h->opt_rank_limit;
+  const bool due = h->opt_flush_every > 0 ? h->pending_steps >= h->opt_flush_every
+                                          : h->pending_k + std::max(2 * m_hi, 2) > h->opt_rank_limit;   // (a step like this one would not fit)
   if (due || h->pending_k + 2 > KTOT)
     if (int rc = flush_pending(h)) return rc;
   return EKF_OK;
@@ -1067,7 +1072,7 @@ extern "C" int ekf_step_detections(ekf_handle* h, const double* lin, const doubl
   HIP_TRY(h, hipMemcpyAsync(ds, hs, sizeof(DetIn) * h->batch, hipMemcpyHostToDevice, h->stream));
   if (int rc = ring_done(h, slot)) return rc;
   const int mcap = cap_for(m_hi);
-  if (h->pending_k + ranks_for(mcap) > KTOT)
+  if (((h->pending_k + ranks_for(mcap) + 3) & ~3) > KTOT)   // (what the step's kernels will write: see enqueue_pass)
     if (int rc = flush_pending(h)) return rc;
   h->acfg.active_bound = h->opt_active_bound;
   launch_associate(h->stream, ds, h->dtagmap, h->dn, h->dneff, h->dmu2[h->cur], h->dP, h->dV, h->dW, h->d_assoc_step,

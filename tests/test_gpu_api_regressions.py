@@ -476,6 +476,37 @@ def test_download_into_pinned_memory_by_kernel_equals_the_copy(sd, n_lm, batch, 
         close(plain_P, oP)
 
 
+@pytest.mark.parametrize("m,steps_per_pass", [(5, 7), (12, 3), (8, 5), (3, 13), (1, 40)])
+def test_online_steps_are_charged_the_ranks_they_append(sd, m, steps_per_pass):
+    """`EkfSlam.step` (landmark indices not known in advance: the per-step kernels) charges a step 2 ranks per landmark of its
+    busiest trajectory -- not the rank slots of the kernel instantiation that ran it (1 / 2 / 4 / 8 / 16 landmarks) -- and
+    flushes when the NEXT step's writes would not fit 80 ranks: m = 5: 7 steps per covariance pass (until round 4: 5),
+    m = 12: 3 (2), m = 3: 13 (10).  Counted with the pass profiler; the state against the oracle."""
+    N, B = 120, 2
+    steps = 2 * steps_per_pass + 1
+    streams = [orc.synthetic_stream(N, steps, m, 900 + t) for t in range(B)]
+    cfg = orc.EkfConfig()
+    with sd.EkfSlam(3 + 2 * N, batch=B) as f:
+        f.set_option("active_bound", 0)
+        for b, s in enumerate(streams):
+            f.set_state_diag(s[0], s[1], b)
+        f.profile_enable(True)
+        for k in range(steps):
+            f.step([s[2][k] for s in streams], [s[3][k] for s in streams], [s[4][k] for s in streams],
+                   [s[5][k] for s in streams], [s[6][k] for s in streams])
+        f.sync()
+        _, launches = f.profile_read()
+        assert launches == 2, (launches, m)                    # two full passes, the last step still pending
+        for b, s in enumerate(streams):
+            mu, P = f.state(b)
+            om, oP = s[0].copy(), np.diag(s[1])
+            for k in range(steps):
+                om, oP = orc.ekf_step_dense(om, oP, s[2][k], s[3][k], s[4][k], s[5][k], s[6][k], cfg)
+            close(mu, om)
+            close(P, oP)
+            assert f.flags(b) == 0
+
+
 def test_a_bank_s_observations_as_arrays_equal_the_lists(sd):
     """`step` / `update` / `step_state` take a whole bank's observations as [batch, m] arrays (one block copy each instead of one
     per trajectory): the same state, bit for bit, as the lists of per-trajectory lists."""
