@@ -43,12 +43,12 @@ void launch_associate(hipStream_t, const DetIn*, int*, int*, int*, double*, doub
 void launch_fill_diag(hipStream_t, double*, int, int, const double*);
 int dense_propagate(hipStream_t, double* P, double* tmp, const double* F, const double* Q, int n, int ld);
 void launch_solve_cad(hipStream_t, const double*, const double*, double*, double*, const int*, const StepIn*, const CadPlan*, int,
-                      CadOut*, unsigned*, const DeviceConfig&, int, long, const double*, int);
+                      CadOut*, unsigned*, const DeviceConfig&, int, long, const double*, int, double*, int, int);
 void launch_gather_cad(hipStream_t, const double*, const double*, const double*, const double*, const StepIn*, const CadPlan*, int,
                        int, const DeviceConfig&, int, long, double*);
 long cadence_gbuf_doubles();
 void launch_panels_cad(hipStream_t, double*, double*, double*, const double*, double*, const int*, const CadOut*,
-                       SolveOut*, unsigned*, int, long, int, int, int);
+                       SolveOut*, unsigned*, int, long, int, int, int, const double*);
 }  // namespace ekf
 
 using namespace ekf;
@@ -135,6 +135,12 @@ struct ekf_handle : ekf::HostPlan {
   SolveOut* dmbox = nullptr;      // per trajectory: that solve's header and records, written through (mailbox_publish)
   unsigned step_seq = 0;          // sequence number of the last single-launch step
   CadOut* dcad = nullptr;         // per trajectory: head + per-landmark records of the cadence in flight (allocated on first use)
+  // The mirrored column entries of a cadence's panel launch, gathered by extra workgroups of its solve launch and laid down
+  // as rows (batch x 83 x ld doubles, allocated on first use; not for banks where that would exceed 1 GiB).  `colbuf_live`:
+  // the solve in flight has filled it (a solve launched beside a covariance pass -- look-ahead -- cannot: P_base is in motion)
+  double* dcolbuf = nullptr;
+  bool colbuf_live = false;
+  int opt_col_gather = 1;         // 1 = gather them beside the solve, 0 = the panel launch gathers everything itself
   long cadences = 0, cadence_traj_steps = 0;   // statistics: fused cadences launched, trajectory-steps they completed
   // The packed cadences of the ekf_stream_run in flight (ekf_host_plan.h: plan_cadences): one CadPlan per (cadence,
   // trajectory), planned on the host for the whole run and uploaded once, stream-ordered, out of pinned memory.  Two copies,
@@ -252,7 +258,7 @@ static void free_all(ekf_handle* h) {
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   void* ptrs[] = {h->dP, h->dmu2[0], h->dmu2[1], h->dV, h->dW, h->ddacc2[0], h->ddacc2[1], h->dscratch, h->dn, h->dflags, h->dso, h->dfac,
                   h->d_ring, h->d_stream, h->dF, h->dQ, h->dTmp, h->dPlin, h->dtagmap, h->dneff, h->d_det, h->d_assoc_step, h->dfloor, h->dqueue, h->dready, h->dmbox,
-                  h->d_assoc_out, h->dcad, h->dshares2[0], h->dshares2[1], h->dgbuf, h->dplan2[0], h->dplan2[1]};
+                  h->d_assoc_out, h->dcad, h->dshares2[0], h->dshares2[1], h->dgbuf, h->dplan2[0], h->dplan2[1], h->dcolbuf};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (h->h_ring) (void)hipHostFree(h->h_ring);
   if (h->h_det) (void)hipHostFree(h->h_det);
@@ -859,12 +865,24 @@ static int enqueue_cadence(ekf_handle* h, int c, bool presolved, bool* next_pres
   for (int b = 0; b < h->batch; ++b) h->neff_enq[b] = rp.entries[(size_t)c * h->batch + b].neff;
   const double* mu_in = h->dmu2[h->cur];
   double* mu_out = h->dmu2[h->cur ^ 1];
-  if (!presolved)
+  if (!presolved) {
+    // (the chain runs on one CU per trajectory: the rest of the chip gathers the panel launch's mirrored column entries
+    //  meanwhile -- where there is a rest, and something to gather)
+    const size_t cb_bytes = sizeof(double) * (size_t)h->batch * CAD_CU * h->ld;
+    double* colbuf = nullptr;
+    if (h->opt_col_gather && cb_bytes <= ((size_t)1 << 30) && h->batch * 2 <= h->cu_count && rp.slots_hi[c] > 0) {
+      if (!h->dcolbuf) HIP_TRY(h, hipMalloc(&h->dcolbuf, cb_bytes));
+      colbuf = h->dcolbuf;
+    }
+    const int col_wgs = h->cu_count - h->batch;
     launch_solve_cad(h->stream, h->dP, mu_in, mu_out, h->ddacc2[h->dcur ^ 1], h->dn, h->d_stream, dpl, h->batch, h->dcad,
-                     h->dflags, h->dcfg, h->ld, h->pstride, nullptr, 0);
+                     h->dflags, h->dcfg, h->ld, h->pstride, nullptr, 0, colbuf, n_hi, col_wgs);
+    h->colbuf_live = colbuf != nullptr;
+  }
   const int ranks = 2 * rp.slots_hi[c], nrp = (ranks + 3) & ~3;   // every trajectory writes the busiest one's ranks (zeros beyond its own)
   launch_panels_cad(h->stream, h->dP, h->dV, h->dW, mu_in, mu_out, h->dn, h->dcad, h->dso, h->dqueue, h->ld,
-                    h->pstride, h->batch, n_hi, nrp);
+                    h->pstride, h->batch, n_hi, nrp, h->colbuf_live ? h->dcolbuf : nullptr);
+  h->colbuf_live = false;
   HIP_TRY(h, hipGetLastError());
   h->dcur ^= 1;
   h->cur ^= 1;
@@ -905,7 +923,8 @@ static int enqueue_cadence(ekf_handle* h, int c, bool presolved, bool* next_pres
   // (the solve first: it is ready to go the moment the gather ends, the pass has an event to wait for -- the one
   //  workgroup per trajectory finds its CU before the pass fills the chip)
   launch_solve_cad(h->stream, h->dP, h->dmu2[h->cur], h->dmu2[h->cur ^ 1], h->ddacc2[h->dcur ^ 1], h->dn, h->d_stream, dpl2,
-                   h->batch, h->dcad, h->dflags, h->dcfg, h->ld, h->pstride, h->dgbuf, (kb + 7) / 8);
+                   h->batch, h->dcad, h->dflags, h->dcfg, h->ld, h->pstride, h->dgbuf, (kb + 7) / 8, nullptr, n_hi, 0);
+  h->colbuf_live = false;                              // (beside the pass P_base is in motion: that cadence's panel launch gathers itself)
   // From here on the next cadence's solve has overwritten dcad, the pose mean and the pending-noise buffer: a failure
   // below cannot be undone.  Whatever happens the two streams are joined again, and a failure marks every trajectory
   // undefined (EKF_ERR_STATE from then on, until it is uploaded again).
@@ -1549,6 +1568,11 @@ extern "C" int ekf_set_option(ekf_handle* h, const char* name, int value) {
   if (!std::strcmp(name, "pack_dense")) {
     if (value < 0 || value > 2) return fail(h, EKF_ERR_ARG, "pack_dense must be 0, 1 or 2");
     h->opt_pack_dense = value;
+    return EKF_OK;
+  }
+  if (!std::strcmp(name, "col_gather")) {
+    if (value != 0 && value != 1) return fail(h, EKF_ERR_ARG, "col_gather must be 0 or 1");
+    h->opt_col_gather = value;
     return EKF_OK;
   }
   if (!std::strcmp(name, "fetch_verify")) {

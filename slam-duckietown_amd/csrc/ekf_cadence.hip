@@ -116,7 +116,8 @@ __global__ __launch_bounds__(64 * CAD_NW) void k_solve_cad(const double* __restr
                                                     const StepIn* __restrict__ in, const CadPlan* __restrict__ plan, int batch,
                                                     CadOut* __restrict__ out, unsigned* __restrict__ flags,
                                                     DeviceConfig cfg, int ld,
-                                                    long pstride, const double* __restrict__ gbuf, int gparts) {
+                                                    long pstride, const double* __restrict__ gbuf, int gparts,
+                                                    double* __restrict__ colbuf, int col_wgs, int n_hi) {
   using G = CadGeom;
   constexpr int GM = G::GM, CU = G::CU;
   __shared__ __attribute__((aligned(16))) double Pc[CAD_ROWS][CAD_CS];
@@ -129,9 +130,93 @@ __global__ __launch_bounds__(64 * CAD_NW) void k_solve_cad(const double* __restr
   __shared__ double2 hS[2][6];                         // linearisation of slot s in hS[s & 1]: {h[0][k], h[1][k]}, k < 5
   __shared__ double2 siS[2];                           // S^-1 of the slot in flight
   __shared__ double2 yS[2];                            // innovation of slot s in yS[s & 1] (for its record)
-  const int b = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if ((int)blockIdx.x >= batch) {
+    // ---- the COLUMN GATHER beside the chain (round 5) ----
+    // The chain keeps one CU per trajectory busy for 55 - 70 us and the rest of the chip idle.  What the panel launch behind it
+    // gathers of the covariance has two halves: P(C_u[a], i) for i >= C_u[a] lies in row C_u[a] (64 state indices: 512
+    // contiguous bytes), for i < C_u[a] it is stored mirrored, as P_base(i, C_u[a]): one 16-byte pair per ROW i, a 64-byte
+    // sector of its own each, and random sectors stream at a third of the rate rows do (PMC: 107 MB more fetched for 62 us
+    // more at N = 2000 x 32 when the landmarks of a cadence are scattered over the map instead of consecutive,
+    // profiles/r05_scattered_indices.txt).  Nothing of that depends on the chain: workgroups batch.. of THIS launch fetch
+    // the mirrored pairs meanwhile -- 512 state indices each, every wave the pairs that lie entirely beyond its 64 indices --
+    // and lay them down coalesced, colbuf[b][a][i]; the panel launch reads them as rows.  (The positions C_u are formed
+    // from the plan exactly as the chain forms them.)
+    // `col_wgs` workgroups (one per CU the chain leaves free, so that all of them are resident at once) share the items
+    // (trajectory, 64 state indices), a wave at a time, all of a wave's loads in flight together.  An item costs what lies
+    // beyond its state indices -- everything for the first strip, nothing for the last -- and there are a few more items than
+    // waves (N = 2000 x 32: 2016 for 1792): dealt strip-major, dearest first, so that the second round is the cheap tail.
+    // (Tickets from a global counter instead: 80 us against 60 -- 3800 atomics on one word; profiles/r05_scattered_indices.txt.)
+    __shared__ int CsG[CAD_NW][128];                   // (per wave: the positions of the trajectory its item belongs to)
+    __shared__ int cntG[CAD_NW][CAD_SLOTS + 1];
+    const int strips = (n_hi + 63) >> 6, items = batch * strips;
+    const int gwave = ((int)blockIdx.x - batch) * CAD_NW + wave;
+    for (int item = gwave; item < items; item += col_wgs * CAD_NW) {
+      const int strip = item / batch, b = item - strip * batch, i0 = 64 * strip, i = i0 + lane;
+      const CadPlan pl = plan[b];
+      const int n = nact[b];
+      if (i0 >= n || i0 >= min(n, pl.neff) || pl.nslots == 0) continue;   // (uniform) nothing of this wave is replayed
+      // the positions C_u of trajectory b, by this wave alone (cad_positions restated for one wave: lane p = touched step p)
+      int* Cw = CsG[wave];
+      int* cw = cntG[wave];
+      Cw[lane] = lane < 3 ? lane : 0;
+      Cw[64 + lane] = 0;
+      int cnt = 0, lo = 0;
+      const StepIn* st = nullptr;
+      if (lane < pl.ns) {
+        st = in + ((long)(pl.t0 + lane) * batch + b);
+        const int m = ((st->flags & FLAG_UPDATE) && cfg.enable_measurement_model) ? min(st->m, MMAX) : 0;
+        lo = lane == 0 ? pl.j0 : 0;
+        const int hi = lane == pl.ns - 1 ? min(pl.jend, m) : m;
+        cnt = max(hi - lo, 0);
+      }
+      if (lane <= CAD_SLOTS) cw[lane] = lane < CAD_SLOTS ? cnt : 0;
+      WAVE_LDS_SYNC();
+      int first = 0;
+      for (int u = 0; u < lane && u < CAD_SLOTS; ++u) first += cw[u];
+      const int nslots = min(pl.nslots, CAD_SLOTS), s0 = GM - nslots;
+      if (lane < pl.ns) {
+        for (int j = 0; j < cnt; ++j) {
+          const int sl = s0 + first + j;
+          if (sl < GM) {
+            const int idx = st->idx[lo + j], pq = G::pa(sl);
+            Cw[pq] = 3 + 2 * idx;
+            Cw[pq + 1] = 4 + 2 * idx;
+          }
+        }
+      }
+      WAVE_LDS_SYNC();
+      const int ii = i < n ? i : n - 1;
+      const double* Pb = P + (long)b * pstride;
+      double* cb = colbuf + ((long)b * CAD_CU) * ld;
+      v2d_u v[CAD_SLOTS];
+      unsigned long long taken = 0ull;                 // (uniform) bit q: pair q is mirrored for this whole wave
+#pragma unroll
+      for (int q = 0; q < CAD_SLOTS; ++q) {
+        const int a = 3 + 2 * q;
+        const int c0 = Cw[a], c1 = Cw[a + 1];
+        const bool take = q < nslots && c1 == c0 + 1 && i0 + 63 <= c0 && (c1 & (PPW - 1)) != 0;   // (uniform: k_panels_cad's condition)
+        v[q].x = 0.0;
+        v[q].y = 0.0;
+        if (take) {
+          v[q] = *reinterpret_cast<const v2d_u*>(Pb + p_index(ld, ii, c0));
+          taken |= 1ull << q;
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < CAD_SLOTS; ++q) {
+        if (((taken >> q) & 1ull) && i < n) {
+          const int a = 3 + 2 * q;
+          cb[(long)a * ld + i] = v[q].x;
+          cb[(long)(a + 1) * ld + i] = v[q].y;
+        }
+      }
+      WAVE_LDS_SYNC();                                 // (the next item rewrites this wave's positions)
+    }
+    return;
+  }
+  const int b = blockIdx.x;
   const double* Pb = P + (long)b * pstride;
   const double* mu_in_b = mu_in + (long)b * ld;
   CadOut& o = out[b];
@@ -715,7 +800,8 @@ __global__ __launch_bounds__(64 * NW) void k_panels_cad(double* __restrict__ P, 
                                                         double* __restrict__ W, const double* __restrict__ mu_in,
                                                         double* __restrict__ mu_out, const int* __restrict__ nact,
                                                         const CadOut* __restrict__ co, SolveOut* __restrict__ so,
-                                                        unsigned* __restrict__ queue, int ld, long pstride, int nrp) {
+                                                        unsigned* __restrict__ queue, int ld, long pstride, int nrp,
+                                                        const double* __restrict__ colbuf) {
   using G = CadGeom;
   constexpr int CU = G::CU, GM = G::GM, NT = 64 * NW;
   __shared__ __attribute__((aligned(16))) double sRec[G::REC];
@@ -759,9 +845,15 @@ __global__ __launch_bounds__(64 * NW) void k_panels_cad(double* __restrict__ P, 
       X[a + 1] = Pb[p_index(ld, min(c1, 2), ii)];
 #else
       if (c1 == c0 + 1 && i0 + 63 <= c0 && (c1 & (PPW - 1)) != 0) {   // (uniform; the pair does not straddle two column panels)
-        const v2d_u v = *reinterpret_cast<const v2d_u*>(Pb + p_index(ld, ii, c0));
-        X[a] = v.x;
-        X[a + 1] = v.y;
+        if (colbuf) {                                  // (uniform) gathered beside the solve, laid down as rows: two coalesced loads
+          const double* cb = colbuf + ((long)b * CAD_CU + a) * ld;
+          X[a] = cb[ii];
+          X[a + 1] = cb[ld + ii];
+        } else {
+          const v2d_u v = *reinterpret_cast<const v2d_u*>(Pb + p_index(ld, ii, c0));
+          X[a] = v.x;
+          X[a + 1] = v.y;
+        }
       } else {
         X[a] = Pb[p_index(ld, min(c0, ii), max(c0, ii))];
         X[a + 1] = Pb[p_index(ld, min(c1, ii), max(c1, ii))];
@@ -882,7 +974,8 @@ __global__ __launch_bounds__(256) void k_panels_cad_ks(double* __restrict__ P, d
                                                        double* __restrict__ W, const double* __restrict__ mu_in,
                                                        double* __restrict__ mu_out, const int* __restrict__ nact,
                                                        const CadOut* __restrict__ co, SolveOut* __restrict__ so,
-                                                       unsigned* __restrict__ queue, int ld, long pstride, int nrp) {
+                                                       unsigned* __restrict__ queue, int ld, long pstride, int nrp,
+                                                       const double* __restrict__ colbuf) {
   using G = CadGeom;
   constexpr int GM = G::GM, CU = G::CU;
   constexpr int LP = (GM + 3) / 4;                     // landmark position-slots per wave
@@ -917,9 +1010,15 @@ __global__ __launch_bounds__(256) void k_panels_cad_ks(double* __restrict__ P, d
       const int a = 3 + 8 * pp + 2 * wave;
       const int c0 = o.C[min(a, CU)], c1 = o.C[min(a + 1, CU)];   // (C[CU] = 0: a position beyond the cadence's)
       if (c1 == c0 + 1 && i0 + 63 <= c0 && (c1 & (PPW - 1)) != 0) {   // (uniform) both mirrored: side by side in row i (see k_panels_cad)
-        const v2d_u v = *reinterpret_cast<const v2d_u*>(Pb + p_index(ld, ii, c0));
-        XL[2 * pp] = v.x;
-        XL[2 * pp + 1] = v.y;
+        if (colbuf && a < CU) {                        // (uniform) gathered beside the solve
+          const double* cb = colbuf + ((long)b * CAD_CU + a) * ld;
+          XL[2 * pp] = cb[ii];
+          XL[2 * pp + 1] = cb[ld + ii];
+        } else {
+          const v2d_u v = *reinterpret_cast<const v2d_u*>(Pb + p_index(ld, ii, c0));
+          XL[2 * pp] = v.x;
+          XL[2 * pp + 1] = v.y;
+        }
       } else {
         XL[2 * pp] = Pb[p_index(ld, min(c0, ii), max(c0, ii))];
         XL[2 * pp + 1] = Pb[p_index(ld, min(c1, ii), max(c1, ii))];
@@ -1048,28 +1147,31 @@ void launch_gather_cad(hipStream_t st, const double* P, const double* V, const d
                      ld, pstride, gbuf);
 }
 
+// `colbuf` (batch x CAD_CU x ld doubles, or nullptr): the launch also gathers the mirrored column entries of the panel launch
+// behind it, on `col_wgs` extra workgroups -- only where P_base is current (not beside a pass: look-ahead)
 void launch_solve_cad(hipStream_t st, const double* P, const double* mu_in, double* mu_out, double* dacc_out,
                       const int* nact, const StepIn* in, const CadPlan* plan, int batch, CadOut* out, unsigned* flags,
-                      const DeviceConfig& cfg, int ld, long pstride, const double* gbuf, int gparts) {
-  hipLaunchKernelGGL(k_solve_cad, dim3(batch), dim3(64 * CAD_NW), 0, st, P, mu_in, mu_out, dacc_out, nact, in, plan, batch, out,
-                     flags, cfg, ld, pstride, gbuf, gparts);
+                      const DeviceConfig& cfg, int ld, long pstride, const double* gbuf, int gparts, double* colbuf, int n_hi,
+                      int col_wgs) {
+  hipLaunchKernelGGL(k_solve_cad, dim3(batch + (colbuf ? col_wgs : 0)), dim3(64 * CAD_NW), 0, st, P, mu_in, mu_out, dacc_out, nact, in,
+                     plan, batch, out, flags, cfg, ld, pstride, gbuf, gparts, colbuf, col_wgs, n_hi);
 }
 
 // `nrp`: the ranks the bank's busiest trajectory appends, padded to a whole k-tile (every trajectory writes that many)
 void launch_panels_cad(hipStream_t st, double* P, double* V, double* W, const double* mu_in, double* mu_out,
                        const int* nact, const CadOut* co, SolveOut* so, unsigned* queue, int ld, long pstride, int batch,
-                       int n_hi, int nrp) {
+                       int n_hi, int nrp, const double* colbuf) {
   // few state indices (the latency regime): four waves split the rows of the panel of 64 state indices (k_panels_cad_ks);
   // up to one wave per SIMD: one wave per workgroup
   if ((long)((n_hi + 63) / 64) * batch <= CAD_KS_WAVES)
     hipLaunchKernelGGL(k_panels_cad_ks, dim3((n_hi + 63) / 64, batch), dim3(256), 0, st, P, V, W, mu_in, mu_out,
-                       nact, co, so, queue, ld, pstride, nrp);
+                       nact, co, so, queue, ld, pstride, nrp, colbuf);
   else if ((long)((n_hi + 63) / 64) * batch <= 1024)
     hipLaunchKernelGGL((k_panels_cad<1>), dim3((n_hi + 63) / 64, batch), dim3(64), 0, st, P, V, W, mu_in, mu_out,
-                       nact, co, so, queue, ld, pstride, nrp);
+                       nact, co, so, queue, ld, pstride, nrp, colbuf);
   else
     hipLaunchKernelGGL((k_panels_cad<4>), dim3((n_hi + 255) / 256, batch), dim3(256), 0, st, P, V, W, mu_in,
-                       mu_out, nact, co, so, queue, ld, pstride, nrp);
+                       mu_out, nact, co, so, queue, ld, pstride, nrp, colbuf);
 }
 
 }  // namespace ekf
