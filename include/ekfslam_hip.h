@@ -134,9 +134,13 @@ int ekf_download_tags(ekf_handle *h, int b, int *m, int *idx, int *tag_id, doubl
 int ekf_download_tag_index(ekf_handle *h, int b, int *tag_of_index, int capacity, int *n_landmarks);
 int ekf_upload_tag_index(ekf_handle *h, int b, const int *tag_of_index, int n_landmarks);
 
-/* Streams of pre-uploaded inputs ([step][batch] and [step][batch][stride] arrays, stride <= EKF_MMAX).
+/* Streams of pre-uploaded inputs ([step][batch] and [step][batch][stride] arrays, stride <= EKF_MMAX; m[step][batch] landmarks
+ * each -- any count per step and trajectory, 0 included: what the windows of src/replay_no_ros.py:280-301 hold).
  * ekf_stream_upload copies and validates `steps` steps of inputs into HBM (blocking);
- * ekf_stream_run enqueues steps [first, first+count) back to back (asynchronous);
+ * ekf_stream_run enqueues steps [first, first+count) back to back (asynchronous).  Where nothing is pending they run as packed
+ * cadences ("fused_cadence"): per covariance pass every trajectory's next 40 landmark updates, whatever steps they belong to --
+ * inside the call the trajectories of a bank advance through the range at their own pace (they are independent filters); when
+ * the call returns every one of them has been enqueued up to first+count;
  * ekf_run_stream = upload + run all. */
 int ekf_stream_upload(ekf_handle *h, int steps, const double *lin, const double *ang, const int *idx,
                       const double *range, const double *bearing, const int *m, int stride);
@@ -150,8 +154,9 @@ int ekf_run_stream(ekf_handle *h, int steps, const double *lin, const double *an
 int ekf_predict_dense(ekf_handle *h, int b, const double *F, const double *Q);
 
 /* The covariance is held as P_base + (pending low-rank update of the last few steps, 2 ranks per observed
- * landmark); the O(n^2) pass over P_base is paid once per `flush_every` steps (option; default 0 = as many
- * steps as fit `rank_limit` = 80 pending ranks: 5 steps at 8 observations per step, 40 at one).  ekf_flush
+ * landmark -- exactly: a step is charged the ranks of its busiest trajectory, whatever the landmark count); the O(n^2) pass over
+ * P_base is paid once per `flush_every` steps (option; default 0 = as many landmark updates as fit `rank_limit` = 80 pending
+ * ranks: 40 -- 5 steps at 8 observations per step, 8 at five, 40 at one).  ekf_flush
  * applies what is pending now (asynchronous).  Every call that reads or rewrites the covariance flushes by
  * itself. */
 int ekf_flush(ekf_handle *h);
@@ -177,8 +182,10 @@ int ekf_profile_read(ekf_handle *h, double *pass_ms_total, long long *pass_launc
  * persistent workgroups, 0 = one per CU; fewer leaves whole CUs to other streams), "fused_step" (1 = small launches
  * run a step as one kernel, the panels gathered beside the solve -- same results; 0 = always two kernels; 2 =
  * diagnostic: the solve never publishes its completion, every bounded wait times out with EKF_FLAG_INTERNAL),
- * "fused_cadence" (1 = ekf_stream_run replays all steps between two covariance passes -- up to 40 landmark updates,
- * src/replay_no_ros.py:368-480 for each -- with one solve launch and one panel launch; equal to the per-step kernels to
+ * "fused_cadence" (1 = ekf_stream_run replays everything between two covariance passes -- a trajectory's next 40 landmark
+ * updates, src/replay_no_ros.py:368-480 for each, and every prediction in between -- with one solve launch and one panel launch;
+ * "col_gather" = 1: the mirrored column entries of that panel launch are fetched beside the solve by the CUs its chain leaves idle,
+ * 0: the panel launch gathers everything itself, same results bit for bit; the fused path is equal to the per-step kernels to
  * rounding (1e-10 relative guaranteed, 1e-13 .. 1e-12 measured; the tests assert 1e-11), not bit for bit; 0 = one step at a time), "lookahead" (1 = where the pass is a
  * small launch, the next cadence's solve runs beside it on the handle's second stream; 0 = strictly in sequence),
  * "pass_share_order" (row-slab pass on static shares: 1 = shares dealt to the XCDs by starting column, 0 = as cut; same
