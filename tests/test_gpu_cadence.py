@@ -494,6 +494,31 @@ def test_packed_cadences_with_wandering_landmark_counts(sd, N, B, steps, hi):
                                       oracle_for=None if B <= 4 else (0, B - 1))
 
 
+@pytest.mark.parametrize("N,B,steps", [(300, 3, 30), (1400, 24, 12), (2100, 2, 12)])
+def test_column_gather_beside_the_solve_is_bit_identical(sd, N, B, steps):
+    """The mirrored column entries of the panel launch (P(C_u[a], i) for i < C_u[a]: one 16-byte pair per row) fetched by extra
+    workgroups of the SOLVE launch and laid down as rows (`col_gather` = 1, the default) against the panel launch gathering
+    everything itself (`col_gather` = 0): the same values by another road -- bit for bit, scattered landmarks, the latency and
+    the throughput shape of the panel launch, a state of two column panels (N = 2100: pairs next to the panel boundary)."""
+    n = 3 + 2 * N
+    means, lin, ang, idx, zr, zb, m = wandering_stream(N, B, steps, lambda k, b, rng: rng.integers(0, 9), 6100 + N)
+    if N > 2048:
+        idx[:, :, 0] = np.where(m > 0, 2046, idx[:, :, 0])     # landmark 2046: columns 4095, 4096 straddle the panels
+        for k in range(steps):
+            for b in range(B):
+                dup = np.nonzero(idx[k, b, 1:m[k, b]] == 2046)[0]
+                idx[k, b, 1 + dup] = 2045 - dup                  # (keep the indices of a step distinct)
+    starts = [dense_start(n, 6200 + t) for t in range(B)]
+    res = {}
+    for cg in (1, 0):
+        res[cg], (nc, ns) = run_stream(sd, n, B, starts, means, lin, ang, idx, zr, zb, m,
+                                       options=[("active_bound", 0), ("lookahead", 0), ("col_gather", cg)])
+        assert ns == steps and nc >= 1
+    for b in range(B):
+        assert np.array_equal(res[1][b][0], res[0][b][0]) and np.array_equal(res[1][b][1], res[0][b][1]), b
+    check_against_per_step_and_oracle(sd, n, B, starts, means, lin, ang, idx, zr, zb, m, res[1], oracle_for=(0,))
+
+
 def test_long_runs_without_observations_inside_a_fused_run(sd):
     """Windows in which no tag is seen (the reference's loop then only predicts, src/replay_no_ros.py:435): 45 such steps at
     the head of the stream are one cadence of 40 predictions that appends no rank anywhere in the bank -- no pass follows,
