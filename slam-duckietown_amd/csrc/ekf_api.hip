@@ -1315,12 +1315,18 @@ extern "C" int ekf_stream_run(ekf_handle* h, int first, int count) {
     // its own cursor, a covariance pass between two cadences.  While ranks are pending (steps enqueued before this call) the
     // per-step kernels append to them until their pass is due.
     if (cadences_possible(h)) {
-      plan_cadences(h, k, first + count, h->run_plan);
+      // (planned and uploaded in pieces of at most 8192 steps: 32 B per cadence and trajectory; a piece ends with every
+      //  trajectory at its last step, and what its last cadence left pending is flushed so that the next piece starts fused)
+      const int piece_end = std::min(first + count, k + 8192);
+      plan_cadences(h, k, piece_end, h->run_plan);
       if (int rc = upload_run_plan(h)) return rc;
       bool presolved = false;                          // the next cadence's solve has been enqueued already (look-ahead)
       for (int c = 0; c < h->run_plan.ncad; ++c)
         if (int rc = enqueue_cadence(h, c, presolved, &presolved)) return rc;
-      break;
+      k = piece_end;
+      if (k < first + count)
+        if (int rc = flush_pending(h)) return rc;
+      continue;
     }
     for (int b = 0; b < h->batch; ++b)
       h->neff_enq[b] = std::min(h->n[b], std::max(h->floor_host[b], h->stream_own[(size_t)k * h->batch + b]));

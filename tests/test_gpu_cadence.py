@@ -519,6 +519,29 @@ def test_column_gather_beside_the_solve_is_bit_identical(sd, N, B, steps):
     check_against_per_step_and_oracle(sd, n, B, starts, means, lin, ang, idx, zr, zb, m, res[1], oracle_for=(0,))
 
 
+def test_a_run_longer_than_one_planning_piece(sd):
+    """ekf_stream_run plans its packed cadences in pieces of 8192 steps (32 B per cadence and trajectory stay bounded): a run
+    of 8300 steps crosses one piece boundary -- every trajectory is brought to the boundary, what is pending there is flushed,
+    the next piece starts fused.  Against the per-step path and the oracle."""
+    N, B, steps = 40, 2, 8300
+    n = 3 + 2 * N
+    means, lin, ang, idx, zr, zb, m = wandering_stream(N, B, steps, lambda k, b, rng: rng.integers(0, 3), 6400)
+    starts = [dense_start(n, 6500 + t) for t in range(B)]
+    opts = [("active_bound", 0), ("small_state", 0)]
+    fused, (nc, ns) = run_stream(sd, n, B, starts, means, lin, ang, idx, zr, zb, m, options=opts)
+    need = max(cadences_needed(m[:8192, b]) for b in range(B)) + max(cadences_needed(m[8192:, b]) for b in range(B))
+    assert nc == need and ns == steps
+    plain, _ = run_stream(sd, n, B, starts, means, lin, ang, idx, zr, zb, m, options=opts + [("fused_cadence", 0)])
+    cfg = orc.EkfConfig()
+    om, oP = means[0].copy(), starts[0].copy()
+    for k in range(steps):
+        mb = m[k, 0]
+        om, oP = orc.ekf_step_dense(om, oP, lin[k, 0], ang[k, 0], idx[k, 0, :mb], zr[k, 0, :mb], zb[k, 0, :mb], cfg)
+    for b in range(B):
+        assert orc.rel_fro(fused[b][0], plain[b][0]) < 1e-9 and orc.rel_fro(fused[b][1], plain[b][1]) < 1e-9   # (8300 steps of rounding)
+    assert orc.rel_fro(fused[0][0], om) < 1e-8 and orc.rel_fro(fused[0][1], oP) < 1e-8
+
+
 def test_long_runs_without_observations_inside_a_fused_run(sd):
     """Windows in which no tag is seen (the reference's loop then only predicts, src/replay_no_ros.py:435): 45 such steps at
     the head of the stream are one cadence of 40 predictions that appends no rank anywhere in the bank -- no pass follows,
