@@ -13,8 +13,7 @@ sys.path.insert(0, ROOT)
 
 NAMES = {0: "w0 start", 1: "w0 (H P) published", 2: "w0 S, K published", 3: "w0 records issued / at b1", 4: "w0 past b1",
          5: "w0 down-date done / at b2", 6: "w0 past b2", 7: "w0 next H read", 8: "w1 start", 9: "w1 at b1", 10: "w1 past b1",
-         11: "w1 mean + next Jacobian done / at b2", 12: "w1 innovation done", 13: "w1 mean updated", 14: "w1 y record issued",
-         15: "-"}
+         11: "w1 mean + next Jacobian done / at b2", 12: "w1 innovation done", 13: "w1 mean updated", 15: "-"}
 
 
 def main():
