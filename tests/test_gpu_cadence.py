@@ -315,6 +315,37 @@ def test_lookahead_solve_beside_the_pass(sd, N, B, m, steps):
     assert orc.rel_fro(res[1][0][0], om) < TIGHT and orc.rel_fro(res[1][0][1], oP) < TIGHT
 
 
+def test_lookahead_with_wandering_landmark_counts(sd):
+    """The look-ahead with packed cadences whose steps are cut by the pass: the next cadence's block is gathered (k_gather_cad,
+    from the plan's positions) while this cadence's ranks are pending, for trajectories that sit at different steps of the
+    stream.  N = 1250 x 2, m ~ U{0..16}: against `lookahead` = 0 to rounding and against the O(n^2) oracle."""
+    N, B, steps = 1250, 2, 14
+    n = 3 + 2 * N
+    means, lin, ang, idx, zr, zb, m = wandering_stream(N, B, steps, lambda k, b, rng: rng.integers(0, 17), 7100)
+    starts = [dense_start(n, 7200 + t) for t in range(B)]
+    res = {}
+    for la in (1, 0):
+        with sd.EkfSlam(n, batch=B) as f:
+            f.set_option("active_bound", 0)
+            f.set_option("lookahead", la)
+            for b in range(B):
+                f.set_state(means[b], starts[b], b)
+            f.run_stream(lin, ang, idx, zr, zb, m)
+            res[la] = [f.state(b) for b in range(B)]
+            assert [f.flags(b) for b in range(B)] == [0] * B
+            nc = cadences(sd, f)[0]
+            assert nc == max(cadences_needed(m[:, b]) for b in range(B)) and nc >= 3
+            assert lookaheads(sd, f) == (nc - 1 if la else 0)
+    cfg = orc.EkfConfig()
+    for b in range(B):
+        assert orc.rel_fro(res[1][b][0], res[0][b][0]) < PATH_TOL and orc.rel_fro(res[1][b][1], res[0][b][1]) < PATH_TOL
+        om, oP = means[b].copy(), starts[b].copy()
+        for k in range(steps):
+            mb = m[k, b]
+            om, oP = orc.ekf_step_structured(om, oP, lin[k, b], ang[k, b], idx[k, b, :mb], zr[k, b, :mb], zb[k, b, :mb], cfg)
+        assert orc.rel_fro(res[1][b][0], om) < TIGHT and orc.rel_fro(res[1][b][1], oP) < TIGHT
+
+
 def test_lookahead_beside_the_row_slab_pass_on_static_shares(sd):
     """A few long trajectories (N = 8000 x 1) take the row-slab pass on equal static shares, on one workgroup per trajectory
     fewer than the chip has CUs, so that the next cadence's solve runs beside it as well.  Here at a size the oracle
