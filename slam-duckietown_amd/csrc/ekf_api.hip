@@ -870,7 +870,10 @@ static int enqueue_cadence(ekf_handle* h, int c, bool presolved, bool* next_pres
     //  meanwhile -- where there is a rest, and something to gather)
     const size_t cb_bytes = sizeof(double) * (size_t)h->batch * CAD_CU * h->ld;
     double* colbuf = nullptr;
-    if (h->opt_col_gather && cb_bytes <= ((size_t)1 << 30) && h->batch * 2 <= h->cu_count && rp.slots_hi[c] > 0) {
+    // (while its items -- trajectories x strips of 64 state indices -- are at most four rounds of the idle CUs' waves: N = 2000:
+    //  up to ~80 trajectories; x 64 +1 - 2 %, x 128 -2 % on scattered landmarks, profiles/r05_scattered_indices.txt)
+    const long col_items = (long)h->batch * ((n_hi + 63) / 64), col_waves = 8L * (h->cu_count - h->batch);
+    if (h->opt_col_gather && cb_bytes <= ((size_t)1 << 30) && col_waves > 0 && col_items <= 4 * col_waves && rp.slots_hi[c] > 0) {
       if (!h->dcolbuf) HIP_TRY(h, hipMalloc(&h->dcolbuf, cb_bytes));
       colbuf = h->dcolbuf;
     }
