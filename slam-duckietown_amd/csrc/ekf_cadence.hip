@@ -67,25 +67,47 @@ constexpr int CAD_DW = CAD_NW - 2;      // waves that share a down-date by rows 
 constexpr int CAD_DCH = 7;              // rows of a down-date chunk (all reads of a chunk in flight together)
 constexpr int CAD_DQ = (CAD_CU - 2 + CAD_DCH * CAD_DW - 1) / (CAD_DCH * CAD_DW) * CAD_DCH;   // rows per down-date wave
 
-// The positions C_u of a trajectory's cadence, formed the same way by the solve and by the look-ahead gather: thread p <
-// CAD_SLOTS takes touched step p of the plan -- its landmark range [lo, hi), the slots in front of it (a 40-entry prefix sum
-// through LDS) -- and writes its landmarks' positions; `per_slot(s, step record, j)` lets the solve pick up the measurements.
-// Returns (to every thread) the number of slots.  cntS / firstS: CAD_SLOTS + 1 ints of LDS each.
-template <class PerSlot>
+// The positions C_u of a trajectory's cadence, formed the same way by the solve and by the look-ahead gather (512 threads
+// each).  Thread p < CAD_SLOTS takes touched step p of the plan: its landmark range [lo, hi) and, through a 40-entry prefix sum
+// in LDS, the slots in front of it.  The landmarks themselves are dealt over all threads -- entry e = (step e / 16, landmark
+// e % 16), up to 640 of them -- and FETCHED BEFORE the counts are known (a record's 16 landmark places always exist): one
+// memory round trip for the whole prologue instead of two dependent ones.  `per_slot(s, range, bearing)` lets the solve pick
+// up the measurements (WANT_Z).  Returns (to every thread) the number of slots.  cntS / firstS / loS: CAD_SLOTS + 1 ints each.
+template <bool WANT_Z, class PerSlot>
 __device__ __forceinline__ int cad_positions(const CadPlan& pl, const StepIn* __restrict__ in, int batch, int b, const DeviceConfig& cfg,
-                                             int tid, int* Cs, int* cntS, int* firstS, PerSlot per_slot) {
+                                             int tid, int* Cs, int* cntS, int* firstS, int* loS, PerSlot per_slot) {
   using G = CadGeom;
+  constexpr int NT = 64 * CAD_NW, EPT = (CAD_SLOTS * MMAX + NT - 1) / NT;   // entries per thread (2)
   if (tid < 128) Cs[tid] = tid < 3 ? tid : 0;
+  int eidx[EPT];
+  double er[EPT], eb[EPT];
+#pragma unroll
+  for (int k = 0; k < EPT; ++k) {
+    const int e = tid + NT * k, p = e / MMAX, q = e - p * MMAX;
+    eidx[k] = 0;
+    er[k] = 0.0;
+    eb[k] = 0.0;
+    if (p < pl.ns) {
+      const StepIn* st = in + ((long)(pl.t0 + p) * batch + b);
+      eidx[k] = st->idx[q];
+      if (WANT_Z) {
+        er[k] = st->range[q];
+        eb[k] = st->bearing[q];
+      }
+    }
+  }
   int cnt = 0, lo = 0;
-  const StepIn* st = nullptr;
   if (tid < pl.ns) {
-    st = in + ((long)(pl.t0 + tid) * batch + b);
+    const StepIn* st = in + ((long)(pl.t0 + tid) * batch + b);
     const int m = ((st->flags & FLAG_UPDATE) && cfg.enable_measurement_model) ? min(st->m, MMAX) : 0;
     lo = tid == 0 ? pl.j0 : 0;
     const int hi = tid == pl.ns - 1 ? min(pl.jend, m) : m;
     cnt = max(hi - lo, 0);
   }
-  if (tid <= CAD_SLOTS) cntS[tid] = tid < CAD_SLOTS ? cnt : 0;
+  if (tid <= CAD_SLOTS) {
+    cntS[tid] = tid < CAD_SLOTS ? cnt : 0;
+    loS[tid] = lo;
+  }
   __syncthreads();
   if (tid <= CAD_SLOTS) {
     int f = 0;
@@ -95,15 +117,19 @@ __device__ __forceinline__ int cad_positions(const CadPlan& pl, const StepIn* __
   __syncthreads();
   const int nslots = min(firstS[CAD_SLOTS], CAD_SLOTS);
   const int s0 = G::GM - nslots;
-  if (tid < pl.ns) {
-    const int f = firstS[tid];
-    for (int j = 0; j < cnt; ++j) {
-      const int s = s0 + f + j;
-      if (s < G::GM) {                                 // (a plan that disagrees with the records cannot write outside)
-        const int idx = st->idx[lo + j], p = G::pa(s);
-        Cs[p] = 3 + 2 * idx;
-        Cs[p + 1] = 4 + 2 * idx;
-        per_slot(s, st, lo + j);
+#pragma unroll
+  for (int k = 0; k < EPT; ++k) {
+    const int e = tid + NT * k, p = e / MMAX, q = e - p * MMAX;
+    if (p < pl.ns) {
+      const int lo_p = loS[p], j = q - lo_p;
+      if (j >= 0 && j < cntS[p]) {
+        const int sl = s0 + firstS[p] + j;
+        if (sl < G::GM) {                              // (a plan that disagrees with the records cannot write outside)
+          const int pq = G::pa(sl);
+          Cs[pq] = 3 + 2 * eidx[k];
+          Cs[pq + 1] = 4 + 2 * eidx[k];
+          per_slot(sl, er[k], eb[k]);
+        }
       }
     }
   }
@@ -125,7 +151,7 @@ __global__ __launch_bounds__(64 * CAD_NW) void k_solve_cad(const double* __restr
   __shared__ int Cs[128];
   __shared__ double2 zS[CAD_SLOTS];                    // (range, bearing) of slot s
   __shared__ double2 laS[CAD_SLOTS];                   // (lin, ang) of touched step p
-  __shared__ int mS[CAD_SLOTS + 1], firstS[CAD_SLOTS + 1], fS[CAD_SLOTS];
+  __shared__ int mS[CAD_SLOTS + 1], firstS[CAD_SLOTS + 1], loS[CAD_SLOTS + 1], fS[CAD_SLOTS];
   __shared__ double mot[4];                            // G[0,2], G[1,2] of the step being predicted
   __shared__ double2 hS[2][6];                         // linearisation of slot s in hS[s & 1]: {h[0][k], h[1][k]}, k < 5
   __shared__ double2 siS[2];                           // S^-1 of the slot in flight
@@ -236,8 +262,8 @@ __global__ __launch_bounds__(64 * CAD_NW) void k_solve_cad(const double* __restr
     fS[tid] = fl;
     laS[tid] = la;
   }
-  const int nslots = cad_positions(pl, in, batch, b, cfg, tid, Cs, mS, firstS,
-                                   [&](int s, const StepIn* st, int j) { zS[s] = make_double2(st->range[j], st->bearing[j]); });
+  const int nslots = cad_positions<true>(pl, in, batch, b, cfg, tid, Cs, mS, firstS, loS,
+                                         [&](int s, double zr, double zb) { zS[s] = make_double2(zr, zb); });
   const int s0 = GM - nslots;
   const int cu = 3 + 2 * nslots;                       // positions in use
   const int neff_eff = min(nact[b], pl.neff);
@@ -700,7 +726,7 @@ __global__ __launch_bounds__(64 * CAD_GW) void k_gather_cad(const double* __rest
   __shared__ __attribute__((aligned(16))) double Vc[8][CAD_VS];      // [k][a]
   __shared__ __attribute__((aligned(16))) double Ms[96][CAD_VS];     // this part's share of M
   __shared__ int Cs[128];
-  __shared__ int cntS[CAD_SLOTS + 1], firstS[CAD_SLOTS + 1];
+  __shared__ int cntS[CAD_SLOTS + 1], firstS[CAD_SLOTS + 1], loS[CAD_SLOTS + 1];
   const int part = blockIdx.x, b = blockIdx.y;
   const int k0 = 8 * part;                             // this workgroup's ranks: k0 .. k0 + 7
   const int tid = threadIdx.x, lane = tid & 63;
@@ -710,7 +736,7 @@ __global__ __launch_bounds__(64 * CAD_GW) void k_gather_cad(const double* __rest
   const double* Wb = W + (long)b * KTOT * ld;
   const int ld16 = ld >> 4;
   const CadPlan pl = plan[b];
-  cad_positions(pl, in, batch, b, cfg, tid, Cs, cntS, firstS, [](int, const StepIn*, int) {});   // (as in k_solve_cad)
+  cad_positions<false>(pl, in, batch, b, cfg, tid, Cs, cntS, firstS, loS, [](int, double, double) {});   // (as in k_solve_cad)
   __syncthreads();
   const int Cl0 = Cs[lane], Cl1 = Cs[64 + lane];
   // (part 0) the base entries first: their latency hides under the staging and the product
