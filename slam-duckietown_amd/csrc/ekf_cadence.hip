@@ -351,21 +351,30 @@ __global__ __launch_bounds__(64 * CAD_NW) void k_solve_cad(const double* __restr
     if (gbuf) {
       // (uniform) look-ahead: the block was gathered (base + the ranks still pending then) by k_gather_cad, in `gparts`
       // parts, added here in a fixed order; all loads of a part are in flight together
+      // (... four parts' loads in flight together: ten dependent round trips were 8 us of a single trajectory's cadence)
+      constexpr int GPB = 4;
 #pragma unroll
-      for (int gp = 0; gp < KTOT / 8; ++gp) {
-        if (gp < gparts) {                             // (uniform)
-          double t0[RQ], t1[RQ];
+      for (int g0 = 0; g0 < KTOT / 8; g0 += GPB) {
+        if (g0 < gparts) {                             // (uniform)
+          double t0[GPB][RQ], t1[GPB][RQ];
 #pragma unroll
-          for (int q = 0; q < RQ; ++q) {
-            const int r = min(wave + CAD_NW * q, max(cu - 1, 0));
-            const double* gb = gbuf + (((long)gp * batch + b) * CAD_ROWS + r) * CAD_CS;
-            t0[q] = gb[lane];
-            t1[q] = gb[lane_b];
+          for (int u = 0; u < GPB; ++u) {
+            const bool on = g0 + u < gparts && g0 + u < KTOT / 8;   // (uniform)
+#pragma unroll
+            for (int q = 0; q < RQ; ++q) {
+              const int r = min(wave + CAD_NW * q, max(cu - 1, 0));
+              const double* gb = gbuf + (((long)(on ? g0 + u : 0) * batch + b) * CAD_ROWS + r) * CAD_CS;
+              t0[u][q] = on ? gb[lane] : 0.0;
+              t1[u][q] = on ? gb[lane_b] : 0.0;
+            }
           }
 #pragma unroll
-          for (int q = 0; q < RQ; ++q) {
-            gv0[q] += t0[q];
-            gv1[q] += t1[q];
+          for (int u = 0; u < GPB; ++u) {
+#pragma unroll
+            for (int q = 0; q < RQ; ++q) {
+              gv0[q] += t0[u][q];
+              gv1[q] += t1[u][q];
+            }
           }
         }
       }
