@@ -103,6 +103,48 @@ def test_config4_shard_n2000_x32_default_cadence(sd):
                 assert np.array_equal(mu, got[b % K][0]) and np.array_equal(P, got[b % K][1])
 
 
+def test_variable_m_leg_n2000_x32_as_benchmarked(sd):
+    """bench.py's `variable_m` leg at its own size and options (N = 2000, 32 trajectories, m ~ U{0..8} per trajectory and step at
+    scattered indices, active bound off): packed cadences with every trajectory on its own cursor, the column gather beside
+    the solve, the row-slab pass behind every cadence -- the paths asserted, trajectories 0 and 1 against the O(n^2) oracle,
+    and trajectory b > 1 -- a replica of trajectory b % 2 sitting elsewhere in the launches, among neighbours at other steps --
+    bit for bit against it."""
+    import slam_duckietown_amd.synthetic as syn
+    N, steps, B, K = 2000, 14, 32, 2
+    n = 3 + 2 * N
+    cfg = orc.EkfConfig()
+    streams = [syn.variable_stream(N, steps, 0, 8, 70 + t) for t in range(K)]
+    starts = [dense_start(n, 17 + t) for t in range(K)]
+    ref = []
+    for t in range(K):
+        s = streams[t]
+        om, oP = s[0].copy(), starts[t].copy()
+        for k in range(steps):
+            mk = s[7][k]
+            om, oP = orc.ekf_step_structured(om, oP, s[2][k], s[3][k], s[4][k][:mk], s[5][k][:mk], s[6][k][:mk], cfg)
+        ref.append((om, oP))
+    pick = [streams[b % K] for b in range(B)]
+    with sd.EkfSlam(n, batch=B) as f:
+        f.set_option("active_bound", 0)
+        for b in range(B):
+            f.set_state(pick[b][0], starts[b % K], b)
+        f.run_stream(*[np.stack([s[i] for s in pick], 1) for i in (2, 3, 4, 5, 6, 7)])
+        cad, covered, _, shares = debug_counters(sd, f)
+        need = max(-(-int(s[7].sum()) // 40) for s in streams)
+        assert covered == steps and need <= cad <= need + 1          # 40 landmark updates per pass (+ the tail)
+        assert f.last_pass().startswith("ekf::k_flush_rs<") and shares == 0
+        got = {}
+        for b in (0, 1, 2, 3, 30, 31):
+            mu, P = f.state(b)
+            assert f.flags(b) == 0 and np.array_equal(P, P.T)
+            if b < K:
+                close(mu, ref[b][0])
+                close(P, ref[b][1])
+                got[b] = (mu, P)
+            else:
+                assert np.array_equal(mu, got[b % K][0]) and np.array_equal(P, got[b % K][1])
+
+
 def test_streaming_80_rank_pass_small(sd):
     """The same instantiation (nontemporal, 15 k-tiles of the V strip in registers + 5 in LDS) forced on a small
     state, every step against the reference-shaped dense path."""
