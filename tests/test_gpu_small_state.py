@@ -274,6 +274,7 @@ def test_polled_hand_over_carries_an_integrity_trailer(sd, N, m):
     lib = sd.load_library()
     s = orc.synthetic_stream(N, 200, m, 70)
     with sd.EkfSlam(3 + 2 * N) as f:
+        f.set_option("small_state", 1)
         f.set_option("fetch_verify", 1)
         f.set_state_diag(s[0], s[1])
         for k in range(200):
