@@ -525,3 +525,22 @@ def test_binding_stages_arguments_without_a_device():
     one._pm, one._stages, one._h = eb._p(one._m, eb._ip), {}, C.c_void_p()
     assert one._obs([5, 6], [1.0, 2.0], [0.1, 0.2])[4] == 2 and one._m[0] == 2          # a flat list is one trajectory's
     assert one._obs([], [], [])[4] == 1 and one._m[0] == 0
+
+
+def test_variable_stream_is_seeded_and_well_formed():
+    """synthetic.variable_stream (bench.py's `variable_m` leg: the shapes the reference's loop produces, src/replay_no_ros.py:280-301):
+    seeded per trajectory, landmark counts in range, indices distinct inside a step and padded with zeros, measurements finite
+    and inside the reference's 1.5 m gate (:289), same world and kinematics as synthetic_stream."""
+    import slam_duckietown_amd.synthetic as syn
+    a = syn.variable_stream(60, 40, 0, 8, 5)
+    b = syn.variable_stream(60, 40, 0, 8, 5)
+    c = syn.variable_stream(60, 40, 0, 8, 6)
+    assert all(np.array_equal(x, y) for x, y in zip(a, b)) and not np.array_equal(a[7], c[7])
+    mean0, diag0, lin, ang, idx, zr, zb, m = a
+    assert idx.shape == (40, 8) and idx.dtype == np.int32 and m.dtype == np.int32 and m.min() >= 0 and m.max() <= 8
+    assert len(set(m.tolist())) > 3                                    # the count really wanders
+    for k in range(40):
+        assert len(set(idx[k, :m[k]].tolist())) == m[k] and (idx[k, m[k]:] == 0).all() and (zr[k, m[k]:] == 0).all()
+        assert (zr[k, :m[k]] > 0).all() and (zr[k, :m[k]] < 1.5).all() and np.isfinite(zb[k]).all()
+    ref = syn.synthetic_stream(60, 40, 8, 5)
+    assert np.array_equal(mean0, ref[0]) and np.array_equal(diag0, ref[1]) and np.array_equal(lin, ref[2]) and np.array_equal(ang, ref[3])
