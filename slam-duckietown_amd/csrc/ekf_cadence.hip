@@ -218,18 +218,40 @@ __global__ __launch_bounds__(64 * CAD_NW) void k_solve_cad(const double* __restr
       double* cb = colbuf + ((long)b * CAD_CU) * ld;
       v2d_u v[CAD_SLOTS];
       unsigned long long taken = 0ull;                 // (uniform) bit q: pair q is mirrored for this whole wave
-#pragma unroll
-      for (int q = 0; q < CAD_SLOTS; ++q) {
-        const int a = 3 + 2 * q;
-        const int c0 = Cw[a], c1 = Cw[a + 1];
-        const bool take = q < nslots && c1 == c0 + 1 && i0 + 63 <= c0 && (c1 & (PPW - 1)) != 0;   // (uniform: k_panels_cad's condition)
-        v[q].x = 0.0;
-        v[q].y = 0.0;
-        if (take) {
-          v[q] = *reinterpret_cast<const v2d_u*>(Pb + p_index(ld, ii, c0));
-          taken |= 1ull << q;
-        }
+      // Pairs whose neighbours in the cadence lie in the same 128-byte line of the row (consecutive landmarks: the 16 columns
+      // of a step share one) want the caches -- eight pairs per line fetched once; a pair alone in its line should stream past
+      // them (nontemporal: scattered landmarks 106 -> 95 us for the launch; clustered ones lose 8 us when they stream).
+      // Decided per ITEM -- one branch around two copies of the loop: a choice per load merges 40 times and the loads wait
+      // for one another (profiles/r05_scattered_indices.txt).
+      int clustered = 0;
+      if (lane < nslots) {
+        const int a = 3 + 2 * lane, c0 = Cw[a];
+        const int cprev = lane > 0 ? Cw[a - 2] : -64, cnext = lane + 1 < nslots ? Cw[a + 2] : -64;
+        clustered = (abs(c0 - cprev) < 16 || abs(c0 - cnext) < 16) ? 1 : 0;
       }
+      const bool stream_past = 2 * __popcll(__ballot(clustered != 0)) < nslots;   // (uniform) most pairs are alone in their lines
+#define EKF_COLG_LOADS(LOAD)                                                                                              \
+  _Pragma("unroll") for (int q = 0; q < CAD_SLOTS; ++q) {                                                                 \
+    const int a = 3 + 2 * q;                                                                                              \
+    const int c0 = Cw[a], c1 = Cw[a + 1];                                                                                 \
+    const bool take = q < nslots && c1 == c0 + 1 && i0 + 63 <= c0 && (c1 & (PPW - 1)) != 0; /* (uniform: k_panels_cad's condition) */ \
+    v[q].x = 0.0;                                                                                                         \
+    v[q].y = 0.0;                                                                                                         \
+    if (take) {                                                                                                           \
+      v[q] = LOAD(reinterpret_cast<const v2d_u*>(Pb + p_index(ld, ii, c0)));                                              \
+      taken |= 1ull << q;                                                                                                 \
+    }                                                                                                                     \
+  }
+#define EKF_LOAD_CACHED(p) (*(p))
+#define EKF_LOAD_STREAM(p) __builtin_nontemporal_load(p)
+      if (stream_past) {
+        EKF_COLG_LOADS(EKF_LOAD_STREAM)
+      } else {
+        EKF_COLG_LOADS(EKF_LOAD_CACHED)
+      }
+#undef EKF_LOAD_STREAM
+#undef EKF_LOAD_CACHED
+#undef EKF_COLG_LOADS
 #pragma unroll
       for (int q = 0; q < CAD_SLOTS; ++q) {
         if (((taken >> q) & 1ull) && i < n) {
@@ -865,7 +887,7 @@ __global__ __launch_bounds__(64 * NW) void k_panels_cad(double* __restrict__ P, 
   double X[CU];
   if (live) {
 #pragma unroll
-    for (int a = 0; a < 3; ++a) X[a] = Pb[p_index(ld, min(a, ii), max(a, ii))];
+    for (int a = 0; a < 3; ++a) X[a] = __builtin_nontemporal_load(Pb + p_index(ld, min(a, ii), max(a, ii)));
     // A landmark's two positions are two ADJACENT state indices c, c + 1.  For the state indices i <= c the entries
     // P(c, i), P(c + 1, i) are stored mirrored, as P_base(i, c), P_base(i, c + 1): side by side in row i.  Those column-
     // direction gathers touch a different cache line per lane (a CU takes about a cycle per line: 42 of this kernel's 92 us
@@ -881,14 +903,17 @@ __global__ __launch_bounds__(64 * NW) void k_panels_cad(double* __restrict__ P, 
 #else
       if (c1 == c0 + 1 && i0 + 63 <= c0 && (c1 & (PPW - 1)) != 0) {   // (uniform; the pair does not straddle two column panels)
         if (colbuf) {                                  // (uniform) gathered beside the solve, laid down as rows: two coalesced loads
-          const double* cb = colbuf + ((long)b * CAD_CU + a) * ld;
-          X[a] = cb[ii];
-          X[a + 1] = cb[ld + ii];
+          const double* cb = colbuf + ((long)b * CAD_CU + a) * ld;   // (each entry is read exactly once: past the caches)
+          X[a] = __builtin_nontemporal_load(cb + ii);
+          X[a + 1] = __builtin_nontemporal_load(cb + ld + ii);
         } else {
           const v2d_u v = *reinterpret_cast<const v2d_u*>(Pb + p_index(ld, ii, c0));
           X[a] = v.x;
           X[a + 1] = v.y;
         }
+      } else if (c1 <= i0) {                           // (uniform) both in the row direction: 512 contiguous bytes each, read once
+        X[a] = __builtin_nontemporal_load(Pb + p_index(ld, c0, ii));
+        X[a + 1] = __builtin_nontemporal_load(Pb + p_index(ld, c1, ii));
       } else {
         X[a] = Pb[p_index(ld, min(c0, ii), max(c0, ii))];
         X[a + 1] = Pb[p_index(ld, min(c1, ii), max(c1, ii))];
@@ -1047,13 +1072,16 @@ __global__ __launch_bounds__(256) void k_panels_cad_ks(double* __restrict__ P, d
       if (c1 == c0 + 1 && i0 + 63 <= c0 && (c1 & (PPW - 1)) != 0) {   // (uniform) both mirrored: side by side in row i (see k_panels_cad)
         if (colbuf && a < CU) {                        // (uniform) gathered beside the solve
           const double* cb = colbuf + ((long)b * CAD_CU + a) * ld;
-          XL[2 * pp] = cb[ii];
-          XL[2 * pp + 1] = cb[ld + ii];
+          XL[2 * pp] = __builtin_nontemporal_load(cb + ii);
+          XL[2 * pp + 1] = __builtin_nontemporal_load(cb + ld + ii);
         } else {
           const v2d_u v = *reinterpret_cast<const v2d_u*>(Pb + p_index(ld, ii, c0));
           XL[2 * pp] = v.x;
           XL[2 * pp + 1] = v.y;
         }
+      } else if (c1 <= i0) {                           // (uniform) both in the row direction: 512 contiguous bytes each, read once
+        XL[2 * pp] = __builtin_nontemporal_load(Pb + p_index(ld, c0, ii));
+        XL[2 * pp + 1] = __builtin_nontemporal_load(Pb + p_index(ld, c1, ii));
       } else {
         XL[2 * pp] = Pb[p_index(ld, min(c0, ii), max(c0, ii))];
         XL[2 * pp + 1] = Pb[p_index(ld, min(c1, ii), max(c1, ii))];
