@@ -643,6 +643,9 @@ def main():
                          "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_s * 1e3, "launches": launches,
                          "steps_per_launch": steps_per_launch,
                          "step_equivalent_GBs": (B * 16.0 * n * n * steps_per_launch / avg_s / 1e9) if avg_s > 0 else 0.0,
+                         # the same bytes over the WHOLE cadence (solve + panel launch + pass + gaps: what `value` is made of)
+                         "whole_cadence_frac": (alg_bytes / (dt / args.steps * steps_per_launch) / 1e9 / HBM_PEAK_GBS)
+                                               if launches > 0 else 0.0,
                          "mfma": {"achieved": 2.0 * ranks * B * tri / avg_s / 1e12 if avg_s > 0 else 0.0,
                                   "unit": "TFLOP/s fp64", "peak_spec": MFMA_F64_SPEC_TF,
                                   "peak_measured": MFMA_F64_MEASURED_TF,
