@@ -91,8 +91,12 @@ def time_filter(sd, sd_syn, shard, grp, device, traj_ids, n_landmarks, m, steps,
     f.flush()
     cad0 = f.cadence_counters()
     dev = {}
-    # every launch of the covariance pass inside the timed region is bracketed by a HIP event pair on the handle's
-    # stream (two event records per pass: no measurable effect on the region)
+    # launches of the covariance pass inside the timed region are bracketed by HIP event pairs on the stream the pass runs
+    # on: every 4th one where the region holds at least 16 (every 2nd from 4 on) -- a record costs its stream ~6 us, which a
+    # single trajectory's 80 us cadence feels (round 5 bracketed every launch: 1.4 % of the headline, 12 % of config 3)
+    expect = (steps * (m if variable is None else (variable[0] + variable[1]) / 2.0)) / 40.0
+    stride = 4 if expect >= 16 else (2 if expect >= 4 else 1)
+    f.set_option("profile_stride", stride)
     f.profile_enable(profile_leg)
 
     def run():
@@ -108,8 +112,13 @@ def time_filter(sd, sd_syn, shard, grp, device, traj_ids, n_landmarks, m, steps,
         clock.stop()
     dev_ms = dev["ms"]
     pass_ms, launches = 0.0, 0
+    time_filter.last_timed = 0
     if profile_leg:
-        pass_ms, launches = f.profile_read()
+        # (callers divide by `launches`: the timed launches' total is scaled to all of them; `last_timed` says how many were timed)
+        pass_ms, timed = f.profile_read()
+        launches = f.profile_passes()
+        pass_ms = pass_ms / max(timed, 1) * launches
+        time_filter.last_timed = timed
         f.profile_enable(False)
     time_filter.last_pass_kernel = f.last_pass()
     cad1 = f.cadence_counters()
@@ -641,6 +650,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "kernel": getattr(time_filter, "last_pass_kernel", "") or "ekf::k_flush",
                          "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_s * 1e3, "launches": launches,
+                         "launches_timed": getattr(time_filter, "last_timed", 0),
                          "steps_per_launch": steps_per_launch,
                          "step_equivalent_GBs": (B * 16.0 * n * n * steps_per_launch / avg_s / 1e9) if avg_s > 0 else 0.0,
                          # the same bytes over the WHOLE cadence (solve + panel launch + pass + gaps: what `value` is made of)

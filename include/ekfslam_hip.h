@@ -171,9 +171,17 @@ const char *ekf_last_error(ekf_handle *h);
 /* --- measurement hooks (HIP events on the handle's own stream) --- */
 int ekf_timer_begin(ekf_handle *h);
 int ekf_timer_end(ekf_handle *h, double *elapsed_ms);          /* synchronises */
-/* When enabled every launch of the covariance pass (flush) kernel is bracketed by an event pair. */
+/* When enabled every launch of the covariance pass (flush) kernel is bracketed by an event pair -- every k-th one with
+ * ekf_set_option("profile_stride", k): an event record costs its stream ~6 us, which a single trajectory's 80 us cadence
+ * feels.  ekf_profile_read: total time and number of the BRACKETED launches (and resets); ekf_profile_passes: all launches of
+ * the pass since profiling was enabled, bracketed or not. */
 int ekf_profile_enable(ekf_handle *h, int on);
 int ekf_profile_read(ekf_handle *h, double *pass_ms_total, long long *pass_launches); /* and resets */
+long long ekf_profile_passes(ekf_handle *h);
+/* With ekf_set_option("profile_kernels", 1) (a diagnostic run: every record costs its stream ~6 us) the other launches of a
+ * fused cadence carry event pairs too: cls 1 the solve launch, 2 the chain (or look-ahead gather) launch, 3 the panel launch,
+ * 0 the pass.  Does not reset: read before ekf_profile_read. */
+int ekf_profile_read_class(ekf_handle *h, int cls, double *ms_total, long long *launches);
 /* Tuning knobs: "flush_every" (steps per covariance pass, 0 = auto), "rank_limit" (auto cadence: pending
  * ranks that trigger the pass, 2..80), "pass_rows_per_block", "pass_streaming" (-1 auto / 0 resident /
  * 1 nontemporal), "active_bound" (0 = treat every state index as correlated), "pass_kernel" (-1 = auto:
@@ -203,7 +211,9 @@ int ekf_profile_read(ekf_handle *h, double *pass_ms_total, long long *pass_launc
  * state into PINNED host memory, e.g. from ekf_host_alloc: 1 = up to 40 MB a kernel mirrors the stored triangle straight into
  * the destination, no mirror pass and no copy engine; 2 = at every size; 0 = never: mirror pass + rectangle copy; same bytes);
  * unknown names fail.
- * "fused_cadence" and "lookahead" change the ORDER in which a step's pending ranks are summed (and whether the look-ahead
+ * "fused_cadence", "lookahead" and "chain" (1 = where the next cadence's solve runs beside this one's pass, its block is
+ * formed from this cadence's records and the solves of a run follow one another on the handle's stream -- panel launch and pass
+ * of every cadence on the second one; 0 = the round-3 look-ahead: the block gathered behind the panel launch) change the ORDER in which a step's pending ranks are summed (and whether the look-ahead
  * applies depends on the device's CU count and the size of the launch): results are equal to rounding across these
  * settings and across devices, bit-identical only for a fixed setting on a fixed device type. */
 int ekf_set_option(ekf_handle *h, const char *name, int value);
@@ -215,8 +225,10 @@ int ekf_last_pass(ekf_handle *h, int *kernel, int *k_tiles, int *streaming);
  * interface stands behind them, they change nothing, and a production caller never needs them) --- */
 /* Fused cadences ekf_stream_run has launched so far and the steps (of the uploaded stream) they covered. */
 int ekf_debug_cadences(ekf_handle *h, long *cadences, long *steps);
-/* Cadences whose solve ran beside the previous covariance pass (look-ahead). */
+/* Cadences whose solve ran beside the previous covariance pass (chained solves or look-ahead), and how many of those had
+ * their block formed from the previous cadence's records (chained solves, option "chain"). */
 long ekf_debug_lookaheads(ekf_handle *h);
+long ekf_debug_chained(ekf_handle *h);
 /* Pieces of the longest static share the last row-slab pass used (0 = work queues / column strips; -1 = NULL handle). */
 int ekf_debug_last_pass_shares(ekf_handle *h);
 /* Launches of the small-state path; ekf_step_fetch calls served by the step's own launch; whole-state downloads written
@@ -228,8 +240,8 @@ long ekf_debug_dense_packs(ekf_handle *h);
  * synchronisation instead): 0 on a platform where the ordering assumption of the polled hand-over holds. */
 long ekf_debug_fetch_retries(ekf_handle *h);
 /* Raw device views behind a stream synchronisation, no flush: the fused cadence's record of trajectory b (returns its
- * size; copies min(bytes, size)); `which` = 0 P_base (allocated doubles), 1 V, 2 W, 3 the pending pose noise, 4 the mean the
- * next step reads (dst == NULL: the count); the words behind the row-slab pass's queue heads
+ * size; copies min(bytes, size)); `which` = 0 P_base (allocated doubles), 1 V, 2 W, 3 the mean buffer the next step reads,
+ * 4 the other mean buffer (dst == NULL: the count); the words behind the row-slab pass's queue heads
  * (where a -DRS_STAMPS build leaves its time stamps). */
 long ekf_debug_cad(ekf_handle *h, int b, void *dst, long bytes);
 long ekf_debug_snapshot(ekf_handle *h, int b, int which, double *dst, long count);

@@ -43,12 +43,20 @@ void launch_associate(hipStream_t, const DetIn*, int*, int*, int*, double*, doub
 void launch_fill_diag(hipStream_t, double*, int, int, const double*);
 int dense_propagate(hipStream_t, double* P, double* tmp, const double* F, const double* Q, int n, int ld);
 void launch_solve_cad(hipStream_t, const double*, const double*, double*, double*, const int*, const StepIn*, const CadPlan*, int,
-                      CadOut*, unsigned*, const DeviceConfig&, int, long, const double*, int, double*, int, int);
+                      CadOut*, unsigned*, const DeviceConfig&, int, long, const double*, int, double*, int, int, bool, const double*);
+void launch_chain_cad(hipStream_t, const double*, const double*, const double*, const double*, const CadOut*, const StepIn*,
+                      const CadPlan*, int, const DeviceConfig&, int, long, double*, double*, double*, double*, unsigned*, unsigned,
+                      unsigned*, int, unsigned);
+void launch_gate(hipStream_t, unsigned*, unsigned, unsigned*, int);
+int panels_cad_workgroups(int, int);
+int chain_gather_workgroups(int, int);
+int chain_sync_words();
+void launch_snap_pose(hipStream_t, const double*, const int*, int, long, int, int, double*);
 void launch_gather_cad(hipStream_t, const double*, const double*, const double*, const double*, const StepIn*, const CadPlan*, int,
                        int, const DeviceConfig&, int, long, double*);
 long cadence_gbuf_doubles();
 void launch_panels_cad(hipStream_t, double*, double*, double*, const double*, double*, const int*, const CadOut*,
-                       SolveOut*, unsigned*, int, long, int, int, int, const double*);
+                       SolveOut*, unsigned*, int, long, int, int, int, const double*, double*, unsigned*, unsigned, unsigned, unsigned*);
 }  // namespace ekf
 
 using namespace ekf;
@@ -118,8 +126,14 @@ struct ekf_handle : ekf::HostPlan {
   AssocConfig acfg{};
   hipEvent_t t0 = nullptr, t1 = nullptr;
   bool profile = false;
+  int profile_stride = 1;         // every how many launches of the pass carry an event pair while profiling ("profile_stride")
+  long prof_seen = 0;
   std::vector<hipEvent_t> prof_pool;
   size_t prof_used = 0;
+  // "profile_kernels" = 1: the cadence's other launches carry event pairs too (a diagnostic run: every record costs its stream
+  // ~6 us); class of pair i: 0 the covariance pass, 1 the solve launch, 2 the chain / look-ahead gather launch, 3 the panel launch
+  int opt_profile_kernels = 0;
+  std::vector<int> prof_cls;
   unsigned* dqueue = nullptr;     // work-queue heads of k_flush_rs (zeroed before every launch)
   // k_flush_rs, equal static shares (a few long trajectories): the piece table.  Two copies on the device and in pinned
   // host memory, used alternately: a rebuilt table is uploaded stream-ordered, without a host synchronisation, while the
@@ -134,7 +148,26 @@ struct ekf_handle : ekf::HostPlan {
   unsigned* dready = nullptr;     // per trajectory: sequence number of the last solve that completed (k_step_split)
   SolveOut* dmbox = nullptr;      // per trajectory: that solve's header and records, written through (mailbox_publish)
   unsigned step_seq = 0;          // sequence number of the last single-launch step
-  CadOut* dcad = nullptr;         // per trajectory: head + per-landmark records of the cadence in flight (allocated on first use)
+  // per trajectory: head + per-landmark records of a cadence (allocated on first use).  Two copies, used alternately by
+  // consecutive cadences (`cpar`): in a chained run the next cadence's solve writes its records while this cadence's panel
+  // launch still reads these
+  CadOut* dcad2[2] = {nullptr, nullptr};
+  int cpar = 0;
+  // Chained solves (round 6; "chain"): the solves of a run follow one another on the handle's stream -- the next cadence's
+  // block comes from this cadence's records (k_chain_cad) -- while panel launch and covariance pass of every cadence run
+  // on the second stream.  dprow3: rows 0..2 of every P after a cadence, left by its panel launch (batch x 3 x ld, two copies
+  // like dcad2); dgmu: the mean at the next cadence's positions (batch x 128).
+  double* dprow3[2] = {nullptr, nullptr};
+  double* dgmu = nullptr;
+  double *dxg = nullptr, *dbg = nullptr;   // the chain launch's gathered rows (batch x 84 x 88 each): written by its gather workgroups
+  unsigned* dsync = nullptr;      // device-scope counters of the chained run's hand-overs (ekf_cadence.hip: SYNC_*)
+  unsigned gather_count = 0;      // gather workgroups launched so far (what the next chain workgroups wait for)
+  unsigned sigma = 0;             // chained transitions so far (the value the run's counters SYNC_SOLVE / SYNC_PASS carry)
+  hipEvent_t ev_solve = nullptr, ev_pass = nullptr, ev_nb = nullptr;
+  bool chain_run = false;         // the run in flight records the transforms (every solve is k_solve_cad<true>)
+  bool aux_pass = false;          // a covariance pass is in flight on the second stream (ev_pass recorded behind it)
+  int opt_chain = 1;
+  long chained = 0;               // statistics: cadences whose block came from k_chain_cad
   // The mirrored column entries of a cadence's panel launch, gathered by extra workgroups of its solve launch and laid down
   // as rows (batch x 83 x ld doubles, allocated on first use; not for banks where that would exceed 1 GiB).  `colbuf_live`:
   // the solve in flight has filled it (a solve launched beside a covariance pass -- look-ahead -- cannot: P_base is in motion)
@@ -258,7 +291,7 @@ static void free_all(ekf_handle* h) {
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   void* ptrs[] = {h->dP, h->dmu2[0], h->dmu2[1], h->dV, h->dW, h->ddacc2[0], h->ddacc2[1], h->dscratch, h->dn, h->dflags, h->dso, h->dfac,
                   h->d_ring, h->d_stream, h->dF, h->dQ, h->dTmp, h->dPlin, h->dtagmap, h->dneff, h->d_det, h->d_assoc_step, h->dfloor, h->dqueue, h->dready, h->dmbox,
-                  h->d_assoc_out, h->dcad, h->dshares2[0], h->dshares2[1], h->dgbuf, h->dplan2[0], h->dplan2[1], h->dcolbuf};
+                  h->d_assoc_out, h->dcad2[0], h->dcad2[1], h->dprow3[0], h->dprow3[1], h->dgmu, h->dxg, h->dbg, h->dsync, h->dshares2[0], h->dshares2[1], h->dgbuf, h->dplan2[0], h->dplan2[1], h->dcolbuf};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (h->h_ring) (void)hipHostFree(h->h_ring);
   if (h->h_det) (void)hipHostFree(h->h_det);
@@ -276,6 +309,7 @@ static void free_all(ekf_handle* h) {
   if (h->t1) (void)hipEventDestroy(h->t1);
   if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
   if (h->ev_join) (void)hipEventDestroy(h->ev_join);
+  for (hipEvent_t e : {h->ev_solve, h->ev_pass, h->ev_nb}) if (e) (void)hipEventDestroy(e);
   if (h->aux) (void)hipStreamSynchronize(h->aux);
   if (h->stream && h->aux) {
     park_stream_pair(h->device, h->stream, h->aux);    // (see g_pairs: the next handle on this device takes the pair over)
@@ -370,6 +404,13 @@ extern "C" int ekf_create(int device, int n_max, int batch, const ekf_config* cf
   }
   CREATE_TRY(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
   CREATE_TRY(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+  {
+    unsigned evf = hipEventDisableTiming;
+    if (const char* e = std::getenv("EKFSLAM_HIP_EVENT_FLAGS")) evf |= (unsigned)std::strtoul(e, nullptr, 0);   // (probe)
+    CREATE_TRY(hipEventCreateWithFlags(&h->ev_solve, evf));
+    CREATE_TRY(hipEventCreateWithFlags(&h->ev_pass, evf));
+    CREATE_TRY(hipEventCreateWithFlags(&h->ev_nb, evf));
+  }
   const size_t ldz = (size_t)h->ld;
   CREATE_TRY(hipMalloc(&h->dP, sizeof(double) * (size_t)h->pstride * batch));
   CREATE_TRY(hipMalloc(&h->dmu2[0], sizeof(double) * ldz * batch));
@@ -667,13 +708,33 @@ extern "C" int ekf_add_landmarks(ekf_handle* h, int b, int first_index, const do
 }
 
 // ---- step machinery -------------------------------------------------------------------------
-static int prof_event(ekf_handle* h, hipEvent_t* ev) {
+static int prof_event(ekf_handle* h, hipEvent_t* ev, int cls = 0) {
+  if ((h->prof_used & 1) == 0) {
+    if (h->prof_cls.size() <= h->prof_used / 2) h->prof_cls.resize(h->prof_used / 2 + 1);
+    h->prof_cls[h->prof_used / 2] = cls;
+  }
   if (h->prof_used == h->prof_pool.size()) {
     hipEvent_t e;
     HIP_TRY(h, hipEventCreate(&e));
     h->prof_pool.push_back(e);
   }
   *ev = h->prof_pool[h->prof_used++];
+  return EKF_OK;
+}
+// (diagnostic) an event pair around the launches between prof_open and prof_close on stream `st`, class `cls`
+struct ProfBracket { hipEvent_t e1 = nullptr; hipStream_t st = nullptr; };
+static int prof_open(ekf_handle* h, int cls, hipStream_t st, ProfBracket* pb) {
+  pb->e1 = nullptr;
+  if (!h->profile || !h->opt_profile_kernels) return EKF_OK;
+  hipEvent_t e0;
+  if (int rc = prof_event(h, &e0, cls)) return rc;
+  if (int rc = prof_event(h, &pb->e1, cls)) return rc;
+  pb->st = st;
+  HIP_TRY(h, hipEventRecord(e0, st));
+  return EKF_OK;
+}
+static int prof_close(ekf_handle* h, ProfBracket* pb) {
+  if (pb->e1) HIP_TRY(h, hipEventRecord(pb->e1, pb->st));
   return EKF_OK;
 }
 
@@ -713,7 +774,9 @@ static int flush_pending(ekf_handle* h, hipStream_t st) {
     if (h->shares_ok > 0) shares = h->dshares2[h->shares_cur];
   }
   hipEvent_t e0 = nullptr, e1 = nullptr;
-  if (h->profile) {
+  // (profiling: every `profile_stride`-th launch of the pass is bracketed by an event pair -- a record costs its stream ~6 us)
+  const bool timed = h->profile && (h->prof_seen++ % h->profile_stride) == 0;
+  if (timed) {
     if (int rc = prof_event(h, &e0)) return rc;
     if (int rc = prof_event(h, &e1)) return rc;
     HIP_TRY(h, hipEventRecord(e0, st));
@@ -729,7 +792,7 @@ static int flush_pending(ekf_handle* h, hipStream_t st) {
     launch_flush(st, p.streaming, h->dP, h->dV, h->dW, h->ddacc2[h->dcur], h->dn, h->dso, h->ld, h->pstride, h->batch,
                  p.e_hi, p.nkt, flush_rows_per_block(h, p.streaming, p.e_hi));
   }
-  if (h->profile) HIP_TRY(h, hipEventRecord(e1, st));
+  if (timed) HIP_TRY(h, hipEventRecord(e1, st));
   HIP_TRY(h, hipGetLastError());
   h->pending_k = 0;                                    // (with no rank pending k_solve takes the pending noise as zero: no clearing)
   h->pending_steps = 0;
@@ -850,22 +913,59 @@ static int upload_run_plan(ekf_handle* h) {
 
 // Cadence c of the run in flight (h->run_plan, uploaded): one solve launch, one panel launch; the covariance pass follows
 // when it is due -- behind every cadence but the run's last, and behind that one when its slots are used up.
-// Look-ahead (small launches, where the covariance pass -- the column-strip kernel -- leaves CUs free): when the pass is
-// due and another cadence follows, that cadence's solve does not wait for the pass.  Its block
-// P[C_u, C_u] is gathered while this cadence's ranks are still pending (k_gather_cad: base entries + the ranks' product
-// at C_u), the pass goes to the handle's second stream between two events, and the solve -- which touches nothing the
-// pass uses -- runs on the handle's own stream beside it; the next cadence's panel launch waits for both.  `presolved`
-// says that this cadence's solve has already been enqueued that way; *next_presolved that the next one's now is.
+//
+// Small launches, where the covariance pass leaves CUs free (the column-strip kernel on at least ~48 MB of covariance; the
+// row-slab pass on static shares: a few long trajectories), do not run solve -> panel -> pass -> solve one behind the
+// other: the only true dependency between two cadences of a trajectory is the sequential landmark recurrence
+// (src/replay_no_ros.py:436-480: landmark j + 1 is linearised at the mean landmark j produced).
+//   * CHAINED SOLVES (round 6, "chain" = 1): every solve of the run also records its cadence as a linear map (k_solve_cad<true>:
+//     CadOut::T, mpose, posefin); k_chain_cad forms the next cadence's block and mean from those records and from P_base as it
+//     stood BEFORE this cadence, so the handle's stream runs  solve_c -> chain_{c+1} -> solve_{c+1} -> ...  while the second
+//     stream runs  panel_c -> pass_c -> panel_{c+1} -> ...  Hand-overs (events): panel_c waits for solve_c; chain_{c+1} waits
+//     for pass_{c-1} (it reads P_base rows >= 3 and the pose rows panel_{c-1} left in dprow3); pass_c waits for chain_{c+1}
+//     (which reads what the pass rewrites).  Two copies of the records and of the pose rows, used alternately.
+//   * LOOK-AHEAD (round 3, "chain" = 0): panel_c -> k_gather_cad (the next block from P_base and the ranks still pending) ->
+//     { pass_c on the second stream | solve_{c+1} } -> join.
+// `presolved` says that this cadence's solve has already been enqueued one of these ways; *next_presolved that the next
+// one's now is.
+static bool beside_the_pass(const ekf_handle* h, const PassPlan& plan) {
+  // (worth it where the pass is the column-strip kernel -- the row-slab pass fills every CU by itself -- and long enough
+  //  to pay for the gather and the two cross-stream hand-overs, ~25 us together: from ~48 MB of covariance.  N = 2000 x 1:
+  //  38.7 k -> 45.1 k steps/s, x 2: 57.6 k -> 61.9 k, x 4: 89.5 k -> 92.1 k; N = 500 x 1 and N = 20 x 1 lose 4 - 9 %;
+  //  N = 8000 x 1 on static shares, the pass on 255 workgroups: 9.35 - 9.58 k -> 9.82 - 10.2 k)
+  // ... or the row-slab pass on static shares that leaves the solves their CUs (a few long trajectories: N = 8000 x 1)
+  // ... and for banks of up to 40 trajectories: every solve workgroup has to find a CU beside the pass, and the gather grows with
+  // the bank (17 us at 32 trajectories, 71 us at 256) -- N = 500 x 32 +5 %, N = 300 x 48 -5 %, N = 200 x 128 -21 %,
+  // N = 100 x 256 -36 % with the look-ahead (tools/opt_probe.sh lookahead=0)
+  const bool small_pass = plan.kernel == 0 && h->batch <= 40 && (double)h->batch * 8.0 * plan.e_hi * plan.e_hi >= 48.0e6;
+  const bool shares_pass = plan.kernel == 2 && (plan.beside || (plan.long_few && h->batch < 8 && h->opt_pass_workgroups > 0 &&
+                                                                  h->opt_pass_workgroups + h->batch <= h->cu_count));
+  return small_pass || shares_pass;
+}
+
+// whatever is still running on the second stream is waited for by the handle's own stream
+static int join_aux(ekf_handle* h) {
+  if (!h->aux_pass) return EKF_OK;
+  HIP_TRY(h, hipEventRecord(h->ev_pass, h->aux));      // (behind the last chained pass: one event per chain of cadences)
+  HIP_TRY(h, hipStreamWaitEvent(h->stream, h->ev_pass, 0));
+  h->aux_pass = false;
+  return EKF_OK;
+}
+
 static int enqueue_cadence(ekf_handle* h, int c, bool presolved, bool* next_presolved) {
   *next_presolved = false;
   const RunPlan& rp = h->run_plan;
   const int n_hi = *std::max_element(h->n.begin(), h->n.end());
   const CadPlan* dpl = h->dplan2[h->plan_cur] + (size_t)c * h->batch;
-  if (!h->dcad) HIP_TRY(h, hipMalloc(&h->dcad, sizeof(CadOut) * h->batch));
+  for (int i = 0; i < 2; ++i)
+    if (!h->dcad2[i]) HIP_TRY(h, hipMalloc(&h->dcad2[i], sizeof(CadOut) * h->batch));
+  CadOut* dcad = h->dcad2[h->cpar];
+  double* prow_out = h->chain_run ? h->dprow3[h->cpar] : nullptr;
   for (int b = 0; b < h->batch; ++b) h->neff_enq[b] = rp.entries[(size_t)c * h->batch + b].neff;
   const double* mu_in = h->dmu2[h->cur];
   double* mu_out = h->dmu2[h->cur ^ 1];
   if (!presolved) {
+    if (int rc = join_aux(h)) return rc;
     // (the chain runs on one CU per trajectory: the rest of the chip gathers the panel launch's mirrored column entries
     //  meanwhile -- where there is a rest, and something to gather)
     const size_t cb_bytes = sizeof(double) * (size_t)h->batch * CAD_CU * h->ld;
@@ -874,21 +974,69 @@ static int enqueue_cadence(ekf_handle* h, int c, bool presolved, bool* next_pres
     //  up to ~80 trajectories; x 64 +1 - 2 %, x 128 -2 % on scattered landmarks, profiles/r05_scattered_indices.txt)
     const long col_items = (long)h->batch * ((n_hi + 63) / 64), col_waves = 8L * (h->cu_count - h->batch);
     if (h->opt_col_gather && cb_bytes <= ((size_t)1 << 30) && col_waves > 0 && col_items <= 4 * col_waves && rp.slots_hi[c] > 0) {
-      if (!h->dcolbuf) HIP_TRY(h, hipMalloc(&h->dcolbuf, cb_bytes));
+      // (an optional optimisation: where its buffer cannot be had the panel launch gathers everything itself, bit-identically)
+      if (!h->dcolbuf && hipMalloc(&h->dcolbuf, cb_bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        h->dcolbuf = nullptr;
+        h->opt_col_gather = 0;
+      }
       colbuf = h->dcolbuf;
     }
     const int col_wgs = h->cu_count - h->batch;
-    launch_solve_cad(h->stream, h->dP, mu_in, mu_out, h->ddacc2[h->dcur ^ 1], h->dn, h->d_stream, dpl, h->batch, h->dcad,
-                     h->dflags, h->dcfg, h->ld, h->pstride, nullptr, 0, colbuf, n_hi, col_wgs);
+    ProfBracket pb;
+    if (int rc = prof_open(h, 1, h->stream, &pb)) return rc;
+    launch_solve_cad(h->stream, h->dP, mu_in, mu_out, h->ddacc2[h->dcur ^ 1], h->dn, h->d_stream, dpl, h->batch, dcad,
+                     h->dflags, h->dcfg, h->ld, h->pstride, nullptr, 0, colbuf, n_hi, col_wgs, h->chain_run, nullptr);
+    if (int rc = prof_close(h, &pb)) return rc;
     h->colbuf_live = colbuf != nullptr;
   }
   const int ranks = 2 * rp.slots_hi[c], nrp = (ranks + 3) & ~3;   // every trajectory writes the busiest one's ranks (zeros beyond its own)
-  launch_panels_cad(h->stream, h->dP, h->dV, h->dW, mu_in, mu_out, h->dn, h->dcad, h->dso, h->dqueue, h->ld,
-                    h->pstride, h->batch, n_hi, nrp, h->colbuf_live ? h->dcolbuf : nullptr);
+  // what follows the panel launch is decided before it is launched (chained: it goes to the second stream)
+  const bool more = c + 1 < rp.ncad;
+  const int pend_after = h->pending_k + ranks, steps_after = h->pending_steps + rp.steps_hi[c];
+  const bool due = pend_after > 0 && (more || pend_after + 2 > std::min(KTOT, h->opt_rank_limit) ||
+                                      (h->opt_flush_every > 0 && steps_after >= h->opt_flush_every));
+  bool beside = false;
+  if (due && more && h->opt_lookahead) {
+    const int pk = h->pending_k;
+    h->pending_k = pend_after;                         // (plan_pass reads the handle)
+    beside = beside_the_pass(h, plan_pass(h));
+    h->pending_k = pk;
+  }
+  const bool chain_next = beside && h->chain_run;
+  hipStream_t pst = h->stream;                         // the panel launch's stream
+  unsigned* psync = nullptr;
+  unsigned head_sigma = 0u, tail_target = 0u;
+  int gw = 0;
+  if (chain_next) {
+    // the second stream: gate (behind pass_{c-1}; ends when solve_c has completed) -> panel_c (ends when the gather workgroups of
+    // chain_{c+1} have read what the pass rewrites) -> pass_c.  No event: a hand-over through the command processor costs the
+    // waiting stream 7 us behind a record and ~19 us across streams (profiles/r06_chained_solves.txt); the counters cost a load.
+    h->sigma += 1u;
+    gw = chain_gather_workgroups(h->batch, h->cu_count);
+    h->gather_count += (unsigned)(h->batch * gw);
+    // (the panel launch is its own gate where each of its workgroups and each solve workgroup has a CU to itself: a tiny launch
+    //  costs the stream ~4 us, 5 % of a single trajectory's cadence)
+    if (panels_cad_workgroups(h->batch, n_hi) + 2 * h->batch <= h->cu_count / 2) head_sigma = h->sigma;
+    else launch_gate(h->aux, h->dsync, h->sigma, h->dflags, h->batch);
+    pst = h->aux;
+    psync = h->dsync;
+    tail_target = h->gather_count;
+  } else if (int rc = join_aux(h)) {
+    return rc;
+  }
+  {
+    ProfBracket pb;
+    if (int rc = prof_open(h, 3, pst, &pb)) return rc;
+    launch_panels_cad(pst, h->dP, h->dV, h->dW, mu_in, mu_out, h->dn, dcad, h->dso, h->dqueue, h->ld,
+                      h->pstride, h->batch, n_hi, nrp, h->colbuf_live ? h->dcolbuf : nullptr, prow_out, psync, head_sigma, tail_target, h->dflags);
+    if (int rc = prof_close(h, &pb)) return rc;
+  }
   h->colbuf_live = false;
   HIP_TRY(h, hipGetLastError());
   h->dcur ^= 1;
   h->cur ^= 1;
+  h->cpar ^= 1;
   h->pending_k += ranks;
   h->pending_steps += rp.steps_hi[c];
   h->cadences += 1;
@@ -897,41 +1045,69 @@ static int enqueue_cadence(ekf_handle* h, int c, bool presolved, bool* next_pres
     h->pending_steps = 0;
     return EKF_OK;
   }
-  const bool more = c + 1 < rp.ncad;
-  const bool due = more || h->pending_k + 2 > std::min(KTOT, h->opt_rank_limit) ||
-                   (h->opt_flush_every > 0 && h->pending_steps >= h->opt_flush_every);
   if (!due) return EKF_OK;
-  // (worth it where the pass is the column-strip kernel -- the row-slab pass fills every CU by itself -- and long enough
-  //  to pay for the gather and the two cross-stream hand-overs, ~25 us together: from ~48 MB of covariance.  N = 2000 x 1:
-  //  38.7 k -> 45.1 k steps/s, x 2: 57.6 k -> 61.9 k, x 4: 89.5 k -> 92.1 k; N = 500 x 1 and N = 20 x 1 lose 4 - 9 %;
-  //  N = 8000 x 1 on static shares, the pass on 255 workgroups: 9.35 - 9.58 k -> 9.82 - 10.2 k)
-  const PassPlan plan = plan_pass(h);
-  // ... or the row-slab pass on static shares that leaves the solves their CUs (a few long trajectories: N = 8000 x 1)
-  // ... and for banks of up to 40 trajectories: every solve workgroup has to find a CU beside the pass, and the gather grows with
-  // the bank (17 us at 32 trajectories, 71 us at 256) -- N = 500 x 32 +5 %, N = 300 x 48 -5 %, N = 200 x 128 -21 %,
-  // N = 100 x 256 -36 % with the look-ahead (tools/opt_probe.sh lookahead=0)
-  const bool small_pass = plan.kernel == 0 && h->batch <= 40 && (double)h->batch * 8.0 * plan.e_hi * plan.e_hi >= 48.0e6;
-  const bool shares_pass = plan.kernel == 2 && (plan.beside || (plan.long_few && h->batch < 8 && h->opt_pass_workgroups > 0 &&
-                                                                  h->opt_pass_workgroups + h->batch <= h->cu_count));
-  if (!more || !h->opt_lookahead || !(small_pass || shares_pass)) return flush_pending(h);
-  // ---- look-ahead: gather (stream) -> { pass (second stream) | solve of the next cadence (stream) } -> join ----
+  if (!beside) return flush_pending(h);
   const CadPlan* dpl2 = dpl + h->batch;
-  const int kb = (h->pending_k + 3) & ~3;
   if (!h->dgbuf) HIP_TRY(h, hipMalloc(&h->dgbuf, sizeof(double) * cadence_gbuf_doubles() * h->batch));
-  launch_gather_cad(h->stream, h->dP, h->dV, h->dW, h->ddacc2[h->dcur], h->d_stream, dpl2, h->batch, kb, h->dcfg, h->ld,
-                    h->pstride, h->dgbuf);
+  int rc = EKF_OK;
+  if (chain_next) {
+    // ---- chained: chain_{c+1} and solve_{c+1} on the handle's stream, pass_c behind the panel launch on the second ----
+    // (after the flips: dmu2[cur ^ 1] is the mean cadence c read -- its landmark entries are the mean before the cadence --,
+    //  dmu2[cur] the one its solve left the pose in; dcad2[cpar ^ 1] cadence c's records, dprow3[cpar] the pose rows BEFORE it)
+    ProfBracket pbc, pbs;
+    if (int rc2 = prof_open(h, 2, h->stream, &pbc)) return rc2;
+    launch_chain_cad(h->stream, h->dP, h->dprow3[h->cpar], h->dmu2[h->cur ^ 1], h->dmu2[h->cur], h->dcad2[h->cpar ^ 1], h->d_stream,
+                     dpl2, h->batch, h->dcfg, h->ld, h->pstride, h->dgbuf, h->dgmu, h->dxg, h->dbg, h->dsync, h->gather_count,
+                     h->dflags, gw, h->sigma);
+    if (int rc2 = prof_close(h, &pbc)) return rc2;
+    if (int rc2 = prof_open(h, 1, h->stream, &pbs)) return rc2;
+    launch_solve_cad(h->stream, h->dP, h->dmu2[h->cur], h->dmu2[h->cur ^ 1], h->ddacc2[h->dcur ^ 1], h->dn, h->d_stream, dpl2,
+                     h->batch, h->dcad2[h->cpar], h->dflags, h->dcfg, h->ld, h->pstride, h->dgbuf, 1, nullptr, n_hi, 0, true, h->dgmu);
+    if (int rc2 = prof_close(h, &pbs)) return rc2;
+    // From here on the next cadence's solve has overwritten the pose mean and the pending-noise buffer: a failure below
+    // cannot be undone.  Whatever happens the streams are joined, and a failure marks every trajectory undefined
+    // (EKF_ERR_STATE from then on, until it is uploaded again).
+    if (hipGetLastError() != hipSuccess) rc = fail(h, EKF_ERR_HIP, "chained solves: launch of the next cadence's solve failed");
+    if (rc == EKF_OK) rc = flush_pending(h, h->aux);
+    h->aux_pass = true;
+    if (rc != EKF_OK) {
+      (void)hipStreamSynchronize(h->aux);
+      (void)hipStreamSynchronize(h->stream);
+      h->aux_pass = false;
+      std::fill(h->host_bad.begin(), h->host_bad.end(), (unsigned char)1);
+      return rc;
+    }
+    h->chained += 1;
+    h->lookaheads += 1;
+    *next_presolved = true;
+    return EKF_OK;
+  }
+  // ---- look-ahead: gather (stream) -> { pass (second stream) | solve of the next cadence (stream) } -> join ----
+  const int kb = (h->pending_k + 3) & ~3;
+  {
+    ProfBracket pb;
+    if (int rc2 = prof_open(h, 2, h->stream, &pb)) return rc2;
+    launch_gather_cad(h->stream, h->dP, h->dV, h->dW, h->ddacc2[h->dcur], h->d_stream, dpl2, h->batch, kb, h->dcfg, h->ld,
+                      h->pstride, h->dgbuf);
+    if (int rc2 = prof_close(h, &pb)) return rc2;
+  }
   HIP_TRY(h, hipGetLastError());
   HIP_TRY(h, hipEventRecord(h->ev_fork, h->stream));
   HIP_TRY(h, hipStreamWaitEvent(h->aux, h->ev_fork, 0));
   // (the solve first: it is ready to go the moment the gather ends, the pass has an event to wait for -- the one
   //  workgroup per trajectory finds its CU before the pass fills the chip)
-  launch_solve_cad(h->stream, h->dP, h->dmu2[h->cur], h->dmu2[h->cur ^ 1], h->ddacc2[h->dcur ^ 1], h->dn, h->d_stream, dpl2,
-                   h->batch, h->dcad, h->dflags, h->dcfg, h->ld, h->pstride, h->dgbuf, (kb + 7) / 8, nullptr, n_hi, 0);
+  {
+    ProfBracket pb;
+    if (int rc2 = prof_open(h, 1, h->stream, &pb)) return rc2;
+    launch_solve_cad(h->stream, h->dP, h->dmu2[h->cur], h->dmu2[h->cur ^ 1], h->ddacc2[h->dcur ^ 1], h->dn, h->d_stream, dpl2,
+                     h->batch, h->dcad2[h->cpar], h->dflags, h->dcfg, h->ld, h->pstride, h->dgbuf, (kb + 7) / 8, nullptr, n_hi, 0,
+                     h->chain_run, nullptr);
+    if (int rc2 = prof_close(h, &pb)) return rc2;
+  }
   h->colbuf_live = false;                              // (beside the pass P_base is in motion: that cadence's panel launch gathers itself)
-  // From here on the next cadence's solve has overwritten dcad, the pose mean and the pending-noise buffer: a failure
+  // From here on the next cadence's solve has overwritten the pose mean and the pending-noise buffer: a failure
   // below cannot be undone.  Whatever happens the two streams are joined again, and a failure marks every trajectory
   // undefined (EKF_ERR_STATE from then on, until it is uploaded again).
-  int rc = EKF_OK;
   if (hipGetLastError() != hipSuccess) rc = fail(h, EKF_ERR_HIP, "look-ahead: launch of the next cadence's solve failed");
   if (rc == EKF_OK) rc = flush_pending(h, h->aux);
   const hipError_t ej = hipEventRecord(h->ev_join, h->aux);
@@ -1323,9 +1499,36 @@ extern "C" int ekf_stream_run(ekf_handle* h, int first, int count) {
       const int piece_end = std::min(first + count, k + 8192);
       plan_cadences(h, k, piece_end, h->run_plan);
       if (int rc = upload_run_plan(h)) return rc;
-      bool presolved = false;                          // the next cadence's solve has been enqueued already (look-ahead)
+      // chained solves: decided per piece -- every solve of it then records its cadence's transform; whether a cadence is
+      // chained to the next is decided where the pass between them is planned (enqueue_cadence).  (Banks of up to 40, as the
+      // look-ahead: every solve and chain workgroup has to find a CU beside the pass.)
+      h->chain_run = h->opt_chain && h->opt_lookahead && h->run_plan.ncad >= 2 && h->batch <= 40;
+      if (h->chain_run) {
+        const int n_hi = *std::max_element(h->n.begin(), h->n.end());
+        for (int i = 0; i < 2; ++i)
+          if (!h->dprow3[i]) HIP_TRY(h, hipMalloc(&h->dprow3[i], sizeof(double) * 3 * (size_t)h->ld * h->batch));
+        if (!h->dxg) {
+          const size_t gw = sizeof(double) * (size_t)h->batch * 84 * 88;
+          HIP_TRY(h, hipMalloc(&h->dxg, gw));
+          HIP_TRY(h, hipMalloc(&h->dbg, gw));
+          HIP_TRY(h, hipMalloc(&h->dsync, sizeof(unsigned) * chain_sync_words()));
+          HIP_TRY(h, hipMemsetAsync(h->dsync, 0, sizeof(unsigned) * chain_sync_words(), h->stream));
+          HIP_TRY(h, hipStreamSynchronize(h->stream));   // (the second stream's launches read the counters too)
+        }
+        // (everything a chained cadence touches exists before its first launch: between the enqueue of a launch that waits on a
+        //  device-side counter and the enqueue of the launch that advances it the host must not block -- an allocation may)
+        if (!h->dgbuf) HIP_TRY(h, hipMalloc(&h->dgbuf, sizeof(double) * cadence_gbuf_doubles() * h->batch));
+        for (int i = 0; i < 2; ++i)
+          if (!h->dcad2[i]) HIP_TRY(h, hipMalloc(&h->dcad2[i], sizeof(CadOut) * h->batch));
+        if (!h->dgmu) HIP_TRY(h, hipMalloc(&h->dgmu, sizeof(double) * (128 * h->batch + 32)));   // (+ 32 words: the stamps of a -DCHAIN_STAMPS build)
+        // the pose rows "before the first cadence": where the previous cadence's panel launch would have left them
+        launch_snap_pose(h->stream, h->dP, h->dn, h->ld, h->pstride, h->batch, n_hi, h->dprow3[h->cpar ^ 1]);
+        HIP_TRY(h, hipGetLastError());
+      }
+      bool presolved = false;                          // the next cadence's solve has been enqueued already (chained / look-ahead)
       for (int c = 0; c < h->run_plan.ncad; ++c)
         if (int rc = enqueue_cadence(h, c, presolved, &presolved)) return rc;
+      if (int rc = join_aux(h)) return rc;
       k = piece_end;
       if (k < first + count)
         if (int rc = flush_pending(h)) return rc;
@@ -1436,6 +1639,14 @@ extern "C" int ekf_profile_enable(ekf_handle* h, int on) {
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   h->profile = on != 0;
   h->prof_used = 0;
+  h->prof_seen = 0;
+  // (the events a run will use exist before it starts: creating one inside the run costs the host tens of microseconds)
+  if (h->profile)
+    while (h->prof_pool.size() < (h->opt_profile_kernels ? 1024u : 128u)) {
+      hipEvent_t e;
+      HIP_TRY(h, hipEventCreate(&e));
+      h->prof_pool.push_back(e);
+    }
   return EKF_OK;
 }
 
@@ -1443,17 +1654,44 @@ extern "C" int ekf_profile_read(ekf_handle* h, double* pass_ms_total, long long*
   if (!h || !pass_ms_total || !pass_launches) return EKF_ERR_ARG;
   HIP_TRY(h, hipSetDevice(h->device));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
+  if (h->aux) HIP_TRY(h, hipStreamSynchronize(h->aux));
   double total = 0.0;
+  long long count = 0;
   for (size_t i = 0; i + 1 < h->prof_used; i += 2) {
+    if (h->prof_cls[i / 2] != 0) continue;
     float ms = 0.f;
     HIP_TRY(h, hipEventElapsedTime(&ms, h->prof_pool[i], h->prof_pool[i + 1]));
     total += ms;
+    count += 1;
   }
   *pass_ms_total = total;
-  *pass_launches = (long long)(h->prof_used / 2);
+  *pass_launches = count;
   h->prof_used = 0;
   return EKF_OK;
 }
+
+// ("profile_kernels" = 1) the same for the cadence's other launches: cls 1 the solve launch, 2 the chain / look-ahead gather
+// launch, 3 the panel launch (0: the covariance pass); does not reset -- read these BEFORE ekf_profile_read
+extern "C" int ekf_profile_read_class(ekf_handle* h, int cls, double* ms_total, long long* launches) {
+  if (!h || !ms_total || !launches) return EKF_ERR_ARG;
+  HIP_TRY(h, hipSetDevice(h->device));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  if (h->aux) HIP_TRY(h, hipStreamSynchronize(h->aux));
+  double total = 0.0;
+  long long count = 0;
+  for (size_t i = 0; i + 1 < h->prof_used; i += 2) {
+    if (h->prof_cls[i / 2] != cls) continue;
+    float ms = 0.f;
+    HIP_TRY(h, hipEventElapsedTime(&ms, h->prof_pool[i], h->prof_pool[i + 1]));
+    total += ms;
+    count += 1;
+  }
+  *ms_total = total;
+  *launches = count;
+  return EKF_OK;
+}
+
+extern "C" long long ekf_profile_passes(ekf_handle* h) { return h ? (long long)h->prof_seen : -1; }
 
 // (diagnostics section of the header: the words behind the queue heads, where a -DRS_STAMPS build of
 //  k_flush_rs leaves its time stamps)
@@ -1488,6 +1726,8 @@ extern "C" int ekf_debug_cadences(ekf_handle* h, long* cadences, long* steps) {
 }
 // (diagnostics section of the header) how many of them had their solve run beside the previous covariance pass
 extern "C" long ekf_debug_lookaheads(ekf_handle* h) { return h ? h->lookaheads : -1; }
+// (diagnostics section of the header) ... and how many of those had their block formed by k_chain_cad (chained solves)
+extern "C" long ekf_debug_chained(ekf_handle* h) { return h ? h->chained : -1; }
 // (diagnostics section of the header) launches of the small-state path so far
 extern "C" long ekf_debug_small_launches(ekf_handle* h) { return h ? h->small_launches : -1; }
 extern "C" long ekf_debug_fused_fetches(ekf_handle* h) { return h ? h->fused_fetches : -1; }
@@ -1496,10 +1736,10 @@ extern "C" long ekf_debug_fetch_retries(ekf_handle* h) { return h ? h->fetch_ret
 
 // (diagnostics section of the header) the fused cadence's record of trajectory b (head + per-landmark records)
 extern "C" long ekf_debug_cad(ekf_handle* h, int b, void* dst, long bytes) {
-  if (!h || b < 0 || b >= h->batch || !h->dcad) return -1;
+  if (!h || b < 0 || b >= h->batch || !h->dcad2[h->cpar ^ 1]) return -1;
   if (hipSetDevice(h->device) != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess) return -1;
   const long have = (long)sizeof(CadOut);
-  if (dst && bytes > 0 && hipMemcpy(dst, h->dcad + b, (size_t)std::min(bytes, have), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  if (dst && bytes > 0 && hipMemcpy(dst, h->dcad2[h->cpar ^ 1] + b, (size_t)std::min(bytes, have), hipMemcpyDeviceToHost) != hipSuccess) return -1;
   return have;
 }
 
@@ -1507,7 +1747,7 @@ extern "C" long ekf_debug_cad(ekf_handle* h, int b, void* dst, long bytes) {
 // no mirror, no status check: which = 0 P_base (device layout, ekf_device.h: rows x ld up to ld = 4096, column panels beyond), 1 V (80 x ld), 2 W (80 x ld, MFMA-tiled), 3 the mean buffer
 // the NEXT step reads, 4 the other mean buffer.  Returns the number of doubles the buffer holds (copies min(count, that)).
 extern "C" long ekf_debug_snapshot(ekf_handle* h, int b, int which, double* dst, long count) {
-  if (!h || b < 0 || b >= h->batch || which < 0 || which > 4) return -1;
+  if (!h || b < 0 || b >= h->batch || which < 0 || which > 5) return -1;
   if (hipSetDevice(h->device) != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess) return -1;
   const double* src = nullptr;
   long have = 0;
@@ -1516,6 +1756,7 @@ extern "C" long ekf_debug_snapshot(ekf_handle* h, int b, int which, double* dst,
     case 1: src = h->dV + (size_t)b * KTOT * h->ld; have = (long)KTOT * h->ld; break;
     case 2: src = h->dW + (size_t)b * KTOT * h->ld; have = (long)KTOT * h->ld; break;
     case 3: src = h->dmu2[h->cur] + (size_t)b * h->ld; have = h->ld; break;
+    case 5: src = h->dgmu; have = h->dgmu ? 128L * h->batch + 32 : 0; break;   // (chained solves: the means at the positions, all trajectories; then a -DCHAIN_STAMPS build's stamps)
     default: src = h->dmu2[h->cur ^ 1] + (size_t)b * h->ld; have = h->ld; break;
   }
   if (dst && count > 0 &&
@@ -1609,6 +1850,21 @@ extern "C" int ekf_set_option(ekf_handle* h, const char* name, int value) {
   if (std::strcmp(name, "lookahead") == 0) {
     if (value != 0 && value != 1) return fail(h, EKF_ERR_ARG, "lookahead must be 0 or 1");
     h->opt_lookahead = value;
+    return EKF_OK;
+  }
+  if (std::strcmp(name, "profile_kernels") == 0) {
+    if (value != 0 && value != 1) return fail(h, EKF_ERR_ARG, "profile_kernels must be 0 or 1");
+    h->opt_profile_kernels = value;
+    return EKF_OK;
+  }
+  if (std::strcmp(name, "profile_stride") == 0) {
+    if (value < 1 || value > 1024) return fail(h, EKF_ERR_ARG, "profile_stride must be in [1, 1024]");
+    h->profile_stride = value;
+    return EKF_OK;
+  }
+  if (std::strcmp(name, "chain") == 0) {
+    if (value != 0 && value != 1) return fail(h, EKF_ERR_ARG, "chain must be 0 or 1");
+    h->opt_chain = value;
     return EKF_OK;
   }
   if (std::strcmp(name, "fused_cadence") == 0) {

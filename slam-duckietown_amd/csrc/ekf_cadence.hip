@@ -27,6 +27,7 @@
 // sequence.  One instantiation of each kernel serves every landmark count (rounds 3 - 4 had one per slot size 1/2/4/8/16).
 // Same algebra as the per-step path in a different summation order: results agree to rounding (1e-10 relative guaranteed, 1e-13 .. 1e-12 measured,
 // tests/test_gpu_cadence.py), not bit for bit.
+#include <algorithm>
 #include <type_traits>
 
 #include "ekf_devfn.h"
@@ -66,6 +67,25 @@ constexpr int CAD_NW = 8;               // waves of the solve workgroup (512 thr
 constexpr int CAD_DW = CAD_NW - 2;      // waves that share a down-date by rows (all but the mean wave and the record wave)
 constexpr int CAD_DCH = 7;              // rows of a down-date chunk (all reads of a chunk in flight together)
 constexpr int CAD_DQ = (CAD_CU - 2 + CAD_DCH * CAD_DW - 1) / (CAD_DCH * CAD_DW) * CAD_DCH;   // rows per down-date wave
+
+constexpr int CHAIN_SPIN_LIMIT = 1 << 20;   // bounded device-scope waits: x (s_sleep + one load past the L2): about a second
+// ---- device-scope hand-overs between kernels that run side by side (the two streams of a chained run) ----
+// The XCDs' L2s are not coherent with one another, and a fence that makes them so writes back / invalidates a whole L2
+// (ekf_kernels.hip: mailbox_publish).  So what crosses between kernels in flight is written THROUGH (device-scope relaxed
+// stores: sc1), waited for (vmcnt), and announced by a counter written the same way; the reader polls the counter and reads
+// with device-scope loads (past its own L2).  Counters only ever grow; a wait is for "at least `target`" in wrap-around
+// arithmetic, bounded (a timeout raises EKF_FLAG_INTERNAL: the state is undefined from there on, like k_step_split's).
+constexpr int SYNC_STRIDE = 32;         // words between two counters (a cache line each)
+enum { SYNC_SOLVE = 0, SYNC_PASS = 1, SYNC_CHAIN = 2, SYNC_GATHER = 3, SYNC_WORDS = 4 * SYNC_STRIDE };
+__device__ __forceinline__ double ld_dev(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_dev(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ bool sync_wait(const unsigned* word, unsigned target) {
+  for (int spin = 0; spin < CHAIN_SPIN_LIMIT; ++spin) {
+    if ((int)(__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) >= 0) return true;
+    __builtin_amdgcn_s_sleep(8);
+  }
+  return false;
+}
 
 // The positions C_u of a trajectory's cadence, formed the same way by the solve and by the look-ahead gather (512 threads
 // each).  Thread p < CAD_SLOTS takes touched step p of the plan: its landmark range [lo, hi) and, through a 40-entry prefix sum
@@ -136,6 +156,11 @@ __device__ __forceinline__ int cad_positions(const CadPlan& pl, const StepIn* __
   return nslots;
 }
 
+// CHAIN (round 6, chained solves): the instantiation of a run whose solves follow one another on the handle's stream
+// (ekf_api.hip: enqueue_cadence).  It also down-dates the pose block behind the LAST landmark and records it
+// (CadOut::posefin): with the per-landmark records that is all k_chain_cad needs to form the next cadence's block without
+// this cadence's panel launch and covariance pass.  `gmu` (with gbuf): the mean at the cadence's positions, from k_chain_cad.
+template <bool CHAIN>
 __global__ __launch_bounds__(64 * CAD_NW) void k_solve_cad(const double* __restrict__ P,
                                                     const double* __restrict__ mu_in, double* __restrict__ mu_out,
                                                     double* __restrict__ dacc_out, const int* __restrict__ nact,
@@ -143,7 +168,8 @@ __global__ __launch_bounds__(64 * CAD_NW) void k_solve_cad(const double* __restr
                                                     CadOut* __restrict__ out, unsigned* __restrict__ flags,
                                                     DeviceConfig cfg, int ld,
                                                     long pstride, const double* __restrict__ gbuf, int gparts,
-                                                    double* __restrict__ colbuf, int col_wgs, int n_hi) {
+                                                    double* __restrict__ colbuf, int col_wgs, int n_hi,
+                                                    const double* __restrict__ gmu) {
   using G = CadGeom;
   constexpr int GM = G::GM, CU = G::CU;
   __shared__ __attribute__((aligned(16))) double Pc[CAD_ROWS][CAD_CS];
@@ -412,8 +438,13 @@ __global__ __launch_bounds__(64 * CAD_NW) void k_solve_cad(const double* __restr
       }
     }
     if (wave == 1) {
-      mu0 = mu_in_b[Cl0];
-      mu1 = mu_in_b[Cl1];
+      if (CHAIN && gmu) {                              // (uniform) chained: the mean at the positions, from k_chain_cad
+        mu0 = gmu[(long)b * 128 + lane];
+        mu1 = gmu[(long)b * 128 + 64 + lane];
+      } else {
+        mu0 = mu_in_b[Cl0];
+        mu1 = mu_in_b[Cl1];
+      }
     }
 #pragma unroll
     for (int q = 0; q < RQ; ++q) {
@@ -424,6 +455,10 @@ __global__ __launch_bounds__(64 * CAD_NW) void k_solve_cad(const double* __restr
       }
     }
   }
+  // wave roles: 0 = the covariance chain (+ a down-date share), 1 = the mean, CAD_NW - 1 = the records (everything the
+  // panel kernel gets goes to memory from there, off the chain), the others: down-date
+  const bool rec_wave = wave == CAD_NW - 1;
+  const int ds = wave == 0 ? 0 : wave - 1;             // down-date slot of this wave (waves 0, 2 .. CAD_NW - 2)
   if (wave == 1) motion(0);
   WG_LDS_BARRIER();
 #ifndef CAD_STAMPS
@@ -440,10 +475,6 @@ __global__ __launch_bounds__(64 * CAD_NW) void k_solve_cad(const double* __restr
 #endif
 
   double dd0 = 0.0, dd1 = 0.0;                         // (wave 0, lanes 0..2) in-place change of P_base(0, l), P_base(1, l)
-  // wave roles: 0 = the covariance chain (+ a down-date share), 1 = the mean, CAD_NW - 1 = the records (everything the
-  // panel kernel gets goes to memory from there, off the chain), the others: down-date
-  const bool rec_wave = wave == CAD_NW - 1;
-  const int ds = wave == 0 ? 0 : wave - 1;             // down-date slot of this wave (waves 0, 2 .. CAD_NW - 2)
   for (int t = 0; t < nsteps; ++t) {
     const int m = __builtin_amdgcn_readfirstlane(mS[t]);
     const int s_first = s0 + __builtin_amdgcn_readfirstlane(firstS[t]);   // (a step without landmarks: the next step's first slot)
@@ -603,7 +634,7 @@ __global__ __launch_bounds__(64 * CAD_NW) void k_solve_cad(const double* __restr
 #ifdef CADS_SKIP_DD                                     /* diagnostic build: the block is never down-dated (wrong results) */
       } else if (false) {
 #else
-      } else if (!last) {
+      } else if (CHAIN || !last) {                     // (CHAIN: the last landmark too -- the pose block behind it is a result)
 #endif
         // down-date (:480) of what lives on: P[r][l] -= K[r, :] . (H P)[:, l] for r, l < pa; rows ds, ds + CAD_DW, ... are
         // this wave's.  Every access is unconditional and every address one base plus a compile-time offset: a row or a
@@ -689,6 +720,9 @@ __global__ __launch_bounds__(64 * CAD_NW) void k_solve_cad(const double* __restr
     o.ddpose[0][lane] = dd0;                           // entry (0, l)
     o.ddpose[1][lane] = dd1;                           // entry (1, l)
   }
+  if constexpr (CHAIN) {
+    if (rec_wave && lane < 16) o.posefin[lane >> 2][lane & 3] = ((lane >> 2) < 3 && (lane & 3) < 3) ? Pc[lane >> 2][lane & 3] : 0.0;
+  }
 }
 
 // What the solve leaves to the panel launch (its workgroup 0 of every trajectory, lanes 0..2 of wave 0): the new ranks'
@@ -697,8 +731,28 @@ __global__ __launch_bounds__(64 * CAD_NW) void k_solve_cad(const double* __restr
 // next covariance pass reads, and (trajectory 0) the work-queue heads of the row-slab pass, which start every pass at zero.
 // nrp == 0 -- no trajectory of the bank observed anything in this cadence, no pass will follow for it -- : the predictions'
 // noise goes to the pose diagonal here (what k_predict_rc does for a single prediction-only step).
+// (chained runs, small launches) the panel launch is its own gate: it runs behind the previous covariance pass -- its first
+// workgroup says so (what the chain launch's gather workgroups wait for) --, and every workgroup waits for the cadence's solve to
+// have completed (announced by the chain launch behind that solve), then drops what its L2 may hold of the records' previous
+// use.  Only where every workgroup of the launch has a CU to itself and the solve workgroups theirs (ekf_api.hip): a waiting
+// workgroup must not keep the solve it waits for from being placed; larger launches get the one-lane gate launch (k_gate).
+__device__ __forceinline__ void panel_head_wait(unsigned* sync, unsigned sigma, unsigned* flags) {
+  if (threadIdx.x == 0) {
+    if (blockIdx.x == 0 && blockIdx.y == 0)
+      __hip_atomic_store(sync + SYNC_PASS * SYNC_STRIDE, sigma - 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (!sync_wait(sync + SYNC_SOLVE * SYNC_STRIDE, sigma)) atomicOr(flags + blockIdx.y, EKF_FLAG_INTERNAL);
+  }
+  __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+}
+
+// `tail_word` (chained runs): the covariance pass behind this launch rewrites P_base, which the gather workgroups of the next
+// chain launch -- on the other stream -- may still be reading: the launch does not end before they have counted themselves
+// off (one lane of the whole launch waits; bounded).
 __device__ __forceinline__ void pose_epilogue(const CadOut& o, double* Pb, double* Vb, double* Wb, SolveOut* so, unsigned* queue,
-                                              int b, int ld, int lane, int nrp) {
+                                              int b, int ld, int lane, int nrp, const unsigned* tail_word = nullptr,
+                                              unsigned tail_target = 0u, unsigned* flags = nullptr) {
+  if (tail_word && b == 0 && lane == 0 && !sync_wait(tail_word, tail_target)) atomicOr(flags, EKF_FLAG_INTERNAL);
   const int ld16 = ld >> 4;
   const int s0 = CAD_SLOTS - o.nslots;
   // one (slot, pose index) pair per lane and round: the loads of a round are in flight together
@@ -858,9 +912,13 @@ __global__ __launch_bounds__(64 * NW) void k_panels_cad(double* __restrict__ P, 
                                                         double* __restrict__ mu_out, const int* __restrict__ nact,
                                                         const CadOut* __restrict__ co, SolveOut* __restrict__ so,
                                                         unsigned* __restrict__ queue, int ld, long pstride, int nrp,
-                                                        const double* __restrict__ colbuf) {
+                                                        const double* __restrict__ colbuf, double* __restrict__ prow3,
+                                                        unsigned* __restrict__ sync, unsigned head_sigma, unsigned tail_target,
+                                                        unsigned* __restrict__ flags) {
   using G = CadGeom;
   constexpr int CU = G::CU, GM = G::GM, NT = 64 * NW;
+  const unsigned* tail_word = sync ? sync + SYNC_GATHER * SYNC_STRIDE : nullptr;
+  if (sync && head_sigma) panel_head_wait(sync, head_sigma, flags);
   __shared__ __attribute__((aligned(16))) double sRec[G::REC];
   __shared__ double2 sG[CAD_SLOTS];
   __shared__ int sF[CAD_SLOTS];
@@ -944,8 +1002,12 @@ __global__ __launch_bounds__(64 * NW) void k_panels_cad(double* __restrict__ P, 
         Wb[wm_index(ld16, k, i)] = 0.0;
       }
       mu_out[(long)b * ld + i] = mu_in[(long)b * ld + i];
+      if (prow3) {                                     // (chained runs) the pose rows as they stand: nothing of this wave changes
+#pragma unroll
+        for (int a = 0; a < 3; ++a) prow3[((long)b * 3 + a) * ld + i] = Pb[p_index(ld, a, i)];
+      }
     }
-    if (blockIdx.x == 0 && wave == 0) pose_epilogue(o, Pb, Vb, Wb, so, queue, b, ld, lane, nrp);
+    if (blockIdx.x == 0 && wave == 0) pose_epilogue(o, Pb, Vb, Wb, so, queue, b, ld, lane, nrp, tail_word, tail_target, flags);
     return;
   }
   double d0 = 0.0, d1 = 0.0, dm = 0.0;
@@ -1017,8 +1079,12 @@ __global__ __launch_bounds__(64 * NW) void k_panels_cad(double* __restrict__ P, 
     Pb[p_col(ld, i)] += d0;                            // entry (0, i)
     Pb[p_col(ld, i) + p_lds(ld)] += d1;                // entry (1, i)
     mu_out[(long)b * ld + i] = mu_in[(long)b * ld + i] + dm;
+    if (prow3) {                                       // (chained runs) P(0..2, i) after the cadence: what the replay ends with
+#pragma unroll
+      for (int a = 0; a < 3; ++a) prow3[((long)b * 3 + a) * ld + i] = X[a];
+    }
   }
-  if (blockIdx.x == 0 && wave == 0) pose_epilogue(o, Pb, Vb, Wb, so, queue, b, ld, lane, nrp);
+  if (blockIdx.x == 0 && wave == 0) pose_epilogue(o, Pb, Vb, Wb, so, queue, b, ld, lane, nrp, tail_word, tail_target, flags);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1035,10 +1101,14 @@ __global__ __launch_bounds__(256) void k_panels_cad_ks(double* __restrict__ P, d
                                                        double* __restrict__ mu_out, const int* __restrict__ nact,
                                                        const CadOut* __restrict__ co, SolveOut* __restrict__ so,
                                                        unsigned* __restrict__ queue, int ld, long pstride, int nrp,
-                                                       const double* __restrict__ colbuf) {
+                                                       const double* __restrict__ colbuf, double* __restrict__ prow3,
+                                                       unsigned* __restrict__ sync, unsigned head_sigma, unsigned tail_target,
+                                                       unsigned* __restrict__ flags) {
   using G = CadGeom;
   constexpr int GM = G::GM, CU = G::CU;
   constexpr int LP = (GM + 3) / 4;                     // landmark position-slots per wave
+  const unsigned* tail_word = sync ? sync + SYNC_GATHER * SYNC_STRIDE : nullptr;
+  if (sync && head_sigma) panel_head_wait(sync, head_sigma, flags);
   __shared__ __attribute__((aligned(16))) double sRec[G::REC + 32];   // (+ what the last record's K reads may overshoot)
   __shared__ double2 sG[CAD_SLOTS];
   __shared__ int sF[CAD_SLOTS];
@@ -1106,8 +1176,12 @@ __global__ __launch_bounds__(256) void k_panels_cad_ks(double* __restrict__ P, d
         Wb[wm_index(ld16, k, i)] = 0.0;
       }
       mu_out[(long)b * ld + i] = mu_in[(long)b * ld + i];
+      if (prow3) {                                     // (chained runs) the pose rows as they stand
+#pragma unroll
+        for (int a = 0; a < 3; ++a) prow3[((long)b * 3 + a) * ld + i] = Pb[p_index(ld, a, i)];
+      }
     }
-    if (blockIdx.x == 0 && wave == 0) pose_epilogue(o, Pb, Vb, Wb, so, queue, b, ld, lane, nrp);
+    if (blockIdx.x == 0 && wave == 0) pose_epilogue(o, Pb, Vb, Wb, so, queue, b, ld, lane, nrp, tail_word, tail_target, flags);
     return;
   }
   const double* recw = sRec + 4 * wave;                // K of this wave's rows: + compile-time offsets
@@ -1192,8 +1266,485 @@ __global__ __launch_bounds__(256) void k_panels_cad_ks(double* __restrict__ P, d
     Pb[p_col(ld, i)] += d0;                            // entry (0, i)
     Pb[p_col(ld, i) + p_lds(ld)] += d1;                // entry (1, i)
     mu_out[(long)b * ld + i] = mu_in[(long)b * ld + i] + dm;
+    if (prow3) {                                       // (chained runs) P(0..2, i) after the cadence
+#pragma unroll
+      for (int a = 0; a < 3; ++a) prow3[((long)b * 3 + a) * ld + i] = XP[a];
+    }
   }
-  if (blockIdx.x == 0 && wave == 0) pose_epilogue(o, Pb, Vb, Wb, so, queue, b, ld, lane, nrp);
+  if (blockIdx.x == 0 && wave == 0) pose_epilogue(o, Pb, Vb, Wb, so, queue, b, ld, lane, nrp, tail_word, tail_target, flags);
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_chain_cad (round 6, chained solves): the block P[C', C'] and the mean at C' of the NEXT cadence from the RECORDS of this
+// one (per landmark H, S^-1, y, K at the positions; per step the motion Jacobian; the pose block behind the last landmark) and
+// the covariance as it stood BEFORE this cadence (P_base behind the previous pass; its rows 0..2 from `prow3`, which the
+// previous panel launch left -- this cadence's own panel launch changes rows 0, 1 of P_base in place and may be running).
+// The only true dependency between two cadences of a trajectory is the sequential landmark recurrence
+// (src/replay_no_ros.py:436-480); this kernel is what lets the solves follow one another on the handle's stream while panel
+// launch and covariance pass of every cadence run on the second one.
+//
+// A cadence is a LINEAR map on the rows P_0(C_u, .) it starts from (C_u: its positions): with M_q the product of its
+// predictions and (I - K H) factors in front of landmark q, restricted to C_u (83 x 83, M_0 = I), landmark q's two rank rows are
+//     V[2q .. 2q+1][i] = T_q P_0(C_u, i),   T_q = H_q M_q   (2 x 83)            for every state index i >= 3,
+// and rows 0..2 of M behind the cadence give the pose rows.  M telescopes (M_{q+1} = M_q - K_q T_q; a prediction adds g x row 2
+// to rows 0, 1), so the T_q satisfy a unit lower block-triangular system whose coefficients are all in the records:
+//     T_q = A_q - sum_{r<q} C_{q,r} T_r,
+//     C_{q,r} = H_q[:, 0..2] G^{(q,r)} K_r[0..2, :] + H_q[:, 3..4] K_r[pa_q .. pa_q + 1, :]      (2 x 2)
+//     A_q     = H_q[:, 0..2] G^{(q,-1)} at the pose positions, H_q[:, 3..4] at positions pa_q, pa_q + 1
+// (G^{(q,r)}: the predictions between landmark r and landmark q -- their g add up, they only ever add multiples of row 2).
+// The kernel forms C and A in parallel (780 coefficient blocks), solves the system blocked -- five blocks of 8 landmarks: the
+// part from earlier blocks on the fp64 matrix cores, the 16 x 16 diagonal block by substitution, columns over lanes -- and
+// gets the pose rows of M as three more rows of the same product.  Then
+//     X  = P_0(C_u, C')                      83 x 83 gathered entries (in flight since the start of the kernel)
+//     E  = [T; mpose] X                      rank rows at C' (80 x 83) and the pose rows after the cadence (3 x 83)
+//     F  = -S^-1 E  (per landmark, 2 x 2)    = W at C'
+//     P(C', C') = P_0(C', C') + F^T E        landmark x landmark;  pose rows / columns from E's last three rows, the pose block
+//                                            from the solve;  mean(C') = mean_0(C') - sum_q F_q^T y_q
+// again on the matrix cores, operands in LDS.  One workgroup per trajectory.
+// ---------------------------------------------------------------------------------------------
+// Diagnostic build (-DCHAIN_STAMPS): s_memtime stamps of k_chain_cad's phases (wave 0 of trajectory 0) behind the means in gmu
+// (batch x 128 doubles, then 32 stamps); tools/chain_stamps.py reads them through ekf_debug_snapshot(which = 5).
+#ifdef CHAIN_STAMPS
+#define CHSTAMP(k)                                                                               \
+  do {                                                                                           \
+    if (wave == 0 && b == 0) {                                                                   \
+      __builtin_amdgcn_sched_barrier(0);                                                         \
+      unsigned long long t_;                                                                     \
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                \
+      __builtin_amdgcn_sched_barrier(0);                                                         \
+      if (lane == 0) reinterpret_cast<unsigned long long*>(gmu + (long)batch * 128)[k] = t_;     \
+    }                                                                                            \
+  } while (0)
+#else
+#define CHSTAMP(k) do { } while (0)
+#endif
+constexpr int CH_NC = 80;               // columns: the landmark positions of the next cadence (5 MFMA tiles)
+constexpr int CH_S = 81;                // LDS row stride of A (odd: rows and columns both spread over the banks)
+constexpr int CH_R = 96;                // rows of the padded operands (6 MFMA tiles: 80 rank rows, the 3 pose rows)
+constexpr int CH_CS = 82;               // LDS row stride of B / the coefficient matrix (even: a 2 x 2 block's row is one 16-byte read)
+constexpr int CH_GW = 12;               // gather workgroups per trajectory at most (12: a row of X and of P_0(C', C') per wave)
+
+__global__ __launch_bounds__(64 * CAD_NW) void k_chain_cad(const double* __restrict__ P, const double* __restrict__ prow3,
+                                                           const double* __restrict__ mu_land, const double* __restrict__ mu_pose,
+                                                           const CadOut* __restrict__ prev, const StepIn* __restrict__ in,
+                                                           const CadPlan* __restrict__ plan, int batch, DeviceConfig cfg, int ld,
+                                                           long pstride, double* __restrict__ gbuf, double* __restrict__ gmu,
+                                                           double* __restrict__ xg, double* __restrict__ bg,
+                                                           unsigned* __restrict__ sync, unsigned gather_target,
+                                                           unsigned* __restrict__ flags, int gw, unsigned sigma) {
+  using G = CadGeom;
+  constexpr int CU = G::CU;
+  __shared__ int Cs[128], Ck[128];
+  __shared__ int cntS[CAD_SLOTS + 1], firstS[CAD_SLOTS + 1], loS[CAD_SLOTS + 1];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if ((int)blockIdx.x >= batch) {
+    // ---- the GATHER workgroups of the launch: X = P_0(C_u, C') and P_0(C', C') as coalesced rows (xg, bg: batch x 84 x 88) ----
+    // 13.8 k scattered 8-byte entries per trajectory, and a CU takes about a cycle per cache line it touches: 13 us on the one CU
+    // of the chain workgroup.  Nothing of it depends on the records' arithmetic: CH_GW workgroups per trajectory fetch 7 rows
+    // of each array apiece (`gw` = CH_GW where the chip has room) while the chain workgroup forms its coefficients, write them through and count themselves off.
+    const int g = (int)blockIdx.x - batch, b = g / gw, part = g - b * gw;
+    const double* Pb = P + (long)b * pstride;
+    const CadOut& op = prev[b];
+    const int cuk = 3 + 2 * min(op.nslots, CAD_SLOTS);
+    if (tid < 128) Ck[tid] = tid < CU ? op.C[tid] : 0;
+    const int cu = 3 + 2 * cad_positions<false>(plan[b], in, batch, b, cfg, tid, Cs, cntS, firstS, loS, [](int, double, double) {});
+    // P_base and the pose rows are what the previous covariance pass (and the panel launch in front of it) left: the gate
+    // launch behind that pass has said so (sigma - 1); the entries are read past this XCD's L2, which may hold older ones
+    if (tid == 0 && !sync_wait(sync + SYNC_PASS * SYNC_STRIDE, sigma - 1u)) atomicOr(flags + b, EKF_FLAG_INTERNAL);
+    __syncthreads();
+    for (int r = part + gw * wave; r < CAD_ROWS; r += gw * CAD_NW) {   // (uniform) rows part, part + gw, ... dealt over the waves
+      double x[2] = {0.0, 0.0}, pb[2] = {0.0, 0.0};
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
+        const int l = 64 * hf + lane;
+        if (l >= 3 && l < cu) {
+          const int Cl = Cs[l];
+          if (r < cuk) {
+            const int Cr = Ck[r];
+            x[hf] = r < 3 ? ld_dev(prow3 + ((long)b * 3 + r) * ld + Cl) : ld_dev(Pb + p_index(ld, min(Cr, Cl), max(Cr, Cl)));
+          }
+          if (r >= 3 && r < cu) {
+            const int Cr = Cs[r];
+            pb[hf] = ld_dev(Pb + p_index(ld, min(Cr, Cl), max(Cr, Cl)));
+          }
+        }
+      }
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
+        const int l = 64 * hf + lane;
+        if (l < CAD_CS) {
+          st_dev(xg + ((long)b * CAD_ROWS + r) * CAD_CS + l, x[hf]);
+          st_dev(bg + ((long)b * CAD_ROWS + r) * CAD_CS + l, pb[hf]);
+        }
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // written through ...
+    __syncthreads();                                   // ... by every wave ...
+    if (tid == 0) __hip_atomic_fetch_add(sync + SYNC_GATHER * SYNC_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ... then counted
+    return;
+  }
+  // Columns: the 80 LANDMARK positions of C' (column j = position 3 + j; the pose columns of X are never used): 5 MFMA tiles.
+  __shared__ __attribute__((aligned(16))) double A[CH_R][CH_S];      // A X -> E (rows 0..79), the pose rows behind the cadence (80..82)
+  __shared__ __attribute__((aligned(16))) double B[CH_R][CH_CS];     // the coefficients C -> Linv C  ->  -F  ->  F^T E
+  __shared__ __attribute__((aligned(16))) double Li[5][16][17];      // inverses of the diagonal blocks I + C_ii
+  __shared__ double2 hS[CAD_SLOTS][5];                 // H_q: {H[0][k], H[1][k]}
+  __shared__ double siS[CAD_SLOTS][4];
+  __shared__ double2 yS[CAD_SLOTS];
+  __shared__ double2 pgS[CAD_SLOTS + 1];               // predictions in front of landmark q, summed from the cadence's start; [nk]: all
+  __shared__ double dmS[5][CH_NC];                     // partial sums of the mean update, 8 landmarks each
+  double (*Cm)[CH_CS] = B;
+  const int b = blockIdx.x;
+  const CadOut& op = prev[b];
+  const CadPlan pl = plan[b];
+  const int nk = min(op.nslots, CAD_SLOTS), s0k = CAD_SLOTS - nk;   // this cadence: landmarks, first slot
+  // this launch runs: the solve in front of it on the stream has completed -- what the gate on the other stream waits for
+  if (tid == 0) __hip_atomic_store(sync + SYNC_SOLVE * SYNC_STRIDE, sigma, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  CHSTAMP(0);
+  if (tid < CAD_SLOTS) {
+    double4_t si = {0.0, 0.0, 0.0, 0.0};
+    double2 y = make_double2(0.0, 0.0);
+    double2 hh[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) hh[k] = make_double2(0.0, 0.0);
+    if (tid < nk) {                                    // landmark tid = slot s0k + tid
+      const double* rec = op.rec + G::rec_off(s0k + tid);
+#pragma unroll
+      for (int k = 0; k < 5; ++k) hh[k] = *reinterpret_cast<const double2*>(rec + 2 * k);
+      const double2 sa = *reinterpret_cast<const double2*>(rec + 10), sb = *reinterpret_cast<const double2*>(rec + 12);
+      si = double4_t{sa.x, sa.y, sb.x, sb.y};
+      y = *reinterpret_cast<const double2*>(rec + 14);
+    }
+#pragma unroll
+    for (int k = 0; k < 5; ++k) hS[tid][k] = hh[k];
+    siS[tid][0] = si[0];
+    siS[tid][1] = si[1];
+    siS[tid][2] = si[2];
+    siS[tid][3] = si[3];
+    yS[tid] = y;
+  }
+  if (tid >= 64 && tid <= 64 + CAD_SLOTS) {
+    // the panel launch applies touched step t's prediction in front of slot sfirst[t] (k_panels_cad: predictions_before);
+    // predictions only ever add multiples of row 2 to rows 0, 1, so their g add up
+    const int q = tid - 64, np = min(op.npred, CAD_SLOTS);
+    double g0 = 0.0, g1 = 0.0;
+    for (int t = 0; t < np; ++t) {
+      if (q == nk || op.sfirst[t] <= s0k + q) {
+        g0 += op.g[t][0];
+        g1 += op.g[t][1];
+      }
+    }
+    pgS[q] = make_double2(g0, g1);
+  }
+  const int nslots = cad_positions<false>(pl, in, batch, b, cfg, tid, Cs, cntS, firstS, loS, [](int, double, double) {});
+  const int cu = 3 + 2 * nslots;                       // the next cadence: positions in use
+  // ---- the coefficients of (I + C) E = A X: zero, then the 2 x 2 blocks (q, r), r < q, and the pose rows (q = nk) ----
+  {
+    double2* z = reinterpret_cast<double2*>(&Cm[0][0]);
+    for (int e = tid; e < CH_R * CH_CS / 2; e += 64 * CAD_NW) z[e] = make_double2(0.0, 0.0);
+  }
+  __syncthreads();
+  CHSTAMP(1);
+  {
+    const int tri = nk * (nk - 1) / 2, items = tri + nk;
+    for (int e = tid; e < items; e += 64 * CAD_NW) {
+      int q, r;
+      if (e < tri) {
+        q = (int)((1.0f + sqrtf(1.0f + 8.0f * (float)e)) * 0.5f);   // q (q - 1) / 2 <= e < q (q + 1) / 2
+        while (q * (q - 1) / 2 > e) --q;
+        while (q * (q + 1) / 2 <= e) ++q;
+        r = e - q * (q - 1) / 2;
+      } else {
+        q = nk;
+        r = e - tri;
+      }
+      const double* rr = op.rec + G::rec_off(s0k + r) + 16;          // K_r[a] = (rr[2a], rr[2a + 1])
+      const double2 k0 = *reinterpret_cast<const double2*>(rr), k1 = *reinterpret_cast<const double2*>(rr + 2),
+                    k2 = *reinterpret_cast<const double2*>(rr + 4);
+      const double2 gq = pgS[q], gr = pgS[r];
+      const double g0 = gq.x - gr.x, g1 = gq.y - gr.y;              // the predictions between landmark r and landmark q
+      if (q < nk) {
+        const int paq = G::pa(s0k + q);
+        const double2 h0 = hS[q][0], h1 = hS[q][1], h2 = hS[q][2], h3 = hS[q][3], h4 = hS[q][4];
+        const double2 ka = *reinterpret_cast<const double2*>(rr + 2 * paq), kb = *reinterpret_cast<const double2*>(rr + 2 * paq + 2);
+        // row w of H_q[:, 0..2] G = (h[w][0], h[w][1], h[w][2] + g0 h[w][0] + g1 h[w][1])
+        const double hx2 = fma(g0, h0.x, fma(g1, h1.x, h2.x)), hy2 = fma(g0, h0.y, fma(g1, h1.y, h2.y));
+        Cm[2 * q][2 * r] = h0.x * k0.x + h1.x * k1.x + hx2 * k2.x + h3.x * ka.x + h4.x * kb.x;
+        Cm[2 * q][2 * r + 1] = h0.x * k0.y + h1.x * k1.y + hx2 * k2.y + h3.x * ka.y + h4.x * kb.y;
+        Cm[2 * q + 1][2 * r] = h0.y * k0.x + h1.y * k1.x + hy2 * k2.x + h3.y * ka.x + h4.y * kb.x;
+        Cm[2 * q + 1][2 * r + 1] = h0.y * k0.y + h1.y * k1.y + hy2 * k2.y + h3.y * ka.y + h4.y * kb.y;
+      } else {                                                      // rows 0..2 of G^{(end, r)} K_r[0..2, :]
+        Cm[KTOT][2 * r] = fma(g0, k2.x, k0.x);
+        Cm[KTOT][2 * r + 1] = fma(g0, k2.y, k0.y);
+        Cm[KTOT + 1][2 * r] = fma(g1, k2.x, k1.x);
+        Cm[KTOT + 1][2 * r + 1] = fma(g1, k2.y, k1.y);
+        Cm[KTOT + 2][2 * r] = k2.x;
+        Cm[KTOT + 2][2 * r + 1] = k2.y;
+      }
+    }
+  }
+  __syncthreads();
+  CHSTAMP(2);
+  const int li = lane & 15, lq = lane >> 4;
+  // ---- the diagonal blocks: Linv_i = (I + C_ii)^-1 by substitution on the identity (wave i, a column per lane), then
+  // Linv_i C_{i,<i} in place (tiles of 16 x 16 over the waves) -- so that a block step of the solve is ONE product ----
+  if (wave < 5 && lane < 16) {
+    const int i = wave, c = lane;
+    double t[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t[k] = k == c ? 1.0 : 0.0;
+#pragma unroll
+    for (int j = 1; j < 8; ++j) {
+      double2 c0[7], c1[7];
+#pragma unroll
+      for (int jp = 0; jp < j; ++jp) {                 // the landmark's coefficients within the block: all reads in flight together
+        c0[jp] = *reinterpret_cast<const double2*>(&Cm[16 * i + 2 * j][16 * i + 2 * jp]);
+        c1[jp] = *reinterpret_cast<const double2*>(&Cm[16 * i + 2 * j + 1][16 * i + 2 * jp]);
+      }
+#pragma unroll
+      for (int jp = 0; jp < j; ++jp) {
+        t[2 * j] = fma(-c0[jp].x, t[2 * jp], t[2 * j]);
+        t[2 * j + 1] = fma(-c1[jp].x, t[2 * jp], t[2 * j + 1]);
+        t[2 * j] = fma(-c0[jp].y, t[2 * jp + 1], t[2 * j]);
+        t[2 * j + 1] = fma(-c1[jp].y, t[2 * jp + 1], t[2 * j + 1]);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) Li[i][k][c] = t[k];
+  }
+  __syncthreads();
+  for (int job = wave; job < 10; job += CAD_NW) {      // (i, j), j < i <= 4: tile (rows of block i, columns of block j)
+    int i = 1, j = job;
+    while (j >= i) {
+      j -= i;
+      ++i;
+    }
+    if (8 * i < nk) {                                  // (uniform)
+      double4_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Li[i][li][4 * kt + lq], Cm[16 * i + 4 * kt + lq][16 * j + li], acc, 0, 0, 0);
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) Cm[16 * i + lq + 4 * reg][16 * j + li] = acc[reg];
+    }
+  }
+  CHSTAMP(3);
+  // ---- the gathered rows are there (the launch's gather workgroups have counted themselves off) ----
+  if (tid == 0 && !sync_wait(sync + SYNC_GATHER * SYNC_STRIDE, gather_target)) atomicOr(flags + b, EKF_FLAG_INTERNAL);
+  __syncthreads();
+  CHSTAMP(4);
+  constexpr int RQ = (CAD_ROWS + CAD_NW - 1) / CAD_NW;               // rows per wave (11)
+  const double* bgb = bg + (long)b * CAD_ROWS * CAD_CS;
+  double p0[RQ][2];                                                  // P_0(C', C') in the layout the block is written in
+#pragma unroll
+  for (int q = 0; q < RQ; ++q) {
+    const int r = wave + CAD_NW * q;
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+      const int l = 64 * hf + lane;
+      p0[q][hf] = (r >= 3 && r < cu && l >= 3 && l < cu) ? ld_dev(bgb + (long)r * CAD_CS + l) : 0.0;
+    }
+  }
+  // ---- the right-hand side A X, row by row: A_q = H_q[:, 0..2] G^{(q,-1)} at the pose positions, H_q[:, 3..4] at the landmark's
+  // own -- five rows of X per landmark, each landmark row of X read exactly once (straight from xg, coalesced); the pose rows
+  // behind the cadence start from G^{(end,-1)} X[0..2].  Columns over lanes (64 + 16), landmarks over waves ----
+  const double* xgb = xg + (long)b * CAD_ROWS * CAD_CS + 3;          // column j = position 3 + j
+  {
+    const int ja = lane, jb = 64 + lane;               // columns; the second part: 16 lanes
+    const bool hb = jb < CH_NC;
+    double xa[3], xb[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      xa[k] = ld_dev(xgb + (long)k * CAD_CS + ja);
+      xb[k] = hb ? ld_dev(xgb + (long)k * CAD_CS + jb) : 0.0;
+    }
+    constexpr int QW = CAD_SLOTS / CAD_NW;             // landmarks per wave (5)
+    double la0[QW], la1[QW], lb0[QW], lb1[QW];
+#pragma unroll
+    for (int u = 0; u < QW; ++u) {
+      const int q = wave + CAD_NW * u;
+      const int paq = q < nk ? G::pa(s0k + q) : 3;     // (uniform)
+      la0[u] = ld_dev(xgb + (long)paq * CAD_CS + ja);
+      la1[u] = ld_dev(xgb + (long)(paq + 1) * CAD_CS + ja);
+      lb0[u] = hb ? ld_dev(xgb + (long)paq * CAD_CS + jb) : 0.0;
+      lb1[u] = hb ? ld_dev(xgb + (long)(paq + 1) * CAD_CS + jb) : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < QW; ++u) {
+      const int q = wave + CAD_NW * u;
+      double2 h[5];
+#pragma unroll
+      for (int k = 0; k < 5; ++k) h[k] = hS[q][k];     // (zeros beyond the cadence's landmarks)
+      const double2 gq = pgS[min(q, nk)];
+      const double hx2 = fma(gq.x, h[0].x, fma(gq.y, h[1].x, h[2].x)), hy2 = fma(gq.x, h[0].y, fma(gq.y, h[1].y, h[2].y));
+      A[2 * q][ja] = h[0].x * xa[0] + h[1].x * xa[1] + hx2 * xa[2] + h[3].x * la0[u] + h[4].x * la1[u];
+      A[2 * q + 1][ja] = h[0].y * xa[0] + h[1].y * xa[1] + hy2 * xa[2] + h[3].y * la0[u] + h[4].y * la1[u];
+      if (hb) {
+        A[2 * q][jb] = h[0].x * xb[0] + h[1].x * xb[1] + hx2 * xb[2] + h[3].x * lb0[u] + h[4].x * lb1[u];
+        A[2 * q + 1][jb] = h[0].y * xb[0] + h[1].y * xb[1] + hy2 * xb[2] + h[3].y * lb0[u] + h[4].y * lb1[u];
+      }
+    }
+    if (wave < 2) {                                    // rows 80 .. 95: the pose rows behind the cadence, then zeros
+      const double2 ge = pgS[nk];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int r = KTOT + 8 * wave + k;
+        const double va = r == KTOT ? fma(ge.x, xa[2], xa[0]) : (r == KTOT + 1 ? fma(ge.y, xa[2], xa[1]) : (r == KTOT + 2 ? xa[2] : 0.0));
+        const double vb = r == KTOT ? fma(ge.x, xb[2], xb[0]) : (r == KTOT + 1 ? fma(ge.y, xb[2], xb[1]) : (r == KTOT + 2 ? xb[2] : 0.0));
+        A[r][ja] = va;
+        if (hb) A[r][jb] = vb;
+      }
+    }
+  }
+  __syncthreads();
+  CHSTAMP(5);
+  // ---- Linv_i (A X)_i in place: 5 blocks x 5 column tiles over the waves ----
+  for (int job = wave; job < 25; job += CAD_NW) {
+    const int i = job / 5, ct = job - 5 * i;
+    if (8 * i < nk) {                                  // (uniform)
+      double4_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Li[i][li][4 * kt + lq], A[16 * i + 4 * kt + lq][16 * ct + li], acc, 0, 0, 0);
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) A[16 * i + lq + 4 * reg][16 * ct + li] = acc[reg];
+    }
+  }
+  __syncthreads();
+  CHSTAMP(6);
+  // ---- the block steps: E_i = Linv_i (A X)_i - (Linv_i C_{i,<i}) E_{<i}; i = 5: the pose rows A_end X - C_end E.  One column
+  // tile per wave (waves 0..4), the landmarks solved so far as k ----
+  for (int i = 1; i <= 5; ++i) {
+    if (i == 5 || 8 * i < nk) {                        // (uniform) something of this block is in use
+      const int kts = i == 5 ? (2 * nk + 3) / 4 : 4 * i;
+      if (wave < 5) {
+        double4_t acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+        int kt = 0;
+        for (; kt + 1 < kts; kt += 2) {
+          acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(Cm[16 * i + li][4 * kt + lq], A[4 * kt + lq][16 * wave + li], acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(Cm[16 * i + li][4 * kt + 4 + lq], A[4 * kt + 4 + lq][16 * wave + li], acc1, 0, 0, 0);
+        }
+        if (kt < kts)
+          acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(Cm[16 * i + li][4 * kt + lq], A[4 * kt + lq][16 * wave + li], acc0, 0, 0, 0);
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) A[16 * i + lq + 4 * reg][16 * wave + li] -= acc0[reg] + acc1[reg];
+      }
+      __syncthreads();
+    }
+  }
+  CHSTAMP(7);
+  // ---- -F = -(E S^-1) per landmark: f = e S^-1 is K at the position (P symmetric), W = -f; and the mean update's partial sums ----
+  for (int e = tid; e < 5 * CH_NC; e += 64 * CAD_NW) {
+    const int g8 = e / CH_NC, c = e - g8 * CH_NC;
+    double dm = 0.0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int q = 8 * g8 + k;
+      const double e0 = A[2 * q][c], e1 = A[2 * q + 1][c];
+      const double f0 = e0 * siS[q][0] + e1 * siS[q][2], f1 = e0 * siS[q][1] + e1 * siS[q][3];
+      B[2 * q][c] = -f0;
+      B[2 * q + 1][c] = -f1;
+      const double2 y = yS[q];
+      dm = fma(f0, y.x, dm);
+      dm = fma(f1, y.y, dm);
+    }
+    dmS[g8][c] = dm;
+  }
+  __syncthreads();
+  CHSTAMP(8);
+  // the mean at C' (src/replay_no_ros.py:476 summed over the cadence): mean_0 + sum_q f_q . y_q
+  if (tid < 128) {
+    double v = 0.0;
+    if (tid < 3) v = mu_pose[(long)b * ld + tid];
+    else if (tid < cu) {
+      const int j = tid - 3;
+      v = ld_dev(mu_land + (long)b * ld + Cs[tid]) + ((((dmS[0][j] + dmS[1][j]) + dmS[2][j]) + dmS[3][j]) + dmS[4][j]);
+    }
+    gmu[(long)b * 128 + tid] = v;
+  }
+  // ---- F^T E, the upper block triangle: 15 tiles of 16 x 16 over the 8 waves, 20 k-tiles; A-operand (-F)^T ----
+  constexpr int TPW = 2;                               // tiles per wave at most
+  double4_t acc[TPW];
+#pragma unroll
+  for (int u = 0; u < TPW; ++u) {
+    acc[u] = double4_t{0.0, 0.0, 0.0, 0.0};
+    const int t = wave + CAD_NW * u;
+    if (t < 15) {                                      // (uniform) tile t of the triangle, row tile rt <= column tile ct
+      int rt = 0, left = t;
+      while (left >= 5 - rt) {
+        left -= 5 - rt;
+        ++rt;
+      }
+      const int ct = rt + left;
+#pragma unroll 5
+      for (int kt = 0; kt < KTOT / 4; ++kt)
+        acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(B[4 * kt + lq][16 * rt + li], A[4 * kt + lq][16 * ct + li], acc[u], 0, 0, 0);
+    }
+  }
+  __syncthreads();
+  CHSTAMP(9);
+#pragma unroll
+  for (int u = 0; u < TPW; ++u) {
+    const int t = wave + CAD_NW * u;
+    if (t < 15) {
+      int rt = 0, left = t;
+      while (left >= 5 - rt) {
+        left -= 5 - rt;
+        ++rt;
+      }
+      const int ct = rt + left;
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) B[16 * rt + lq + 4 * reg][16 * ct + li] = acc[u][reg];
+    }
+  }
+  __syncthreads();
+  // ---- the block, in the layout k_solve_cad reads its look-ahead parts in (one part): landmark x landmark entries from the
+  // product's upper triangle BY POSITION (exactly symmetric), pose rows / columns from E's last three rows, the pose block from
+  // the solve ----
+  double* gb = gbuf + (long)b * CAD_ROWS * CAD_CS;
+#pragma unroll
+  for (int q = 0; q < RQ; ++q) {
+    const int r = wave + CAD_NW * q;
+    if (r < CAD_ROWS) {                                // (uniform)
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
+        const int l = 64 * hf + lane;
+        if (l < CAD_CS) {
+          double v = 0.0;
+          if (r < cu && l < cu) {
+            if (r < 3 && l < 3) v = op.posefin[r][l];
+            else if (r < 3) v = A[KTOT + r][l - 3];
+            else if (l < 3) v = A[KTOT + l][r - 3];
+            else v = p0[q][hf] + B[min(r, l) - 3][max(r, l) - 3];
+          }
+          gb[(long)r * CAD_CS + l] = v;
+        }
+      }
+    }
+  }
+  CHSTAMP(10);
+}
+
+// (chained runs) the gate in front of a cadence's panel launch on the second stream: it runs behind the previous covariance pass
+// -- and says so (what the chain launch's gather workgroups wait for) --, and it ends when the cadence's solve has completed
+// (announced by the chain launch behind that solve).  One lane: it cannot keep the solve from finding its CUs, whatever the
+// order in which the host's enqueues reach the two streams.
+__global__ void k_gate(unsigned* __restrict__ sync, unsigned sigma, unsigned* __restrict__ flags, int batch) {
+  if (threadIdx.x != 0) return;
+  __hip_atomic_store(sync + SYNC_PASS * SYNC_STRIDE, sigma - 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (!sync_wait(sync + SYNC_SOLVE * SYNC_STRIDE, sigma))
+    for (int b = 0; b < batch; ++b) atomicOr(flags + b, EKF_FLAG_INTERNAL);
+}
+
+// (chained runs, once per run) rows 0..2 of every trajectory's P_base -> prow3: what the first chained block reads while the
+// first panel launch changes rows 0, 1 in place
+__global__ __launch_bounds__(256) void k_snap_pose(const double* __restrict__ P, const int* __restrict__ nact, int ld, long pstride,
+                                                   double* __restrict__ prow3) {
+  const int b = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= nact[b] || i < 3) return;
+  const double* Pb = P + (long)b * pstride;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) prow3[((long)b * 3 + a) * ld + i] = Pb[p_index(ld, a, i)];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1212,29 +1763,62 @@ void launch_gather_cad(hipStream_t st, const double* P, const double* V, const d
 
 // `colbuf` (batch x CAD_CU x ld doubles, or nullptr): the launch also gathers the mirrored column entries of the panel launch
 // behind it, on `col_wgs` extra workgroups -- only where P_base is current (not beside a pass: look-ahead)
+// `chain`: the instantiation that also records the cadence's transform (CadOut::T, mpose, posefin) for k_chain_cad; `gmu`
+// (with gbuf, one part): block and mean come from k_chain_cad
 void launch_solve_cad(hipStream_t st, const double* P, const double* mu_in, double* mu_out, double* dacc_out,
                       const int* nact, const StepIn* in, const CadPlan* plan, int batch, CadOut* out, unsigned* flags,
                       const DeviceConfig& cfg, int ld, long pstride, const double* gbuf, int gparts, double* colbuf, int n_hi,
-                      int col_wgs) {
-  hipLaunchKernelGGL(k_solve_cad, dim3(batch + (colbuf ? col_wgs : 0)), dim3(64 * CAD_NW), 0, st, P, mu_in, mu_out, dacc_out, nact, in,
-                     plan, batch, out, flags, cfg, ld, pstride, gbuf, gparts, colbuf, col_wgs, n_hi);
+                      int col_wgs, bool chain, const double* gmu) {
+  if (chain)
+    hipLaunchKernelGGL(k_solve_cad<true>, dim3(batch + (colbuf ? col_wgs : 0)), dim3(64 * CAD_NW), 0, st, P, mu_in, mu_out, dacc_out,
+                       nact, in, plan, batch, out, flags, cfg, ld, pstride, gbuf, gparts, colbuf, col_wgs, n_hi, gmu);
+  else
+    hipLaunchKernelGGL(k_solve_cad<false>, dim3(batch + (colbuf ? col_wgs : 0)), dim3(64 * CAD_NW), 0, st, P, mu_in, mu_out, dacc_out,
+                       nact, in, plan, batch, out, flags, cfg, ld, pstride, gbuf, gparts, colbuf, col_wgs, n_hi, nullptr);
+}
+
+// (chained runs) the next cadence's block and mean from the records `prev` of the cadence whose solve has just run
+// gather workgroups per trajectory: each counts itself off on the launch's gather counter.  (Every workgroup of the launch
+// reserves the chain workgroup's LDS, a CU apiece: as many as leave the chip half free for what runs beside the launch.)
+int chain_gather_workgroups(int batch, int cus) { return std::max(1, std::min(CH_GW, (cus / 2 - batch) / std::max(batch, 1))); }
+int chain_sync_words() { return SYNC_WORDS; }
+void launch_chain_cad(hipStream_t st, const double* P, const double* prow3, const double* mu_land, const double* mu_pose,
+                      const CadOut* prev, const StepIn* in, const CadPlan* plan, int batch, const DeviceConfig& cfg, int ld,
+                      long pstride, double* gbuf, double* gmu, double* xg, double* bg, unsigned* sync, unsigned gather_target,
+                      unsigned* flags, int gw, unsigned sigma) {
+  hipLaunchKernelGGL(k_chain_cad, dim3(batch * (1 + gw)), dim3(64 * CAD_NW), 0, st, P, prow3, mu_land, mu_pose, prev, in, plan,
+                     batch, cfg, ld, pstride, gbuf, gmu, xg, bg, sync, gather_target, flags, gw, sigma);
+}
+
+void launch_gate(hipStream_t st, unsigned* sync, unsigned sigma, unsigned* flags, int batch) {
+  hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, st, sync, sigma, flags, batch);
+}
+// workgroups of the panel launch (what decides between the launch being its own gate and the gate launch)
+int panels_cad_workgroups(int batch, int n_hi) {
+  const long waves = (long)((n_hi + 63) / 64) * batch;
+  return (int)(waves <= 1024 ? waves : (long)((n_hi + 255) / 256) * batch);
+}
+
+void launch_snap_pose(hipStream_t st, const double* P, const int* nact, int ld, long pstride, int batch, int n_hi, double* prow3) {
+  hipLaunchKernelGGL(k_snap_pose, dim3((n_hi + 255) / 256, batch), dim3(256), 0, st, P, nact, ld, pstride, prow3);
 }
 
 // `nrp`: the ranks the bank's busiest trajectory appends, padded to a whole k-tile (every trajectory writes that many)
 void launch_panels_cad(hipStream_t st, double* P, double* V, double* W, const double* mu_in, double* mu_out,
                        const int* nact, const CadOut* co, SolveOut* so, unsigned* queue, int ld, long pstride, int batch,
-                       int n_hi, int nrp, const double* colbuf) {
+                       int n_hi, int nrp, const double* colbuf, double* prow3, unsigned* sync, unsigned head_sigma, unsigned tail_target,
+                       unsigned* flags) {
   // few state indices (the latency regime): four waves split the rows of the panel of 64 state indices (k_panels_cad_ks);
   // up to one wave per SIMD: one wave per workgroup
   if ((long)((n_hi + 63) / 64) * batch <= CAD_KS_WAVES)
     hipLaunchKernelGGL(k_panels_cad_ks, dim3((n_hi + 63) / 64, batch), dim3(256), 0, st, P, V, W, mu_in, mu_out,
-                       nact, co, so, queue, ld, pstride, nrp, colbuf);
+                       nact, co, so, queue, ld, pstride, nrp, colbuf, prow3, sync, head_sigma, tail_target, flags);
   else if ((long)((n_hi + 63) / 64) * batch <= 1024)
     hipLaunchKernelGGL((k_panels_cad<1>), dim3((n_hi + 63) / 64, batch), dim3(64), 0, st, P, V, W, mu_in, mu_out,
-                       nact, co, so, queue, ld, pstride, nrp, colbuf);
+                       nact, co, so, queue, ld, pstride, nrp, colbuf, prow3, sync, head_sigma, tail_target, flags);
   else
     hipLaunchKernelGGL((k_panels_cad<4>), dim3((n_hi + 255) / 256, batch), dim3(256), 0, st, P, V, W, mu_in,
-                       mu_out, nact, co, so, queue, ld, pstride, nrp, colbuf);
+                       mu_out, nact, co, so, queue, ld, pstride, nrp, colbuf, prow3, sync, head_sigma, tail_target, flags);
 }
 
 }  // namespace ekf

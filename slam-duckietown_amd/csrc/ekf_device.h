@@ -161,6 +161,7 @@ struct alignas(16) CadHead {
 struct alignas(16) CadOut : CadHead {
   double rec[CAD_REC_MAX];
   double posevw[CAD_SLOTS][3][4];   // the new ranks' entries at the pose's state indices l < 3: V[2s][l], V[2s+1][l], W[l][2s], W[l][2s+1]
+  double posefin[4][4];             // (k_solve_cad<true>: chained runs) the pose block P(l, l') after the cadence, motion noise included
 };
 static_assert(sizeof(CadHead) % 16 == 0, "CadHead must stay 16-byte granular");
 static_assert(sizeof(CadPlan) == 32, "CadPlan is 32 bytes");

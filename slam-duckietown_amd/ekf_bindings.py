@@ -134,11 +134,14 @@ ABI = {
     "ekf_timer_end": (C.c_int, [C.c_void_p, _dp]),
     "ekf_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "ekf_profile_read": (C.c_int, [C.c_void_p, _dp, C.POINTER(C.c_longlong)]),
+    "ekf_profile_passes": (C.c_longlong, [C.c_void_p]),
+    "ekf_profile_read_class": (C.c_int, [C.c_void_p, C.c_int, _dp, C.POINTER(C.c_longlong)]),
     "ekf_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
     "ekf_last_pass": (C.c_int, [C.c_void_p, _ip, _ip, _ip]),
     # diagnostics (the header's last section)
     "ekf_debug_cadences": (C.c_int, [C.c_void_p, C.POINTER(C.c_long), C.POINTER(C.c_long)]),
     "ekf_debug_lookaheads": (C.c_long, [C.c_void_p]),
+    "ekf_debug_chained": (C.c_long, [C.c_void_p]),
     "ekf_debug_last_pass_shares": (C.c_int, [C.c_void_p]),
     "ekf_debug_small_launches": (C.c_long, [C.c_void_p]),
     "ekf_debug_fused_fetches": (C.c_long, [C.c_void_p]),
@@ -657,9 +660,21 @@ class EkfSlam:
         self._check(self._lib.ekf_profile_enable(self._h, int(on)))
 
     def profile_read(self):
+        """(total ms, number) of the launches of the covariance pass that carried an event pair since the last read."""
         ms, cnt = C.c_double(), C.c_longlong()
         self._check(self._lib.ekf_profile_read(self._h, C.byref(ms), C.byref(cnt)))
         return ms.value, cnt.value
+
+    def profile_read_class(self, cls: int):
+        """(total ms, number) of the bracketed launches of class `cls` (1 solve, 2 chain / gather, 3 panel; needs the option
+        "profile_kernels"); read before `profile_read`, which resets."""
+        ms, cnt = C.c_double(), C.c_longlong()
+        self._check(self._lib.ekf_profile_read_class(self._h, int(cls), C.byref(ms), C.byref(cnt)))
+        return ms.value, cnt.value
+
+    def profile_passes(self) -> int:
+        """All launches of the covariance pass since profiling was enabled (with "profile_stride" = k every k-th is timed)."""
+        return int(self._lib.ekf_profile_passes(self._h))
 
     def last_pass(self) -> str:
         """Name of the kernel the last covariance pass launched (e.g. ``ekf::k_flush_rs<20, true, false>``: k-tiles,

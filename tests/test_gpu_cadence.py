@@ -282,37 +282,54 @@ def lookaheads(sd, f):
     return lib.ekf_debug_lookaheads(f._h)
 
 
-@pytest.mark.parametrize("N,B,m,steps", [(1250, 1, 8, 26), (700, 4, 8, 17), (900, 2, 1, 125), (1000, 2, 16, 9)])
+def chained(sd, f):
+    lib = sd.load_library()
+    return lib.ekf_debug_chained(f._h)
+
+
+# the three orders a run's cadences can be enqueued in (csrc/ekf_api.hip: enqueue_cadence): chained solves (round 6, default),
+# the round-3 look-ahead, everything one behind the other
+MODES = {"chain": (("lookahead", 1), ("chain", 1)), "lookahead": (("lookahead", 1), ("chain", 0)), "plain": (("lookahead", 0),)}
+
+
+@pytest.mark.parametrize("N,B,m,steps", [(1250, 1, 8, 26), (700, 4, 8, 17), (900, 2, 1, 125), (1000, 2, 16, 9), (2000, 1, 8, 22)])
 def test_lookahead_solve_beside_the_pass(sd, N, B, m, steps):
-    """Small launches with at least ~48 MB of covariance (N = 1250 x 1, 700 x 4, 900 x 2, 1000 x 2 here): the solve of the
-    next cadence runs beside the covariance pass of this one (its block gathered
-    from P_base and the still pending ranks by k_gather_cad, the pass on the handle's second stream).  Against the same
-    stream without it (`lookahead=0`: every solve behind its pass) to PATH_TOL, against the oracle to 1e-9; dense starting
-    covariances, so that the gathered block carries every term (base, ranks, pending pose noise)."""
+    """Small launches with at least ~48 MB of covariance (N = 1250 x 1, 700 x 4, 900 x 2, 1000 x 2, and BASELINE config 3,
+    N = 2000 x 1): the solve of the next cadence runs beside the covariance pass of this one.  Round 6, CHAINED (the default):
+    the solves follow one another on the handle's stream, each block formed by k_chain_cad from the previous cadence's records
+    (T, S^-1, the pose rows of its transform) and P_base as it stood before that cadence, panel launch and pass on the second
+    stream.  Round 3, look-ahead (`chain=0`): the block from P_base and the still pending ranks (k_gather_cad).  Both against
+    the same stream with every solve behind its pass (`lookahead=0`) to PATH_TOL, against the oracle to 1e-9, the road taken
+    asserted; dense starting covariances, so that the block carries every term."""
     n = 3 + 2 * N
     streams = [orc.synthetic_stream(N, steps, m, 1200 + t) for t in range(B)]
     starts = [dense_start(n, 1300 + t) for t in range(B)]
     args = (stack(streams, 2), stack(streams, 3), stack(streams, 4), stack(streams, 5), stack(streams, 6))
     res = {}
-    for la in (1, 0):
+    for mode, opts in MODES.items():
         with sd.EkfSlam(n, batch=B) as f:
             f.set_option("active_bound", 0)
-            f.set_option("lookahead", la)
+            for name, value in opts:
+                f.set_option(name, value)
             for b in range(B):
                 f.set_state(streams[b][0], starts[b], b)
             f.run_stream(*args)
-            res[la] = [f.state(b) for b in range(B)]
+            res[mode] = [f.state(b) for b in range(B)]
             assert [f.flags(b) for b in range(B)] == [0] * B
-            want = (-(-steps * m // 40) - 1) if la else 0                     # every cadence but the first is looked ahead
-            assert lookaheads(sd, f) == want, (lookaheads(sd, f), want)
-    for b in range(B):
-        assert orc.rel_fro(res[1][b][0], res[0][b][0]) < PATH_TOL and orc.rel_fro(res[1][b][1], res[0][b][1]) < PATH_TOL
+            want = (-(-steps * m // 40) - 1) if mode != "plain" else 0       # every cadence but the first is solved ahead
+            assert lookaheads(sd, f) == want, (mode, lookaheads(sd, f), want)
+            assert chained(sd, f) == (want if mode == "chain" else 0), (mode, chained(sd, f))
+    for mode in ("chain", "lookahead"):
+        for b in range(B):
+            assert orc.rel_fro(res[mode][b][0], res["plain"][b][0]) < PATH_TOL, mode
+            assert orc.rel_fro(res[mode][b][1], res["plain"][b][1]) < PATH_TOL, mode
     cfg = orc.EkfConfig()
     s = streams[0]
     om, oP = s[0].copy(), starts[0].copy()
     for k in range(steps):                             # (the O(n^2) form of the oracle: n is in the thousands here)
         om, oP = orc.ekf_step_structured(om, oP, s[2][k], s[3][k], s[4][k], s[5][k], s[6][k], cfg)
-    assert orc.rel_fro(res[1][0][0], om) < TIGHT and orc.rel_fro(res[1][0][1], oP) < TIGHT
+    for mode in ("chain", "lookahead"):
+        assert orc.rel_fro(res[mode][0][0], om) < TIGHT and orc.rel_fro(res[mode][0][1], oP) < TIGHT, mode
 
 
 def test_lookahead_with_wandering_landmark_counts(sd):
@@ -324,26 +341,30 @@ def test_lookahead_with_wandering_landmark_counts(sd):
     means, lin, ang, idx, zr, zb, m = wandering_stream(N, B, steps, lambda k, b, rng: rng.integers(0, 17), 7100)
     starts = [dense_start(n, 7200 + t) for t in range(B)]
     res = {}
-    for la in (1, 0):
+    for mode, opts in MODES.items():
         with sd.EkfSlam(n, batch=B) as f:
             f.set_option("active_bound", 0)
-            f.set_option("lookahead", la)
+            for name, value in opts:
+                f.set_option(name, value)
             for b in range(B):
                 f.set_state(means[b], starts[b], b)
             f.run_stream(lin, ang, idx, zr, zb, m)
-            res[la] = [f.state(b) for b in range(B)]
+            res[mode] = [f.state(b) for b in range(B)]
             assert [f.flags(b) for b in range(B)] == [0] * B
             nc = cadences(sd, f)[0]
             assert nc == max(cadences_needed(m[:, b]) for b in range(B)) and nc >= 3
-            assert lookaheads(sd, f) == (nc - 1 if la else 0)
+            assert lookaheads(sd, f) == (nc - 1 if mode != "plain" else 0)
+            assert chained(sd, f) == (nc - 1 if mode == "chain" else 0)
     cfg = orc.EkfConfig()
     for b in range(B):
-        assert orc.rel_fro(res[1][b][0], res[0][b][0]) < PATH_TOL and orc.rel_fro(res[1][b][1], res[0][b][1]) < PATH_TOL
         om, oP = means[b].copy(), starts[b].copy()
         for k in range(steps):
             mb = m[k, b]
             om, oP = orc.ekf_step_structured(om, oP, lin[k, b], ang[k, b], idx[k, b, :mb], zr[k, b, :mb], zb[k, b, :mb], cfg)
-        assert orc.rel_fro(res[1][b][0], om) < TIGHT and orc.rel_fro(res[1][b][1], oP) < TIGHT
+        for mode in ("chain", "lookahead"):
+            assert orc.rel_fro(res[mode][b][0], res["plain"][b][0]) < PATH_TOL, mode
+            assert orc.rel_fro(res[mode][b][1], res["plain"][b][1]) < PATH_TOL, mode
+            assert orc.rel_fro(res[mode][b][0], om) < TIGHT and orc.rel_fro(res[mode][b][1], oP) < TIGHT, mode
 
 
 def test_lookahead_beside_the_row_slab_pass_on_static_shares(sd):
@@ -358,27 +379,29 @@ def test_lookahead_beside_the_row_slab_pass_on_static_shares(sd):
     starts = [dense_start(n, 2400 + t) for t in range(B)]
     args = (stack(streams, 2), stack(streams, 3), stack(streams, 4), stack(streams, 5), stack(streams, 6))
     res = {}
-    for la in (1, 0):
+    for mode, opts in MODES.items():
         with sd.EkfSlam(n, batch=B) as f:
-            for name, value in (("active_bound", 0), ("pass_streaming", 1), ("pass_kernel", 2), ("pass_workgroups", 8),
-                                ("lookahead", la)):
+            for name, value in (("active_bound", 0), ("pass_streaming", 1), ("pass_kernel", 2), ("pass_workgroups", 8)) + opts:
                 f.set_option(name, value)
             for b in range(B):
                 f.set_state(streams[b][0], starts[b], b)
             f.run_stream(*args)
             f.flush()
-            res[la] = [f.state(b) for b in range(B)]
+            res[mode] = [f.state(b) for b in range(B)]
             assert [f.flags(b) for b in range(B)] == [0] * B
             assert lib.ekf_debug_last_pass_shares(f._h) >= 1
-            assert (lookaheads(sd, f) >= 4) if la else (lookaheads(sd, f) == 0)
-    for b in range(B):
-        assert orc.rel_fro(res[1][b][0], res[0][b][0]) < PATH_TOL and orc.rel_fro(res[1][b][1], res[0][b][1]) < PATH_TOL
+            assert (lookaheads(sd, f) >= 4) if mode != "plain" else (lookaheads(sd, f) == 0)
+            assert chained(sd, f) == (lookaheads(sd, f) if mode == "chain" else 0)
     cfg = orc.EkfConfig()
     s = streams[1]
     om, oP = s[0].copy(), starts[1].copy()
     for k in range(steps):
         om, oP = orc.ekf_step_dense(om, oP, s[2][k], s[3][k], s[4][k], s[5][k], s[6][k], cfg)
-    assert orc.rel_fro(res[1][1][0], om) < TIGHT and orc.rel_fro(res[1][1][1], oP) < TIGHT
+    for mode in ("chain", "lookahead"):
+        for b in range(B):
+            assert orc.rel_fro(res[mode][b][0], res["plain"][b][0]) < PATH_TOL, mode
+            assert orc.rel_fro(res[mode][b][1], res["plain"][b][1]) < PATH_TOL, mode
+        assert orc.rel_fro(res[mode][1][0], om) < TIGHT and orc.rel_fro(res[mode][1][1], oP) < TIGHT, mode
 
 
 def test_stream_run_in_pieces_with_flushes_and_downloads_in_between(sd):
