@@ -32,7 +32,9 @@ The JSON line also carries
   obs_5, obs_12, variable_m, constant_m4   the shapes the reference's loop produces (src/replay_no_ros.py:280-301, :436): landmark
                 counts that are no power of two, and m ~ uniform{0..8} per trajectory and step at scattered indices (beside a
                 constant m = 4, the same mean): steps/s, landmark updates/s, passes per step, fused fraction
-  sclk_mhz      shader clock sampled during the headline's timed region
+  sclk_mhz      shader clock sampled during the headline's timed region where that is at least 50 ms (else null), and
+                `sclk_mhz_steady_state` over the steady_state leg
+  single_trajectory.cadence_us   where a single trajectory's cadence goes: period, the launches' own durations, bubbles
   `--leg NAME` runs one secondary leg alone and prints it.
   (rank 0, N = 1 only, except sclk_mhz and rank_dt_ms).
 """
@@ -122,6 +124,10 @@ def time_filter(sd, sd_syn, shard, grp, device, traj_ids, n_landmarks, m, steps,
         f.profile_enable(False)
     time_filter.last_pass_kernel = f.last_pass()
     cad1 = f.cadence_counters()
+    try:
+        time_filter.last_chained = int(sd.load_library().ekf_debug_chained(f._h))
+    except Exception:
+        time_filter.last_chained = None
     # which path the timed steps took: (fused cadences, steps they covered), and the landmark updates they held
     time_filter.last_cadences = (cad1[0] - cad0[0], cad1[1] - cad0[1])
     time_filter.last_updates = int(mm[warmup:].sum()) if mm is not None else len(traj_ids) * steps * m
@@ -218,7 +224,7 @@ class ClockSampler:
             return None
         a = np.array(self.samples)
         return {"min": float(a.min()), "mean": float(a.mean()), "max": float(a.max()), "samples": int(a.size),
-                "source": "rsmi_dev_gpu_clk_freq_get(RSMI_CLK_TYPE_SYS) sampled during the headline's timed region"}
+                "source": "rsmi_dev_gpu_clk_freq_get(RSMI_CLK_TYPE_SYS) sampled from a host thread during the timed region"}
 
 
 def pmc_traffic(key, options):
@@ -382,7 +388,7 @@ def online_step_leg(sd, sd_syn, device, n_landmarks, batch, m, steps, warmup, op
                     "16-slot input ring for the device)"}
 
 
-def drop_in_leg(sd, sd_syn, n_landmarks, m, calls, warm):
+def drop_in_leg(sd, sd_syn, n_landmarks, m, calls, warm, trust_identity=False):
     """`EKF_pose_estimation(ang, lin, mean, cov, dt, detections, TAG_INDEX)` exactly as the reference's loop calls it
     (src/replay_no_ros.py:229-237: the returned mean / covariance are passed back in): host association, the step on the
     GPU, and the download of the n x n covariance EVERY call (8 n^2 bytes over PCIe) -- what a user who changes nothing
@@ -393,17 +399,23 @@ def drop_in_leg(sd, sd_syn, n_landmarks, m, calls, warm):
     mean, cov = mean0.copy(), np.diag(diag0)
     eye = np.eye(3)
     times = []
-    for k in range(warm + calls):
-        xr, yr = zr[k] * np.cos(zb[k]), zr[k] * np.sin(zb[k])
-        tags = [SimpleNamespace(tag_id=1000 + int(i), pose_R=eye, pose_t=np.array([[-y], [0.0], [x]]), pose_err=0.0)
-                for i, x, y in zip(idx[k], xr, yr)]
-        t0 = time.perf_counter()
-        mean, cov, _tags = sd.EKF_pose_estimation(ang[k], lin[k], mean, cov, 0.7, [(float(k), tags)], tag_index)
-        if k >= warm:
-            times.append(time.perf_counter() - t0)
+    from slam_duckietown_amd import ekf_bindings as eb
+    eb.DROP_IN_TRUST_IDENTITY = bool(trust_identity)
+    try:
+        for k in range(warm + calls):
+            xr, yr = zr[k] * np.cos(zb[k]), zr[k] * np.sin(zb[k])
+            tags = [SimpleNamespace(tag_id=1000 + int(i), pose_R=eye, pose_t=np.array([[-y], [0.0], [x]]), pose_err=0.0)
+                    for i, x, y in zip(idx[k], xr, yr)]
+            t0 = time.perf_counter()
+            mean, cov, _tags = sd.EKF_pose_estimation(ang[k], lin[k], mean, cov, 0.7, [(float(k), tags)], tag_index)
+            if k >= warm:
+                times.append(time.perf_counter() - t0)
+    finally:
+        eb.DROP_IN_TRUST_IDENTITY = False
     assert np.isfinite(mean).all() and np.isfinite(cov).all() and len(mean) == 3 + 2 * n_landmarks
     med = float(np.median(times))
-    return {"workload": f"EKF_pose_estimation per call incl. the covariance download, N={n_landmarks}, m={m}, {calls} calls",
+    return {"workload": f"EKF_pose_estimation per call incl. the covariance download, N={n_landmarks}, m={m}, {calls} calls"
+                        + (", DROP_IN_TRUST_IDENTITY (no upload of the arrays the previous call returned)" if trust_identity else ""),
             "ms_per_call": med * 1e3, "value": 1.0 / med, "unit": "steps/s", "download_bytes_per_call": 8 * len(mean) ** 2}
 
 
@@ -477,6 +489,37 @@ def cpu_baseline(n_landmarks, m, budget_s=14.0):
             "by_config": by}
 
 
+def cadence_breakdown(sd, sd_syn, device, n_landmarks, m, options, steps=100, warmup=20):
+    """Per-kernel device time of a fused cadence from HIP event pairs around EVERY launch ("profile_kernels": a diagnostic
+    run of its own -- each record costs its stream ~6 us, so this run is slower than the timed one; the durations are what
+    it is for).  -> us per launch: solve, chain (or look-ahead gather), panel, pass."""
+    n = 3 + 2 * n_landmarks
+    streams, lin, ang, idx, zr, zb, mm = make_streams(sd_syn, [0], n_landmarks, warmup + steps, m)
+    f = sd.EkfSlam(n, batch=1, device=device)
+    for opt in options:
+        name, value = opt.split("=")
+        f.set_option(name, int(value))
+    f.set_state_diag(streams[0][0], streams[0][1], 0)
+    f.stream_upload(lin, ang, idx, zr, zb, mm)
+    f.stream_run(0, warmup)
+    f.flush()
+    f.set_option("profile_kernels", 1)
+    f.set_option("profile_stride", 1)
+    f.profile_enable(True)
+    f.stream_run(warmup, steps)
+    f.flush()
+    f.sync()
+    out = {}
+    for key, cls in (("solve", 1), ("chain_or_gather", 2), ("panel", 3)):
+        ms, cnt = f.profile_read_class(cls)
+        out[key] = ms / max(cnt, 1) * 1e3
+    ms, cnt = f.profile_read()
+    out["pass"] = ms / max(cnt, 1) * 1e3
+    f.profile_enable(False)
+    f.close()
+    return out
+
+
 SECONDARY_LEGS = ["single_trajectory", "obs_1_per_step", "obs_5", "obs_12", "variable_m", "constant_m4", "config5", "steady_state", "config1", "config2", "online_step",
                   "drop_in", "dense_propagate"]
 
@@ -497,9 +540,32 @@ def secondary_leg(name, args):
         dt1, p1, l1, _ = time_filter(sd, sd_syn, shard, grp, dev, [0], args.landmarks, args.obs, steps1, warm1,
                                      options=args.option)
         a1 = 16.0 * tri / ((p1 / max(l1, 1)) * 1e-3) / 1e9 if p1 > 0 else 0.0
-        return {name: {"workload": f"N={args.landmarks}, m={args.obs}, 1 trajectory (BASELINE config 3), {steps1} steps",
-                       "value": steps1 / dt1, "unit": "steps/s", "pass_avg_launch_ms": p1 / max(l1, 1), "pass_launches": l1,
-                       "pass_achieved_GBs": a1, "pass_frac_of_hbm_peak": a1 / HBM_PEAK_GBS}}
+        leg = {"workload": f"N={args.landmarks}, m={args.obs}, 1 trajectory (BASELINE config 3), {steps1} steps",
+               "value": steps1 / dt1, "unit": "steps/s", "pass_avg_launch_ms": p1 / max(l1, 1), "pass_launches": l1,
+               "pass_launches_timed": getattr(time_filter, "last_timed", 0),
+               "pass_achieved_GBs": a1, "pass_frac_of_hbm_peak": a1 / HBM_PEAK_GBS,
+               "chained_solves": getattr(time_filter, "last_chained", None)}
+        # where a cadence's time goes: the period from the timed run above, the launches' own durations from an instrumented
+        # run (event pairs around every launch).  Chained: the handle's stream runs solve + chain, the second stream panel +
+        # pass, side by side; look-ahead ("chain=0"): panel -> gather -> { solve | pass }
+        try:
+            br = cadence_breakdown(sd, sd_syn, dev, args.landmarks, args.obs, args.option)
+            period = dt1 / steps1 * (40.0 / max(args.obs, 1)) * 1e6
+            main_busy, second_busy = br["solve"] + br["chain_or_gather"], br["panel"] + br["pass"]
+            chained_run = bool(leg["chained_solves"])
+            critical = max(main_busy, second_busy) if chained_run else br["panel"] + br["chain_or_gather"] + max(br["solve"], br["pass"])
+            leg["cadence_us"] = {"period": period, **br, "stream_busy": main_busy, "second_stream_busy": second_busy,
+                                 "critical_path": critical, "bubbles": period - critical,
+                                 "note": "period: the timed run; kernel durations: HIP event pairs around every launch in an "
+                                         "instrumented run of its own (option profile_kernels; every record costs its stream "
+                                         "~6 us, and in a chained run a launch's duration includes what it waits for on the "
+                                         "device-side counters: the panel launch its solve and the next chain launch's "
+                                         "gathers, the chain launch the previous pass); critical_path: the busier stream when "
+                                         "the solves are chained, else panel + gather + max(solve, pass); the un-instrumented "
+                                         "timeline is profiles/r06_chained_solves.txt"}
+        except Exception as e:                          # (a measurement aid: never fails the line)
+            leg["cadence_us"] = {"error": str(e)}
+        return {name: leg}
     if name == "obs_1_per_step":
         # one observation per step: 2 ranks per step, a covariance pass every 40 steps -- timed over whole
         # cadences only (a shorter run would charge a full pass to a fraction of the steps it serves)
@@ -530,13 +596,19 @@ def secondary_leg(name, args):
         # timed region behind a full sweep: what a long-running filter sees.
         sweep = -(-args.landmarks // max(args.obs, 1)) + 10
         steps = max(args.steps, 100)
+        clk = ClockSampler(dev, period_s=0.001)
         dts, ps, ls, _ = time_filter(sd, sd_syn, shard, grp, dev, traj_ids, args.landmarks, args.obs, steps, sweep,
-                                     options=args.option)
+                                     options=args.option, clock=clk)
         avg = ps / max(ls, 1)
+        per_launch_s = dts / steps * (steps / max(ls, 1))           # the whole cadence: solve + panel launch + pass + gaps
         return {name: {"workload": f"the headline workload timed behind a full sweep of the landmarks ({sweep} warm-up steps: "
                                    f"dense covariance), {steps} steps",
                        "value": B * steps / dts, "unit": "steps/s", "pass_avg_launch_ms": avg, "pass_launches": ls,
-                       "pass_frac_of_hbm_peak": (B * 16.0 * tri / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS) if avg > 0 else 0.0}}
+                       "pass_launches_timed": getattr(time_filter, "last_timed", 0),
+                       "pass_frac_of_hbm_peak": (B * 16.0 * tri / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS) if avg > 0 else 0.0,
+                       "whole_cadence_frac": (B * 16.0 * tri / per_launch_s / 1e9 / HBM_PEAK_GBS) if ls > 0 else 0.0,
+                       # the shader clock over this leg's timed region (tens of ms: enough samples to mean something)
+                       "sclk_mhz": clk.summary() if dts >= 0.015 else None}}
     if name == "config1":
         # N = 20 fits a CU's LDS: the small-state path (csrc/ekf_small.hip) runs the whole stream as ONE launch, P resident in LDS;
         # a bank of such filters (a Monte-Carlo run at the reference's map size) is one workgroup per trajectory
@@ -559,7 +631,9 @@ def secondary_leg(name, args):
     if name == "drop_in":
         return {name: {"N12": drop_in_leg(sd, sd_syn, 12, 3, 200, 10), "N20": drop_in_leg(sd, sd_syn, 20, args.obs, 200, 10),
                        "N500": drop_in_leg(sd, sd_syn, 500, args.obs, 40, 5),
-                       f"N{args.landmarks}": drop_in_leg(sd, sd_syn, args.landmarks, args.obs, 12, 3)}}
+                       f"N{args.landmarks}": drop_in_leg(sd, sd_syn, args.landmarks, args.obs, 12, 3),
+                       # the same with the opt-in residency for large states (ekf_bindings.DROP_IN_TRUST_IDENTITY)
+                       f"N{args.landmarks}_trusted": drop_in_leg(sd, sd_syn, args.landmarks, args.obs, 12, 3, trust_identity=True)}}
     if name == "dense_propagate":
         return {name: dense_propagate_leg(sd, dev, args.landmarks)}
     raise SystemExit(f"unknown leg {name}")
@@ -674,8 +748,10 @@ def main():
             # (HIP events on the handle's stream): host dispatch skew and device time can be told apart from one line
             "rank_dt_ms": [x * 1e3 for x in rank_dts],
             "rank_device_ms_per_step": list(rank_dev_ms),
-            # the shader clock while the timed region ran (sampled every 2 ms from a host thread)
-            "sclk_mhz": clk.summary(),
+            # the shader clock while the timed region ran (sampled every 2 ms from a host thread) -- only where the region is
+            # long enough for the samples to see it (>= 50 ms; the driver's 20 steps are 3.6 ms: two samples of the idle clock);
+            # `sclk_mhz_steady_state` is the same over the steady_state leg
+            "sclk_mhz": clk.summary() if dt >= 0.05 else None,
         }
         if os.environ.get("EKFSLAM_HIP_VARIANT"):      # a diagnostic build of the library was timed: not a product number
             out["library_variant"] = os.environ["EKFSLAM_HIP_VARIANT"]
@@ -696,7 +772,9 @@ def main():
                 out["roofline"]["avg_launch_ms_steady_state"] = ss["pass_avg_launch_ms"]
                 out["roofline"]["frac_steady_state"] = ss["pass_frac_of_hbm_peak"]
                 out["roofline"]["achieved_steady_state"] = ss["pass_frac_of_hbm_peak"] * HBM_PEAK_GBS
+                out["roofline"]["whole_cadence_frac_steady_state"] = ss.get("whole_cadence_frac")
                 out["value_steady_state"] = ss["value"]
+                out["sclk_mhz_steady_state"] = ss.get("sclk_mhz")
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.landmarks, args.obs)
     if rank == 0:

@@ -141,7 +141,13 @@ int ekf_upload_tag_index(ekf_handle *h, int b, const int *tag_of_index, int n_la
  * cadences ("fused_cadence"): per covariance pass every trajectory's next 40 landmark updates, whatever steps they belong to --
  * inside the call the trajectories of a bank advance through the range at their own pace (they are independent filters); when
  * the call returns every one of them has been enqueued up to first+count;
- * ekf_run_stream = upload + run all. */
+ * ekf_run_stream = upload + run all.
+ * Driving a stream in SHORT pieces: a cadence only forms where nothing is pending, and a call's last cadence leaves its ranks
+ * pending unless its 40 slots are used up (right for one long run, and for online steps behind it) -- the next call then runs the
+ * per-step kernels until the pass is due, so the "40 landmark updates per pass" only hold for long calls.  With
+ * ekf_set_option("run_end_flush", 1) every call ends with the covariance pass of what it left pending and every piece runs
+ * fused (one pass per call: worth it from ~40 landmark updates per call).  The plan of a call's cadences is made and uploaded
+ * per call (32 B per cadence and trajectory). */
 int ekf_stream_upload(ekf_handle *h, int steps, const double *lin, const double *ang, const int *idx,
                       const double *range, const double *bearing, const int *m, int stride);
 int ekf_stream_run(ekf_handle *h, int first, int count);
@@ -206,7 +212,7 @@ int ekf_profile_read_class(ekf_handle *h, int cls, double *ms_total, long long *
  * behind the state it wrote to pinned memory, 0 = it waits for the stream; same results.  The polled hand-over assumes that
  * the kernel's posted writes to coherent pinned memory become visible in fence -> release order -- validated on MI355X;
  * every hand-over carries a second copy of its sequence number written by another wave, compared before the data is
- * trusted, and "fetch_verify" = 1 also compares an XOR checksum of the whole payload; a mismatch waits for the stream
+ * trusted, and "fetch_verify" = 1 (the default since round 6; ~1 us per call) also compares an XOR checksum of the whole payload -- a platform that reorders posted writes could deliver the trailer before other payload lines --; a mismatch waits for the stream
  * instead and is counted, ekf_debug_fetch_retries), "pack_dense" (downloads of a whole
  * state into PINNED host memory, e.g. from ekf_host_alloc: 1 = up to 40 MB a kernel mirrors the stored triangle straight into
  * the destination, no mirror pass and no copy engine; 2 = at every size; 0 = never: mirror pass + rectangle copy; same bytes);
@@ -241,7 +247,8 @@ long ekf_debug_dense_packs(ekf_handle *h);
 long ekf_debug_fetch_retries(ekf_handle *h);
 /* Raw device views behind a stream synchronisation, no flush: the fused cadence's record of trajectory b (returns its
  * size; copies min(bytes, size)); `which` = 0 P_base (allocated doubles), 1 V, 2 W, 3 the mean buffer the next step reads,
- * 4 the other mean buffer (dst == NULL: the count); the words behind the row-slab pass's queue heads
+ * 4 the other mean buffer, 5 (chained runs, every trajectory: b is ignored) the mean at the positions of the last chained
+ * cadence, 128 doubles per trajectory (dst == NULL: the count); the words behind the row-slab pass's queue heads
  * (where a -DRS_STAMPS build leaves its time stamps). */
 long ekf_debug_cad(ekf_handle *h, int b, void *dst, long bytes);
 long ekf_debug_snapshot(ekf_handle *h, int b, int which, double *dst, long count);

@@ -167,6 +167,7 @@ struct ekf_handle : ekf::HostPlan {
   bool chain_run = false;         // the run in flight records the transforms (every solve is k_solve_cad<true>)
   bool aux_pass = false;          // a covariance pass is in flight on the second stream (ev_pass recorded behind it)
   int opt_chain = 1;
+  int opt_run_end_flush = 0;      // 1 = ekf_stream_run applies what its last cadence left pending, so that the next call starts fused
   long chained = 0;               // statistics: cadences whose block came from k_chain_cad
   // The mirrored column entries of a cadence's panel launch, gathered by extra workgroups of its solve launch and laid down
   // as rows (batch x 83 x ld doubles, allocated on first use; not for banks where that would exceed 1 GiB).  `colbuf_live`:
@@ -199,7 +200,7 @@ struct ekf_handle : ekf::HostPlan {
   bool fetched = false;
   unsigned long long fetch_seq = 0;   // ... and the sequence number that launch releases behind it (polled by the host)
   int opt_fetch_spin = 1;
-  int opt_fetch_verify = 0;       // 1 = ekf_step_fetch also checks the payload's XOR checksum before it trusts a polled hand-over
+  int opt_fetch_verify = 1;       // 1 (default) = ekf_step_fetch checks the payload's XOR checksum before it trusts a polled hand-over (~1 us of the 10 - 15 us the polling saves); 0 = the trailer's second sequence number only
   long fetch_retries = 0;         // statistics: hand-overs whose integrity trailer did not match (answered after a stream sync)
   int opt_zero_copy_inputs = 1;   // small-state online steps read their records from the pinned ring (no staged copy)
   int last_kernel = -1, last_nkt = 0, last_streaming = 0;   // what the last covariance pass launched
@@ -1542,6 +1543,12 @@ extern "C" int ekf_stream_run(ekf_handle* h, int first, int count) {
   if (count > 0)
     for (int b = 0; b < h->batch; ++b)
       h->neff[b] = std::max(h->neff[b], std::min(h->n[b], h->stream_own[(size_t)(first + count - 1) * h->batch + b]));
+  // A cadence only forms where nothing is pending (its panel is gathered from P_base alone).  A run's last cadence leaves its
+  // ranks pending unless its slots are used up -- right for one long run and for online steps behind it, but a caller that
+  // drives the stream in SHORT pieces would alternate between one short cadence and the per-step kernels: "run_end_flush" = 1
+  // applies them here (one covariance pass per call) and every piece runs fused.
+  if (h->opt_run_end_flush && h->opt_fused_cadence)
+    if (int rc = flush_pending(h)) return rc;
   return EKF_OK;
 }
 
@@ -1850,6 +1857,11 @@ extern "C" int ekf_set_option(ekf_handle* h, const char* name, int value) {
   if (std::strcmp(name, "lookahead") == 0) {
     if (value != 0 && value != 1) return fail(h, EKF_ERR_ARG, "lookahead must be 0 or 1");
     h->opt_lookahead = value;
+    return EKF_OK;
+  }
+  if (std::strcmp(name, "run_end_flush") == 0) {
+    if (value != 0 && value != 1) return fail(h, EKF_ERR_ARG, "run_end_flush must be 0 or 1");
+    h->opt_run_end_flush = value;
     return EKF_OK;
   }
   if (std::strcmp(name, "profile_kernels") == 0) {

@@ -58,7 +58,10 @@ __device__ __forceinline__ double wrap_pi(double a) {
 }
 
 // 1 / x from the hardware estimate (v_rcp_f64: ~1e-8 relative... in fact 2^-26) and two Newton steps -- each squares the error:
-// <= 1 ulp for finite non-zero x, inf / NaN / 0 behave like the IEEE division (1/0 = inf, 1/inf = 0, NaN through).  The IEEE
+// <= 1 ulp for finite NORMAL x whose reciprocal is normal too; inf / NaN / 0 behave like the IEEE division (1/0 = inf,
+// 1/inf = 0, NaN through).  Where the estimate itself is not finite or zero -- x subnormal (v_rcp_f64 gives inf there), 0 or
+// inf -- or x is so large that 1/x is subnormal, the Newton terms would turn the estimate into NaN / lose its bits: those take
+// the IEEE division (a branch that is never taken on the solve's chain: S = H P H^T + Q with Q = meas_sigma^2 > 0).  The IEEE
 // division behind `1.0 / x` is a v_div_scale / v_div_fmas / v_div_fixup sequence of ~250 dependent cycles on the solve's chain.
 __device__ __forceinline__ double fast_recip(double x) {
   double r = __builtin_amdgcn_rcp(x);
@@ -66,8 +69,10 @@ __device__ __forceinline__ double fast_recip(double x) {
   const double r1 = fma(r, e0, r);
   const double e1 = fma(-x, r1, 1.0);
   const double r2 = fma(r1, e1, r1);
-  // (x = 0 or inf: the estimate is already exact -- inf or 0 -- and the Newton terms would make NaN of it)
-  return (x == 0.0 || fabs(x) == __builtin_inf()) ? r : r2;
+  const double ax = fabs(x);
+  // (2.2250738585072014e-308 = DBL_MIN; 1 / x is normal for |x| <= 2^1022)
+  if (!(ax >= 2.2250738585072014e-308 && ax <= 4.49423283715578976932e307)) return 1.0 / x;
+  return r2;
 }
 
 // Innovation and 2x5 Jacobian of one range/bearing observation (src/replay_no_ros.py:443-469), in two parts: the

@@ -2024,13 +2024,8 @@ __global__ __launch_bounds__(512, 2) void k_flush_rs(double* __restrict__ P, con
       constexpr int NE = FIRST ? 0 : 4, NV = STAGE ? 1 : 0;
       // (the loads of tile t+2 go out right behind the image write of tile t+1 -- their registers are free from there --
       //  not at the end of the tile: worth ~1 % of the pass, profiles/r04_pass_layout.txt)
-#ifdef RS_LATE_N3                                        /* diagnostic build: round 3's order, the loads of tile t+2 last */
-      constexpr int OVA = 0, OW0 = OVA + NV, OE1A = OW0 + NE, OE2A = OE1A + NE, OE1B = OE2A + NE, OE2B = OE1B + NE,
-                    OVB = OE2B + NE, ON1 = OVB + NV, ON2 = ON1 + 8, OWB = ON2 + 16, ON3 = OWB + NV, NSIDE = ON3 + 8;
-#else
       constexpr int OVA = 0, OW0 = OVA + NV, OE1A = OW0 + NE, OE2A = OE1A + NE, OE1B = OE2A + NE, OE2B = OE1B + NE,
                     OC = OE2B + NE, OVB = OC, ON1 = OVB + NV, ON3 = ON1 + 8, ON2 = ON3 + 8, OWB = ON2 + 16, NSIDE = OWB + NV;
-#endif
       const __amdgpu_buffer_rsrc_t rsP = rs_rsrc(Pb);
       const unsigned off_prev = tile_off(t - 1);       // tile t-1 (FIRST: unused)
 #ifdef RS_SKIP_PMEM

@@ -105,6 +105,63 @@ def test_drop_in_beyond_the_small_records_uploads_and_recycles_buffers(sd):
     close(P2, ocov)
 
 
+def test_drop_in_trust_identity_is_opt_in_for_large_states(sd):
+    """`DROP_IN_TRUST_IDENTITY`: beyond 131 x 131 the default uploads every call -- an in-place edit of
+    the returned covariance is seen, like the reference (src/replay_no_ros.py:229-237 passes the arrays straight back) --; with
+    the switch on, a call that gets the very objects the previous call returned skips the upload: unedited arrays give the
+    oracle's results with no upload at all, an in-place edit is (documentedly) NOT seen, and FRESH arrays are still uploaded."""
+    from slam_duckietown_amd import ekf_bindings as eb
+    N, m, calls = 80, 6, 8
+    mean0, diag0, lin, ang, idx, zr, zb = orc.synthetic_stream(N, calls, m, 9)
+    ocfg = orc.EkfConfig()
+
+    def dets(k):
+        xr, yr = zr[k] * np.cos(zb[k]), zr[k] * np.sin(zb[k])
+        return [(float(k), [NS(tag_id=1000 + int(i), pose_R=np.eye(3), pose_t=np.array([[-y], [0.0], [x]]), pose_err=0.0)
+                            for i, x, y in zip(idx[k], xr, yr)])]
+
+    uploads = []
+    real_set_state = eb.EkfSlam.set_state
+
+    def counting_set_state(self, *a, **kw):
+        uploads.append(1)
+        return real_set_state(self, *a, **kw)
+
+    eb.EkfSlam.set_state = counting_set_state
+    try:
+        for trusted in (False, True):
+            eb.DROP_IN_TRUST_IDENTITY = trusted
+            ti, oti = {1000 + i: i for i in range(N)}, {1000 + i: i for i in range(N)}
+            mean, cov = mean0.copy(), np.diag(diag0)
+            omean, ocov = mean0.copy(), np.diag(diag0)
+            del uploads[:]
+            for k in range(calls):
+                mean, cov, _ = eb.EKF_pose_estimation(ang[k], lin[k], mean, cov, 0.7, dets(k), ti)
+                omean, ocov, _ = orc.ekf_pose_estimation_dense(ang[k], lin[k], omean, ocov, 0.7, dets(k), oti, ocfg)
+                close(mean, omean)
+                close(cov, ocov)
+            assert len(uploads) == (1 if trusted else calls)        # (the first call's arrays are the caller's own)
+            # an in-place edit far from the pose block, then one more call
+            k = 0
+            cov[-1, -1] *= 1.5
+            seen_cov = ocov.copy()
+            seen_cov[-1, -1] *= 1.5
+            m2, c2, _ = eb.EKF_pose_estimation(ang[k], lin[k], mean, cov, 0.7, dets(k), ti)
+            want_seen = orc.ekf_pose_estimation_dense(ang[k], lin[k], omean, seen_cov, 0.7, dets(k), dict(oti), ocfg)
+            want_unseen = orc.ekf_pose_estimation_dense(ang[k], lin[k], omean, ocov, 0.7, dets(k), dict(oti), ocfg)
+            close(c2, want_unseen[1] if trusted else want_seen[1])
+            assert orc.rel_fro(c2, (want_seen if trusted else want_unseen)[1]) > 1e-6      # the two really differ
+            # fresh arrays (copies) are uploaded whatever the switch says
+            n_up = len(uploads)
+            m3, c3, _ = eb.EKF_pose_estimation(ang[1], lin[1], np.array(m2), np.array(c2), 0.7, dets(1), ti)
+            assert len(uploads) == n_up + 1
+            w3 = orc.ekf_pose_estimation_dense(ang[1], lin[1], m2, c2, 0.7, dets(1), dict(oti), ocfg)
+            close(c3, w3[1])
+    finally:
+        eb.EkfSlam.set_state = real_set_state
+        eb.DROP_IN_TRUST_IDENTITY = False
+
+
 def test_uploaded_stream_follows_later_state_changes(sd):
     """ekf_stream_upload bakes the active bound that follows from the stream's own observations; a dense upload, a
     second run of the same stream or a toggled option between upload and run must still give the dense reference

@@ -103,6 +103,59 @@ def test_config4_shard_n2000_x32_default_cadence(sd):
                 assert np.array_equal(mu, got[b % K][0]) and np.array_equal(P, got[b % K][1])
 
 
+def _oracle_stream(args):
+    """(worker process) one trajectory's stream through the O(n^2) oracle from a block-diagonal start."""
+    N, steps, m, tid = args
+    s = orc.synthetic_stream(N, steps, m, tid)
+    cfg = orc.EkfConfig()
+    om, oP = s[0].copy(), np.diag(s[1])
+    for k in range(steps):
+        om, oP = orc.ekf_step_structured(om, oP, s[2][k], s[3][k], s[4][k], s[5][k], s[6][k], cfg)
+    return om, oP
+
+
+def test_steady_state_leg_n2000_x32_as_benchmarked(sd):
+    """The regime bench.py's `steady_state` leg (and `value_steady_state` / `roofline.frac_steady_state`) times: the headline
+    workload -- N = 2000, m = 8, 32 trajectories, the library's defaults, block-diagonal start -- BEHIND a full sweep of the
+    landmarks, where every landmark has been observed, the covariance is dense and V / W carry no exact zeros.  270 steps =
+    the sweep (250) + four more cadences, as one uploaded stream; trajectories 0 and 1 (two different streams) against
+    `oracle.ekf_step_structured` over all 270 steps (two worker processes: ~0.2 s per step each), trajectory b > 1 -- a
+    replica of trajectory b % 2 elsewhere in the launches -- bit for bit against it; the path asserted: 54 fused cadences
+    covering every step, the last full pass `k_flush_rs<20, true, false>` on the work queues.
+    Reference: src/replay_no_ros.py:368-480 (the step), :476-480 (mean and covariance update)."""
+    import concurrent.futures as cf
+    import slam_duckietown_amd.synthetic as syn
+    N, steps, m, B, K = 2000, 270, 8, 32, 2
+    n = 3 + 2 * N
+    with cf.ProcessPoolExecutor(max_workers=K) as pool:
+        futures = [pool.submit(_oracle_stream, (N, steps, m, t)) for t in range(K)]   # (run beside the GPU part below)
+        streams = [syn.synthetic_stream(N, steps, m, t) for t in range(K)]
+        pick = [streams[b % K] for b in range(B)]
+        with sd.EkfSlam(n, batch=B) as f:
+            for b in range(B):
+                f.set_state_diag(pick[b][0], pick[b][1], b)
+            f.run_stream(*[np.stack([s[i] for s in pick], 1) for i in (2, 3, 4, 5, 6)])
+            cad, covered, _, shares = debug_counters(sd, f)
+            assert (cad, covered) == (steps * m // 40, steps)                # 54 cadences of 5 steps
+            f.flush()
+            assert f.last_pass() == "ekf::k_flush_rs<20, true, false>" and shares == 0
+            got = {}
+            for b in (0, 1, 2, 3, 16, 31):
+                mu, P = f.state(b)
+                assert f.flags(b) == 0 and np.array_equal(P, P.T)
+                if b < K:
+                    got[b] = (mu, P)
+                else:
+                    assert np.array_equal(mu, got[b % K][0]) and np.array_equal(P, got[b % K][1])
+        # dense behind the sweep: every landmark is correlated with the pose and with its neighbours
+        assert np.count_nonzero(got[0][1][3:, 0]) == n - 3
+        for t in range(K):
+            om, oP = futures[t].result()
+            close(got[t][0], om)
+            close(got[t][1], oP)
+            close(got[t][1].sum(axis=1), oP.sum(axis=1))
+
+
 def test_variable_m_leg_n2000_x32_as_benchmarked(sd):
     """bench.py's `variable_m` leg at its own size and options (N = 2000, 32 trajectories, m ~ U{0..8} per trajectory and step at
     scattered indices, active bound off): packed cadences with every trajectory on its own cursor, the column gather beside

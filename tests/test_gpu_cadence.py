@@ -436,6 +436,35 @@ def test_stream_run_in_pieces_with_flushes_and_downloads_in_between(sd):
     assert orc.rel_fro(mu, whole[0][0]) < PATH_TOL and orc.rel_fro(P, whole[0][1]) < PATH_TOL
 
 
+def test_short_pieces_with_run_end_flush_all_run_fused(sd):
+    """a caller that drives `stream_run` in short pieces.  By default a piece's last cadence leaves its ranks
+    pending, and the next piece runs the per-step kernels until the pass is due; with `run_end_flush` = 1 every piece ends with
+    its covariance pass and EVERY step of every piece runs as a fused cadence -- counted -- with the whole stream's result
+    to rounding either way."""
+    N, B, m, steps = 150, 2, 3, 36
+    n = 3 + 2 * N
+    streams = [orc.synthetic_stream(N, steps, m, 8800 + t) for t in range(B)]
+    starts = [dense_start(n, 8900 + t) for t in range(B)]
+    args = (stack(streams, 2), stack(streams, 3), stack(streams, 4), stack(streams, 5), stack(streams, 6))
+    whole, _ = run_stream(sd, n, B, starts, [s[0] for s in streams], *args, options=[("active_bound", 0)])
+    covered = {}
+    for ref in (0, 1):
+        with sd.EkfSlam(n, batch=B) as f:
+            f.set_option("active_bound", 0)
+            f.set_option("small_state", 0)
+            f.set_option("run_end_flush", ref)
+            for b in range(B):
+                f.set_state(streams[b][0], starts[b], b)
+            f.stream_upload(*args)
+            for k in range(0, steps, 4):                  # 12 landmark updates per piece
+                f.stream_run(k, 4)
+            out = [f.state(b) for b in range(B)]
+            covered[ref] = cadences(sd, f)[1]
+        for b in range(B):
+            assert orc.rel_fro(out[b][0], whole[b][0]) < PATH_TOL and orc.rel_fro(out[b][1], whole[b][1]) < PATH_TOL
+    assert covered[1] == steps and covered[0] < steps
+
+
 def test_slot_size_changes_along_the_stream(sd):
     """The number of observations per step wanders (runs of 8, 3, 1, 16, 8, 2, 5 landmarks; the second trajectory anything
     up to that): until round 4 a cadence only took steps of one rank-slot size and the stream alternated between fused
