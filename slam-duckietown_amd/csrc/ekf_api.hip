@@ -937,7 +937,7 @@ static bool beside_the_pass(const ekf_handle* h, const PassPlan& plan) {
   // ... or the row-slab pass on static shares that leaves the solves their CUs (a few long trajectories: N = 8000 x 1)
   // ... and for banks of up to 40 trajectories: every solve workgroup has to find a CU beside the pass, and the gather grows with
   // the bank (17 us at 32 trajectories, 71 us at 256) -- N = 500 x 32 +5 %, N = 300 x 48 -5 %, N = 200 x 128 -21 %,
-  // N = 100 x 256 -36 % with the look-ahead (tools/opt_probe.sh lookahead=0)
+  // N = 100 x 256 -36 % with the look-ahead (bench.py --option lookahead=0; round 4)
   const bool small_pass = plan.kernel == 0 && h->batch <= 40 && (double)h->batch * 8.0 * plan.e_hi * plan.e_hi >= 48.0e6;
   const bool shares_pass = plan.kernel == 2 && (plan.beside || (plan.long_few && h->batch < 8 && h->opt_pass_workgroups > 0 &&
                                                                   h->opt_pass_workgroups + h->batch <= h->cu_count));
