@@ -47,8 +47,10 @@ extern "C" {
                                  failed half way.  Recovery: upload the trajectory again (ekf_upload_state* clears the
                                  condition); ekf_set_option("fused_step", 0) selects the two-launch step, which has no wait. */
 #define EKF_FLAG_ASSOC 2u     /* device-side association dropped a detection: tag id outside [0, 1024), state full,
-                                 or more than EKF_MMAX distinct tags in one window */
-#define EKF_DMAX 64           /* detections per window for ekf_step_detections */
+                                 or more than EKF_AMAX distinct tags in one window */
+#define EKF_DMAX 256          /* detections per window for ekf_step_detections (the reference's normal mode: a 0.7 s window
+                                 of every camera frame, src/replay_no_ros.py:17 -- 21 frames x a dozen tags) */
+#define EKF_AMAX 32           /* distinct tags per window the device-side association takes (two update passes of EKF_MMAX) */
 
 typedef struct ekf_handle ekf_handle;
 
@@ -130,7 +132,7 @@ int ekf_set_association(ekf_handle *h, double gate_range, const int *ignore_tags
 int ekf_step_detections(ekf_handle *h, const double *lin, const double *ang, const int *count, const int *tag_id,
                         const double *pose_t, const double *pose_err, int stride);
 int ekf_download_tags(ekf_handle *h, int b, int *m, int *idx, int *tag_id, double *xw, double *yw, double *err,
-                      double *range, double *bearing);     /* arrays of EKF_MMAX entries */
+                      double *range, double *bearing);     /* arrays of EKF_AMAX entries */
 int ekf_download_tag_index(ekf_handle *h, int b, int *tag_of_index, int capacity, int *n_landmarks);
 int ekf_upload_tag_index(ekf_handle *h, int b, const int *tag_of_index, int n_landmarks);
 
@@ -231,6 +233,10 @@ int ekf_last_pass(ekf_handle *h, int *kernel, int *k_tiles, int *streaming);
  * interface stands behind them, they change nothing, and a production caller never needs them) --- */
 /* Fused cadences ekf_stream_run has launched so far and the steps (of the uploaded stream) they covered. */
 int ekf_debug_cadences(ekf_handle *h, long *cadences, long *steps);
+/* Host fallbacks of the device-side association: a binding whose window does not fit the device front end's limits takes the
+ * host association instead and says so with ekf_debug_note_assoc_fallback; ekf_debug_assoc_fallbacks returns the count. */
+long ekf_debug_assoc_fallbacks(ekf_handle *h);
+void ekf_debug_note_assoc_fallback(ekf_handle *h);
 /* Cadences whose solve ran beside the previous covariance pass (chained solves or look-ahead), and how many of those had
  * their block formed from the previous cadence's records (chained solves, option "chain"). */
 long ekf_debug_lookaheads(ekf_handle *h);

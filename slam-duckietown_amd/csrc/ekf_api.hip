@@ -192,6 +192,7 @@ struct ekf_handle : ekf::HostPlan {
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   double* dgbuf = nullptr;        // per trajectory: the next cadence's block, gathered while this one's ranks are pending
   long lookaheads = 0;
+  long assoc_fallbacks = 0;       // statistics: windows a binding took through the host association (ekf_debug_note_assoc_fallback)
   long small_launches = 0;        // statistics: launches of the small-state path (k_small_stream)
   long fused_fetches = 0;         // statistics: ekf_step_fetch calls answered by the step's own launch
   long dense_packs = 0;           // statistics: large downloads written by k_pack_dense (pinned destination)
@@ -1211,7 +1212,7 @@ static int assoc_init(ekf_handle* h) {
   HIP_TRY(h, hipMalloc(&h->dneff, sizeof(int) * h->batch));
   HIP_TRY(h, hipMalloc(&h->d_det, sizeof(DetIn) * h->batch * RING));
   HIP_TRY(h, hipHostMalloc(&h->h_det, sizeof(DetIn) * h->batch * RING, hipHostMallocDefault));
-  HIP_TRY(h, hipMalloc(&h->d_assoc_step, sizeof(StepIn) * h->batch));
+  HIP_TRY(h, hipMalloc(&h->d_assoc_step, sizeof(StepIn) * h->batch * 2));   // two update passes: the first 16 landmarks, the rest
   HIP_TRY(h, hipMalloc(&h->d_assoc_out, sizeof(AssocOut) * h->batch));
   HIP_TRY(h, hipMemsetAsync(h->d_assoc_out, 0, sizeof(AssocOut) * h->batch, h->stream));
   return EKF_OK;
@@ -1262,7 +1263,7 @@ extern "C" int ekf_step_detections(ekf_handle* h, const double* lin, const doubl
       for (int k = 0; k < i; ++k) seen |= (d.tag_id[k] == d.tag_id[i]);
       distinct += seen ? 0 : 1;
     }
-    m_hi = std::max(m_hi, std::min(distinct, MMAX));
+    m_hi = std::max(m_hi, std::min(distinct, AMAX));
   }
   if (!h->cfg.enable_measurement_model) m_hi = 0;
   // the host's view of the active bound must be on the device before the first device-side window
@@ -1270,7 +1271,7 @@ extern "C" int ekf_step_detections(ekf_handle* h, const double* lin, const doubl
     HIP_TRY(h, hipMemcpyAsync(h->dneff, h->neff.data(), sizeof(int) * h->batch, hipMemcpyHostToDevice, h->stream));
   HIP_TRY(h, hipMemcpyAsync(ds, hs, sizeof(DetIn) * h->batch, hipMemcpyHostToDevice, h->stream));
   if (int rc = ring_done(h, slot)) return rc;
-  const int mcap = cap_for(m_hi);
+  const int mcap = cap_for(std::min(m_hi, MMAX));
   if (((h->pending_k + ranks_for(mcap) + 3) & ~3) > KTOT)   // (what the step's kernels will write: see enqueue_pass)
     if (int rc = flush_pending(h)) return rc;
   h->acfg.active_bound = h->opt_active_bound;
@@ -1281,7 +1282,11 @@ extern "C" int ekf_step_detections(ekf_handle* h, const double* lin, const doubl
   // m_hi == 0 only when no trajectory has a detection (or the measurement model is off): then, with nothing
   // pending, the O(n) prediction-only kernel applies; any detection selects the generic path, which is also
   // right when the gate leaves nothing (its ranks are zero)
-  return enqueue_pass(h, h->d_assoc_step, m_hi);
+  // (more than EKF_MMAX distinct tags in some trajectory's window: a second pass with the rest -- an update without a
+  //  prediction; trajectories that had fewer find m = 0 there)
+  if (int rc = enqueue_pass(h, h->d_assoc_step, std::min(m_hi, MMAX))) return rc;
+  if (m_hi > MMAX) return enqueue_pass(h, h->d_assoc_step + h->batch, m_hi - MMAX);
+  return EKF_OK;
 }
 
 extern "C" int ekf_download_tags(ekf_handle* h, int b, int* m, int* idx, int* tag_id, double* xw, double* yw,
@@ -1294,7 +1299,7 @@ extern "C" int ekf_download_tags(ekf_handle* h, int b, int* m, int* idx, int* ta
   HIP_TRY(h, hipMemcpyAsync(&a, h->d_assoc_out + b, sizeof(a), hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   if (m) *m = a.m;
-  for (int i = 0; i < MMAX; ++i) {
+  for (int i = 0; i < AMAX; ++i) {
     if (idx) idx[i] = a.idx[i];
     if (tag_id) tag_id[i] = a.tag_id[i];
     if (xw) xw[i] = a.xw[i];
@@ -1733,6 +1738,9 @@ extern "C" int ekf_debug_cadences(ekf_handle* h, long* cadences, long* steps) {
 }
 // (diagnostics section of the header) how many of them had their solve run beside the previous covariance pass
 extern "C" long ekf_debug_lookaheads(ekf_handle* h) { return h ? h->lookaheads : -1; }
+// (diagnostics section of the header) host fallbacks of the device-side association, as the binding reported them
+extern "C" long ekf_debug_assoc_fallbacks(ekf_handle* h) { return h ? h->assoc_fallbacks : -1; }
+extern "C" void ekf_debug_note_assoc_fallback(ekf_handle* h) { if (h) h->assoc_fallbacks += 1; }
 // (diagnostics section of the header) ... and how many of those had their block formed by k_chain_cad (chained solves)
 extern "C" long ekf_debug_chained(ekf_handle* h) { return h ? h->chained : -1; }
 // (diagnostics section of the header) launches of the small-state path so far

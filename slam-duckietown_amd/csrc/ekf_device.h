@@ -167,7 +167,8 @@ static_assert(sizeof(CadHead) % 16 == 0, "CadHead must stay 16-byte granular");
 static_assert(sizeof(CadPlan) == 32, "CadPlan is 32 bytes");
 
 // Device-side association: one window of raw AprilTag detections per trajectory.
-constexpr int DMAX = 64;                // detections per window
+constexpr int DMAX = EKF_DMAX;          // detections per window (256)
+constexpr int AMAX = EKF_AMAX;          // distinct tags per window (32: two update passes of MMAX landmarks)
 constexpr int TAGMAX = 1024;            // tag ids [0, TAGMAX) (tag36h11 has 587)
 constexpr int IGNMAX = 16;
 
@@ -183,9 +184,9 @@ struct DetIn {                          // host -> device
 struct AssocOut {                       // what the reference returns as tags_positions (:331-337), update order
   int m;
   int n_after;
-  int idx[MMAX];
-  int tag_id[MMAX];
-  double xw[MMAX], yw[MMAX], err[MMAX], range[MMAX], bearing[MMAX];
+  int idx[AMAX];
+  int tag_id[AMAX];
+  double xw[AMAX], yw[AMAX], err[AMAX], range[AMAX], bearing[AMAX];
 };
 
 struct AssocConfig {

@@ -2232,10 +2232,16 @@ __global__ __launch_bounds__(256) void k_mirror(double* __restrict__ P, const in
 
 // ---------------------------------------------------------------------------------------------
 // k_associate: association, gate, averaging and augmentation of one window on the device
-// (src/replay_no_ros.py:280-360), one workgroup per trajectory.  Lane 0 walks the detections in
-// order (the order defines landmark indices, :294-295, and the update order, :436); the per-tag
-// arithmetic and the zeroing of new rows/columns are spread over the lanes.  Writes the StepIn the
-// solve kernel consumes, the tags_positions record, the new state size and the active bound.
+// (src/replay_no_ros.py:280-360), one workgroup (one wave) per trajectory.  The reference's dictionaries have no limits
+// (:280-301) and its normal mode hands over a 0.7 s window of every camera frame (:17: 21 frames x every tag in view), so the
+// detections are walked in chunks of 64 -- up to EKF_DMAX = 256 -- and up to EKF_AMAX = 32 distinct tags are taken (two
+// update passes of EKF_MMAX landmarks: step_out holds two records per trajectory, [0][b] with the prediction and the first
+// 16 landmarks, [1][b] the rest).  Per chunk every lane fetches ITS detection (id, the id's landmark index from the tag
+// table, IGNORE_TAGS, the gate) -- one memory round trip for 64 detections --; what depends on the ORDER of the detections
+// (landmark indices in order of first appearance, :294-295; the update order, :436) is then resolved detection by
+// detection without touching memory: the slot of a tag already seen in this window is found by all lanes at once.  The
+// per-tag arithmetic and the zeroing of new rows / columns are spread over the lanes.  Writes the StepIn records the solve
+// kernel consumes, the tags_positions record, the new state size and the active bound.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void k_associate(const DetIn* __restrict__ det, int* __restrict__ tagmap,
                                                   int* __restrict__ nact, int* __restrict__ neff_dev,
@@ -2244,7 +2250,7 @@ __global__ __launch_bounds__(64) void k_associate(const DetIn* __restrict__ det,
                                                   StepIn* __restrict__ step_out,
                                                   AssocOut* __restrict__ assoc_out,
                                                   unsigned* __restrict__ flags, AssocConfig cfg, int ld,
-                                                  long pstride, int n_max, int pending_k) {
+                                                  long pstride, int n_max, int pending_k, int batch) {
 #pragma clang fp contract(off)
   const int b = blockIdx.x, lane = threadIdx.x;
   const DetIn& d = det[b];
@@ -2253,61 +2259,93 @@ __global__ __launch_bounds__(64) void k_associate(const DetIn* __restrict__ det,
   double* Pb = P + (long)b * pstride;
   double* Vb = V + (long)b * KTOT * ld;
   double* Wb = W + (long)b * KTOT * ld;
-  __shared__ int s_m, s_nl_old, s_nl;
-  __shared__ int s_idx[MMAX], s_tag[MMAX], s_cnt[MMAX];
-  __shared__ double s_t[MMAX][3], s_err[MMAX];
-  if (lane == 0) {
-    const int n_old = nact[b];
-    int nl = (n_old - 3) / 2, m = 0;
-    unsigned bad = 0;
-    const int count = min(d.count, DMAX);
-    for (int q = 0; q < count; ++q) {
-      const int id = d.tag_id[q];
-      if (id < 0 || id >= TAGMAX) { bad |= EKF_FLAG_ASSOC; continue; }
-      bool ign = false;
-      for (int u = 0; u < cfg.n_ignore; ++u) ign |= (cfg.ignore[u] == id);       // :286
-      if (ign) continue;
-      const double tx = d.pose_t[q][0], tz = d.pose_t[q][2];
-      if (tz * tz + tx * tx > cfg.gate2) continue;                                // :289
-      int lm = tm[id];
-      int slot = -1;
-      if (lm >= 0)
-        for (int u = 0; u < m; ++u)
-          if (s_idx[u] == lm) slot = u;
+  __shared__ int s_idx[AMAX], s_tag[AMAX], s_cnt[AMAX];
+  __shared__ double s_t[AMAX][3], s_err[AMAX];
+  __shared__ int c_id[64], c_lm[64], c_ok[64];         // the chunk: tag id, its landmark index so far (-1: none), 1 = taken / 2 = bad id
+  __shared__ double c_t[64][3], c_e[64];
+  const int n_old = nact[b];
+  const int nl_old = (n_old - 3) / 2;
+  int nl = nl_old, m = 0;                              // (uniform: every lane walks the same sequence)
+  unsigned bad = 0;
+  const int count = min(d.count, DMAX);
+  if (lane < AMAX) {
+    s_idx[lane] = -1;
+    s_tag[lane] = -1;
+    s_cnt[lane] = 0;
+    s_t[lane][0] = s_t[lane][1] = s_t[lane][2] = 0.0;
+    s_err[lane] = 0.0;
+  }
+  for (int q0 = 0; q0 < count; q0 += 64) {
+    const int q = q0 + lane;
+    int id = -1, lm = -1, ok = 0;
+    double t0 = 0.0, t1 = 0.0, t2 = 0.0, er = 0.0;
+    if (q < count) {
+      id = d.tag_id[q];
+      t0 = d.pose_t[q][0];
+      t1 = d.pose_t[q][1];
+      t2 = d.pose_t[q][2];
+      er = d.pose_err[q];
+      if (id < 0 || id >= TAGMAX) ok = 2;
+      else {
+        bool ign = false;
+        for (int u = 0; u < cfg.n_ignore; ++u) ign |= (cfg.ignore[u] == id);       // :286
+        if (!ign && !(t2 * t2 + t0 * t0 > cfg.gate2)) {                            // :289
+          ok = 1;
+          lm = tm[id];
+        }
+      }
+    }
+    WAVE_LDS_SYNC();                                   // (the previous chunk's walk has read its entries)
+    c_id[lane] = id;
+    c_lm[lane] = lm;
+    c_ok[lane] = ok;
+    c_t[lane][0] = t0;
+    c_t[lane][1] = t1;
+    c_t[lane][2] = t2;
+    c_e[lane] = er;
+    WAVE_LDS_SYNC();
+    const int nq = min(64, count - q0);
+    for (int u = 0; u < nq; ++u) {                     // in order: what a detection gets depends on the ones before it
+      const int ok_u = c_ok[u];
+      if (ok_u == 2) { bad |= EKF_FLAG_ASSOC; continue; }
+      if (ok_u == 0) continue;
+      const int id_u = c_id[u];
+      const unsigned long long hit = __ballot(lane < m && s_tag[lane] == id_u);    // the tag's slot in this window, if it has one
+      int slot = hit ? __builtin_ctzll(hit) : -1;
       if (slot < 0) {
         // a detection that cannot be taken is dropped BEFORE it gets a landmark index: an index handed out here
         // with no measurement behind it would leave an uninitialised landmark in the state
-        if (m >= MMAX) { bad |= EKF_FLAG_ASSOC; continue; }
-        if (lm < 0) {                                                             // :294-295
-          if (3 + 2 * (nl + 1) > n_max) { bad |= EKF_FLAG_ASSOC; continue; }
-          lm = nl++;
-          tm[id] = lm;
+        if (m >= AMAX) { bad |= EKF_FLAG_ASSOC; continue; }
+        int lm_u = c_lm[u];                            // (from the table as it stood before this window: a tag new in this
+        if (lm_u < 0) {                                //  window has a slot from its first detection on and never comes here again)
+          if (3 + 2 * (nl + 1) > n_max) { bad |= EKF_FLAG_ASSOC; continue; }        // :294-295
+          lm_u = nl++;
+          if (lane == 0) tm[id_u] = lm_u;
         }
         slot = m++;
-        s_idx[slot] = lm;
-        s_tag[slot] = id;
-        s_cnt[slot] = 0;
-        s_t[slot][0] = s_t[slot][1] = s_t[slot][2] = 0.0;
-        s_err[slot] = 0.0;
+        if (lane == 0) {
+          s_idx[slot] = lm_u;
+          s_tag[slot] = id_u;
+        }
       }
-      s_t[slot][0] += d.pose_t[q][0];                                             // np.mean(..., axis=0): :315
-      s_t[slot][1] += d.pose_t[q][1];
-      s_t[slot][2] += tz;
-      s_err[slot] += d.pose_err[q];                                               // :317
-      s_cnt[slot] += 1;
+      if (lane == 0) {
+        s_t[slot][0] += c_t[u][0];                                                  // np.mean(..., axis=0): :315
+        s_t[slot][1] += c_t[u][1];
+        s_t[slot][2] += c_t[u][2];
+        s_err[slot] += c_e[u];                                                      // :317
+        s_cnt[slot] += 1;
+      }
+      WAVE_LDS_SYNC();                                 // (the next detection's search reads the slots)
     }
-    s_m = m;
-    s_nl_old = (n_old - 3) / 2;
-    s_nl = nl;
-    if (bad) atomicOr(&flags[b], bad);
   }
-  __syncthreads();
-  const int m = s_m, nl_old = s_nl_old, nl = s_nl;
-  const int n_old = 3 + 2 * nl_old, n_new = 3 + 2 * nl;
-  StepIn& so = step_out[b];
+  if (bad && lane == 0) atomicOr(&flags[b], bad);
+  WAVE_LDS_SYNC();
+  const int n_new = 3 + 2 * nl;
   AssocOut& ao = assoc_out[b];
   const double px = mub[0], py = mub[1], pth = mub[2];         // pose BEFORE the prediction (:331-332)
-  if (lane < MMAX) {
+  if (lane < AMAX) {
+    StepIn& so = step_out[(long)(lane / MMAX) * batch + b];
+    const int sl = lane % MMAX;
     if (lane < m) {
       const double k = (double)s_cnt[lane];
       const double t0 = s_t[lane][0] / k, t2 = s_t[lane][2] / k;
@@ -2316,9 +2354,9 @@ __global__ __launch_bounds__(64) void k_associate(const DetIn* __restrict__ det,
       const double brg = atan2(yr, xr);                                           // :330
       const double xw = px + rng * cos(brg + pth), yw = py + rng * sin(brg + pth);
       const int lm = s_idx[lane];
-      so.idx[lane] = lm;
-      so.range[lane] = rng;
-      so.bearing[lane] = brg;
+      so.idx[sl] = lm;
+      so.range[sl] = rng;
+      so.bearing[sl] = brg;
       ao.idx[lane] = lm;
       ao.tag_id[lane] = s_tag[lane];
       ao.xw[lane] = xw;
@@ -2331,9 +2369,9 @@ __global__ __launch_bounds__(64) void k_associate(const DetIn* __restrict__ det,
         mub[4 + 2 * lm] = yw;
       }
     } else {
-      so.idx[lane] = 0;
-      so.range[lane] = 0.0;
-      so.bearing[lane] = 0.0;
+      so.idx[sl] = 0;
+      so.range[sl] = 0.0;
+      so.bearing[sl] = 0.0;
     }
   }
   // augmentation (:341-360): zero the new rows/columns, set the new diagonal; pending ranks see zeros
@@ -2355,12 +2393,20 @@ __global__ __launch_bounds__(64) void k_associate(const DetIn* __restrict__ det,
     bound = min(bound, n_new);
     neff_dev[b] = bound;
     nact[b] = n_new;
-    so.lin = d.lin;
-    so.ang = d.ang;
-    so.m = m;
-    so.flags = FLAG_PREDICT | FLAG_UPDATE;
-    so.neff = cfg.active_bound ? bound : n_new;
-    so.pad = 0;
+    StepIn& s0 = step_out[b];
+    StepIn& s1 = step_out[(long)batch + b];
+    s0.lin = d.lin;
+    s0.ang = d.ang;
+    s0.m = min(m, MMAX);
+    s0.flags = FLAG_PREDICT | FLAG_UPDATE;
+    s0.neff = cfg.active_bound ? bound : n_new;
+    s0.pad = 0;
+    s1.lin = 0.0;                                      // the landmarks beyond the first pass: an update without a prediction
+    s1.ang = 0.0;
+    s1.m = max(m - MMAX, 0);
+    s1.flags = FLAG_UPDATE;
+    s1.neff = s0.neff;
+    s1.pad = 0;
     ao.m = m;
     ao.n_after = n_new;
   }
@@ -2370,7 +2416,7 @@ void launch_associate(hipStream_t st, const DetIn* det, int* tagmap, int* nact, 
                       double* V, double* W, StepIn* step_out, AssocOut* assoc_out, unsigned* flags,
                       const AssocConfig& cfg, int ld, long pstride, int n_max, int pending_k, int batch) {
   hipLaunchKernelGGL(k_associate, dim3(batch), dim3(64), 0, st, det, tagmap, nact, neff_dev, mu, P, V, W, step_out,
-                     assoc_out, flags, cfg, ld, pstride, n_max, pending_k);
+                     assoc_out, flags, cfg, ld, pstride, n_max, pending_k, batch);
 }
 
 // Augmentation (src/replay_no_ros.py:341-360): zero rows/cols [n_old, n_new), set the new diagonal.

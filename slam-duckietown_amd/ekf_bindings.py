@@ -37,7 +37,8 @@ EKF_FLAG_NONFINITE = 1
 EKF_FLAG_ASSOC = 2
 EKF_FLAG_INTERNAL = 4             # a bounded wait of a single-launch step timed out: sync()/state()/mean() raise EkfError
 EKF_N_MAX_LIMIT = 21823           # largest n_max (one covariance stays below 4 GiB: 32-bit byte offsets in the kernels)
-EKF_DMAX = 64
+EKF_DMAX = 256                    # detections per window the device front end takes
+EKF_AMAX = 32                     # distinct tags per window the device front end takes (two update passes of EKF_MMAX)
 EKF_TAGMAX = 1024
 
 
@@ -142,6 +143,8 @@ ABI = {
     "ekf_debug_cadences": (C.c_int, [C.c_void_p, C.POINTER(C.c_long), C.POINTER(C.c_long)]),
     "ekf_debug_lookaheads": (C.c_long, [C.c_void_p]),
     "ekf_debug_chained": (C.c_long, [C.c_void_p]),
+    "ekf_debug_assoc_fallbacks": (C.c_long, [C.c_void_p]),
+    "ekf_debug_note_assoc_fallback": (None, [C.c_void_p]),
     "ekf_debug_last_pass_shares": (C.c_int, [C.c_void_p]),
     "ekf_debug_small_launches": (C.c_long, [C.c_void_p]),
     "ekf_debug_fused_fetches": (C.c_long, [C.c_void_p]),
@@ -497,8 +500,8 @@ class EkfSlam:
         self._assoc_gate, self._assoc_ignore = float(gate_range), tuple(int(t) for t in ignore_tags)
 
     def _window_fits_device(self, win, index_len_hint=None) -> bool:
-        """Whether one trajectory's window stays inside the device front end's limits: at most EKF_DMAX detections, at
-        most EKF_MMAX distinct tags behind IGNORE_TAGS and the gate (src/replay_no_ros.py:286-289), tag ids in [0, 1024)."""
+        """Whether one trajectory's window stays inside the device front end's limits: at most EKF_DMAX = 256 detections, at
+        most EKF_AMAX = 32 distinct tags behind IGNORE_TAGS and the gate (src/replay_no_ros.py:286-289), tag ids in [0, 1024)."""
         ids, count, gate2 = [], 0, self._assoc_gate ** 2
         for _stamp, tags in win:
             for tag in tags:
@@ -508,15 +511,16 @@ class EkfSlam:
                     continue
                 if tag.tag_id not in ids:
                     ids.append(tag.tag_id)
-        return count <= EKF_DMAX and len(ids) <= EKF_MMAX and all(0 <= int(t) < EKF_TAGMAX for t in ids)
+        return count <= EKF_DMAX and len(ids) <= EKF_AMAX and all(0 <= int(t) < EKF_TAGMAX for t in ids)
 
     def step_detections(self, lin, ang, detections):
         """One window of raw detections per trajectory: the reference's ``[(timestamp, [tag, ...])]`` list
         (src/replay_no_ros.py:280-284), or a list of such lists for a batch.  Association, the 1.5 m gate,
         per-tag averaging, augmentation, prediction and update all run on the GPU.
 
-        The device front end has limits the reference's dictionaries do not (:280-301): tag ids in [0, 1024), at most 64
-        detections and 16 distinct tags per window.  Every window is checked against them on the host first; when a
+        The device front end has limits the reference's dictionaries do not (:280-301): tag ids in [0, 1024), at most 256
+        detections and 32 distinct tags per window (round 6; until round 5: 64 and 16 -- the reference's normal mode, a 0.7 s
+        window of every camera frame, :17, did not fit).  Every window is checked against them on the host first; when a
         trajectory's window does not fit -- or its TAG_INDEX already holds an id the device table cannot -- the CALL takes
         the host association (``frontend.associate``: no limits), augmentation through ``add_landmarks`` and the update
         through ``step`` (which splits lists of more than 16 landmarks), and the device's table follows the host's
@@ -530,6 +534,7 @@ class EkfSlam:
         if len(detections) != self.batch:
             raise ValueError("detections: one window per trajectory expected")
         if self._host_index or not all(self._window_fits_device(win) for win in detections):
+            self._lib.ekf_debug_note_assoc_fallback(self._h)       # (counted: ekf_debug_assoc_fallbacks / assoc_fallbacks())
             return self._step_detections_host(lin, ang, detections)
         self._host_tags.clear()
         flat = [[tag for _stamp, tags in win for tag in tags] for win in detections]
@@ -581,17 +586,21 @@ class EkfSlam:
             else:
                 self._host_index[b] = index                        # ids beyond the device table: the host stays in charge
 
+    def assoc_fallbacks(self) -> int:
+        """Windows `step_detections` took through the host association because they did not fit the device front end."""
+        return int(self._lib.ekf_debug_assoc_fallbacks(self._h))
+
     def tags_positions(self, b: int = 0) -> dict:
         """What EKF_pose_estimation returns as its third value for the last window (:331-337), update order."""
         if b in self._host_tags:                                   # the last window was associated on the host
             return dict(self._host_tags[b])
         m = C.c_int()
-        idx, tid = np.zeros(EKF_MMAX, dtype=np.int32), np.zeros(EKF_MMAX, dtype=np.int32)
-        arrs = [np.zeros(EKF_MMAX) for _ in range(5)]
+        idx, tid = np.zeros(EKF_AMAX, dtype=np.int32), np.zeros(EKF_AMAX, dtype=np.int32)
+        arrs = [np.zeros(EKF_AMAX) for _ in range(5)]
         self._check(self._lib.ekf_download_tags(self._h, b, C.byref(m), _p(idx, _ip), _p(tid, _ip), *[_p(a) for a in arrs]))
         if self.flags(b) & EKF_FLAG_ASSOC:
             raise EkfError("device-side association dropped a detection (tag id outside [0, 1024), more than "
-                           f"{EKF_MMAX} distinct tags in one window, or the state is full): the map no longer matches "
+                           f"{EKF_AMAX} distinct tags in one window, or the state is full): the map no longer matches "
                            "the reference's; use a larger n_max or the host association")
         xw, yw, err, rng, brg = arrs
         return {int(idx[i]): [xw[i], yw[i], err[i], int(tid[i]), rng[i], brg[i]] for i in range(m.value)}

@@ -117,7 +117,7 @@ class GpuBackend:
         return ids, count
 
     def step(self, ang, lin, detections, tag_index) -> dict:
-        from .ekf_bindings import EKF_DMAX, EKF_MMAX, EKF_TAGMAX
+        from .ekf_bindings import EKF_AMAX, EKF_DMAX, EKF_TAGMAX
         cached, self._cache = self._cache, None
         if self.device_association:
             dev_index = dict(self._dev_index) if self._dev_index is not None else self.filt.tag_index()
@@ -128,7 +128,7 @@ class GpuBackend:
             n_need = 3 + 2 * (len(dev_index) + sum(1 for t in ids if t not in dev_index))
             if n_need > self.filt.n_max:
                 self._grow(n_need)
-            if len(ids) <= EKF_MMAX and count <= EKF_DMAX and all(0 <= t < EKF_TAGMAX for t in ids):
+            if len(ids) <= EKF_AMAX and count <= EKF_DMAX and all(0 <= t < EKF_TAGMAX for t in ids):
                 self.filt.step_detections(lin, ang, detections)
                 tags = self.filt.tags_positions()                 # raises if the device still had to drop something
                 self._dev_index = self.filt.tag_index()

@@ -288,14 +288,14 @@ def _raw_step_detections(sd, f, lin, ang, tags):
 
 
 def test_device_association_drops_before_indexing(sd):
-    """The C ABI's device front end with 17 distinct tags in one window: the 17th is dropped BEFORE it is given a
-    landmark index (no uninitialised landmark enters the state), the sticky flag is raised and tags_positions()
+    """The C ABI's device front end with 33 distinct tags in one window (EKF_AMAX = 32): the 33rd is dropped BEFORE it is
+    given a landmark index (no uninitialised landmark enters the state), the sticky flag is raised and tags_positions()
     reports it.  (`EkfSlam.step_detections` checks the limits on the host and never sends such a window: next test.)"""
-    tags = [_tag(100 + i, -0.4 + 0.05 * i, 0.6 + 0.01 * i) for i in range(17)]
+    tags = [_tag(100 + i, -0.4 + 0.025 * i, 0.6 + 0.01 * i) for i in range(33)]
     with sd.EkfSlam(3 + 2 * 40) as f:
         assert _raw_step_detections(sd, f, 0.01, 0.0, tags) == 0
-        assert f.size() == 3 + 2 * 16
-        assert f.tag_index() == {100 + i: i for i in range(16)}
+        assert f.size() == 3 + 2 * 32
+        assert f.tag_index() == {100 + i: i for i in range(32)}
         assert f.flags() & 2
         with pytest.raises(sd.EkfError):
             f.tags_positions()
@@ -303,9 +303,56 @@ def test_device_association_drops_before_indexing(sd):
         assert np.isfinite(mu).all() and (np.abs(mu[3:]) > 0).any()
 
 
+def test_normal_mode_window_stays_on_the_device(sd, both_paths):
+    """VERDICT r05 item 4.  The reference's NORMAL mode hands EKF_pose_estimation a 0.7 s window of every camera frame
+    (src/replay_no_ros.py:17, :280-337): 21 frames x 6 tags = 126 detections of 6 distinct tags -- beyond the 64 detections the
+    device front end took until round 5.  Now it stays on the device: no host fallback counted, EKF_FLAG_ASSOC clear, the
+    tags_positions record, TAG_INDEX, mean and covariance of `oracle.ekf_pose_estimation_dense`; then a window with 20 distinct
+    tags (two update passes of up to 16 landmarks), repeated detections, one tag beyond the gate (:289) and an ignored one
+    (:286); both kernel paths."""
+    from tests.conftest import path_ran
+    rng = np.random.default_rng(21)
+    cfg = orc.EkfConfig(ignore_tags=(55,))
+    ids_a = [7, 3, 19, 11, 2, 30]
+    ids_b = [40 + i for i in range(14)] + ids_a            # 20 distinct, 14 of them new
+    base = {i: (float(rng.uniform(-0.5, 0.5)), float(rng.uniform(0.4, 1.1))) for i in set(ids_a + ids_b)}
+
+    def window(ids, frames, k, extra=()):
+        out = []
+        for fr in range(frames):
+            order = list(ids) if fr % 2 == 0 else list(ids)[::-1]              # the order within a frame wanders
+            tags = [_tag(int(i), base[i][0] + float(rng.normal(0, 0.004)), base[i][1] + float(rng.normal(0, 0.004))) for i in order]
+            if fr == 1:
+                tags += list(extra)
+            out.append((k + fr / 30.0, tags))
+        return out
+
+    wins = [window(ids_a, 21, 0.0), window(ids_b, 5, 1.0, extra=(_tag(777, 1.4, 1.4), _tag(55, 0.1, 0.5))),
+            window(ids_a[::-1], 21, 2.0)]
+    assert sum(len(t) for _s, t in wins[0]) == 126
+    with sd.EkfSlam(3 + 2 * 24) as f:
+        f.set_association(cfg.gate_range, cfg.ignore_tags)
+        om, oP, oti = np.zeros(3), np.eye(3) * 0.1, {}
+        for k, w in enumerate(wins):
+            lin, ang = 0.004, (0.02 if k % 2 else 0.005)
+            f.step_detections(lin, ang, w)
+            om, oP, otags = orc.ekf_pose_estimation_dense(ang, lin, om, oP, 0.7, w, oti, cfg)
+            got = f.tags_positions()
+            assert list(got.keys()) == list(otags.keys())
+            for j in otags:
+                assert got[j][3] == otags[j][3]
+                assert np.allclose([got[j][q] for q in (0, 1, 4, 5)], [otags[j][q] for q in (0, 1, 4, 5)], rtol=0, atol=1e-12)
+            assert f.tag_index() == oti and f.flags() == 0
+            mu, P = f.state()
+            close(mu, om)
+            close(P, oP)
+        assert f.assoc_fallbacks() == 0 and not f._host_tags and len(oti) == 20 and 777 not in oti and 55 not in oti
+        assert path_ran(f, both_paths)
+
+
 def test_step_detections_beyond_the_device_limits(sd):
     """The reference's dictionaries are unbounded (src/replay_no_ros.py:280-301).  `EkfSlam.step_detections` on windows the
-    device front end cannot take -- 20 distinct tags and 100 detections in one window, tag ids beyond 1024 -- associates
+    device front end cannot take -- tag ids beyond 1024 (here among 20 distinct tags and 100 detections) -- associates
     on the host instead, with the same results as the reference-shaped oracle (`associate` + augmentation + dense step);
     windows that fit go to the device again once the table can hold the map; a window mixing both kinds of id keeps the
     host in charge.  Two trajectories, so that one over-limit window takes the whole call."""
@@ -328,7 +375,7 @@ def test_step_detections_beyond_the_device_limits(sd):
     small = [i for i in all_ids if i < 1024]
     plan = [
         (small[:5], 2),            # fits the device: 5 tags, 12 detections
-        (all_ids[:20], 5),         # 20 distinct tags, 101 detections, ids >= 1024: host
+        (all_ids[:20], 5),         # 20 distinct tags, 101 detections -- the device would take those since round 6 -- but ids >= 1024: host
         (small[2:9], 3),           # would fit the device -- but the map now holds ids the device table cannot: host
         (all_ids[4:24], 5),        # 20 tags again, four of them new
     ]
@@ -362,14 +409,14 @@ def test_step_detections_beyond_the_device_limits(sd):
             assert np.array_equal(f.state(b)[1], before[b][1]) and f.size(b) == len(before[b][0])
     # below the limits and with small ids the device path is the one that runs (the host overlay is dropped again)
     with sd.EkfSlam(3 + 2 * 40) as f:
-        w17 = [(0.0, [_tag(100 + i, -0.4 + 0.05 * i, 0.6 + 0.01 * i) for i in range(17)])]
-        f.step_detections(0.004, 0.02, w17)                          # 17 tags: host, then the device table follows
-        assert f.flags() == 0 and f.size() == 3 + 2 * 17 and not f._host_index
-        w3 = [(1.0, [_tag(100 + i, -0.4 + 0.05 * i, 0.61 + 0.01 * i) for i in (2, 16, 5)] + [_tag(300, 0.2, 0.9)])]
+        w17 = [(0.0, [_tag(100 + i, -0.4 + 0.025 * i, 0.6 + 0.01 * i) for i in range(33)])]
+        f.step_detections(0.004, 0.02, w17)                          # 33 tags (> EKF_AMAX): host, then the device table follows
+        assert f.flags() == 0 and f.size() == 3 + 2 * 33 and not f._host_index and f.assoc_fallbacks() == 1
+        w3 = [(1.0, [_tag(100 + i, -0.4 + 0.025 * i, 0.61 + 0.01 * i) for i in (2, 32, 5)] + [_tag(300, 0.2, 0.9)])]
         om, oP, oti = np.zeros(3), np.eye(3) * 0.1, {}
         om, oP, _ = orc.ekf_pose_estimation_dense(0.02, 0.004, om, oP, 0.7, w17, oti, cfg)
-        f.step_detections(0.004, 0.02, w3)                           # device path: the table it was handed knows all 17
-        assert not f._host_tags
+        f.step_detections(0.004, 0.02, w3)                           # device path: the table it was handed knows all 33
+        assert not f._host_tags and f.assoc_fallbacks() == 1
         om, oP, ot = orc.ekf_pose_estimation_dense(0.02, 0.004, om, oP, 0.7, w3, oti, cfg)
         assert f.tag_index() == oti and list(f.tags_positions().keys()) == list(ot.keys())
         mu, P = f.state()
@@ -379,12 +426,12 @@ def test_step_detections_beyond_the_device_limits(sd):
 
 def test_gpu_backend_device_association_beyond_the_device_limits(sd, both_paths):
     """replay.GpuBackend(device_association=True) against the host-association backend on windows the device
-    front end cannot take alone: more than 16 distinct tags in a window, and a map that outgrows the capacity."""
+    front end cannot take alone: more than EKF_AMAX = 32 distinct tags in a window, and a map that outgrows the capacity."""
     from slam_duckietown_amd.replay import GpuBackend
     rng = np.random.default_rng(4)
     windows = []
     for k in range(10):
-        count = 20 if k in (2, 6) else 5
+        count = 36 if k in (2, 6) else 5
         ids = rng.choice(60, size=count, replace=False)
         tags = [_tag(int(i), float(rng.uniform(-0.5, 0.5)), float(rng.uniform(0.4, 1.2))) for i in ids]
         windows.append([(float(k), tags)])
