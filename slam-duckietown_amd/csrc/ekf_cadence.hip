@@ -296,6 +296,24 @@ __global__ __launch_bounds__(64 * CAD_NW) void k_solve_cad(const double* __restr
   CadOut& o = out[b];
   const CadPlan pl = plan[b];
   const int nsteps = pl.ns;                            // touched steps
+  // (chained) block and mean come from k_chain_cad, whole (84 x 88, zeros beyond the positions in use): fetched before the
+  // positions are formed -- nothing of it depends on them -- so that the two round trips overlap (2 us of the launch)
+  constexpr int RQP = (CAD_CU + CAD_NW - 1) / CAD_NW;  // rows per wave
+  double pre0[CHAIN ? RQP : 1], pre1[CHAIN ? RQP : 1], pmu0 = 0.0, pmu1 = 0.0;
+  if constexpr (CHAIN) {
+    if (gmu) {                                         // (uniform)
+#pragma unroll
+      for (int q = 0; q < RQP; ++q) {
+        const double* gb = gbuf + ((long)b * CAD_ROWS + min(wave + CAD_NW * q, CAD_ROWS - 1)) * CAD_CS;
+        pre0[q] = gb[lane];
+        pre1[q] = gb[min(64 + lane, CAD_CS - 1)];
+      }
+      if (wave == 1) {
+        pmu0 = gmu[(long)b * 128 + lane];
+        pmu1 = gmu[(long)b * 128 + 64 + lane];
+      }
+    }
+  }
 
   // ---- inputs: the plan's steps (thread p: touched step p), their landmarks' slots and positions ----
   if (tid < CAD_SLOTS) {
@@ -396,7 +414,15 @@ __global__ __launch_bounds__(64 * CAD_NW) void k_solve_cad(const double* __restr
       gv0[q] = 0.0;
       gv1[q] = 0.0;
     }
-    if (gbuf) {
+    if (CHAIN && gmu) {                                // (uniform) chained: fetched at the top of the launch
+      if constexpr (CHAIN) {
+#pragma unroll
+        for (int q = 0; q < RQ; ++q) {
+          gv0[q] = pre0[q];
+          gv1[q] = pre1[q];
+        }
+      }
+    } else if (gbuf) {
       // (uniform) look-ahead: the block was gathered (base + the ranks still pending then) by k_gather_cad, in `gparts`
       // parts, added here in a fixed order; all loads of a part are in flight together
       // (... four parts' loads in flight together: ten dependent round trips were 8 us of a single trajectory's cadence)
@@ -439,8 +465,8 @@ __global__ __launch_bounds__(64 * CAD_NW) void k_solve_cad(const double* __restr
     }
     if (wave == 1) {
       if (CHAIN && gmu) {                              // (uniform) chained: the mean at the positions, from k_chain_cad
-        mu0 = gmu[(long)b * 128 + lane];
-        mu1 = gmu[(long)b * 128 + 64 + lane];
+        mu0 = pmu0;
+        mu1 = pmu1;
       } else {
         mu0 = mu_in_b[Cl0];
         mu1 = mu_in_b[Cl1];
@@ -1488,6 +1514,10 @@ __global__ __launch_bounds__(64 * CAD_NW) void k_chain_cad(const double* __restr
   const int li = lane & 15, lq = lane >> 4;
   // ---- the diagonal blocks: Linv_i = (I + C_ii)^-1 by substitution on the identity (wave i, a column per lane), then
   // Linv_i C_{i,<i} in place (tiles of 16 x 16 over the waves) -- so that a block step of the solve is ONE product ----
+  if (tid == 64 * (CAD_NW - 1)) {
+    // (meanwhile, one lane of an idle wave) the gathered rows are there: the launch's gather workgroups have counted themselves off
+    if (!sync_wait(sync + SYNC_GATHER * SYNC_STRIDE, gather_target)) atomicOr(flags + b, EKF_FLAG_INTERNAL);
+  }
   if (wave < 5 && lane < 16) {
     const int i = wave, c = lane;
     double t[16];
@@ -1513,6 +1543,41 @@ __global__ __launch_bounds__(64 * CAD_NW) void k_chain_cad(const double* __restr
     for (int k = 0; k < 16; ++k) Li[i][k][c] = t[k];
   }
   __syncthreads();
+  CHSTAMP(3);
+  // ---- the gathered rows: everything this workgroup reads of them is requested here, the products below run under the
+  // round trip ----
+  constexpr int RQ = (CAD_ROWS + CAD_NW - 1) / CAD_NW;               // rows per wave (11)
+  const double* bgb = bg + (long)b * CAD_ROWS * CAD_CS;
+  double p0[RQ][2];                                                  // P_0(C', C') in the layout the block is written in
+#pragma unroll
+  for (int q = 0; q < RQ; ++q) {
+    const int r = wave + CAD_NW * q;
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+      const int l = 64 * hf + lane;
+      p0[q][hf] = (r >= 3 && r < cu && l >= 3 && l < cu) ? ld_dev(bgb + (long)r * CAD_CS + l) : 0.0;
+    }
+  }
+  const double* xgb = xg + (long)b * CAD_ROWS * CAD_CS + 3;          // column j = position 3 + j
+  const int ja = lane, jb = 64 + lane;                 // columns; the second part: 16 lanes
+  const bool hb = jb < CH_NC;
+  double xa[3], xb[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    xa[k] = ld_dev(xgb + (long)k * CAD_CS + ja);
+    xb[k] = hb ? ld_dev(xgb + (long)k * CAD_CS + jb) : 0.0;
+  }
+  constexpr int QW = CAD_SLOTS / CAD_NW;               // landmarks per wave (5)
+  double la0[QW], la1[QW], lb0[QW], lb1[QW];
+#pragma unroll
+  for (int u = 0; u < QW; ++u) {
+    const int q = wave + CAD_NW * u;
+    const int paq = q < nk ? G::pa(s0k + q) : 3;       // (uniform)
+    la0[u] = ld_dev(xgb + (long)paq * CAD_CS + ja);
+    la1[u] = ld_dev(xgb + (long)(paq + 1) * CAD_CS + ja);
+    lb0[u] = hb ? ld_dev(xgb + (long)paq * CAD_CS + jb) : 0.0;
+    lb1[u] = hb ? ld_dev(xgb + (long)(paq + 1) * CAD_CS + jb) : 0.0;
+  }
   for (int job = wave; job < 10; job += CAD_NW) {      // (i, j), j < i <= 4: tile (rows of block i, columns of block j)
     int i = 1, j = job;
     while (j >= i) {
@@ -1528,47 +1593,11 @@ __global__ __launch_bounds__(64 * CAD_NW) void k_chain_cad(const double* __restr
       for (int reg = 0; reg < 4; ++reg) Cm[16 * i + lq + 4 * reg][16 * j + li] = acc[reg];
     }
   }
-  CHSTAMP(3);
-  // ---- the gathered rows are there (the launch's gather workgroups have counted themselves off) ----
-  if (tid == 0 && !sync_wait(sync + SYNC_GATHER * SYNC_STRIDE, gather_target)) atomicOr(flags + b, EKF_FLAG_INTERNAL);
-  __syncthreads();
   CHSTAMP(4);
-  constexpr int RQ = (CAD_ROWS + CAD_NW - 1) / CAD_NW;               // rows per wave (11)
-  const double* bgb = bg + (long)b * CAD_ROWS * CAD_CS;
-  double p0[RQ][2];                                                  // P_0(C', C') in the layout the block is written in
-#pragma unroll
-  for (int q = 0; q < RQ; ++q) {
-    const int r = wave + CAD_NW * q;
-#pragma unroll
-    for (int hf = 0; hf < 2; ++hf) {
-      const int l = 64 * hf + lane;
-      p0[q][hf] = (r >= 3 && r < cu && l >= 3 && l < cu) ? ld_dev(bgb + (long)r * CAD_CS + l) : 0.0;
-    }
-  }
   // ---- the right-hand side A X, row by row: A_q = H_q[:, 0..2] G^{(q,-1)} at the pose positions, H_q[:, 3..4] at the landmark's
   // own -- five rows of X per landmark, each landmark row of X read exactly once (straight from xg, coalesced); the pose rows
   // behind the cadence start from G^{(end,-1)} X[0..2].  Columns over lanes (64 + 16), landmarks over waves ----
-  const double* xgb = xg + (long)b * CAD_ROWS * CAD_CS + 3;          // column j = position 3 + j
   {
-    const int ja = lane, jb = 64 + lane;               // columns; the second part: 16 lanes
-    const bool hb = jb < CH_NC;
-    double xa[3], xb[3];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      xa[k] = ld_dev(xgb + (long)k * CAD_CS + ja);
-      xb[k] = hb ? ld_dev(xgb + (long)k * CAD_CS + jb) : 0.0;
-    }
-    constexpr int QW = CAD_SLOTS / CAD_NW;             // landmarks per wave (5)
-    double la0[QW], la1[QW], lb0[QW], lb1[QW];
-#pragma unroll
-    for (int u = 0; u < QW; ++u) {
-      const int q = wave + CAD_NW * u;
-      const int paq = q < nk ? G::pa(s0k + q) : 3;     // (uniform)
-      la0[u] = ld_dev(xgb + (long)paq * CAD_CS + ja);
-      la1[u] = ld_dev(xgb + (long)(paq + 1) * CAD_CS + ja);
-      lb0[u] = hb ? ld_dev(xgb + (long)paq * CAD_CS + jb) : 0.0;
-      lb1[u] = hb ? ld_dev(xgb + (long)(paq + 1) * CAD_CS + jb) : 0.0;
-    }
 #pragma unroll
     for (int u = 0; u < QW; ++u) {
       const int q = wave + CAD_NW * u;

@@ -11,8 +11,8 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
-NAMES = ["start", "records + positions staged, C zeroed", "coefficients", "Linv, Linv C", "gathered rows there", "A X in LDS",
-         "Linv A X", "E solved", "-F + mean partials", "F^T E", "block written"]
+NAMES = ["start", "records + positions staged, C zeroed", "coefficients", "Linv; gathered rows there", "loads issued, Linv C",
+         "A X in LDS", "Linv A X", "E solved", "-F + mean partials", "F^T E", "block written"]
 
 
 def main():
