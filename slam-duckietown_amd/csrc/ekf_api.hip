@@ -1510,6 +1510,17 @@ extern "C" int ekf_stream_run(ekf_handle* h, int first, int count) {
       // look-ahead: every solve and chain workgroup has to find a CU beside the pass.)
       h->chain_run = h->opt_chain && h->opt_lookahead && h->run_plan.ncad >= 2 && h->batch <= 40;
       if (h->chain_run) {
+        // ... and only where a pass of this bank can leave CUs to a solve beside it at all (with every state index active and a
+        // full cadence pending: the headline's 32 x N = 2000 never does -- its solves stay the plain instantiation)
+        const std::vector<int> enq = h->neff_enq;
+        const int pk = h->pending_k;
+        h->neff_enq = h->n;
+        h->pending_k = KTOT;
+        h->chain_run = beside_the_pass(h, plan_pass(h));
+        h->neff_enq = enq;
+        h->pending_k = pk;
+      }
+      if (h->chain_run) {
         const int n_hi = *std::max_element(h->n.begin(), h->n.end());
         for (int i = 0; i < 2; ++i)
           if (!h->dprow3[i]) HIP_TRY(h, hipMalloc(&h->dprow3[i], sizeof(double) * 3 * (size_t)h->ld * h->batch));

@@ -8,7 +8,7 @@ rocprofv3 --pmc $C --output-format csv -d $OUT/dense -o run -- python3 tools/den
 echo "dense done"
 rocprofv3 --pmc $C --output-format csv -d $OUT/flush -o run -- python3 bench.py --steps 12 --warmup 4 --no-cpu-baseline --no-single > $OUT/flush.log 2>&1
 echo "flush done"
-rocprofv3 --pmc $C --output-format csv -d $OUT/flush_n8000 -o run -- python3 -W ignore tools/flush_time.py --landmarks 8000 --trajectories 1 > $OUT/flush_n8000.log 2>&1
+rocprofv3 --pmc $C --output-format csv -d $OUT/flush_n8000 -o run -- python3 -W ignore tools/flush_time.py --landmarks 8000 --trajectories 1 --option chain=0 > $OUT/flush_n8000.log 2>&1
 echo "flush n8000 done"
 python3 - <<'PY'
 import csv, glob, collections
