@@ -43,10 +43,11 @@ void launch_associate(hipStream_t, const DetIn*, int*, int*, int*, double*, doub
 void launch_fill_diag(hipStream_t, double*, int, int, const double*);
 int dense_propagate(hipStream_t, double* P, double* tmp, const double* F, const double* Q, int n, int ld);
 void launch_solve_cad(hipStream_t, const double*, const double*, double*, double*, const int*, const StepIn*, const CadPlan*, int,
-                      CadOut*, unsigned*, const DeviceConfig&, int, long, const double*, int, double*, int, int, bool, const double*);
+                      CadOut*, unsigned*, const DeviceConfig&, int, long, const double*, int, double*, int, int, bool, const double*,
+                      unsigned*, unsigned, const CadPre*);
 void launch_chain_cad(hipStream_t, const double*, const double*, const double*, const double*, const CadOut*, const StepIn*,
                       const CadPlan*, int, const DeviceConfig&, int, long, double*, double*, double*, double*, unsigned*, unsigned,
-                      unsigned*, int, unsigned);
+                      unsigned*, int, unsigned, const CadPre*, CadPre*, const CadPlan*);
 void launch_gate(hipStream_t, unsigned*, unsigned, unsigned*, int);
 int panels_cad_workgroups(int, int);
 int chain_gather_workgroups(int, int);
@@ -56,7 +57,9 @@ void launch_gather_cad(hipStream_t, const double*, const double*, const double*,
                        int, const DeviceConfig&, int, long, double*);
 long cadence_gbuf_doubles();
 void launch_panels_cad(hipStream_t, double*, double*, double*, const double*, double*, const int*, const CadOut*,
-                       SolveOut*, unsigned*, int, long, int, int, int, const double*, double*, unsigned*, unsigned, unsigned, unsigned*);
+                       SolveOut*, unsigned*, int, long, int, int, int, const double*, double*, unsigned*, unsigned, unsigned, unsigned*,
+                       bool, unsigned);
+bool panels_cad_latency_regime(int, int);
 }  // namespace ekf
 
 using namespace ekf;
@@ -163,10 +166,18 @@ struct ekf_handle : ekf::HostPlan {
   unsigned* dsync = nullptr;      // device-scope counters of the chained run's hand-overs (ekf_cadence.hip: SYNC_*)
   unsigned gather_count = 0;      // gather workgroups launched so far (what the next chain workgroups wait for)
   unsigned sigma = 0;             // chained transitions so far (the value the run's counters SYNC_SOLVE / SYNC_PASS carry)
+  // a cadence's inputs formed one cadence ahead (CadPre): two copies, by the cadence's serial number (pre_serial: whose inputs a
+  // copy holds; serials count every cadence of the handle)
+  CadPre* dpre[2] = {nullptr, nullptr};
+  long pre_serial[2] = {-1, -1};
+  long cad_serial = 0;
+  int opt_pre_positions = 1;
   hipEvent_t ev_solve = nullptr, ev_pass = nullptr, ev_nb = nullptr;
   bool chain_run = false;         // the run in flight records the transforms (every solve is k_solve_cad<true>)
   bool aux_pass = false;          // a covariance pass is in flight on the second stream (ev_pass recorded behind it)
   int opt_chain = 1;
+  int opt_panel_own_gate = 1;     // 1 = small panel launches are their own gate (panel_head_wait); 0 = always the one-lane gate launch
+  int opt_panel_tform = 1;        // 1 = a chained cadence's panel launch in the latency regime takes the triangular-solve form (k_panels_cad_tf)
   int opt_run_end_flush = 0;      // 1 = ekf_stream_run applies what its last cadence left pending, so that the next call starts fused
   long chained = 0;               // statistics: cadences whose block came from k_chain_cad
   // The mirrored column entries of a cadence's panel launch, gathered by extra workgroups of its solve launch and laid down
@@ -293,7 +304,7 @@ static void free_all(ekf_handle* h) {
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   void* ptrs[] = {h->dP, h->dmu2[0], h->dmu2[1], h->dV, h->dW, h->ddacc2[0], h->ddacc2[1], h->dscratch, h->dn, h->dflags, h->dso, h->dfac,
                   h->d_ring, h->d_stream, h->dF, h->dQ, h->dTmp, h->dPlin, h->dtagmap, h->dneff, h->d_det, h->d_assoc_step, h->dfloor, h->dqueue, h->dready, h->dmbox,
-                  h->d_assoc_out, h->dcad2[0], h->dcad2[1], h->dprow3[0], h->dprow3[1], h->dgmu, h->dxg, h->dbg, h->dsync, h->dshares2[0], h->dshares2[1], h->dgbuf, h->dplan2[0], h->dplan2[1], h->dcolbuf};
+                  h->d_assoc_out, h->dcad2[0], h->dcad2[1], h->dprow3[0], h->dprow3[1], h->dgmu, h->dxg, h->dbg, h->dsync, h->dpre[0], h->dpre[1], h->dshares2[0], h->dshares2[1], h->dgbuf, h->dplan2[0], h->dplan2[1], h->dcolbuf};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (h->h_ring) (void)hipHostFree(h->h_ring);
   if (h->h_det) (void)hipHostFree(h->h_det);
@@ -963,6 +974,7 @@ static int enqueue_cadence(ekf_handle* h, int c, bool presolved, bool* next_pres
     if (!h->dcad2[i]) HIP_TRY(h, hipMalloc(&h->dcad2[i], sizeof(CadOut) * h->batch));
   CadOut* dcad = h->dcad2[h->cpar];
   double* prow_out = h->chain_run ? h->dprow3[h->cpar] : nullptr;
+  const long serial = h->cad_serial++;                 // this cadence's number (CadPre copies are looked up by it)
   for (int b = 0; b < h->batch; ++b) h->neff_enq[b] = rp.entries[(size_t)c * h->batch + b].neff;
   const double* mu_in = h->dmu2[h->cur];
   double* mu_out = h->dmu2[h->cur ^ 1];
@@ -988,7 +1000,7 @@ static int enqueue_cadence(ekf_handle* h, int c, bool presolved, bool* next_pres
     ProfBracket pb;
     if (int rc = prof_open(h, 1, h->stream, &pb)) return rc;
     launch_solve_cad(h->stream, h->dP, mu_in, mu_out, h->ddacc2[h->dcur ^ 1], h->dn, h->d_stream, dpl, h->batch, dcad,
-                     h->dflags, h->dcfg, h->ld, h->pstride, nullptr, 0, colbuf, n_hi, col_wgs, h->chain_run, nullptr);
+                     h->dflags, h->dcfg, h->ld, h->pstride, nullptr, 0, colbuf, n_hi, col_wgs, h->chain_run, nullptr, nullptr, 0u, nullptr);
     if (int rc = prof_close(h, &pb)) return rc;
     h->colbuf_live = colbuf != nullptr;
   }
@@ -1019,7 +1031,7 @@ static int enqueue_cadence(ekf_handle* h, int c, bool presolved, bool* next_pres
     h->gather_count += (unsigned)(h->batch * gw);
     // (the panel launch is its own gate where each of its workgroups and each solve workgroup has a CU to itself: a tiny launch
     //  costs the stream ~4 us, 5 % of a single trajectory's cadence)
-    if (panels_cad_workgroups(h->batch, n_hi) + 2 * h->batch <= h->cu_count / 2) head_sigma = h->sigma;
+    if (h->opt_panel_own_gate && panels_cad_workgroups(h->batch, n_hi) + 2 * h->batch <= h->cu_count / 2) head_sigma = h->sigma;
     else launch_gate(h->aux, h->dsync, h->sigma, h->dflags, h->batch);
     pst = h->aux;
     psync = h->dsync;
@@ -1031,7 +1043,9 @@ static int enqueue_cadence(ekf_handle* h, int c, bool presolved, bool* next_pres
     ProfBracket pb;
     if (int rc = prof_open(h, 3, pst, &pb)) return rc;
     launch_panels_cad(pst, h->dP, h->dV, h->dW, mu_in, mu_out, h->dn, dcad, h->dso, h->dqueue, h->ld,
-                      h->pstride, h->batch, n_hi, nrp, h->colbuf_live ? h->dcolbuf : nullptr, prow_out, psync, head_sigma, tail_target, h->dflags);
+                      h->pstride, h->batch, n_hi, nrp, h->colbuf_live ? h->dcolbuf : nullptr, prow_out, psync, head_sigma, tail_target, h->dflags,
+                      chain_next && h->opt_panel_tform && !h->colbuf_live && panels_cad_latency_regime(h->batch, n_hi),
+                      chain_next ? h->sigma : 0u);
     if (int rc = prof_close(h, &pb)) return rc;
   }
   h->colbuf_live = false;
@@ -1058,13 +1072,18 @@ static int enqueue_cadence(ekf_handle* h, int c, bool presolved, bool* next_pres
     //  dmu2[cur] the one its solve left the pose in; dcad2[cpar ^ 1] cadence c's records, dprow3[cpar] the pose rows BEFORE it)
     ProfBracket pbc, pbs;
     if (int rc2 = prof_open(h, 2, h->stream, &pbc)) return rc2;
+    // the next cadence's inputs if an earlier chain launch formed them; the one after it: formed by this launch
+    const CadPre* pre_in = (h->opt_pre_positions && h->pre_serial[(serial + 1) & 1] == serial + 1) ? h->dpre[(serial + 1) & 1] : nullptr;
+    CadPre* pre_out = (h->opt_pre_positions && c + 2 < rp.ncad) ? h->dpre[(serial + 2) & 1] : nullptr;
     launch_chain_cad(h->stream, h->dP, h->dprow3[h->cpar], h->dmu2[h->cur ^ 1], h->dmu2[h->cur], h->dcad2[h->cpar ^ 1], h->d_stream,
                      dpl2, h->batch, h->dcfg, h->ld, h->pstride, h->dgbuf, h->dgmu, h->dxg, h->dbg, h->dsync, h->gather_count,
-                     h->dflags, gw, h->sigma);
+                     h->dflags, gw, h->sigma, pre_in, pre_out, pre_out ? dpl2 + h->batch : nullptr);
+    if (pre_out) h->pre_serial[(serial + 2) & 1] = serial + 2;
     if (int rc2 = prof_close(h, &pbc)) return rc2;
     if (int rc2 = prof_open(h, 1, h->stream, &pbs)) return rc2;
     launch_solve_cad(h->stream, h->dP, h->dmu2[h->cur], h->dmu2[h->cur ^ 1], h->ddacc2[h->dcur ^ 1], h->dn, h->d_stream, dpl2,
-                     h->batch, h->dcad2[h->cpar], h->dflags, h->dcfg, h->ld, h->pstride, h->dgbuf, 1, nullptr, n_hi, 0, true, h->dgmu);
+                     h->batch, h->dcad2[h->cpar], h->dflags, h->dcfg, h->ld, h->pstride, h->dgbuf, 1, nullptr, n_hi, 0, true, h->dgmu,
+                     h->dsync, h->sigma, pre_in);
     if (int rc2 = prof_close(h, &pbs)) return rc2;
     // From here on the next cadence's solve has overwritten the pose mean and the pending-noise buffer: a failure below
     // cannot be undone.  Whatever happens the streams are joined, and a failure marks every trajectory undefined
@@ -1103,7 +1122,7 @@ static int enqueue_cadence(ekf_handle* h, int c, bool presolved, bool* next_pres
     if (int rc2 = prof_open(h, 1, h->stream, &pb)) return rc2;
     launch_solve_cad(h->stream, h->dP, h->dmu2[h->cur], h->dmu2[h->cur ^ 1], h->ddacc2[h->dcur ^ 1], h->dn, h->d_stream, dpl2,
                      h->batch, h->dcad2[h->cpar], h->dflags, h->dcfg, h->ld, h->pstride, h->dgbuf, (kb + 7) / 8, nullptr, n_hi, 0,
-                     h->chain_run, nullptr);
+                     h->chain_run, nullptr, nullptr, 0u, nullptr);
     if (int rc2 = prof_close(h, &pb)) return rc2;
   }
   h->colbuf_live = false;                              // (beside the pass P_base is in motion: that cadence's panel launch gathers itself)
@@ -1535,8 +1554,10 @@ extern "C" int ekf_stream_run(ekf_handle* h, int first, int count) {
         // (everything a chained cadence touches exists before its first launch: between the enqueue of a launch that waits on a
         //  device-side counter and the enqueue of the launch that advances it the host must not block -- an allocation may)
         if (!h->dgbuf) HIP_TRY(h, hipMalloc(&h->dgbuf, sizeof(double) * cadence_gbuf_doubles() * h->batch));
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 2; ++i) {
           if (!h->dcad2[i]) HIP_TRY(h, hipMalloc(&h->dcad2[i], sizeof(CadOut) * h->batch));
+          if (!h->dpre[i]) HIP_TRY(h, hipMalloc(&h->dpre[i], sizeof(CadPre) * h->batch));
+        }
         if (!h->dgmu) HIP_TRY(h, hipMalloc(&h->dgmu, sizeof(double) * (128 * h->batch + 32)));   // (+ 32 words: the stamps of a -DCHAIN_STAMPS build)
         // the pose rows "before the first cadence": where the previous cadence's panel launch would have left them
         launch_snap_pose(h->stream, h->dP, h->dn, h->ld, h->pstride, h->batch, n_hi, h->dprow3[h->cpar ^ 1]);
@@ -1876,6 +1897,21 @@ extern "C" int ekf_set_option(ekf_handle* h, const char* name, int value) {
   if (std::strcmp(name, "lookahead") == 0) {
     if (value != 0 && value != 1) return fail(h, EKF_ERR_ARG, "lookahead must be 0 or 1");
     h->opt_lookahead = value;
+    return EKF_OK;
+  }
+  if (std::strcmp(name, "pre_positions") == 0) {
+    if (value != 0 && value != 1) return fail(h, EKF_ERR_ARG, "pre_positions must be 0 or 1");
+    h->opt_pre_positions = value;
+    return EKF_OK;
+  }
+  if (std::strcmp(name, "panel_own_gate") == 0) {
+    if (value != 0 && value != 1) return fail(h, EKF_ERR_ARG, "panel_own_gate must be 0 or 1");
+    h->opt_panel_own_gate = value;
+    return EKF_OK;
+  }
+  if (std::strcmp(name, "panel_tform") == 0) {
+    if (value != 0 && value != 1) return fail(h, EKF_ERR_ARG, "panel_tform must be 0 or 1");
+    h->opt_panel_tform = value;
     return EKF_OK;
   }
   if (std::strcmp(name, "run_end_flush") == 0) {

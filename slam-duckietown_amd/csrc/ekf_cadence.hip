@@ -76,7 +76,7 @@ constexpr int CHAIN_SPIN_LIMIT = 1 << 20;   // bounded device-scope waits: x (s_
 // with device-scope loads (past its own L2).  Counters only ever grow; a wait is for "at least `target`" in wrap-around
 // arithmetic, bounded (a timeout raises EKF_FLAG_INTERNAL: the state is undefined from there on, like k_step_split's).
 constexpr int SYNC_STRIDE = 32;         // words between two counters (a cache line each)
-enum { SYNC_SOLVE = 0, SYNC_PASS = 1, SYNC_CHAIN = 2, SYNC_GATHER = 3, SYNC_WORDS = 4 * SYNC_STRIDE };
+enum { SYNC_SOLVE = 0, SYNC_PASS = 1, SYNC_START = 2, SYNC_GATHER = 3, SYNC_WORDS = 4 * SYNC_STRIDE };
 __device__ __forceinline__ double ld_dev(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_dev(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ bool sync_wait(const unsigned* word, unsigned target) {
@@ -169,7 +169,8 @@ __global__ __launch_bounds__(64 * CAD_NW) void k_solve_cad(const double* __restr
                                                     DeviceConfig cfg, int ld,
                                                     long pstride, const double* __restrict__ gbuf, int gparts,
                                                     double* __restrict__ colbuf, int col_wgs, int n_hi,
-                                                    const double* __restrict__ gmu) {
+                                                    const double* __restrict__ gmu, unsigned* __restrict__ sync,
+                                                    unsigned start_sigma, const CadPre* __restrict__ pre) {
   using G = CadGeom;
   constexpr int GM = G::GM, CU = G::CU;
   __shared__ __attribute__((aligned(16))) double Pc[CAD_ROWS][CAD_CS];
@@ -296,6 +297,12 @@ __global__ __launch_bounds__(64 * CAD_NW) void k_solve_cad(const double* __restr
   CadOut& o = out[b];
   const CadPlan pl = plan[b];
   const int nsteps = pl.ns;                            // touched steps
+  // (chained) this workgroup is placed: the previous cadence's covariance pass may fill the rest of the chip now (the panel launch
+  // in front of it waits for this word -- a pass that got there first keeps every CU busy for its whole duration, and the solve,
+  // which needs a CU to itself, 20 us from being placed: profiles/r06_chained_solves.txt)
+  if constexpr (CHAIN) {
+    if (sync && threadIdx.x == 0) __hip_atomic_store(sync + SYNC_START * SYNC_STRIDE, start_sigma, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
   // (chained) block and mean come from k_chain_cad, whole (84 x 88, zeros beyond the positions in use): fetched before the
   // positions are formed -- nothing of it depends on them -- so that the two round trips overlap (2 us of the launch)
   constexpr int RQP = (CAD_CU + CAD_NW - 1) / CAD_NW;  // rows per wave
@@ -316,20 +323,38 @@ __global__ __launch_bounds__(64 * CAD_NW) void k_solve_cad(const double* __restr
   }
 
   // ---- inputs: the plan's steps (thread p: touched step p), their landmarks' slots and positions ----
-  if (tid < CAD_SLOTS) {
-    int fl = 0;
-    double2 la = make_double2(0.0, 0.0);
-    if (tid < nsteps) {
-      const StepIn& st = in[(long)(pl.t0 + tid) * batch + b];
-      fl = st.flags;
-      if (tid == 0 && pl.j0 > 0) fl &= ~FLAG_PREDICT;   // a step cut by the previous cadence: its prediction has happened
-      la = make_double2(st.lin, st.ang);
+  int nslots;
+  if (CHAIN && pre) {
+    // (uniform) chained: formed one cadence ahead by the chain launch's positions workgroup (CadPre) -- one coalesced round trip
+    const CadPre& pp = pre[b];
+    if (tid < 128) Cs[tid] = pp.C[tid];
+    if (tid <= CAD_SLOTS) {
+      mS[tid] = pp.cnt[tid];
+      firstS[tid] = pp.first[tid];
+      loS[tid] = pp.lo[tid];
     }
-    fS[tid] = fl;
-    laS[tid] = la;
+    if (tid < CAD_SLOTS) {
+      fS[tid] = pp.fl[tid];
+      laS[tid] = make_double2(pp.la[tid][0], pp.la[tid][1]);
+      zS[tid] = make_double2(pp.z[tid][0], pp.z[tid][1]);
+    }
+    nslots = pp.nslots;
+  } else {
+    if (tid < CAD_SLOTS) {
+      int fl = 0;
+      double2 la = make_double2(0.0, 0.0);
+      if (tid < nsteps) {
+        const StepIn& st = in[(long)(pl.t0 + tid) * batch + b];
+        fl = st.flags;
+        if (tid == 0 && pl.j0 > 0) fl &= ~FLAG_PREDICT;   // a step cut by the previous cadence: its prediction has happened
+        la = make_double2(st.lin, st.ang);
+      }
+      fS[tid] = fl;
+      laS[tid] = la;
+    }
+    nslots = cad_positions<true>(pl, in, batch, b, cfg, tid, Cs, mS, firstS, loS,
+                                 [&](int s, double zr, double zb) { zS[s] = make_double2(zr, zb); });
   }
-  const int nslots = cad_positions<true>(pl, in, batch, b, cfg, tid, Cs, mS, firstS, loS,
-                                         [&](int s, double zr, double zb) { zS[s] = make_double2(zr, zb); });
   const int s0 = GM - nslots;
   const int cu = 3 + 2 * nslots;                       // positions in use
   const int neff_eff = min(nact[b], pl.neff);
@@ -777,8 +802,13 @@ __device__ __forceinline__ void panel_head_wait(unsigned* sync, unsigned sigma, 
 // off (one lane of the whole launch waits; bounded).
 __device__ __forceinline__ void pose_epilogue(const CadOut& o, double* Pb, double* Vb, double* Wb, SolveOut* so, unsigned* queue,
                                               int b, int ld, int lane, int nrp, const unsigned* tail_word = nullptr,
-                                              unsigned tail_target = 0u, unsigned* flags = nullptr) {
-  if (tail_word && b == 0 && lane == 0 && !sync_wait(tail_word, tail_target)) atomicOr(flags, EKF_FLAG_INTERNAL);
+                                              unsigned tail_target = 0u, unsigned* flags = nullptr, unsigned start_sigma = 0u) {
+  if (tail_word && b == 0 && lane == 0) {
+    bool ok = sync_wait(tail_word, tail_target);
+    // ... nor before the next cadence's solve has been placed (tail_word - SYNC_GATHER + SYNC_START: the same counter block)
+    if (start_sigma) ok = sync_wait(tail_word + (SYNC_START - SYNC_GATHER) * SYNC_STRIDE, start_sigma) && ok;
+    if (!ok) atomicOr(flags, EKF_FLAG_INTERNAL);
+  }
   const int ld16 = ld >> 4;
   const int s0 = CAD_SLOTS - o.nslots;
   // one (slot, pose index) pair per lane and round: the loads of a round are in flight together
@@ -940,7 +970,7 @@ __global__ __launch_bounds__(64 * NW) void k_panels_cad(double* __restrict__ P, 
                                                         unsigned* __restrict__ queue, int ld, long pstride, int nrp,
                                                         const double* __restrict__ colbuf, double* __restrict__ prow3,
                                                         unsigned* __restrict__ sync, unsigned head_sigma, unsigned tail_target,
-                                                        unsigned* __restrict__ flags) {
+                                                        unsigned* __restrict__ flags, unsigned start_sigma) {
   using G = CadGeom;
   constexpr int CU = G::CU, GM = G::GM, NT = 64 * NW;
   const unsigned* tail_word = sync ? sync + SYNC_GATHER * SYNC_STRIDE : nullptr;
@@ -1033,7 +1063,7 @@ __global__ __launch_bounds__(64 * NW) void k_panels_cad(double* __restrict__ P, 
         for (int a = 0; a < 3; ++a) prow3[((long)b * 3 + a) * ld + i] = Pb[p_index(ld, a, i)];
       }
     }
-    if (blockIdx.x == 0 && wave == 0) pose_epilogue(o, Pb, Vb, Wb, so, queue, b, ld, lane, nrp, tail_word, tail_target, flags);
+    if (blockIdx.x == 0 && wave == 0) pose_epilogue(o, Pb, Vb, Wb, so, queue, b, ld, lane, nrp, tail_word, tail_target, flags, start_sigma);
     return;
   }
   double d0 = 0.0, d1 = 0.0, dm = 0.0;
@@ -1110,7 +1140,7 @@ __global__ __launch_bounds__(64 * NW) void k_panels_cad(double* __restrict__ P, 
       for (int a = 0; a < 3; ++a) prow3[((long)b * 3 + a) * ld + i] = X[a];
     }
   }
-  if (blockIdx.x == 0 && wave == 0) pose_epilogue(o, Pb, Vb, Wb, so, queue, b, ld, lane, nrp, tail_word, tail_target, flags);
+  if (blockIdx.x == 0 && wave == 0) pose_epilogue(o, Pb, Vb, Wb, so, queue, b, ld, lane, nrp, tail_word, tail_target, flags, start_sigma);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1129,7 +1159,7 @@ __global__ __launch_bounds__(256) void k_panels_cad_ks(double* __restrict__ P, d
                                                        unsigned* __restrict__ queue, int ld, long pstride, int nrp,
                                                        const double* __restrict__ colbuf, double* __restrict__ prow3,
                                                        unsigned* __restrict__ sync, unsigned head_sigma, unsigned tail_target,
-                                                       unsigned* __restrict__ flags) {
+                                                       unsigned* __restrict__ flags, unsigned start_sigma) {
   using G = CadGeom;
   constexpr int GM = G::GM, CU = G::CU;
   constexpr int LP = (GM + 3) / 4;                     // landmark position-slots per wave
@@ -1207,7 +1237,7 @@ __global__ __launch_bounds__(256) void k_panels_cad_ks(double* __restrict__ P, d
         for (int a = 0; a < 3; ++a) prow3[((long)b * 3 + a) * ld + i] = Pb[p_index(ld, a, i)];
       }
     }
-    if (blockIdx.x == 0 && wave == 0) pose_epilogue(o, Pb, Vb, Wb, so, queue, b, ld, lane, nrp, tail_word, tail_target, flags);
+    if (blockIdx.x == 0 && wave == 0) pose_epilogue(o, Pb, Vb, Wb, so, queue, b, ld, lane, nrp, tail_word, tail_target, flags, start_sigma);
     return;
   }
   const double* recw = sRec + 4 * wave;                // K of this wave's rows: + compile-time offsets
@@ -1297,7 +1327,7 @@ __global__ __launch_bounds__(256) void k_panels_cad_ks(double* __restrict__ P, d
       for (int a = 0; a < 3; ++a) prow3[((long)b * 3 + a) * ld + i] = XP[a];
     }
   }
-  if (blockIdx.x == 0 && wave == 0) pose_epilogue(o, Pb, Vb, Wb, so, queue, b, ld, lane, nrp, tail_word, tail_target, flags);
+  if (blockIdx.x == 0 && wave == 0) pose_epilogue(o, Pb, Vb, Wb, so, queue, b, ld, lane, nrp, tail_word, tail_target, flags, start_sigma);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1350,6 +1380,154 @@ constexpr int CH_R = 96;                // rows of the padded operands (6 MFMA t
 constexpr int CH_CS = 82;               // LDS row stride of B / the coefficient matrix (even: a 2 x 2 block's row is one 16-byte read)
 constexpr int CH_GW = 12;               // gather workgroups per trajectory at most (12: a row of X and of P_0(C', C') per wave)
 
+// ---- pieces shared by k_chain_cad and k_panels_cad_tf: the cadence's records as the triangular system (I + C) E = A X ----
+struct ChainRec {                       // (LDS) the small parts of the records, by landmark q = slot s0k + q
+  double2 hS[CAD_SLOTS][5];             // H_q: {H[0][k], H[1][k]}
+  double siS[CAD_SLOTS][4];             // S_q^-1, row-major
+  double2 yS[CAD_SLOTS];                // innovation
+  double2 pgS[CAD_SLOTS + 1];           // predictions in front of landmark q, summed from the cadence's start; [nk]: all
+};
+// threads 0 .. 39 and 64 .. 104 of the workgroup; a barrier behind it
+__device__ __forceinline__ void chain_stage_records(const CadOut& op, int nk, int s0k, ChainRec& R, int tid) {
+  using G = CadGeom;
+  double2 (&hS)[CAD_SLOTS][5] = R.hS;
+  double (&siS)[CAD_SLOTS][4] = R.siS;
+  double2 (&yS)[CAD_SLOTS] = R.yS;
+  double2 (&pgS)[CAD_SLOTS + 1] = R.pgS;
+  if (tid < CAD_SLOTS) {
+    double4_t si = {0.0, 0.0, 0.0, 0.0};
+    double2 y = make_double2(0.0, 0.0);
+    double2 hh[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) hh[k] = make_double2(0.0, 0.0);
+    if (tid < nk) {                                    // landmark tid = slot s0k + tid
+      const double* rec = op.rec + G::rec_off(s0k + tid);
+#pragma unroll
+      for (int k = 0; k < 5; ++k) hh[k] = *reinterpret_cast<const double2*>(rec + 2 * k);
+      const double2 sa = *reinterpret_cast<const double2*>(rec + 10), sb = *reinterpret_cast<const double2*>(rec + 12);
+      si = double4_t{sa.x, sa.y, sb.x, sb.y};
+      y = *reinterpret_cast<const double2*>(rec + 14);
+    }
+#pragma unroll
+    for (int k = 0; k < 5; ++k) hS[tid][k] = hh[k];
+    siS[tid][0] = si[0];
+    siS[tid][1] = si[1];
+    siS[tid][2] = si[2];
+    siS[tid][3] = si[3];
+    yS[tid] = y;
+  }
+  if (tid >= 64 && tid <= 64 + CAD_SLOTS) {
+    // the panel launch applies touched step t's prediction in front of slot sfirst[t] (k_panels_cad: predictions_before);
+    // predictions only ever add multiples of row 2 to rows 0, 1, so their g add up
+    const int q = tid - 64, np = min(op.npred, CAD_SLOTS);
+    double g0 = 0.0, g1 = 0.0;
+    for (int t = 0; t < np; ++t) {
+      if (q == nk || op.sfirst[t] <= s0k + q) {
+        g0 += op.g[t][0];
+        g1 += op.g[t][1];
+      }
+    }
+    pgS[q] = make_double2(g0, g1);
+  }
+}
+// the 2 x 2 blocks C_{q,r}, r < q, and the rows behind the cadence (q = nk) into Cm (zeroed, a barrier in front); all threads
+__device__ __forceinline__ void chain_coefficient_blocks(const CadOut& op, int nk, int s0k, const ChainRec& R, double (*Cm)[CH_CS],
+                                                         int tid) {
+  using G = CadGeom;
+  const double2 (&hS)[CAD_SLOTS][5] = R.hS;
+  const double2 (&pgS)[CAD_SLOTS + 1] = R.pgS;
+  {
+    const int tri = nk * (nk - 1) / 2, items = tri + nk;
+    for (int e = tid; e < items; e += 64 * CAD_NW) {
+      int q, r;
+      if (e < tri) {
+        q = (int)((1.0f + sqrtf(1.0f + 8.0f * (float)e)) * 0.5f);   // q (q - 1) / 2 <= e < q (q + 1) / 2
+        while (q * (q - 1) / 2 > e) --q;
+        while (q * (q + 1) / 2 <= e) ++q;
+        r = e - q * (q - 1) / 2;
+      } else {
+        q = nk;
+        r = e - tri;
+      }
+      const double* rr = op.rec + G::rec_off(s0k + r) + 16;          // K_r[a] = (rr[2a], rr[2a + 1])
+      const double2 k0 = *reinterpret_cast<const double2*>(rr), k1 = *reinterpret_cast<const double2*>(rr + 2),
+                    k2 = *reinterpret_cast<const double2*>(rr + 4);
+      const double2 gq = pgS[q], gr = pgS[r];
+      const double g0 = gq.x - gr.x, g1 = gq.y - gr.y;              // the predictions between landmark r and landmark q
+      if (q < nk) {
+        const int paq = G::pa(s0k + q);
+        const double2 h0 = hS[q][0], h1 = hS[q][1], h2 = hS[q][2], h3 = hS[q][3], h4 = hS[q][4];
+        const double2 ka = *reinterpret_cast<const double2*>(rr + 2 * paq), kb = *reinterpret_cast<const double2*>(rr + 2 * paq + 2);
+        // row w of H_q[:, 0..2] G = (h[w][0], h[w][1], h[w][2] + g0 h[w][0] + g1 h[w][1])
+        const double hx2 = fma(g0, h0.x, fma(g1, h1.x, h2.x)), hy2 = fma(g0, h0.y, fma(g1, h1.y, h2.y));
+        Cm[2 * q][2 * r] = h0.x * k0.x + h1.x * k1.x + hx2 * k2.x + h3.x * ka.x + h4.x * kb.x;
+        Cm[2 * q][2 * r + 1] = h0.x * k0.y + h1.x * k1.y + hx2 * k2.y + h3.x * ka.y + h4.x * kb.y;
+        Cm[2 * q + 1][2 * r] = h0.y * k0.x + h1.y * k1.x + hy2 * k2.x + h3.y * ka.x + h4.y * kb.x;
+        Cm[2 * q + 1][2 * r + 1] = h0.y * k0.y + h1.y * k1.y + hy2 * k2.y + h3.y * ka.y + h4.y * kb.y;
+      } else {                                                      // rows 0..2 of G^{(end, r)} K_r[0..2, :]
+        Cm[KTOT][2 * r] = fma(g0, k2.x, k0.x);
+        Cm[KTOT][2 * r + 1] = fma(g0, k2.y, k0.y);
+        Cm[KTOT + 1][2 * r] = fma(g1, k2.x, k1.x);
+        Cm[KTOT + 1][2 * r + 1] = fma(g1, k2.y, k1.y);
+        Cm[KTOT + 2][2 * r] = k2.x;
+        Cm[KTOT + 2][2 * r + 1] = k2.y;
+        // rows 83, 84 (the panel form of the launch): what the cadence's predictions alone add to rows 0, 1 -- the in-place
+        // share of P_base(0, i), P_base(1, i) beside the ranks -- is  ge_p X[2]  minus these coefficients times E
+        Cm[KTOT + 3][2 * r] = g0 * k2.x;
+        Cm[KTOT + 3][2 * r + 1] = g0 * k2.y;
+        Cm[KTOT + 4][2 * r] = g1 * k2.x;
+        Cm[KTOT + 4][2 * r + 1] = g1 * k2.y;
+      }
+    }
+  }
+}
+// Linv_i = (I + C_ii)^-1 by substitution on the identity (wave i < 5, a column per lane); barriers around it are the caller's
+__device__ __forceinline__ void chain_invert_diagonal(const double (*Cm)[CH_CS], double (*Li)[16][17], int wave, int lane) {
+  if (wave < 5 && lane < 16) {
+    const int i = wave, c = lane;
+    double t[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t[k] = k == c ? 1.0 : 0.0;
+#pragma unroll
+    for (int j = 1; j < 8; ++j) {
+      double2 c0[7], c1[7];
+#pragma unroll
+      for (int jp = 0; jp < j; ++jp) {                 // the landmark's coefficients within the block: all reads in flight together
+        c0[jp] = *reinterpret_cast<const double2*>(&Cm[16 * i + 2 * j][16 * i + 2 * jp]);
+        c1[jp] = *reinterpret_cast<const double2*>(&Cm[16 * i + 2 * j + 1][16 * i + 2 * jp]);
+      }
+#pragma unroll
+      for (int jp = 0; jp < j; ++jp) {
+        t[2 * j] = fma(-c0[jp].x, t[2 * jp], t[2 * j]);
+        t[2 * j + 1] = fma(-c1[jp].x, t[2 * jp], t[2 * j + 1]);
+        t[2 * j] = fma(-c0[jp].y, t[2 * jp + 1], t[2 * j]);
+        t[2 * j + 1] = fma(-c1[jp].y, t[2 * jp + 1], t[2 * j + 1]);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) Li[i][k][c] = t[k];
+  }
+}
+// Linv_i C_{i,<i} in place (tiles of 16 x 16 over the waves): a block step of the solve becomes ONE product
+__device__ __forceinline__ void chain_scale_blocks(double (*Cm)[CH_CS], const double (*Li)[16][17], int nk, int wave, int lane) {
+  const int li = lane & 15, lq = lane >> 4;
+  for (int job = wave; job < 10; job += CAD_NW) {      // (i, j), j < i <= 4: tile (rows of block i, columns of block j)
+    int i = 1, j = job;
+    while (j >= i) {
+      j -= i;
+      ++i;
+    }
+    if (8 * i < nk) {                                  // (uniform)
+      double4_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Li[i][li][4 * kt + lq], Cm[16 * i + 4 * kt + lq][16 * j + li], acc, 0, 0, 0);
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) Cm[16 * i + lq + 4 * reg][16 * j + li] = acc[reg];
+    }
+  }
+}
+
 __global__ __launch_bounds__(64 * CAD_NW) void k_chain_cad(const double* __restrict__ P, const double* __restrict__ prow3,
                                                            const double* __restrict__ mu_land, const double* __restrict__ mu_pose,
                                                            const CadOut* __restrict__ prev, const StepIn* __restrict__ in,
@@ -1357,13 +1535,52 @@ __global__ __launch_bounds__(64 * CAD_NW) void k_chain_cad(const double* __restr
                                                            long pstride, double* __restrict__ gbuf, double* __restrict__ gmu,
                                                            double* __restrict__ xg, double* __restrict__ bg,
                                                            unsigned* __restrict__ sync, unsigned gather_target,
-                                                           unsigned* __restrict__ flags, int gw, unsigned sigma) {
+                                                           unsigned* __restrict__ flags, int gw, unsigned sigma,
+                                                           const CadPre* __restrict__ pre_in, CadPre* __restrict__ pre_out,
+                                                           const CadPlan* __restrict__ plan2) {
   using G = CadGeom;
   constexpr int CU = G::CU;
   __shared__ int Cs[128], Ck[128];
   __shared__ int cntS[CAD_SLOTS + 1], firstS[CAD_SLOTS + 1], loS[CAD_SLOTS + 1];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if ((int)blockIdx.x >= batch * (1 + gw)) {
+    // ---- the POSITIONS workgroups of the launch (one per trajectory, where another cadence follows the next one): the inputs of
+    // the cadence AFTER the next as its solve, its chain launch and that launch's gather workgroups need them (CadPre) ----
+    const int b = (int)blockIdx.x - batch * (1 + gw);
+    __shared__ double2 zP[CAD_SLOTS];
+    const CadPlan pl2 = plan2[b];
+    if (tid < CAD_SLOTS) zP[tid] = make_double2(0.0, 0.0);
+    __syncthreads();
+    const int ns2 = cad_positions<true>(pl2, in, batch, b, cfg, tid, Cs, cntS, firstS, loS,
+                                        [&](int s, double zr, double zb) { zP[s] = make_double2(zr, zb); });
+    __syncthreads();
+    CadPre& po = pre_out[b];
+    if (tid < 128) po.C[tid] = Cs[tid];
+    if (tid <= CAD_SLOTS) {
+      po.cnt[tid] = cntS[tid];
+      po.first[tid] = firstS[tid];
+      po.lo[tid] = loS[tid];
+    }
+    if (tid < CAD_SLOTS) {
+      int fl = 0;
+      double lin = 0.0, ang = 0.0;
+      if (tid < pl2.ns) {
+        const StepIn& st = in[(long)(pl2.t0 + tid) * batch + b];
+        fl = st.flags;
+        if (tid == 0 && pl2.j0 > 0) fl &= ~FLAG_PREDICT;   // a step cut by the previous cadence: its prediction has happened
+        lin = st.lin;
+        ang = st.ang;
+      }
+      po.fl[tid] = fl;
+      po.la[tid][0] = lin;
+      po.la[tid][1] = ang;
+      po.z[tid][0] = zP[tid].x;
+      po.z[tid][1] = zP[tid].y;
+    }
+    if (tid == 0) po.nslots = ns2;
+    return;
+  }
   if ((int)blockIdx.x >= batch) {
     // ---- the GATHER workgroups of the launch: X = P_0(C_u, C') and P_0(C', C') as coalesced rows (xg, bg: batch x 84 x 88) ----
     // 13.8 k scattered 8-byte entries per trajectory, and a CU takes about a cycle per cache line it touches: 13 us on the one CU
@@ -1374,7 +1591,14 @@ __global__ __launch_bounds__(64 * CAD_NW) void k_chain_cad(const double* __restr
     const CadOut& op = prev[b];
     const int cuk = 3 + 2 * min(op.nslots, CAD_SLOTS);
     if (tid < 128) Ck[tid] = tid < CU ? op.C[tid] : 0;
-    const int cu = 3 + 2 * cad_positions<false>(plan[b], in, batch, b, cfg, tid, Cs, cntS, firstS, loS, [](int, double, double) {});
+    int ns1;
+    if (pre_in) {                                      // (uniform) formed one cadence ahead
+      if (tid < 128) Cs[tid] = pre_in[b].C[tid];
+      ns1 = pre_in[b].nslots;
+    } else {
+      ns1 = cad_positions<false>(plan[b], in, batch, b, cfg, tid, Cs, cntS, firstS, loS, [](int, double, double) {});
+    }
+    const int cu = 3 + 2 * ns1;
     // P_base and the pose rows are what the previous covariance pass (and the panel launch in front of it) left: the gate
     // launch behind that pass has said so (sigma - 1); the entries are read past this XCD's L2, which may hold older ones
     if (tid == 0 && !sync_wait(sync + SYNC_PASS * SYNC_STRIDE, sigma - 1u)) atomicOr(flags + b, EKF_FLAG_INTERNAL);
@@ -1414,10 +1638,11 @@ __global__ __launch_bounds__(64 * CAD_NW) void k_chain_cad(const double* __restr
   __shared__ __attribute__((aligned(16))) double A[CH_R][CH_S];      // A X -> E (rows 0..79), the pose rows behind the cadence (80..82)
   __shared__ __attribute__((aligned(16))) double B[CH_R][CH_CS];     // the coefficients C -> Linv C  ->  -F  ->  F^T E
   __shared__ __attribute__((aligned(16))) double Li[5][16][17];      // inverses of the diagonal blocks I + C_ii
-  __shared__ double2 hS[CAD_SLOTS][5];                 // H_q: {H[0][k], H[1][k]}
-  __shared__ double siS[CAD_SLOTS][4];
-  __shared__ double2 yS[CAD_SLOTS];
-  __shared__ double2 pgS[CAD_SLOTS + 1];               // predictions in front of landmark q, summed from the cadence's start; [nk]: all
+  __shared__ ChainRec R;
+  double2 (&hS)[CAD_SLOTS][5] = R.hS;
+  double (&siS)[CAD_SLOTS][4] = R.siS;
+  double2 (&yS)[CAD_SLOTS] = R.yS;
+  double2 (&pgS)[CAD_SLOTS + 1] = R.pgS;
   __shared__ double dmS[5][CH_NC];                     // partial sums of the mean update, 8 landmarks each
   double (*Cm)[CH_CS] = B;
   const int b = blockIdx.x;
@@ -1427,42 +1652,14 @@ __global__ __launch_bounds__(64 * CAD_NW) void k_chain_cad(const double* __restr
   // this launch runs: the solve in front of it on the stream has completed -- what the gate on the other stream waits for
   if (tid == 0) __hip_atomic_store(sync + SYNC_SOLVE * SYNC_STRIDE, sigma, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   CHSTAMP(0);
-  if (tid < CAD_SLOTS) {
-    double4_t si = {0.0, 0.0, 0.0, 0.0};
-    double2 y = make_double2(0.0, 0.0);
-    double2 hh[5];
-#pragma unroll
-    for (int k = 0; k < 5; ++k) hh[k] = make_double2(0.0, 0.0);
-    if (tid < nk) {                                    // landmark tid = slot s0k + tid
-      const double* rec = op.rec + G::rec_off(s0k + tid);
-#pragma unroll
-      for (int k = 0; k < 5; ++k) hh[k] = *reinterpret_cast<const double2*>(rec + 2 * k);
-      const double2 sa = *reinterpret_cast<const double2*>(rec + 10), sb = *reinterpret_cast<const double2*>(rec + 12);
-      si = double4_t{sa.x, sa.y, sb.x, sb.y};
-      y = *reinterpret_cast<const double2*>(rec + 14);
-    }
-#pragma unroll
-    for (int k = 0; k < 5; ++k) hS[tid][k] = hh[k];
-    siS[tid][0] = si[0];
-    siS[tid][1] = si[1];
-    siS[tid][2] = si[2];
-    siS[tid][3] = si[3];
-    yS[tid] = y;
+  chain_stage_records(op, nk, s0k, R, tid);
+  int nslots;
+  if (pre_in) {                                        // (uniform) the next cadence's positions, formed one cadence ahead
+    if (tid < 128) Cs[tid] = pre_in[b].C[tid];
+    nslots = pre_in[b].nslots;
+  } else {
+    nslots = cad_positions<false>(pl, in, batch, b, cfg, tid, Cs, cntS, firstS, loS, [](int, double, double) {});
   }
-  if (tid >= 64 && tid <= 64 + CAD_SLOTS) {
-    // the panel launch applies touched step t's prediction in front of slot sfirst[t] (k_panels_cad: predictions_before);
-    // predictions only ever add multiples of row 2 to rows 0, 1, so their g add up
-    const int q = tid - 64, np = min(op.npred, CAD_SLOTS);
-    double g0 = 0.0, g1 = 0.0;
-    for (int t = 0; t < np; ++t) {
-      if (q == nk || op.sfirst[t] <= s0k + q) {
-        g0 += op.g[t][0];
-        g1 += op.g[t][1];
-      }
-    }
-    pgS[q] = make_double2(g0, g1);
-  }
-  const int nslots = cad_positions<false>(pl, in, batch, b, cfg, tid, Cs, cntS, firstS, loS, [](int, double, double) {});
   const int cu = 3 + 2 * nslots;                       // the next cadence: positions in use
   // ---- the coefficients of (I + C) E = A X: zero, then the 2 x 2 blocks (q, r), r < q, and the pose rows (q = nk) ----
   {
@@ -1471,44 +1668,7 @@ __global__ __launch_bounds__(64 * CAD_NW) void k_chain_cad(const double* __restr
   }
   __syncthreads();
   CHSTAMP(1);
-  {
-    const int tri = nk * (nk - 1) / 2, items = tri + nk;
-    for (int e = tid; e < items; e += 64 * CAD_NW) {
-      int q, r;
-      if (e < tri) {
-        q = (int)((1.0f + sqrtf(1.0f + 8.0f * (float)e)) * 0.5f);   // q (q - 1) / 2 <= e < q (q + 1) / 2
-        while (q * (q - 1) / 2 > e) --q;
-        while (q * (q + 1) / 2 <= e) ++q;
-        r = e - q * (q - 1) / 2;
-      } else {
-        q = nk;
-        r = e - tri;
-      }
-      const double* rr = op.rec + G::rec_off(s0k + r) + 16;          // K_r[a] = (rr[2a], rr[2a + 1])
-      const double2 k0 = *reinterpret_cast<const double2*>(rr), k1 = *reinterpret_cast<const double2*>(rr + 2),
-                    k2 = *reinterpret_cast<const double2*>(rr + 4);
-      const double2 gq = pgS[q], gr = pgS[r];
-      const double g0 = gq.x - gr.x, g1 = gq.y - gr.y;              // the predictions between landmark r and landmark q
-      if (q < nk) {
-        const int paq = G::pa(s0k + q);
-        const double2 h0 = hS[q][0], h1 = hS[q][1], h2 = hS[q][2], h3 = hS[q][3], h4 = hS[q][4];
-        const double2 ka = *reinterpret_cast<const double2*>(rr + 2 * paq), kb = *reinterpret_cast<const double2*>(rr + 2 * paq + 2);
-        // row w of H_q[:, 0..2] G = (h[w][0], h[w][1], h[w][2] + g0 h[w][0] + g1 h[w][1])
-        const double hx2 = fma(g0, h0.x, fma(g1, h1.x, h2.x)), hy2 = fma(g0, h0.y, fma(g1, h1.y, h2.y));
-        Cm[2 * q][2 * r] = h0.x * k0.x + h1.x * k1.x + hx2 * k2.x + h3.x * ka.x + h4.x * kb.x;
-        Cm[2 * q][2 * r + 1] = h0.x * k0.y + h1.x * k1.y + hx2 * k2.y + h3.x * ka.y + h4.x * kb.y;
-        Cm[2 * q + 1][2 * r] = h0.y * k0.x + h1.y * k1.x + hy2 * k2.x + h3.y * ka.x + h4.y * kb.x;
-        Cm[2 * q + 1][2 * r + 1] = h0.y * k0.y + h1.y * k1.y + hy2 * k2.y + h3.y * ka.y + h4.y * kb.y;
-      } else {                                                      // rows 0..2 of G^{(end, r)} K_r[0..2, :]
-        Cm[KTOT][2 * r] = fma(g0, k2.x, k0.x);
-        Cm[KTOT][2 * r + 1] = fma(g0, k2.y, k0.y);
-        Cm[KTOT + 1][2 * r] = fma(g1, k2.x, k1.x);
-        Cm[KTOT + 1][2 * r + 1] = fma(g1, k2.y, k1.y);
-        Cm[KTOT + 2][2 * r] = k2.x;
-        Cm[KTOT + 2][2 * r + 1] = k2.y;
-      }
-    }
-  }
+  chain_coefficient_blocks(op, nk, s0k, R, Cm, tid);
   __syncthreads();
   CHSTAMP(2);
   const int li = lane & 15, lq = lane >> 4;
@@ -1518,30 +1678,7 @@ __global__ __launch_bounds__(64 * CAD_NW) void k_chain_cad(const double* __restr
     // (meanwhile, one lane of an idle wave) the gathered rows are there: the launch's gather workgroups have counted themselves off
     if (!sync_wait(sync + SYNC_GATHER * SYNC_STRIDE, gather_target)) atomicOr(flags + b, EKF_FLAG_INTERNAL);
   }
-  if (wave < 5 && lane < 16) {
-    const int i = wave, c = lane;
-    double t[16];
-#pragma unroll
-    for (int k = 0; k < 16; ++k) t[k] = k == c ? 1.0 : 0.0;
-#pragma unroll
-    for (int j = 1; j < 8; ++j) {
-      double2 c0[7], c1[7];
-#pragma unroll
-      for (int jp = 0; jp < j; ++jp) {                 // the landmark's coefficients within the block: all reads in flight together
-        c0[jp] = *reinterpret_cast<const double2*>(&Cm[16 * i + 2 * j][16 * i + 2 * jp]);
-        c1[jp] = *reinterpret_cast<const double2*>(&Cm[16 * i + 2 * j + 1][16 * i + 2 * jp]);
-      }
-#pragma unroll
-      for (int jp = 0; jp < j; ++jp) {
-        t[2 * j] = fma(-c0[jp].x, t[2 * jp], t[2 * j]);
-        t[2 * j + 1] = fma(-c1[jp].x, t[2 * jp], t[2 * j + 1]);
-        t[2 * j] = fma(-c0[jp].y, t[2 * jp + 1], t[2 * j]);
-        t[2 * j + 1] = fma(-c1[jp].y, t[2 * jp + 1], t[2 * j + 1]);
-      }
-    }
-#pragma unroll
-    for (int k = 0; k < 16; ++k) Li[i][k][c] = t[k];
-  }
+  chain_invert_diagonal(Cm, Li, wave, lane);
   __syncthreads();
   CHSTAMP(3);
   // ---- the gathered rows: everything this workgroup reads of them is requested here, the products below run under the
@@ -1578,21 +1715,7 @@ __global__ __launch_bounds__(64 * CAD_NW) void k_chain_cad(const double* __restr
     lb0[u] = hb ? ld_dev(xgb + (long)paq * CAD_CS + jb) : 0.0;
     lb1[u] = hb ? ld_dev(xgb + (long)(paq + 1) * CAD_CS + jb) : 0.0;
   }
-  for (int job = wave; job < 10; job += CAD_NW) {      // (i, j), j < i <= 4: tile (rows of block i, columns of block j)
-    int i = 1, j = job;
-    while (j >= i) {
-      j -= i;
-      ++i;
-    }
-    if (8 * i < nk) {                                  // (uniform)
-      double4_t acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-      for (int kt = 0; kt < 4; ++kt)
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Li[i][li][4 * kt + lq], Cm[16 * i + 4 * kt + lq][16 * j + li], acc, 0, 0, 0);
-#pragma unroll
-      for (int reg = 0; reg < 4; ++reg) Cm[16 * i + lq + 4 * reg][16 * j + li] = acc[reg];
-    }
-  }
+  chain_scale_blocks(Cm, Li, nk, wave, lane);
   CHSTAMP(4);
   // ---- the right-hand side A X, row by row: A_q = H_q[:, 0..2] G^{(q,-1)} at the pose positions, H_q[:, 3..4] at the landmark's
   // own -- five rows of X per landmark, each landmark row of X read exactly once (straight from xg, coalesced); the pose rows
@@ -1754,6 +1877,216 @@ __global__ __launch_bounds__(64 * CAD_NW) void k_chain_cad(const double* __restr
   CHSTAMP(10);
 }
 
+// ---------------------------------------------------------------------------------------------
+// k_panels_cad_tf (round 6): the panel launch of a CHAINED cadence in the latency regime, as the same triangular solve
+// k_chain_cad uses -- the cadence's rank rows at the state indices i of this workgroup are  E = (I + C)^-1 (A X)  with
+// X = P_0(C_u, i)  -- instead of the replay of its 40 landmarks one after the other (k_panels_cad_ks: 0.7 us per landmark,
+// 27 us for a single trajectory's panel launch whatever the number of CUs it has to itself).  One 8-wave workgroup per 64 state
+// indices: every workgroup forms the coefficients C, the inverses of their diagonal blocks and Linv C from the records itself
+// (as k_chain_cad does beside it: nothing to hand over), gathers its 83 x 64 entries of X meanwhile, forms A X (five rows of X
+// per landmark) in LDS and takes five block steps on the matrix cores, 4 column tiles on 4 waves -- ~70 dependent MFMAs.
+// Rows of the product: 0..79 the rank rows (V; W = -S^-1-scaled), 80..82 the pose rows behind the cadence (-> prow3 for the
+// next chained block), 83..84 what the cadence's predictions add to P_base(0, i), P_base(1, i) in place.  Same algebra as
+// the replay in a different order of summation: equal to rounding (tests/test_gpu_cadence.py), not bit for bit.
+// ---------------------------------------------------------------------------------------------
+constexpr int TF_S = 65;                // LDS row stride of the right-hand sides (64 state indices)
+
+__global__ __launch_bounds__(64 * CAD_NW) void k_panels_cad_tf(double* __restrict__ P, double* __restrict__ V,
+                                                               double* __restrict__ W, const double* __restrict__ mu_in,
+                                                               double* __restrict__ mu_out, const int* __restrict__ nact,
+                                                               const CadOut* __restrict__ co, SolveOut* __restrict__ so,
+                                                               unsigned* __restrict__ queue, int ld, long pstride, int nrp,
+                                                               double* __restrict__ prow3, unsigned* __restrict__ sync,
+                                                               unsigned head_sigma, unsigned tail_target,
+                                                               unsigned* __restrict__ flags, unsigned start_sigma) {
+  using G = CadGeom;
+  constexpr int GM = G::GM, CU = G::CU;
+  __shared__ __attribute__((aligned(16))) double A[CH_R][TF_S];      // A X -> the rows of the product
+  __shared__ __attribute__((aligned(16))) double Cm[CH_R][CH_CS];    // the coefficients C -> Linv C
+  __shared__ __attribute__((aligned(16))) double Li[5][16][17];
+  __shared__ ChainRec R;
+  __shared__ double xpS[3][64];                        // X[0..2][i]: the pose rows of this workgroup's state indices
+  __shared__ double dmS[5][64];
+  __shared__ int Ck[128];
+  const unsigned* tail_word = sync ? sync + SYNC_GATHER * SYNC_STRIDE : nullptr;
+  if (sync && head_sigma) panel_head_wait(sync, head_sigma, flags);
+  const int b = blockIdx.y;
+  const int n = nact[b];
+  const int i0 = blockIdx.x * 64;
+  if (i0 >= n) return;
+  const CadOut& o = co[b];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nslots = min(o.nslots, GM), npred = o.npred, neff = o.neff;
+  const int s0 = GM - nslots;
+  const int ld16 = ld >> 4;
+  double* Pb = P + (long)b * pstride;
+  double* Vb = V + (long)b * KTOT * ld;
+  double* Wb = W + (long)b * KTOT * ld;
+  const int i = i0 + lane;
+  const bool act = i < n;
+  const int ii = act ? i : n - 1;                      // idle lanes shadow the last state index (no stores)
+  const bool actw = act && i >= 3;                     // the pose's state indices are the solve's
+  const bool live = i0 < neff && (nslots > 0 || npred > 0);   // (uniform) this workgroup has something to do
+  if (!live) {
+    // beyond the active bound the rows and columns of P are exactly zero off the diagonal (and an idle trajectory appends
+    // nothing): the cadence's ranks are zero there and the mean is carried over
+    if (actw && wave == 0) {
+      for (int k = 0; k < nrp; ++k) {
+        Vb[(long)k * ld + i] = 0.0;
+        Wb[wm_index(ld16, k, i)] = 0.0;
+      }
+      mu_out[(long)b * ld + i] = mu_in[(long)b * ld + i];
+      if (prow3) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) prow3[((long)b * 3 + a) * ld + i] = Pb[p_index(ld, a, i)];
+      }
+    }
+    if (blockIdx.x == 0 && wave == 0) pose_epilogue(o, Pb, Vb, Wb, so, queue, b, ld, lane, nrp, tail_word, tail_target, flags, start_sigma);
+    return;
+  }
+  // ---- the gathers first (nothing of them depends on the records' arithmetic): position pair p = wave + 8 q (positions
+  // 3 + 2 p, 4 + 2 p: the two state indices of ONE landmark, the rows of slot GM - 1 - p), lanes = state indices ----
+  if (tid < 128) Ck[tid] = tid < CU ? o.C[tid] : 0;
+  chain_stage_records(o, nslots, s0, R, tid);
+  __syncthreads();
+  constexpr int PQ = GM / CAD_NW;                      // pairs per wave (5)
+  double x0[PQ], x1[PQ], xp = 0.0;
+#pragma unroll
+  for (int q = 0; q < PQ; ++q) {
+    const int a = 3 + 2 * (wave + CAD_NW * q);
+    const int c0 = Ck[a], c1 = Ck[a + 1];
+    if (c1 == c0 + 1 && i0 + 63 <= c0 && (c1 & (PPW - 1)) != 0) {   // (uniform) both mirrored: side by side in row i (see k_panels_cad)
+      const v2d_u v = *reinterpret_cast<const v2d_u*>(Pb + p_index(ld, ii, c0));
+      x0[q] = v.x;
+      x1[q] = v.y;
+    } else {
+      x0[q] = Pb[p_index(ld, min(c0, ii), max(c0, ii))];
+      x1[q] = Pb[p_index(ld, min(c1, ii), max(c1, ii))];
+    }
+  }
+  if (wave < 3) xp = Pb[p_index(ld, min(wave, ii), max(wave, ii))];
+  // ---- the coefficients (k_chain_cad's, formed again here: the two launches run side by side) ----
+  {
+    double2* z = reinterpret_cast<double2*>(&Cm[0][0]);
+    for (int e = tid; e < CH_R * CH_CS / 2; e += 64 * CAD_NW) z[e] = make_double2(0.0, 0.0);
+  }
+  if (wave < 3) xpS[wave][lane] = xp;
+  __syncthreads();
+  chain_coefficient_blocks(o, nslots, s0, R, Cm, tid);
+  __syncthreads();
+  chain_invert_diagonal(Cm, Li, wave, lane);
+  __syncthreads();
+  chain_scale_blocks(Cm, Li, nslots, wave, lane);
+  // ---- A X: landmark q's rows from the pose rows and ITS pair of rows of X (the wave that gathered the pair has them) ----
+  {
+    const double xa0 = xpS[0][lane], xa1 = xpS[1][lane], xa2 = xpS[2][lane];
+#pragma unroll
+    for (int q = 0; q < PQ; ++q) {
+      const int p = wave + CAD_NW * q, sl = GM - 1 - p, lq_ = sl - s0;   // the slot at this pair, its landmark number
+      if (lq_ >= 0) {                                  // (uniform) the pair is in use
+        double2 h[5];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) h[k] = R.hS[lq_][k];
+        const double2 gq = R.pgS[lq_];
+        const double hx2 = fma(gq.x, h[0].x, fma(gq.y, h[1].x, h[2].x)), hy2 = fma(gq.x, h[0].y, fma(gq.y, h[1].y, h[2].y));
+        A[2 * lq_][lane] = h[0].x * xa0 + h[1].x * xa1 + hx2 * xa2 + h[3].x * x0[q] + h[4].x * x1[q];
+        A[2 * lq_ + 1][lane] = h[0].y * xa0 + h[1].y * xa1 + hy2 * xa2 + h[3].y * x0[q] + h[4].y * x1[q];
+      } else {                                         // rows of landmarks the cadence does not have: zero
+        const int zr = 2 * (nslots + (p - nslots));    // (p >= nslots: rows 2 p, 2 p + 1 are beyond the cadence's)
+        A[zr][lane] = 0.0;
+        A[zr + 1][lane] = 0.0;
+      }
+    }
+    if (wave < 2) {                                    // rows 80 .. 95: the pose rows behind the cadence, the in-place rows, zeros
+      const double2 ge = R.pgS[nslots];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int r = KTOT + 8 * wave + k;
+        A[r][lane] = r == KTOT ? fma(ge.x, xa2, xa0) : (r == KTOT + 1 ? fma(ge.y, xa2, xa1) : (r == KTOT + 2 ? xa2 :
+                     (r == KTOT + 3 ? ge.x * xa2 : (r == KTOT + 4 ? ge.y * xa2 : 0.0))));
+      }
+    }
+  }
+  __syncthreads();
+  const int li = lane & 15, lq = lane >> 4;
+  // ---- Linv_i (A X)_i in place: 5 blocks x 4 column tiles over the waves ----
+  for (int job = wave; job < 20; job += CAD_NW) {
+    const int bi = job >> 2, ct = job & 3;
+    if (8 * bi < nslots) {                             // (uniform)
+      double4_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Li[bi][li][4 * kt + lq], A[16 * bi + 4 * kt + lq][16 * ct + li], acc, 0, 0, 0);
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) A[16 * bi + lq + 4 * reg][16 * ct + li] = acc[reg];
+    }
+  }
+  __syncthreads();
+  // ---- the block steps (a column tile per wave, waves 0..3: one per SIMD); bi = 5: the rows behind the cadence ----
+  for (int bi = 1; bi <= 5; ++bi) {
+    if (bi == 5 || 8 * bi < nslots) {                  // (uniform)
+      const int kts = bi == 5 ? (2 * nslots + 3) / 4 : 4 * bi;
+      if (wave < 4) {
+        double4_t acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+        int kt = 0;
+        for (; kt + 1 < kts; kt += 2) {
+          acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(Cm[16 * bi + li][4 * kt + lq], A[4 * kt + lq][16 * wave + li], acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(Cm[16 * bi + li][4 * kt + 4 + lq], A[4 * kt + 4 + lq][16 * wave + li], acc1, 0, 0, 0);
+        }
+        if (kt < kts)
+          acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(Cm[16 * bi + li][4 * kt + lq], A[4 * kt + lq][16 * wave + li], acc0, 0, 0, 0);
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) A[16 * bi + lq + 4 * reg][16 * wave + li] -= acc0[reg] + acc1[reg];
+      }
+      __syncthreads();
+    }
+  }
+  // ---- results: V rows and W (-S^-1-scaled) of the cadence's ranks, zero ranks up to the bank's count, the mean, the in-place
+  // share of rows 0, 1, the pose rows behind the cadence.  Landmarks over waves (5 each), state indices over lanes ----
+  {
+    double dm = 0.0;
+#pragma unroll
+    for (int u = 0; u < PQ; ++u) {
+      const int q = wave + CAD_NW * u;
+      if (q < nslots) {                                // (uniform)
+        const double e0 = A[2 * q][lane], e1 = A[2 * q + 1][lane];
+        const double f0 = e0 * R.siS[q][0] + e1 * R.siS[q][2], f1 = e0 * R.siS[q][1] + e1 * R.siS[q][3];
+        const double2 y = R.yS[q];
+        dm = fma(f0, y.x, dm);
+        dm = fma(f1, y.y, dm);
+        if (actw) {
+          Vb[(long)(2 * q) * ld + i] = e0;
+          Vb[(long)(2 * q + 1) * ld + i] = e1;
+          Wb[wm_index(ld16, 2 * q, i)] = -f0;
+          Wb[wm_index(ld16, 2 * q + 1, i)] = -f1;
+        }
+      }
+    }
+    if (wave < 5) dmS[wave][lane] = 0.0;
+    __syncthreads();
+    // (the mean's sum over the landmarks in a fixed order: wave w adds into row w % 5 in two rounds)
+    if (wave < 5) dmS[wave][lane] = dm;
+    __syncthreads();
+    if (wave >= 5) dmS[wave - 5][lane] += dm;
+    __syncthreads();
+  }
+  if (wave == 0 && actw) {
+    for (int k = 2 * nslots; k < nrp; ++k) {           // fewer ranks than the bank's busiest trajectory (and the k-tile pad): zeros
+      Vb[(long)k * ld + i] = 0.0;
+      Wb[wm_index(ld16, k, i)] = 0.0;
+    }
+    Pb[p_col(ld, i)] += A[KTOT + 3][lane];             // entry (0, i)
+    Pb[p_col(ld, i) + p_lds(ld)] += A[KTOT + 4][lane]; // entry (1, i)
+    mu_out[(long)b * ld + i] = mu_in[(long)b * ld + i] + ((((dmS[0][lane] + dmS[1][lane]) + dmS[2][lane]) + dmS[3][lane]) + dmS[4][lane]);
+    if (prow3) {
+#pragma unroll
+      for (int a = 0; a < 3; ++a) prow3[((long)b * 3 + a) * ld + i] = A[KTOT + a][lane];
+    }
+  }
+  if (blockIdx.x == 0 && wave == 0) pose_epilogue(o, Pb, Vb, Wb, so, queue, b, ld, lane, nrp, tail_word, tail_target, flags, start_sigma);
+}
+
 // (chained runs) the gate in front of a cadence's panel launch on the second stream: it runs behind the previous covariance pass
 // -- and says so (what the chain launch's gather workgroups wait for) --, and it ends when the cadence's solve has completed
 // (announced by the chain launch behind that solve).  One lane: it cannot keep the solve from finding its CUs, whatever the
@@ -1797,13 +2130,15 @@ void launch_gather_cad(hipStream_t st, const double* P, const double* V, const d
 void launch_solve_cad(hipStream_t st, const double* P, const double* mu_in, double* mu_out, double* dacc_out,
                       const int* nact, const StepIn* in, const CadPlan* plan, int batch, CadOut* out, unsigned* flags,
                       const DeviceConfig& cfg, int ld, long pstride, const double* gbuf, int gparts, double* colbuf, int n_hi,
-                      int col_wgs, bool chain, const double* gmu) {
+                      int col_wgs, bool chain, const double* gmu, unsigned* sync, unsigned start_sigma, const CadPre* pre) {
   if (chain)
     hipLaunchKernelGGL(k_solve_cad<true>, dim3(batch + (colbuf ? col_wgs : 0)), dim3(64 * CAD_NW), 0, st, P, mu_in, mu_out, dacc_out,
-                       nact, in, plan, batch, out, flags, cfg, ld, pstride, gbuf, gparts, colbuf, col_wgs, n_hi, gmu);
+                       nact, in, plan, batch, out, flags, cfg, ld, pstride, gbuf, gparts, colbuf, col_wgs, n_hi, gmu, sync, start_sigma,
+                       pre);
   else
     hipLaunchKernelGGL(k_solve_cad<false>, dim3(batch + (colbuf ? col_wgs : 0)), dim3(64 * CAD_NW), 0, st, P, mu_in, mu_out, dacc_out,
-                       nact, in, plan, batch, out, flags, cfg, ld, pstride, gbuf, gparts, colbuf, col_wgs, n_hi, nullptr);
+                       nact, in, plan, batch, out, flags, cfg, ld, pstride, gbuf, gparts, colbuf, col_wgs, n_hi, nullptr, nullptr, 0u,
+                       nullptr);
 }
 
 // (chained runs) the next cadence's block and mean from the records `prev` of the cadence whose solve has just run
@@ -1814,15 +2149,19 @@ int chain_sync_words() { return SYNC_WORDS; }
 void launch_chain_cad(hipStream_t st, const double* P, const double* prow3, const double* mu_land, const double* mu_pose,
                       const CadOut* prev, const StepIn* in, const CadPlan* plan, int batch, const DeviceConfig& cfg, int ld,
                       long pstride, double* gbuf, double* gmu, double* xg, double* bg, unsigned* sync, unsigned gather_target,
-                      unsigned* flags, int gw, unsigned sigma) {
-  hipLaunchKernelGGL(k_chain_cad, dim3(batch * (1 + gw)), dim3(64 * CAD_NW), 0, st, P, prow3, mu_land, mu_pose, prev, in, plan,
-                     batch, cfg, ld, pstride, gbuf, gmu, xg, bg, sync, gather_target, flags, gw, sigma);
+                      unsigned* flags, int gw, unsigned sigma, const CadPre* pre_in, CadPre* pre_out, const CadPlan* plan2) {
+  // (workgroups: the chain workgroup of every trajectory, its gather workgroups, and -- where a cadence follows the next one --
+  //  the positions workgroup that forms that cadence's inputs ahead)
+  hipLaunchKernelGGL(k_chain_cad, dim3(batch * (1 + gw + (pre_out ? 1 : 0))), dim3(64 * CAD_NW), 0, st, P, prow3, mu_land, mu_pose,
+                     prev, in, plan, batch, cfg, ld, pstride, gbuf, gmu, xg, bg, sync, gather_target, flags, gw, sigma, pre_in, pre_out,
+                     plan2);
 }
 
 void launch_gate(hipStream_t st, unsigned* sync, unsigned sigma, unsigned* flags, int batch) {
   hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, st, sync, sigma, flags, batch);
 }
 // workgroups of the panel launch (what decides between the launch being its own gate and the gate launch)
+bool panels_cad_latency_regime(int batch, int n_hi) { return (long)((n_hi + 63) / 64) * batch <= CAD_KS_WAVES; }
 int panels_cad_workgroups(int batch, int n_hi) {
   const long waves = (long)((n_hi + 63) / 64) * batch;
   return (int)(waves <= 1024 ? waves : (long)((n_hi + 255) / 256) * batch);
@@ -1836,18 +2175,24 @@ void launch_snap_pose(hipStream_t st, const double* P, const int* nact, int ld, 
 void launch_panels_cad(hipStream_t st, double* P, double* V, double* W, const double* mu_in, double* mu_out,
                        const int* nact, const CadOut* co, SolveOut* so, unsigned* queue, int ld, long pstride, int batch,
                        int n_hi, int nrp, const double* colbuf, double* prow3, unsigned* sync, unsigned head_sigma, unsigned tail_target,
-                       unsigned* flags) {
+                       unsigned* flags, bool tform, unsigned start_sigma) {
+  // (chained cadences in the latency regime: the triangular-solve form, one 8-wave workgroup per 64 state indices)
+  if (tform) {
+    hipLaunchKernelGGL(k_panels_cad_tf, dim3((n_hi + 63) / 64, batch), dim3(64 * CAD_NW), 0, st, P, V, W, mu_in, mu_out, nact, co, so,
+                       queue, ld, pstride, nrp, prow3, sync, head_sigma, tail_target, flags, start_sigma);
+    return;
+  }
   // few state indices (the latency regime): four waves split the rows of the panel of 64 state indices (k_panels_cad_ks);
   // up to one wave per SIMD: one wave per workgroup
   if ((long)((n_hi + 63) / 64) * batch <= CAD_KS_WAVES)
     hipLaunchKernelGGL(k_panels_cad_ks, dim3((n_hi + 63) / 64, batch), dim3(256), 0, st, P, V, W, mu_in, mu_out,
-                       nact, co, so, queue, ld, pstride, nrp, colbuf, prow3, sync, head_sigma, tail_target, flags);
+                       nact, co, so, queue, ld, pstride, nrp, colbuf, prow3, sync, head_sigma, tail_target, flags, start_sigma);
   else if ((long)((n_hi + 63) / 64) * batch <= 1024)
     hipLaunchKernelGGL((k_panels_cad<1>), dim3((n_hi + 63) / 64, batch), dim3(64), 0, st, P, V, W, mu_in, mu_out,
-                       nact, co, so, queue, ld, pstride, nrp, colbuf, prow3, sync, head_sigma, tail_target, flags);
+                       nact, co, so, queue, ld, pstride, nrp, colbuf, prow3, sync, head_sigma, tail_target, flags, start_sigma);
   else
     hipLaunchKernelGGL((k_panels_cad<4>), dim3((n_hi + 255) / 256, batch), dim3(256), 0, st, P, V, W, mu_in,
-                       mu_out, nact, co, so, queue, ld, pstride, nrp, colbuf, prow3, sync, head_sigma, tail_target, flags);
+                       mu_out, nact, co, so, queue, ld, pstride, nrp, colbuf, prow3, sync, head_sigma, tail_target, flags, start_sigma);
 }
 
 }  // namespace ekf

@@ -163,6 +163,18 @@ struct alignas(16) CadOut : CadHead {
   double posevw[CAD_SLOTS][3][4];   // the new ranks' entries at the pose's state indices l < 3: V[2s][l], V[2s+1][l], W[l][2s], W[l][2s+1]
   double posefin[4][4];             // (k_solve_cad<true>: chained runs) the pose block P(l, l') after the cadence, motion noise included
 };
+// (chained runs) a cadence's inputs as k_solve_cad needs them -- positions, per-step counts and slots, motion inputs,
+// measurements -- formed ONE CADENCE AHEAD by an otherwise idle workgroup of the chain launch (cad_positions is two dependent
+// memory round trips: 2.5 us at the head of the solve, of the chain launch and of its gather workgroups)
+struct alignas(16) CadPre {
+  int nslots, pad[3];
+  int C[128];                                // gathered state indices by position (0 beyond the cadence's)
+  int cnt[CAD_SLOTS + 4], first[CAD_SLOTS + 4], lo[CAD_SLOTS + 4];   // per touched step: landmarks, slots in front of it, first landmark
+  int fl[CAD_SLOTS];                         // per touched step: StepIn.flags (a first step cut by the previous cadence: no prediction)
+  double la[CAD_SLOTS][2];                   // per touched step: (lin, ang)
+  double z[CAD_SLOTS][2];                    // per slot: (range, bearing)
+};
+static_assert(sizeof(CadPre) % 16 == 0, "CadPre must stay 16-byte granular");
 static_assert(sizeof(CadHead) % 16 == 0, "CadHead must stay 16-byte granular");
 static_assert(sizeof(CadPlan) == 32, "CadPlan is 32 bytes");
 

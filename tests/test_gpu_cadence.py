@@ -332,6 +332,37 @@ def test_lookahead_solve_beside_the_pass(sd, N, B, m, steps):
         assert orc.rel_fro(res[mode][0][0], om) < TIGHT and orc.rel_fro(res[mode][0][1], oP) < TIGHT, mode
 
 
+def test_chained_solves_options_agree(sd):
+    """The pieces of the chained order one by one (N = 900 x 2, m ~ U{0..12}: cadences cut steps, trajectories at different
+    steps): the cadence's inputs formed one cadence ahead (`pre_positions`) and the panel launch as its own gate
+    (`panel_own_gate`, against the one-lane gate launch) change WHEN things are computed, not what: bit for bit.  The
+    triangular-solve form of the chained panel launch (`panel_tform`, k_panels_cad_tf) against the replay form
+    (k_panels_cad_ks): the same algebra in another order of summation, equal to PATH_TOL; every variant chained at every cadence."""
+    N, B, steps = 900, 2, 16
+    n = 3 + 2 * N
+    means, lin, ang, idx, zr, zb, m = wandering_stream(N, B, steps, lambda k, b, rng: rng.integers(0, 13), 9100)
+    starts = [dense_start(n, 9200 + t) for t in range(B)]
+    res = {}
+    for key, opts in {"default": (), "inline_positions": (("pre_positions", 0),), "gate_launch": (("panel_own_gate", 0),),
+                      "replay_panel": (("panel_tform", 0),)}.items():
+        with sd.EkfSlam(n, batch=B) as f:
+            f.set_option("active_bound", 0)
+            for name, value in opts:
+                f.set_option(name, value)
+            for b in range(B):
+                f.set_state(means[b], starts[b], b)
+            f.run_stream(lin, ang, idx, zr, zb, m)
+            res[key] = [f.state(b) for b in range(B)]
+            assert [f.flags(b) for b in range(B)] == [0] * B
+            nc = cadences(sd, f)[0]
+            assert nc >= 3 and chained(sd, f) == nc - 1
+    for b in range(B):
+        for key in ("inline_positions", "gate_launch"):
+            assert np.array_equal(res[key][b][0], res["default"][b][0]) and np.array_equal(res[key][b][1], res["default"][b][1]), key
+        assert orc.rel_fro(res["replay_panel"][b][0], res["default"][b][0]) < PATH_TOL
+        assert orc.rel_fro(res["replay_panel"][b][1], res["default"][b][1]) < PATH_TOL
+
+
 def test_lookahead_with_wandering_landmark_counts(sd):
     """The look-ahead with packed cadences whose steps are cut by the pass: the next cadence's block is gathered (k_gather_cad,
     from the plan's positions) while this cadence's ranks are pending, for trajectories that sit at different steps of the
