@@ -47,7 +47,8 @@ void launch_solve_cad(hipStream_t, const double*, const double*, double*, double
                       unsigned*, unsigned, const CadPre*);
 void launch_chain_cad(hipStream_t, const double*, const double*, const double*, const double*, const CadOut*, const StepIn*,
                       const CadPlan*, int, const DeviceConfig&, int, long, double*, double*, double*, double*, unsigned*, unsigned,
-                      unsigned*, int, unsigned, const CadPre*, CadPre*, const CadPlan*);
+                      unsigned*, int, unsigned, const CadPre*, CadPre*, const CadPlan*, bool);
+void launch_mark(hipStream_t, unsigned*, unsigned);
 void launch_gate(hipStream_t, unsigned*, unsigned, unsigned*, int);
 int panels_cad_workgroups(int, int);
 int chain_gather_workgroups(int, int);
@@ -172,6 +173,11 @@ struct ekf_handle : ekf::HostPlan {
   long pre_serial[2] = {-1, -1};
   long cad_serial = 0;
   int opt_pre_positions = 1;
+  // covariance (MB, whole bank) from which the next solve runs beside the pass in a chained run.  0: always -- with the counters'
+  // hand-overs chaining wins at every size tried (N = 12 .. 1000, banks of 1 .. 32: +25 .. +43 %); the round-3 look-ahead, whose
+  // hand-overs are events (~25 us per cadence), keeps its 48 MB
+  int opt_beside_min_mb = 0;
+  int opt_lookahead_min_mb = 48;
   hipEvent_t ev_solve = nullptr, ev_pass = nullptr, ev_nb = nullptr;
   bool chain_run = false;         // the run in flight records the transforms (every solve is k_solve_cad<true>)
   bool aux_pass = false;          // a covariance pass is in flight on the second stream (ev_pass recorded behind it)
@@ -950,7 +956,8 @@ static bool beside_the_pass(const ekf_handle* h, const PassPlan& plan) {
   // ... and for banks of up to 40 trajectories: every solve workgroup has to find a CU beside the pass, and the gather grows with
   // the bank (17 us at 32 trajectories, 71 us at 256) -- N = 500 x 32 +5 %, N = 300 x 48 -5 %, N = 200 x 128 -21 %,
   // N = 100 x 256 -36 % with the look-ahead (bench.py --option lookahead=0; round 4)
-  const bool small_pass = plan.kernel == 0 && h->batch <= 40 && (double)h->batch * 8.0 * plan.e_hi * plan.e_hi >= 48.0e6;
+  const bool small_pass = plan.kernel == 0 && h->batch <= 40 &&
+                          (double)h->batch * 8.0 * plan.e_hi * plan.e_hi >= 1.0e6 * (h->opt_chain ? h->opt_beside_min_mb : h->opt_lookahead_min_mb);
   const bool shares_pass = plan.kernel == 2 && (plan.beside || (plan.long_few && h->batch < 8 && h->opt_pass_workgroups > 0 &&
                                                                   h->opt_pass_workgroups + h->batch <= h->cu_count));
   return small_pass || shares_pass;
@@ -1021,35 +1028,60 @@ static int enqueue_cadence(ekf_handle* h, int c, bool presolved, bool* next_pres
   hipStream_t pst = h->stream;                         // the panel launch's stream
   unsigned* psync = nullptr;
   unsigned head_sigma = 0u, tail_target = 0u;
-  int gw = 0;
+  const CadPlan* dpl2 = dpl + h->batch;
+  int rc = EKF_OK;
   if (chain_next) {
-    // the second stream: gate (behind pass_{c-1}; ends when solve_c has completed) -> panel_c (ends when the gather workgroups of
-    // chain_{c+1} have read what the pass rewrites) -> pass_c.  No event: a hand-over through the command processor costs the
-    // waiting stream 7 us behind a record and ~19 us across streams (profiles/r06_chained_solves.txt); the counters cost a load.
+    // ---- chained.  The handle's stream: chain_{c+1} -> solve_{c+1}; the second stream: [gate ->] panel_c -> pass_c -> mark.
+    // No event: a hand-over through the command processor costs the waiting stream 7 us behind a record and ~19 us across
+    // streams (profiles/r06_chained_solves.txt); the counters cost a load.  ENQUEUED IN THIS ORDER: every device-side wait is
+    // for a launch that is already in its queue (chain_{c+1}'s gathers: the previous transition's mark; panel_c: chain_{c+1}'s
+    // start and gathers, solve_{c+1}'s start), so nothing can hang where the runtime maps both streams onto one hardware queue --
+    // and the host calls nothing that may block in between (every buffer exists before the run).
     h->sigma += 1u;
-    gw = chain_gather_workgroups(h->batch, h->cu_count);
+    const int gw = chain_gather_workgroups(h->batch, h->cu_count);
     h->gather_count += (unsigned)(h->batch * gw);
+    // (dmu2[cur] is the mean cadence c reads -- its landmark entries are the mean before the cadence --, dmu2[cur ^ 1] the one
+    //  its solve left the pose in; dcad2[cpar] cadence c's records, dprow3[cpar ^ 1] the pose rows BEFORE it)
+    ProfBracket pbc, pbs;
+    if (int rc2 = prof_open(h, 2, h->stream, &pbc)) return rc2;
+    // the next cadence's inputs if an earlier chain launch formed them; the one after it: formed by this launch
+    const CadPre* pre_in = (h->opt_pre_positions && h->pre_serial[(serial + 1) & 1] == serial + 1) ? h->dpre[(serial + 1) & 1] : nullptr;
+    CadPre* pre_out = (h->opt_pre_positions && c + 2 < rp.ncad) ? h->dpre[(serial + 2) & 1] : nullptr;
+    launch_chain_cad(h->stream, h->dP, h->dprow3[h->cpar ^ 1], h->dmu2[h->cur], h->dmu2[h->cur ^ 1], dcad, h->d_stream,
+                     dpl2, h->batch, h->dcfg, h->ld, h->pstride, h->dgbuf, h->dgmu, h->dxg, h->dbg, h->dsync, h->gather_count,
+                     h->dflags, gw, h->sigma, pre_in, pre_out, pre_out ? dpl2 + h->batch : nullptr, h->aux_pass);
+    if (pre_out) h->pre_serial[(serial + 2) & 1] = serial + 2;
+    if (int rc2 = prof_close(h, &pbc)) return rc2;
+    if (int rc2 = prof_open(h, 1, h->stream, &pbs)) return rc2;
+    launch_solve_cad(h->stream, h->dP, h->dmu2[h->cur ^ 1], h->dmu2[h->cur], h->ddacc2[h->dcur], h->dn, h->d_stream, dpl2,
+                     h->batch, h->dcad2[h->cpar ^ 1], h->dflags, h->dcfg, h->ld, h->pstride, h->dgbuf, 1, nullptr, n_hi, 0, true, h->dgmu,
+                     h->dsync, h->sigma, pre_in);
+    if (int rc2 = prof_close(h, &pbs)) return rc2;
+    // From here on the next cadence's solve overwrites the pose mean and the pending-noise buffer: a failure below cannot be
+    // undone.  Whatever happens the streams are joined, and a failure marks every trajectory undefined (EKF_ERR_STATE from
+    // then on, until it is uploaded again).
+    if (hipGetLastError() != hipSuccess) rc = fail(h, EKF_ERR_HIP, "chained solves: launch of the next cadence's solve failed");
     // (the panel launch is its own gate where each of its workgroups and each solve workgroup has a CU to itself: a tiny launch
-    //  costs the stream ~4 us, 5 % of a single trajectory's cadence)
+    //  costs the stream ~4 us)
     if (h->opt_panel_own_gate && panels_cad_workgroups(h->batch, n_hi) + 2 * h->batch <= h->cu_count / 2) head_sigma = h->sigma;
     else launch_gate(h->aux, h->dsync, h->sigma, h->dflags, h->batch);
     pst = h->aux;
     psync = h->dsync;
     tail_target = h->gather_count;
-  } else if (int rc = join_aux(h)) {
-    return rc;
+  } else if (int rc2 = join_aux(h)) {
+    return rc2;
   }
   {
     ProfBracket pb;
-    if (int rc = prof_open(h, 3, pst, &pb)) return rc;
+    if (int rc2 = prof_open(h, 3, pst, &pb)) return rc2;
     launch_panels_cad(pst, h->dP, h->dV, h->dW, mu_in, mu_out, h->dn, dcad, h->dso, h->dqueue, h->ld,
                       h->pstride, h->batch, n_hi, nrp, h->colbuf_live ? h->dcolbuf : nullptr, prow_out, psync, head_sigma, tail_target, h->dflags,
                       chain_next && h->opt_panel_tform && !h->colbuf_live && panels_cad_latency_regime(h->batch, n_hi),
                       chain_next ? h->sigma : 0u);
-    if (int rc = prof_close(h, &pb)) return rc;
+    if (int rc2 = prof_close(h, &pb)) return rc2;
   }
   h->colbuf_live = false;
-  HIP_TRY(h, hipGetLastError());
+  if (hipGetLastError() != hipSuccess && rc == EKF_OK) rc = fail(h, EKF_ERR_HIP, "fused cadence: launch of the panel kernel failed");
   h->dcur ^= 1;
   h->cur ^= 1;
   h->cpar ^= 1;
@@ -1057,39 +1089,11 @@ static int enqueue_cadence(ekf_handle* h, int c, bool presolved, bool* next_pres
   h->pending_steps += rp.steps_hi[c];
   h->cadences += 1;
   h->cadence_traj_steps += rp.steps_sum[c];
-  if (h->pending_k == 0) {                             // nothing observed anywhere in the bank: the panel launch has applied the noise
-    h->pending_steps = 0;
-    return EKF_OK;
-  }
-  if (!due) return EKF_OK;
-  if (!beside) return flush_pending(h);
-  const CadPlan* dpl2 = dpl + h->batch;
-  if (!h->dgbuf) HIP_TRY(h, hipMalloc(&h->dgbuf, sizeof(double) * cadence_gbuf_doubles() * h->batch));
-  int rc = EKF_OK;
   if (chain_next) {
-    // ---- chained: chain_{c+1} and solve_{c+1} on the handle's stream, pass_c behind the panel launch on the second ----
-    // (after the flips: dmu2[cur ^ 1] is the mean cadence c read -- its landmark entries are the mean before the cadence --,
-    //  dmu2[cur] the one its solve left the pose in; dcad2[cpar ^ 1] cadence c's records, dprow3[cpar] the pose rows BEFORE it)
-    ProfBracket pbc, pbs;
-    if (int rc2 = prof_open(h, 2, h->stream, &pbc)) return rc2;
-    // the next cadence's inputs if an earlier chain launch formed them; the one after it: formed by this launch
-    const CadPre* pre_in = (h->opt_pre_positions && h->pre_serial[(serial + 1) & 1] == serial + 1) ? h->dpre[(serial + 1) & 1] : nullptr;
-    CadPre* pre_out = (h->opt_pre_positions && c + 2 < rp.ncad) ? h->dpre[(serial + 2) & 1] : nullptr;
-    launch_chain_cad(h->stream, h->dP, h->dprow3[h->cpar], h->dmu2[h->cur ^ 1], h->dmu2[h->cur], h->dcad2[h->cpar ^ 1], h->d_stream,
-                     dpl2, h->batch, h->dcfg, h->ld, h->pstride, h->dgbuf, h->dgmu, h->dxg, h->dbg, h->dsync, h->gather_count,
-                     h->dflags, gw, h->sigma, pre_in, pre_out, pre_out ? dpl2 + h->batch : nullptr);
-    if (pre_out) h->pre_serial[(serial + 2) & 1] = serial + 2;
-    if (int rc2 = prof_close(h, &pbc)) return rc2;
-    if (int rc2 = prof_open(h, 1, h->stream, &pbs)) return rc2;
-    launch_solve_cad(h->stream, h->dP, h->dmu2[h->cur], h->dmu2[h->cur ^ 1], h->ddacc2[h->dcur ^ 1], h->dn, h->d_stream, dpl2,
-                     h->batch, h->dcad2[h->cpar], h->dflags, h->dcfg, h->ld, h->pstride, h->dgbuf, 1, nullptr, n_hi, 0, true, h->dgmu,
-                     h->dsync, h->sigma, pre_in);
-    if (int rc2 = prof_close(h, &pbs)) return rc2;
-    // From here on the next cadence's solve has overwritten the pose mean and the pending-noise buffer: a failure below
-    // cannot be undone.  Whatever happens the streams are joined, and a failure marks every trajectory undefined
-    // (EKF_ERR_STATE from then on, until it is uploaded again).
-    if (hipGetLastError() != hipSuccess) rc = fail(h, EKF_ERR_HIP, "chained solves: launch of the next cadence's solve failed");
+    // pass_c behind the panel launch on the second stream, then the mark the next chain launch's gather workgroups wait for
     if (rc == EKF_OK) rc = flush_pending(h, h->aux);
+    launch_mark(h->aux, h->dsync, h->sigma);
+    if (hipGetLastError() != hipSuccess && rc == EKF_OK) rc = fail(h, EKF_ERR_HIP, "chained solves: launch of the mark failed");
     h->aux_pass = true;
     if (rc != EKF_OK) {
       (void)hipStreamSynchronize(h->aux);
@@ -1103,6 +1107,14 @@ static int enqueue_cadence(ekf_handle* h, int c, bool presolved, bool* next_pres
     *next_presolved = true;
     return EKF_OK;
   }
+  if (rc != EKF_OK) return rc;
+  if (h->pending_k == 0) {                             // nothing observed anywhere in the bank: the panel launch has applied the noise
+    h->pending_steps = 0;
+    return EKF_OK;
+  }
+  if (!due) return EKF_OK;
+  if (!beside) return flush_pending(h);
+  if (!h->dgbuf) HIP_TRY(h, hipMalloc(&h->dgbuf, sizeof(double) * cadence_gbuf_doubles() * h->batch));
   // ---- look-ahead: gather (stream) -> { pass (second stream) | solve of the next cadence (stream) } -> join ----
   const int kb = (h->pending_k + 3) & ~3;
   {
@@ -1794,7 +1806,7 @@ extern "C" long ekf_debug_cad(ekf_handle* h, int b, void* dst, long bytes) {
 // no mirror, no status check: which = 0 P_base (device layout, ekf_device.h: rows x ld up to ld = 4096, column panels beyond), 1 V (80 x ld), 2 W (80 x ld, MFMA-tiled), 3 the mean buffer
 // the NEXT step reads, 4 the other mean buffer.  Returns the number of doubles the buffer holds (copies min(count, that)).
 extern "C" long ekf_debug_snapshot(ekf_handle* h, int b, int which, double* dst, long count) {
-  if (!h || b < 0 || b >= h->batch || which < 0 || which > 5) return -1;
+  if (!h || b < 0 || b >= h->batch || which < 0 || which > 6) return -1;
   if (hipSetDevice(h->device) != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess) return -1;
   const double* src = nullptr;
   long have = 0;
@@ -1803,6 +1815,7 @@ extern "C" long ekf_debug_snapshot(ekf_handle* h, int b, int which, double* dst,
     case 1: src = h->dV + (size_t)b * KTOT * h->ld; have = (long)KTOT * h->ld; break;
     case 2: src = h->dW + (size_t)b * KTOT * h->ld; have = (long)KTOT * h->ld; break;
     case 3: src = h->dmu2[h->cur] + (size_t)b * h->ld; have = h->ld; break;
+    case 6: src = h->dgbuf ? h->dgbuf + (size_t)b * 84 * 88 : nullptr; have = h->dgbuf ? 84L * 88 : 0; break;   // (chained solves: the last chained block of trajectory b, 84 x 88)
     case 5: src = h->dgmu; have = h->dgmu ? 128L * h->batch + 32 : 0; break;   // (chained solves: the means at the positions, all trajectories; then a -DCHAIN_STAMPS build's stamps)
     default: src = h->dmu2[h->cur ^ 1] + (size_t)b * h->ld; have = h->ld; break;
   }
@@ -1897,6 +1910,16 @@ extern "C" int ekf_set_option(ekf_handle* h, const char* name, int value) {
   if (std::strcmp(name, "lookahead") == 0) {
     if (value != 0 && value != 1) return fail(h, EKF_ERR_ARG, "lookahead must be 0 or 1");
     h->opt_lookahead = value;
+    return EKF_OK;
+  }
+  if (std::strcmp(name, "lookahead_min_mb") == 0) {
+    if (value < 0 || value > 100000) return fail(h, EKF_ERR_ARG, "lookahead_min_mb out of range");
+    h->opt_lookahead_min_mb = value;
+    return EKF_OK;
+  }
+  if (std::strcmp(name, "beside_min_mb") == 0) {
+    if (value < 0 || value > 100000) return fail(h, EKF_ERR_ARG, "beside_min_mb out of range");
+    h->opt_beside_min_mb = value;
     return EKF_OK;
   }
   if (std::strcmp(name, "pre_positions") == 0) {

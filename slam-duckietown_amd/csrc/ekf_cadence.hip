@@ -782,15 +782,11 @@ __global__ __launch_bounds__(64 * CAD_NW) void k_solve_cad(const double* __restr
 // next covariance pass reads, and (trajectory 0) the work-queue heads of the row-slab pass, which start every pass at zero.
 // nrp == 0 -- no trajectory of the bank observed anything in this cadence, no pass will follow for it -- : the predictions'
 // noise goes to the pose diagonal here (what k_predict_rc does for a single prediction-only step).
-// (chained runs, small launches) the panel launch is its own gate: it runs behind the previous covariance pass -- its first
-// workgroup says so (what the chain launch's gather workgroups wait for) --, and every workgroup waits for the cadence's solve to
-// have completed (announced by the chain launch behind that solve), then drops what its L2 may hold of the records' previous
-// use.  Only where every workgroup of the launch has a CU to itself and the solve workgroups theirs (ekf_api.hip): a waiting
+// (chained runs, small launches) the panel launch is its own gate: every workgroup waits for the cadence's solve to have
+// completed (announced by the chain launch behind that solve), then drops what its L2 may hold of the records' previous use.  Only where every workgroup of the launch has a CU to itself and the solve workgroups theirs (ekf_api.hip): a waiting
 // workgroup must not keep the solve it waits for from being placed; larger launches get the one-lane gate launch (k_gate).
 __device__ __forceinline__ void panel_head_wait(unsigned* sync, unsigned sigma, unsigned* flags) {
   if (threadIdx.x == 0) {
-    if (blockIdx.x == 0 && blockIdx.y == 0)
-      __hip_atomic_store(sync + SYNC_PASS * SYNC_STRIDE, sigma - 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (!sync_wait(sync + SYNC_SOLVE * SYNC_STRIDE, sigma)) atomicOr(flags + blockIdx.y, EKF_FLAG_INTERNAL);
   }
   __syncthreads();
@@ -1537,7 +1533,7 @@ __global__ __launch_bounds__(64 * CAD_NW) void k_chain_cad(const double* __restr
                                                            unsigned* __restrict__ sync, unsigned gather_target,
                                                            unsigned* __restrict__ flags, int gw, unsigned sigma,
                                                            const CadPre* __restrict__ pre_in, CadPre* __restrict__ pre_out,
-                                                           const CadPlan* __restrict__ plan2) {
+                                                           const CadPlan* __restrict__ plan2, int wait_pass) {
   using G = CadGeom;
   constexpr int CU = G::CU;
   __shared__ int Cs[128], Ck[128];
@@ -1599,9 +1595,10 @@ __global__ __launch_bounds__(64 * CAD_NW) void k_chain_cad(const double* __restr
       ns1 = cad_positions<false>(plan[b], in, batch, b, cfg, tid, Cs, cntS, firstS, loS, [](int, double, double) {});
     }
     const int cu = 3 + 2 * ns1;
-    // P_base and the pose rows are what the previous covariance pass (and the panel launch in front of it) left: the gate
-    // launch behind that pass has said so (sigma - 1); the entries are read past this XCD's L2, which may hold older ones
-    if (tid == 0 && !sync_wait(sync + SYNC_PASS * SYNC_STRIDE, sigma - 1u)) atomicOr(flags + b, EKF_FLAG_INTERNAL);
+    // P_base and the pose rows are what the previous covariance pass (and the panel launch in front of it) left: the mark launch
+    // behind that pass has said so (sigma - 1; `wait_pass` = 0: no chained pass is in flight, the stream's order covers it); the
+    // entries are read past this XCD's L2, which may hold older ones
+    if (tid == 0 && wait_pass && !sync_wait(sync + SYNC_PASS * SYNC_STRIDE, sigma - 1u)) atomicOr(flags + b, EKF_FLAG_INTERNAL);
     __syncthreads();
     for (int r = part + gw * wave; r < CAD_ROWS; r += gw * CAD_NW) {   // (uniform) rows part, part + gw, ... dealt over the waves
       double x[2] = {0.0, 0.0}, pb[2] = {0.0, 0.0};
@@ -1864,7 +1861,10 @@ __global__ __launch_bounds__(64 * CAD_NW) void k_chain_cad(const double* __restr
         if (l < CAD_CS) {
           double v = 0.0;
           if (r < cu && l < cu) {
-            if (r < 3 && l < 3) v = op.posefin[r][l];
+            // (the pose block's UPPER triangle, like every gather from P_base: the solve's simple-form arithmetic keeps its block
+            //  symmetric to rounding only, and an antisymmetric part handed from solve to solve grows -- x 1.16 per cadence at
+            //  N = 40, 1e-16 -> 1e-4 in 1200 steps; profiles/r06_chained_solves.txt)
+            if (r < 3 && l < 3) v = op.posefin[min(r, l)][max(r, l)];
             else if (r < 3) v = A[KTOT + r][l - 3];
             else if (l < 3) v = A[KTOT + l][r - 3];
             else v = p0[q][hf] + B[min(r, l) - 3][max(r, l) - 3];
@@ -2087,15 +2087,22 @@ __global__ __launch_bounds__(64 * CAD_NW) void k_panels_cad_tf(double* __restric
   if (blockIdx.x == 0 && wave == 0) pose_epilogue(o, Pb, Vb, Wb, so, queue, b, ld, lane, nrp, tail_word, tail_target, flags, start_sigma);
 }
 
-// (chained runs) the gate in front of a cadence's panel launch on the second stream: it runs behind the previous covariance pass
-// -- and says so (what the chain launch's gather workgroups wait for) --, and it ends when the cadence's solve has completed
+// (chained runs) the gate in front of a cadence's panel launch on the second stream: it ends when the cadence's solve has completed
 // (announced by the chain launch behind that solve).  One lane: it cannot keep the solve from finding its CUs, whatever the
 // order in which the host's enqueues reach the two streams.
 __global__ void k_gate(unsigned* __restrict__ sync, unsigned sigma, unsigned* __restrict__ flags, int batch) {
   if (threadIdx.x != 0) return;
-  __hip_atomic_store(sync + SYNC_PASS * SYNC_STRIDE, sigma - 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (!sync_wait(sync + SYNC_SOLVE * SYNC_STRIDE, sigma))
     for (int b = 0; b < batch; ++b) atomicOr(flags + b, EKF_FLAG_INTERNAL);
+}
+
+// (chained runs) behind a chained cadence's covariance pass on the second stream: "the pass of transition sigma is done" -- what
+// the NEXT chain launch's gather workgroups wait for.  A launch of its own, enqueued with its pass: every wait of the chained
+// order is for a launch that was enqueued EARLIER, so the order stays free of deadlock even where the runtime maps the handle's
+// two streams onto ONE hardware queue (HIP multiplexes streams onto a few: then the launches simply run in the order they were
+// enqueued -- no overlap, no hang).
+__global__ void k_mark(unsigned* __restrict__ sync, unsigned sigma) {
+  if (threadIdx.x == 0) __hip_atomic_store(sync + SYNC_PASS * SYNC_STRIDE, sigma, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // (chained runs, once per run) rows 0..2 of every trajectory's P_base -> prow3: what the first chained block reads while the
@@ -2149,13 +2156,16 @@ int chain_sync_words() { return SYNC_WORDS; }
 void launch_chain_cad(hipStream_t st, const double* P, const double* prow3, const double* mu_land, const double* mu_pose,
                       const CadOut* prev, const StepIn* in, const CadPlan* plan, int batch, const DeviceConfig& cfg, int ld,
                       long pstride, double* gbuf, double* gmu, double* xg, double* bg, unsigned* sync, unsigned gather_target,
-                      unsigned* flags, int gw, unsigned sigma, const CadPre* pre_in, CadPre* pre_out, const CadPlan* plan2) {
+                      unsigned* flags, int gw, unsigned sigma, const CadPre* pre_in, CadPre* pre_out, const CadPlan* plan2,
+                      bool wait_pass) {
   // (workgroups: the chain workgroup of every trajectory, its gather workgroups, and -- where a cadence follows the next one --
   //  the positions workgroup that forms that cadence's inputs ahead)
   hipLaunchKernelGGL(k_chain_cad, dim3(batch * (1 + gw + (pre_out ? 1 : 0))), dim3(64 * CAD_NW), 0, st, P, prow3, mu_land, mu_pose,
                      prev, in, plan, batch, cfg, ld, pstride, gbuf, gmu, xg, bg, sync, gather_target, flags, gw, sigma, pre_in, pre_out,
-                     plan2);
+                     plan2, wait_pass ? 1 : 0);
 }
+
+void launch_mark(hipStream_t st, unsigned* sync, unsigned sigma) { hipLaunchKernelGGL(k_mark, dim3(1), dim3(64), 0, st, sync, sigma); }
 
 void launch_gate(hipStream_t st, unsigned* sync, unsigned sigma, unsigned* flags, int batch) {
   hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, st, sync, sigma, flags, batch);
