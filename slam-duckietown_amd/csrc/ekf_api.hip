@@ -419,7 +419,18 @@ extern "C" int ekf_create(int device, int n_max, int batch, const ekf_config* cf
   CREATE_TRY(hipSetDevice(device));
   if (!take_stream_pair(device, &h->stream, &h->aux)) {
     CREATE_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
-    CREATE_TRY(hipStreamCreateWithFlags(&h->aux, hipStreamNonBlocking));
+    // The second stream gets the LOWEST priority: the runtime multiplexes streams onto a few hardware queues per priority level,
+    // so a priority of its own keeps it off the hardware queue of the handle's own stream however many streams the process has
+    // created (two streams on one queue run one behind the other: the chained order stays correct -- every wait is for an
+    // earlier-enqueued launch -- but nothing overlaps); and what runs there (panel launches, covariance passes) is the work
+    // that may wait.  No measurable effect on a fresh process (profiles/r06_chained_solves.txt).
+    int least = 0, greatest = 0;
+    if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) least = 0;
+    if (const char* e = std::getenv("EKFSLAM_HIP_AUX_PRIORITY")) least = std::atoi(e);
+    if (hipStreamCreateWithPriority(&h->aux, hipStreamNonBlocking, least) != hipSuccess) {
+      (void)hipGetLastError();
+      CREATE_TRY(hipStreamCreateWithFlags(&h->aux, hipStreamNonBlocking));
+    }
   }
   CREATE_TRY(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
   CREATE_TRY(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
