@@ -219,9 +219,14 @@ int ekf_profile_read_class(ekf_handle *h, int cls, double *ms_total, long long *
  * state into PINNED host memory, e.g. from ekf_host_alloc: 1 = up to 40 MB a kernel mirrors the stored triangle straight into
  * the destination, no mirror pass and no copy engine; 2 = at every size; 0 = never: mirror pass + rectangle copy; same bytes);
  * unknown names fail.
- * "fused_cadence", "lookahead" and "chain" (1 = where the next cadence's solve runs beside this one's pass, its block is
- * formed from this cadence's records and the solves of a run follow one another on the handle's stream -- panel launch and pass
- * of every cadence on the second one; 0 = the round-3 look-ahead: the block gathered behind the panel launch) change the ORDER in which a step's pending ranks are summed (and whether the look-ahead
+ * "fused_cadence", "lookahead" and "chain" (1 = where the next cadence's solve runs beside this one's pass -- banks of up to 40
+ * trajectories whose pass leaves CUs free: every size with "chain" = 1, from "lookahead_min_mb" = 48 MB of covariance with the
+ * round-3 look-ahead --, its block is formed from this cadence's records and the solves of a run follow one another on the
+ * handle's stream, panel launch and pass of every cadence on the second one; 0 = the round-3 look-ahead: the block gathered behind
+ * the panel launch; sub-options of the chained order, all 1 by default: "panel_tform" (small panel launches as a triangular solve on
+ * the matrix cores instead of the replay of the landmarks one after the other), "panel_own_gate" (small panel launches wait for
+ * their solve themselves instead of behind a one-lane gate launch), "pre_positions" (a cadence's inputs are formed one cadence
+ * ahead), "beside_min_mb" (0: chain at every size)) change the ORDER in which a step's pending ranks are summed (and whether the look-ahead
  * applies depends on the device's CU count and the size of the launch): results are equal to rounding across these
  * settings and across devices, bit-identical only for a fixed setting on a fixed device type. */
 int ekf_set_option(ekf_handle *h, const char *name, int value);
