@@ -223,9 +223,9 @@ int ekf_profile_read_class(ekf_handle *h, int cls, double *ms_total, long long *
  * trajectories whose pass leaves CUs free: every size with "chain" = 1, from "lookahead_min_mb" = 48 MB of covariance with the
  * round-3 look-ahead --, its block is formed from this cadence's records and the solves of a run follow one another on the
  * handle's stream, panel launch and pass of every cadence on the second one; 0 = the round-3 look-ahead: the block gathered behind
- * the panel launch; sub-options of the chained order, all 1 by default: "panel_tform" (small panel launches as a triangular solve on
- * the matrix cores instead of the replay of the landmarks one after the other), "panel_own_gate" (small panel launches wait for
- * their solve themselves instead of behind a one-lane gate launch), "pre_positions" (a cadence's inputs are formed one cadence
+ * the panel launch; sub-options of the chained order: "panel_tform" (1) (small panel launches as a triangular solve on
+ * the matrix cores instead of the replay of the landmarks one after the other), "panel_own_gate" (default 0; 1 = small panel launches wait for
+ * their solve themselves instead of behind a one-lane gate launch), "pre_positions" (1: a cadence's inputs are formed one cadence
  * ahead), "beside_min_mb" (0: chain at every size)) change the ORDER in which a step's pending ranks are summed (and whether the look-ahead
  * applies depends on the device's CU count and the size of the launch): results are equal to rounding across these
  * settings and across devices, bit-identical only for a fixed setting on a fixed device type. */

@@ -182,7 +182,10 @@ struct ekf_handle : ekf::HostPlan {
   bool chain_run = false;         // the run in flight records the transforms (every solve is k_solve_cad<true>)
   bool aux_pass = false;          // a covariance pass is in flight on the second stream (ev_pass recorded behind it)
   int opt_chain = 1;
-  int opt_panel_own_gate = 1;     // 1 = small panel launches are their own gate (panel_head_wait); 0 = always the one-lane gate launch
+  // 0 (default) = a one-lane gate launch in front of every chained panel launch: ~5 us of the second stream, which has them to
+  // spare (no measurable cost: 62.2 against 61.5 k at N = 2000 x 1, profiles/r06_chained_solves.txt), and no workgroup of a large
+  // launch ever spins; 1 = small panel launches (each workgroup a CU to itself) are their own gate (panel_head_wait)
+  int opt_panel_own_gate = 0;
   int opt_panel_tform = 1;        // 1 = a chained cadence's panel launch in the latency regime takes the triangular-solve form (k_panels_cad_tf)
   int opt_run_end_flush = 0;      // 1 = ekf_stream_run applies what its last cadence left pending, so that the next call starts fused
   long chained = 0;               // statistics: cadences whose block came from k_chain_cad
@@ -1072,8 +1075,8 @@ static int enqueue_cadence(ekf_handle* h, int c, bool presolved, bool* next_pres
     // undone.  Whatever happens the streams are joined, and a failure marks every trajectory undefined (EKF_ERR_STATE from
     // then on, until it is uploaded again).
     if (hipGetLastError() != hipSuccess) rc = fail(h, EKF_ERR_HIP, "chained solves: launch of the next cadence's solve failed");
-    // (the panel launch is its own gate where each of its workgroups and each solve workgroup has a CU to itself: a tiny launch
-    //  costs the stream ~4 us)
+    // (a one-lane gate in front of the panel launch; with "panel_own_gate" a small panel launch -- each of its workgroups and each
+    //  solve workgroup a CU to itself -- waits for its solve itself)
     if (h->opt_panel_own_gate && panels_cad_workgroups(h->batch, n_hi) + 2 * h->batch <= h->cu_count / 2) head_sigma = h->sigma;
     else launch_gate(h->aux, h->dsync, h->sigma, h->dflags, h->batch);
     pst = h->aux;

@@ -335,7 +335,7 @@ def test_lookahead_solve_beside_the_pass(sd, N, B, m, steps):
 def test_chained_solves_options_agree(sd):
     """The pieces of the chained order one by one (N = 900 x 2, m ~ U{0..12}: cadences cut steps, trajectories at different
     steps): the cadence's inputs formed one cadence ahead (`pre_positions`) and the panel launch as its own gate
-    (`panel_own_gate`, against the one-lane gate launch) change WHEN things are computed, not what: bit for bit.  The
+    (`panel_own_gate` = 1, against the default one-lane gate launch) change WHEN things are computed, not what: bit for bit.  The
     triangular-solve form of the chained panel launch (`panel_tform`, k_panels_cad_tf) against the replay form
     (k_panels_cad_ks): the same algebra in another order of summation, equal to PATH_TOL; every variant chained at every cadence."""
     N, B, steps = 900, 2, 16
@@ -343,7 +343,7 @@ def test_chained_solves_options_agree(sd):
     means, lin, ang, idx, zr, zb, m = wandering_stream(N, B, steps, lambda k, b, rng: rng.integers(0, 13), 9100)
     starts = [dense_start(n, 9200 + t) for t in range(B)]
     res = {}
-    for key, opts in {"default": (), "inline_positions": (("pre_positions", 0),), "gate_launch": (("panel_own_gate", 0),),
+    for key, opts in {"default": (), "inline_positions": (("pre_positions", 0),), "gate_launch": (("panel_own_gate", 1),),
                       "replay_panel": (("panel_tform", 0),)}.items():
         with sd.EkfSlam(n, batch=B) as f:
             f.set_option("active_bound", 0)
