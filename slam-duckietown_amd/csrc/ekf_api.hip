@@ -178,7 +178,7 @@ struct ekf_handle : ekf::HostPlan {
   // hand-overs are events (~25 us per cadence), keeps its 48 MB
   int opt_beside_min_mb = 0;
   int opt_lookahead_min_mb = 48;
-  hipEvent_t ev_solve = nullptr, ev_pass = nullptr, ev_nb = nullptr;
+  hipEvent_t ev_pass = nullptr;   // recorded on the second stream when a chain of cadences ends (join_aux): the only event of the chained order
   bool chain_run = false;         // the run in flight records the transforms (every solve is k_solve_cad<true>)
   bool aux_pass = false;          // a covariance pass is in flight on the second stream (ev_pass recorded behind it)
   int opt_chain = 1;
@@ -331,7 +331,7 @@ static void free_all(ekf_handle* h) {
   if (h->t1) (void)hipEventDestroy(h->t1);
   if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
   if (h->ev_join) (void)hipEventDestroy(h->ev_join);
-  for (hipEvent_t e : {h->ev_solve, h->ev_pass, h->ev_nb}) if (e) (void)hipEventDestroy(e);
+  if (h->ev_pass) (void)hipEventDestroy(h->ev_pass);
   if (h->aux) (void)hipStreamSynchronize(h->aux);
   if (h->stream && h->aux) {
     park_stream_pair(h->device, h->stream, h->aux);    // (see g_pairs: the next handle on this device takes the pair over)
@@ -437,13 +437,7 @@ extern "C" int ekf_create(int device, int n_max, int batch, const ekf_config* cf
   }
   CREATE_TRY(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
   CREATE_TRY(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
-  {
-    unsigned evf = hipEventDisableTiming;
-    if (const char* e = std::getenv("EKFSLAM_HIP_EVENT_FLAGS")) evf |= (unsigned)std::strtoul(e, nullptr, 0);   // (probe)
-    CREATE_TRY(hipEventCreateWithFlags(&h->ev_solve, evf));
-    CREATE_TRY(hipEventCreateWithFlags(&h->ev_pass, evf));
-    CREATE_TRY(hipEventCreateWithFlags(&h->ev_nb, evf));
-  }
+  CREATE_TRY(hipEventCreateWithFlags(&h->ev_pass, hipEventDisableTiming));
   const size_t ldz = (size_t)h->ld;
   CREATE_TRY(hipMalloc(&h->dP, sizeof(double) * (size_t)h->pstride * batch));
   CREATE_TRY(hipMalloc(&h->dmu2[0], sizeof(double) * ldz * batch));
@@ -951,12 +945,14 @@ static int upload_run_plan(ekf_handle* h) {
 // row-slab pass on static shares: a few long trajectories), do not run solve -> panel -> pass -> solve one behind the
 // other: the only true dependency between two cadences of a trajectory is the sequential landmark recurrence
 // (src/replay_no_ros.py:436-480: landmark j + 1 is linearised at the mean landmark j produced).
-//   * CHAINED SOLVES (round 6, "chain" = 1): every solve of the run also records its cadence as a linear map (k_solve_cad<true>:
-//     CadOut::T, mpose, posefin); k_chain_cad forms the next cadence's block and mean from those records and from P_base as it
-//     stood BEFORE this cadence, so the handle's stream runs  solve_c -> chain_{c+1} -> solve_{c+1} -> ...  while the second
-//     stream runs  panel_c -> pass_c -> panel_{c+1} -> ...  Hand-overs (events): panel_c waits for solve_c; chain_{c+1} waits
-//     for pass_{c-1} (it reads P_base rows >= 3 and the pose rows panel_{c-1} left in dprow3); pass_c waits for chain_{c+1}
-//     (which reads what the pass rewrites).  Two copies of the records and of the pose rows, used alternately.
+//   * CHAINED SOLVES (round 6, "chain" = 1): every solve of the run also records the pose block behind its cadence
+//     (k_solve_cad<true>: CadOut::posefin); k_chain_cad forms the next cadence's block and mean from the cadence's records and
+//     from P_base as it stood BEFORE the cadence, so the handle's stream runs  solve_c -> chain_{c+1} -> solve_{c+1} -> ...  while
+//     the second stream runs  gate -> panel_c -> pass_c -> mark -> gate -> ...  Hand-overs are device-scope counters (ekf_cadence.hip:
+//     SYNC_*): the gate waits for solve_c (announced by chain_{c+1}'s start); panel_c ends when chain_{c+1}'s gather workgroups
+//     have read what the pass rewrites and solve_{c+1} has been placed; chain_{c+1}'s gathers wait for the mark behind pass_{c-1}.
+//     A transition is ENQUEUED chain, solve, gate, panel, pass, mark: every wait is for an earlier-enqueued launch.  Two copies of
+//     the records, of the pose rows (dprow3) and of the inputs formed ahead (CadPre), used alternately.
 //   * LOOK-AHEAD (round 3, "chain" = 0): panel_c -> k_gather_cad (the next block from P_base and the ranks still pending) ->
 //     { pass_c on the second stream | solve_{c+1} } -> join.
 // `presolved` says that this cadence's solve has already been enqueued one of these ways; *next_presolved that the next

@@ -1344,15 +1344,19 @@ __global__ __launch_bounds__(256) void k_panels_cad_ks(double* __restrict__ P, d
 //     C_{q,r} = H_q[:, 0..2] G^{(q,r)} K_r[0..2, :] + H_q[:, 3..4] K_r[pa_q .. pa_q + 1, :]      (2 x 2)
 //     A_q     = H_q[:, 0..2] G^{(q,-1)} at the pose positions, H_q[:, 3..4] at positions pa_q, pa_q + 1
 // (G^{(q,r)}: the predictions between landmark r and landmark q -- their g add up, they only ever add multiples of row 2).
-// The kernel forms C and A in parallel (780 coefficient blocks), solves the system blocked -- five blocks of 8 landmarks: the
-// part from earlier blocks on the fp64 matrix cores, the 16 x 16 diagonal block by substitution, columns over lanes -- and
-// gets the pose rows of M as three more rows of the same product.  Then
-//     X  = P_0(C_u, C')                      83 x 83 gathered entries (in flight since the start of the kernel)
-//     E  = [T; mpose] X                      rank rows at C' (80 x 83) and the pose rows after the cadence (3 x 83)
+// The rank rows at the next positions C' are wanted, E = T X with X = P_0(C_u, C'): the kernel solves for them DIRECTLY,
+//     (I + C) E = A X          (A X: five rows of X per landmark -- the product T X never forms)
+// -- the 780 coefficient blocks in parallel, the inverses of the five 16 x 16 diagonal blocks by substitution on the identity
+// (Linv_i; Linv_i C_{i,<i} and Linv_i (A X)_i as products), then five block steps on the fp64 matrix cores, a column tile of
+// the 80 landmark positions of C' per wave -- and gets the pose rows behind the cadence as three more rows of the same
+// product (rows 0..2 of M).  Then
 //     F  = -S^-1 E  (per landmark, 2 x 2)    = W at C'
-//     P(C', C') = P_0(C', C') + F^T E        landmark x landmark;  pose rows / columns from E's last three rows, the pose block
-//                                            from the solve;  mean(C') = mean_0(C') - sum_q F_q^T y_q
-// again on the matrix cores, operands in LDS.  One workgroup per trajectory.
+//     P(C', C') = P_0(C', C') + F^T E        landmark x landmark (the upper block triangle: 15 tiles);  pose rows / columns from
+//                                            E's last three rows, the pose block from the solve (its upper triangle);
+//     mean(C') = mean_0(C') - sum_q F_q^T y_q
+// X and P_0(C', C') -- 13.8 k scattered entries -- are fetched by GATHER workgroups of the same launch while the chain
+// workgroup forms its coefficients; a POSITIONS workgroup forms the inputs of the cadence after the next (CadPre).
+// Operands in LDS.  One chain workgroup per trajectory.
 // ---------------------------------------------------------------------------------------------
 // Diagnostic build (-DCHAIN_STAMPS): s_memtime stamps of k_chain_cad's phases (wave 0 of trajectory 0) behind the means in gmu
 // (batch x 128 doubles, then 32 stamps); tools/chain_stamps.py reads them through ekf_debug_snapshot(which = 5).
@@ -2132,7 +2136,7 @@ void launch_gather_cad(hipStream_t st, const double* P, const double* V, const d
 
 // `colbuf` (batch x CAD_CU x ld doubles, or nullptr): the launch also gathers the mirrored column entries of the panel launch
 // behind it, on `col_wgs` extra workgroups -- only where P_base is current (not beside a pass: look-ahead)
-// `chain`: the instantiation that also records the cadence's transform (CadOut::T, mpose, posefin) for k_chain_cad; `gmu`
+// `chain`: the instantiation that also records the pose block behind the cadence (CadOut::posefin) for k_chain_cad; `gmu`
 // (with gbuf, one part): block and mean come from k_chain_cad
 void launch_solve_cad(hipStream_t st, const double* P, const double* mu_in, double* mu_out, double* dacc_out,
                       const int* nact, const StepIn* in, const CadPlan* plan, int batch, CadOut* out, unsigned* flags,
