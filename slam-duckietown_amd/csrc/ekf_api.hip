@@ -59,7 +59,7 @@ void launch_gather_cad(hipStream_t, const double*, const double*, const double*,
 long cadence_gbuf_doubles();
 void launch_panels_cad(hipStream_t, double*, double*, double*, const double*, double*, const int*, const CadOut*,
                        SolveOut*, unsigned*, int, long, int, int, int, const double*, double*, unsigned*, unsigned, unsigned, unsigned*,
-                       bool, unsigned);
+                       bool, unsigned, int);
 bool panels_cad_latency_regime(int, int);
 }  // namespace ekf
 
@@ -186,6 +186,7 @@ struct ekf_handle : ekf::HostPlan {
   // spare (no measurable cost: 62.2 against 61.5 k at N = 2000 x 1, profiles/r06_chained_solves.txt), and no workgroup of a large
   // launch ever spins; 1 = small panel launches (each workgroup a CU to itself) are their own gate (panel_head_wait)
   int opt_panel_own_gate = 0;
+  int opt_panel_shape = 0;        // diagnostics: 0 = the panel launch's shape by its size; 1 k_panels_cad_ks, 2 k_panels_cad<1>, 3 k_panels_cad<4> whatever the size
   int opt_panel_tform = 1;        // 1 = a chained cadence's panel launch in the latency regime takes the triangular-solve form (k_panels_cad_tf)
   int opt_run_end_flush = 0;      // 1 = ekf_stream_run applies what its last cadence left pending, so that the next call starts fused
   long chained = 0;               // statistics: cadences whose block came from k_chain_cad
@@ -1087,7 +1088,7 @@ static int enqueue_cadence(ekf_handle* h, int c, bool presolved, bool* next_pres
     launch_panels_cad(pst, h->dP, h->dV, h->dW, mu_in, mu_out, h->dn, dcad, h->dso, h->dqueue, h->ld,
                       h->pstride, h->batch, n_hi, nrp, h->colbuf_live ? h->dcolbuf : nullptr, prow_out, psync, head_sigma, tail_target, h->dflags,
                       chain_next && h->opt_panel_tform && !h->colbuf_live && panels_cad_latency_regime(h->batch, n_hi),
-                      chain_next ? h->sigma : 0u);
+                      chain_next ? h->sigma : 0u, h->opt_panel_shape);
     if (int rc2 = prof_close(h, &pb)) return rc2;
   }
   h->colbuf_live = false;
@@ -1940,6 +1941,11 @@ extern "C" int ekf_set_option(ekf_handle* h, const char* name, int value) {
   if (std::strcmp(name, "panel_own_gate") == 0) {
     if (value != 0 && value != 1) return fail(h, EKF_ERR_ARG, "panel_own_gate must be 0 or 1");
     h->opt_panel_own_gate = value;
+    return EKF_OK;
+  }
+  if (std::strcmp(name, "panel_shape") == 0) {
+    if (value < 0 || value > 5) return fail(h, EKF_ERR_ARG, "panel_shape must be 0 .. 5");
+    h->opt_panel_shape = value;
     return EKF_OK;
   }
   if (std::strcmp(name, "panel_tform") == 0) {

@@ -277,6 +277,28 @@ def test_all_three_shapes_of_the_panel_launch_agree(sd):
         assert orc.rel_fro(res[3][b][0], plain[b][0]) < PATH_TOL and orc.rel_fro(res[3][b][1], plain[b][1]) < PATH_TOL
 
 
+def test_forced_panel_shapes_agree_bit_for_bit(sd):
+    """`panel_shape` forces a shape of the panel launch whatever its size (diagnostics; 4 / 5: k_panels_cad_h2, the panel of a
+    state index split over two lanes -- 43 rows each, the landmark's e handed over by v_permlane32_swap).  Every shape performs
+    the same operations in the same order on every entry: N = 1300 x 30 (the size takes k_panels_cad<4>) and N = 2100 x 3 (dense
+    covariances), every forced shape against the shape the size selects -- bit for bit."""
+    for N, B, steps, m in ((1300, 30, 7, 8), (2100, 3, 9, 5)):
+        n = 3 + 2 * N
+        streams = [orc.synthetic_stream(N, steps, m, 1500 + t) for t in range(3)]
+        pick = [streams[b % 3] for b in range(B)]
+        args = (stack(pick, 2), stack(pick, 3), stack(pick, 4), stack(pick, 5), stack(pick, 6))
+        starts = [s[1] for s in pick] if B > 3 else [dense_start(n, 1600 + t) for t in range(B)]   # (the small bank: dense covariances)
+        res = {}
+        for shape in (0, 1, 3, 4, 5):
+            out, (nc, ns) = run_stream(sd, n, B, starts, [s[0] for s in pick], *args, diag=B > 3,
+                                       options=[("active_bound", 0), ("lookahead", 0), ("panel_shape", shape)])
+            assert nc >= 1 and ns == steps
+            res[shape] = out
+        for shape in (1, 3, 4, 5):
+            for b in range(B):
+                assert np.array_equal(res[0][b][0], res[shape][b][0]) and np.array_equal(res[0][b][1], res[shape][b][1]), (N, shape, b)
+
+
 def lookaheads(sd, f):
     lib = sd.load_library()
     return lib.ekf_debug_lookaheads(f._h)
