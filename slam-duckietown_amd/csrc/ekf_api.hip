@@ -1944,7 +1944,7 @@ extern "C" int ekf_set_option(ekf_handle* h, const char* name, int value) {
     return EKF_OK;
   }
   if (std::strcmp(name, "panel_shape") == 0) {
-    if (value < 0 || value > 5) return fail(h, EKF_ERR_ARG, "panel_shape must be 0 .. 5");
+    if (value < 0 || value > 3) return fail(h, EKF_ERR_ARG, "panel_shape must be 0 .. 3");
     h->opt_panel_shape = value;
     return EKF_OK;
   }

@@ -959,6 +959,22 @@ __global__ __launch_bounds__(64 * CAD_GW) void k_gather_cad(const double* __rest
 // NW waves of 64 state indices per workgroup share one staging of the records (LDS, 16-byte broadcast reads at
 // compile-time offsets); after the single barrier the waves never synchronise again.
 // ---------------------------------------------------------------------------------------------
+template <class F, int... S>
+__device__ __forceinline__ void static_for_slots(F&& f, std::integer_sequence<int, S...>) {
+  (f(std::integral_constant<int, S>{}), ...);
+}
+// x -= k[lane 16 r + L of every row of 16 lanes r] * e: the fp64 DPP broadcast of this part (v_fmac_f64_dpp row_newbcast, the
+// negation a source modifier): the same fused operation as fma(-k, e, x), with k read from ANOTHER lane's register
+template <int L>
+__device__ __forceinline__ void fnmac_row_bcast(double& x, double k, double e) {
+  asm volatile("v_fmac_f64_dpp %0, -%1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(x) : "v"(k), "v"(e), "n"(L));
+}
+
+// Round 6: the K rows of a landmark's down-date are not read as one LDS broadcast each (83 ds_read_b128 for the first landmark,
+// 1 720 per wave and cadence: the compute phase was bound by what the LDS returns, 64 lanes x 16 B per read) but SIXTEEN ROWS
+// PER READ -- lane l takes row 16 g + (l & 15) of group g -- and handed to the FMAs by the DPP broadcast within each row of 16
+// lanes: <= 6 reads per landmark; N = 2000 x 32: 75 - 77 -> 66 - 68 us (profiles/r06_panel_launch.txt).  The same fused
+// operations in the same order as the broadcast reads of k_panels_cad_ks: the shapes still agree bit for bit.
 template <int NW>
 __global__ __launch_bounds__(64 * NW) void k_panels_cad(double* __restrict__ P, double* __restrict__ V,
                                                         double* __restrict__ W, const double* __restrict__ mu_in,
@@ -972,7 +988,7 @@ __global__ __launch_bounds__(64 * NW) void k_panels_cad(double* __restrict__ P, 
   constexpr int CU = G::CU, GM = G::GM, NT = 64 * NW;
   const unsigned* tail_word = sync ? sync + SYNC_GATHER * SYNC_STRIDE : nullptr;
   if (sync && head_sigma) panel_head_wait(sync, head_sigma, flags);
-  __shared__ __attribute__((aligned(16))) double sRec[G::REC];
+  __shared__ __attribute__((aligned(16))) double sRec[G::REC + 32];   // (+ what the last records' grouped K reads overshoot)
   __shared__ double2 sG[CAD_SLOTS];
   __shared__ int sF[CAD_SLOTS];
   const int b = blockIdx.y;
@@ -1039,6 +1055,7 @@ __global__ __launch_bounds__(64 * NW) void k_panels_cad(double* __restrict__ P, 
     const double2* src = reinterpret_cast<const double2*>(o.rec);
     double2* dst = reinterpret_cast<double2*>(sRec);
     for (int e = G::rec_off(s0) / 2 + tid; e < G::REC / 2; e += NT) dst[e] = src[e];
+    if (tid < 16) dst[G::REC / 2 + tid] = make_double2(0.0, 0.0);
     if (tid < CAD_SLOTS) {
       sF[tid] = o.sfirst[tid];
       sG[tid] = *reinterpret_cast<const double2*>(o.g[tid]);
@@ -1078,13 +1095,21 @@ __global__ __launch_bounds__(64 * NW) void k_panels_cad(double* __restrict__ P, 
       ++tp;
     }
   };
-#pragma unroll
-  for (int s = 0; s < GM; ++s) {                       // (s, and with it every index of X and of the records, is compile-time)
+  // (the slots as a compile-time sequence: s, and with it every index of X and of the records, is a constant)
+  auto slot = [&](auto sc) {
+    constexpr int s = decltype(sc)::value;
     if (s >= s0) {                                     // (uniform)
       predictions_before(s);
-      const int pa = G::pa(s), off = G::rec_off(s);
+      constexpr int pa = G::pa(s), off = G::rec_off(s);
       const int kr = 2 * (s - s0);
       const double2* R = reinterpret_cast<const double2*>(__builtin_assume_aligned(sRec + off, 16));
+      constexpr int NG = (pa + 15) / 16;
+      double2 kg[NG];
+      {                                                // the K rows, sixteen per read: issued in front of the e chain
+        const double2* Rl = R + 8 + (lane & 15);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) kg[g] = Rl[16 * g];
+      }
       double2 hk[5];
 #pragma unroll
       for (int k = 0; k < 5; ++k) hk[k] = R[k];
@@ -1111,18 +1136,19 @@ __global__ __launch_bounds__(64 * NW) void k_panels_cad(double* __restrict__ P, 
       }
       // x[a] -= K_s[C_u[a], :] . (H_s P_s)[:, i], what lives on (behind the last slot: the pose rows, for the predictions of
       // steps that observe nothing)
-#pragma unroll
 #ifdef CADP_SKIP_DD                                     /* diagnostic build: only the rows the next landmark reads are down-dated */
-      for (int a = 0; a < (pa < 5 ? pa : 5); ++a) {
+      constexpr int ND = pa < 5 ? pa : 5;
 #else
-      for (int a = 0; a < pa; ++a) {
+      constexpr int ND = pa;
 #endif
-        const double2 kc = R[8 + a];
-        X[a] = fma(-kc.x, e0, X[a]);
-        X[a] = fma(-kc.y, e1, X[a]);
-      }
+      static_for_slots([&](auto ac) {                  // X[a] = fma(-K[a].x, e0, X[a]); X[a] = fma(-K[a].y, e1, X[a])
+        constexpr int a = decltype(ac)::value;
+        fnmac_row_bcast<(a & 15)>(X[a], kg[a >> 4].x, e0);
+        fnmac_row_bcast<(a & 15)>(X[a], kg[a >> 4].y, e1);
+      }, std::make_integer_sequence<int, ND>{});
     }
-  }
+  };
+  static_for_slots(slot, std::make_integer_sequence<int, GM>{});
   predictions_before(GM);                              // steps behind the last landmark
   if (actw) {
     for (int k = 2 * nslots; k < nrp; ++k) {           // fewer ranks than the bank's busiest trajectory (and the k-tile pad): zeros
@@ -1135,206 +1161,6 @@ __global__ __launch_bounds__(64 * NW) void k_panels_cad(double* __restrict__ P, 
     if (prow3) {                                       // (chained runs) P(0..2, i) after the cadence: what the replay ends with
 #pragma unroll
       for (int a = 0; a < 3; ++a) prow3[((long)b * 3 + a) * ld + i] = X[a];
-    }
-  }
-  if (blockIdx.x == 0 && wave == 0) pose_epilogue(o, Pb, Vb, Wb, so, queue, b, ld, lane, nrp, tail_word, tail_target, flags, start_sigma);
-}
-
-// ---------------------------------------------------------------------------------------------
-// k_panels_cad_h2 (round 6): the throughput form with the panel of a state index split over TWO lanes.  k_panels_cad keeps
-// all 83 rows of X[:, i] in one lane: 212 VGPRs, two waves per SIMD, and at that occupancy the launch is bound by neither HBM
-// nor the vector pipe (0.35 of the HBM peak at N = 2000 x 32).  Here lanes l and l + 32 of a wave share state index
-// i0 + (l & 31): both keep the pose rows, landmark position-slot q (positions 3 + 2q, 4 + 2q) belongs to half q & 1 -- 43
-// rows per lane, four waves per SIMD.  Per landmark BOTH halves run the five-FMA chain of e = (H P)[:, i] on the pair of rows
-// with the owner's local number (the other half's result is garbage), one v_permlane32_swap per dword hands the owner's to
-// both (no LDS, no barrier), each half down-dates its own rows -- the same operations in the same order as k_panels_cad: the
-// forms agree bit for bit -- and the rank stores are shared: half 0 writes the two V entries, half 1 the two W entries.
-// ---------------------------------------------------------------------------------------------
-template <class F, int... S>
-__device__ __forceinline__ void static_for_slots(F&& f, std::integer_sequence<int, S...>) {
-  (f(std::integral_constant<int, S>{}), ...);
-}
-__device__ __forceinline__ double half_bcast(double v, int owner) {   // (owner: compile-time) lane l <- lane (l & 31) + 32 owner
-  const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
-  const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);   // a[0]: the lower half's values in both halves, a[1]: the upper's
-  const auto c = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
-  return owner == 0 ? __hiloint2double((int)c[0], (int)a[0]) : __hiloint2double((int)c[1], (int)a[1]);
-}
-
-template <int NW, int OCC>
-__global__ __launch_bounds__(64 * NW, OCC) void k_panels_cad_h2(double* __restrict__ P, double* __restrict__ V,
-                                                              double* __restrict__ W, const double* __restrict__ mu_in,
-                                                              double* __restrict__ mu_out, const int* __restrict__ nact,
-                                                              const CadOut* __restrict__ co, SolveOut* __restrict__ so,
-                                                              unsigned* __restrict__ queue, int ld, long pstride, int nrp,
-                                                              const double* __restrict__ colbuf, double* __restrict__ prow3,
-                                                              unsigned* __restrict__ sync, unsigned head_sigma, unsigned tail_target,
-                                                              unsigned* __restrict__ flags, unsigned start_sigma) {
-  using G = CadGeom;
-  constexpr int CU = G::CU, GM = G::GM, NT = 64 * NW, LP = GM / 2;   // LP: landmark position-slots per half (20)
-  const unsigned* tail_word = sync ? sync + SYNC_GATHER * SYNC_STRIDE : nullptr;
-  if (sync && head_sigma) panel_head_wait(sync, head_sigma, flags);
-  __shared__ __attribute__((aligned(16))) double sRec[G::REC + 32];   // (+ what a record's K reads may overshoot into a dead row)
-  __shared__ double2 sG[CAD_SLOTS];
-  __shared__ int sF[CAD_SLOTS];
-  __shared__ int sC[CU + 1];
-  const int b = blockIdx.y;
-  const int n = nact[b];
-  const int w0 = blockIdx.x * (32 * NW);
-  if (w0 >= n) return;
-  const CadOut& o = co[b];
-  const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int nslots = o.nslots, npred = o.npred, neff = o.neff;
-  const int s0 = GM - nslots;                          // slots in use: s0 .. GM - 1
-  const int ld16 = ld >> 4;
-  double* Pb = P + (long)b * pstride;
-  double* Vb = V + (long)b * KTOT * ld;
-  double* Wb = W + (long)b * KTOT * ld;
-  const int i0 = w0 + wave * 32, i = i0 + (lane & 31);
-  const bool act = i < n;
-  const int ii = act ? i : n - 1;                      // idle lanes shadow the last state index (no stores)
-  const bool actw = act && i >= 3;                     // the pose's state indices are the solve's
-  const bool busy = nslots > 0 || npred > 0;           // (uniform) this trajectory does something in this cadence
-  const bool live = i0 < neff && i0 < n && busy;       // (uniform) this wave replays
-  if (w0 < neff && busy) {                             // (uniform) some wave of this workgroup replays: stage the records, the positions
-    const double2* src = reinterpret_cast<const double2*>(o.rec);
-    double2* dst = reinterpret_cast<double2*>(sRec);
-    for (int e = G::rec_off(s0) / 2 + tid; e < G::REC / 2; e += NT) dst[e] = src[e];
-    if (tid < 16) dst[G::REC / 2 + tid] = make_double2(0.0, 0.0);
-    if (tid < CAD_SLOTS) {
-      sF[tid] = o.sfirst[tid];
-      sG[tid] = *reinterpret_cast<const double2*>(o.g[tid]);
-    }
-    for (int e = tid; e <= CU; e += NT) sC[e] = o.C[e];
-  }
-  __syncthreads();
-  if (i0 >= n) return;
-  if (!live) {
-    // beyond the active bound the rows and columns of P are exactly zero off the diagonal (and an idle trajectory appends
-    // nothing): the cadence's ranks are zero there and the mean is carried over
-    if (actw && half == 0) {
-      for (int k = 0; k < nrp; ++k) {
-        Vb[(long)k * ld + i] = 0.0;
-        Wb[wm_index(ld16, k, i)] = 0.0;
-      }
-      mu_out[(long)b * ld + i] = mu_in[(long)b * ld + i];
-      if (prow3) {                                     // (chained runs) the pose rows as they stand: nothing of this wave changes
-#pragma unroll
-        for (int a = 0; a < 3; ++a) prow3[((long)b * 3 + a) * ld + i] = Pb[p_index(ld, a, i)];
-      }
-    }
-    if (blockIdx.x == 0 && wave == 0) pose_epilogue(o, Pb, Vb, Wb, so, queue, b, ld, lane, nrp, tail_word, tail_target, flags, start_sigma);
-    return;
-  }
-  // the gather (see k_panels_cad).  Local pair p of half h is position-slot 2p + h: positions 3 + 4p + 2h, 4 + 4p + 2h.  One load
-  // per entry at a selected address -- the two halves of a wave want different sources, and a branch per pair would put the
-  // panel into scratch memory: a pair that is mirrored for the whole 64-index strip of this wave comes from colbuf (laid down
-  // as rows beside the solve: the column gather's condition), everything else from P_base (min, max).
-  double XP[3], XL[2 * LP];
-#pragma unroll
-  for (int a = 0; a < 3; ++a) XP[a] = __builtin_nontemporal_load(Pb + p_index(ld, min(a, ii), max(a, ii)));
-  {
-    const int i0s = i0 & ~63;
-#pragma unroll
-    for (int p = 0; p < LP; ++p) {
-      const int a = 3 + 4 * p + 2 * half;
-      const int c0 = sC[a], c1 = sC[a + 1];
-      const double* q0 = Pb + p_index(ld, min(c0, ii), max(c0, ii));
-      const double* q1 = Pb + p_index(ld, min(c1, ii), max(c1, ii));
-      if (colbuf && c1 == c0 + 1 && i0s + 63 <= c0 && (c1 & (PPW - 1)) != 0) {
-        q0 = colbuf + ((long)b * CAD_CU + a) * ld + ii;
-        q1 = q0 + ld;
-      }
-      XL[2 * p] = __builtin_nontemporal_load(q0);
-      XL[2 * p + 1] = __builtin_nontemporal_load(q1);
-    }
-  }
-  const double* rech = sRec + 4 * half;                // K of this half's rows: + compile-time offsets
-  double* Vi = Vb + i;
-  double* Wi = Wb + wm_index(ld16, 0, i);
-  double d0 = 0.0, d1 = 0.0, dm = 0.0;
-  int tp = 0;                                          // (uniform) next touched step whose prediction is due
-  auto predictions_before = [&](int s) {               // prediction (:430): rows 0, 1 (see k_panels_cad)
-    while (tp < npred && sF[tp] <= s) {
-      const double2 g = sG[tp];
-      const double t0 = g.x * XP[2], t1 = g.y * XP[2];
-      XP[0] += t0;
-      XP[1] += t1;
-      d0 += t0;
-      d1 += t1;
-      ++tp;
-    }
-  };
-  // (the slots as a compile-time sequence, not an unrolled loop: the unroller prices every slot at the full 20 pairs and gives up)
-  auto slot = [&](auto sc) {
-    constexpr int s = decltype(sc)::value;
-    if (s >= s0) {                                     // (uniform)
-      predictions_before(s);
-      constexpr int pa = G::pa(s), off = G::rec_off(s);
-      const int kr = 2 * (s - s0);
-      constexpr int q = GM - 1 - s, OH = q & 1, PL = q >> 1;   // the landmark's position-slot: owner half, its local pair
-      const double2* R = reinterpret_cast<const double2*>(__builtin_assume_aligned(sRec + off, 16));
-      double2 hk[5];
-#pragma unroll
-      for (int k = 0; k < 5; ++k) hk[k] = R[k];
-      const double2 s01 = R[5], s23 = R[6], yy = R[7];
-      double e0 = hk[0].x * XP[0], e1 = hk[0].y * XP[0];      // (H_s P_s)[:, i] = h5 . x[sel]: the owner half's is the landmark's
-#pragma unroll
-      for (int k = 1; k < 5; ++k) {
-        const double xv = (k < 3) ? XP[k] : XL[2 * PL + (k - 3)];
-        e0 = fma(hk[k].x, xv, e0);
-        e1 = fma(hk[k].y, xv, e1);
-      }
-      e0 = half_bcast(e0, OH);
-      e1 = half_bcast(e1, OH);
-      const double f0 = e0 * s01.x + e1 * s23.x;       // K_s[i, :] = (H_s P_s)[:, i]^T S^-1  (P symmetric)
-      const double f1 = e0 * s01.y + e1 * s23.y;
-      dm += f0 * yy.x + f1 * yy.y;                     // :476
-      if (actw) {                                      // half 0: V[kr][i], V[kr + 1][i]; half 1: W[i][kr], W[i][kr + 1]
-        const long vo = (long)kr * ld, wo = (long)(kr >> 2) * ld * 4 + (kr & 3) * 16;
-        double* p0 = half ? Wi + wo : Vi + vo;
-        p0[0] = half ? -f0 : e0;
-        p0[half ? 16 : ld] = half ? -f1 : e1;
-      }
-      // x[a] -= K_s[C_u[a], :] . (H_s P_s)[:, i], what lives on: the pose rows in both halves ...
-#pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        const double2 kc = R[8 + k];
-        XP[k] = fma(-kc.x, e0, XP[k]);
-        XP[k] = fma(-kc.y, e1, XP[k]);
-      }
-      // ... own landmark rows at positions 3 + 4p + 2 half + e < pa; for an odd q the pair at the boundary is live in half 0 and
-      // the landmark's own (from here on dead) pair in half 1: what lands in a dead row does not matter
-      const double2* Rh = reinterpret_cast<const double2*>(__builtin_assume_aligned(rech + off + 16, 16));
-      constexpr int NP = (pa - 3 + 3) / 4;             // pairs with 3 + 4p < pa: some half's rows of them are live
-#pragma unroll
-      for (int p = 0; p < NP; ++p) {
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-          const double2 kc = Rh[3 + 4 * p + e];
-          XL[2 * p + e] = fma(-kc.x, e0, XL[2 * p + e]);
-          XL[2 * p + e] = fma(-kc.y, e1, XL[2 * p + e]);
-        }
-      }
-    }
-  };
-  static_for_slots(slot, std::make_integer_sequence<int, GM>{});
-  predictions_before(GM);                              // steps behind the last landmark
-  if (actw) {
-    for (int k = 2 * nslots; k < nrp; ++k) {           // fewer ranks than the bank's busiest trajectory (and the k-tile pad): zeros
-      if (half) Wb[wm_index(ld16, k, i)] = 0.0;
-      else Vb[(long)k * ld + i] = 0.0;
-    }
-    if (half) {
-      Pb[p_col(ld, i) + p_lds(ld)] += d1;              // entry (1, i)
-      if (prow3) {                                     // (chained runs) P(0..2, i) after the cadence: what the replay ends with
-#pragma unroll
-        for (int a = 0; a < 3; ++a) prow3[((long)b * 3 + a) * ld + i] = XP[a];
-      }
-    } else {
-      Pb[p_col(ld, i)] += d0;                          // entry (0, i)
-      mu_out[(long)b * ld + i] = mu_in[(long)b * ld + i] + dm;
     }
   }
   if (blockIdx.x == 0 && wave == 0) pose_epilogue(o, Pb, Vb, Wb, so, queue, b, ld, lane, nrp, tail_word, tail_target, flags, start_sigma);
@@ -2402,13 +2228,7 @@ void launch_panels_cad(hipStream_t st, double* P, double* V, double* W, const do
   // (`shape`: 0 = by the size of the launch; 1 .. 3 force a shape -- diagnostics, option "panel_shape")
   const long waves = (long)((n_hi + 63) / 64) * batch;
   if (shape == 0) shape = waves <= CAD_KS_WAVES ? 1 : (waves <= 1024 ? 2 : 3);
-  if (shape == 4)
-    hipLaunchKernelGGL((k_panels_cad_h2<4, 4>), dim3((n_hi + 127) / 128, batch), dim3(256), 0, st, P, V, W, mu_in, mu_out,
-                       nact, co, so, queue, ld, pstride, nrp, colbuf, prow3, sync, head_sigma, tail_target, flags, start_sigma);
-  else if (shape == 5)
-    hipLaunchKernelGGL((k_panels_cad_h2<4, 3>), dim3((n_hi + 127) / 128, batch), dim3(256), 0, st, P, V, W, mu_in, mu_out,
-                       nact, co, so, queue, ld, pstride, nrp, colbuf, prow3, sync, head_sigma, tail_target, flags, start_sigma);
-  else if (shape == 1)
+  if (shape == 1)
     hipLaunchKernelGGL(k_panels_cad_ks, dim3((n_hi + 63) / 64, batch), dim3(256), 0, st, P, V, W, mu_in, mu_out,
                        nact, co, so, queue, ld, pstride, nrp, colbuf, prow3, sync, head_sigma, tail_target, flags, start_sigma);
   else if (shape == 2)
