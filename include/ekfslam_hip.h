@@ -217,7 +217,9 @@ int ekf_profile_read_class(ekf_handle *h, int cls, double *ms_total, long long *
  * trusted, and "fetch_verify" = 1 (the default since round 6; ~1 us per call) also compares an XOR checksum of the whole payload -- a platform that reorders posted writes could deliver the trailer before other payload lines --; a mismatch waits for the stream
  * instead and is counted, ekf_debug_fetch_retries), "pack_dense" (downloads of a whole
  * state into PINNED host memory, e.g. from ekf_host_alloc: 1 = up to 40 MB a kernel mirrors the stored triangle straight into
- * the destination, no mirror pass and no copy engine; 2 = at every size; 0 = never: mirror pass + rectangle copy; same bytes);
+ * the destination, no mirror pass and no copy engine; 2 = at every size; 0 = never: mirror pass + rectangle copy; same bytes),
+ * "panel_shape" (diagnostics: 0 = a fused cadence's panel launch takes the shape its size selects, 1 .. 3 force the row-split
+ * latency form / one wave per workgroup / four waves per workgroup; the same result bit for bit);
  * unknown names fail.
  * "fused_cadence", "lookahead" and "chain" (1 = where the next cadence's solve runs beside this one's pass -- banks of up to 40
  * trajectories whose pass leaves CUs free: every size with "chain" = 1, from "lookahead_min_mb" = 48 MB of covariance with the
