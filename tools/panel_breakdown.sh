@@ -1,3 +1,7 @@
+# where the panel launch's time goes (profiles/r06_panel_launch.txt section 4): the headline's kernel trace on diagnostic builds of the
+# cadence kernels that leave a part out (timing only, wrong results).  Build them first, here or on the box:
+#   for v in "nodd -DCADP_SKIP_DD" "nost -DCADP_SKIP_STORE" "nog -DCADP_SKIP_GATHER" "none -DCADP_SKIP_DD -DCADP_SKIP_STORE -DCADP_SKIP_GATHER"; do
+#     set -- $v; t=$1; shift; make -C slam-duckietown_amd/csrc variant_cad TAG=$t EXTRA="$*"; done
 export TMPDIR=/tmp
 OUT=gpurun_out/pbrk; rm -rf $OUT; mkdir -p $OUT
 for v in "" nodd nost nog none; do
