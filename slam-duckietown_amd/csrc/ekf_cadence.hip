@@ -1141,11 +1141,19 @@ __global__ __launch_bounds__(64 * NW) void k_panels_cad(double* __restrict__ P, 
 #else
       constexpr int ND = pa;
 #endif
-      static_for_slots([&](auto ac) {                  // X[a] = fma(-K[a].x, e0, X[a]); X[a] = fma(-K[a].y, e1, X[a])
-        constexpr int a = decltype(ac)::value;
-        fnmac_row_bcast<(a & 15)>(X[a], kg[a >> 4].x, e0);
-        fnmac_row_bcast<(a & 15)>(X[a], kg[a >> 4].y, e1);
-      }, std::make_integer_sequence<int, ND>{});
+      // X[a] = fma(-K[a].x, e0, X[a]); X[a] = fma(-K[a].y, e1, X[a]) -- per group of 16 rows first every e0 term, then every e1
+      // term (the order within a row is what it was; two dependent DPP operations back to back cost a wait state each)
+      static_for_slots([&](auto gc) {
+        constexpr int g = decltype(gc)::value, NA = (ND - 16 * g) < 16 ? (ND - 16 * g) : 16;
+        static_for_slots([&](auto ac) {
+          constexpr int a = 16 * g + decltype(ac)::value;
+          fnmac_row_bcast<(a & 15)>(X[a], kg[g].x, e0);
+        }, std::make_integer_sequence<int, NA>{});
+        static_for_slots([&](auto ac) {
+          constexpr int a = 16 * g + decltype(ac)::value;
+          fnmac_row_bcast<(a & 15)>(X[a], kg[g].y, e1);
+        }, std::make_integer_sequence<int, NA>{});
+      }, std::make_integer_sequence<int, (ND + 15) / 16>{});
     }
   };
   static_for_slots(slot, std::make_integer_sequence<int, GM>{});
