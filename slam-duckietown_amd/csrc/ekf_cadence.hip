@@ -975,6 +975,16 @@ __device__ __forceinline__ void fnmac_row_bcast(double& x, double k, double e) {
 // PER READ -- lane l takes row 16 g + (l & 15) of group g -- and handed to the FMAs by the DPP broadcast within each row of 16
 // lanes: <= 6 reads per landmark; N = 2000 x 32: 75 - 77 -> 66 - 68 us (profiles/r06_panel_launch.txt).  The same fused
 // operations in the same order as the broadcast reads of k_panels_cad_ks: the shapes still agree bit for bit.
+#ifdef CADP_STAMPS                                      /* diagnostic build: s_memtime stamps of one wave of the panel launch, printed */
+#define PSTAMP(k)                                                                  \
+  do {                                                                             \
+    __builtin_amdgcn_sched_barrier(0);                                             \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(pst_[k])::"memory"); \
+    __builtin_amdgcn_sched_barrier(0);                                             \
+  } while (0)
+#else
+#define PSTAMP(k) do { } while (0)
+#endif
 template <int NW>
 __global__ __launch_bounds__(64 * NW) void k_panels_cad(double* __restrict__ P, double* __restrict__ V,
                                                         double* __restrict__ W, const double* __restrict__ mu_in,
@@ -1010,58 +1020,102 @@ __global__ __launch_bounds__(64 * NW) void k_panels_cad(double* __restrict__ P, 
   const bool actw = act && i >= 3;                     // the pose's state indices are the solve's
   const bool busy = nslots > 0 || npred > 0;           // (uniform) this trajectory does something in this cadence
   const bool live = i0 < neff && i0 < n && busy;       // (uniform) this wave replays
-  // the gather does not depend on the staged records: all of it is issued before the barrier
+#ifdef CADP_STAMPS
+  unsigned long long pst_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+  PSTAMP(0);
+#ifdef CADP_STAGGER                                     /* diagnostic build: every other workgroup starts late (x 3.4 us) */
+  if (NW == 4 && (blockIdx.x & 1)) {
+#pragma unroll
+    for (int z = 0; z < CADP_STAGGER; ++z) __builtin_amdgcn_s_sleep(127);
+  }
+#endif
+  // The records of the cadence (what a workgroup shares) are REQUESTED first, then the gather -- nothing of it depends on the
+  // staged records -- and only then are the records written to LDS: one memory round trip for both.  (Round 6.  The staging loop
+  // used to follow the gather and wait for every load in flight at each of its eight iterations: nine round trips.)
+  const bool stage = w0 < neff && busy;                // (uniform) some wave of this workgroup replays
+  constexpr int SQ = 8;                                // staged 16-byte entries per thread and round
+  const double2* rsrc = reinterpret_cast<const double2*>(o.rec);
+  double2* rdst = reinterpret_cast<double2*>(sRec);
+  const int e0s = G::rec_off(s0) / 2 + tid;
+  double stx[SQ], sty[SQ];                             // (plain doubles: arrays of double2 end up in scratch)
+  int sf = 0;
+  double sgx = 0.0, sgy = 0.0;
+  if (stage) {
+#pragma unroll
+    for (int q = 0; q < SQ; ++q) {
+      const double2 t = rsrc[min(e0s + q * NT, G::REC / 2 - 1)];
+      stx[q] = t.x;
+      sty[q] = t.y;
+    }
+    if (tid < CAD_SLOTS) {
+      sf = o.sfirst[tid];
+      const double2 t = *reinterpret_cast<const double2*>(o.g[tid]);
+      sgx = t.x;
+      sgy = t.y;
+    }
+  }
+  // The gather: ONE load per entry at a selected address, every one of them independent of the others -- 83 loads in flight.
+  // (A branch per pair of positions -- by whether the pair is mirrored for the whole wave, lies in the row direction or
+  //  straddles it -- merged its loads in one temporary, and every pair waited for the pair before it: 40 round trips.)
+  // A landmark's two positions are two ADJACENT state indices c, c + 1.  For the state indices i <= c the entries P(c, i),
+  // P(c + 1, i) are stored mirrored, as P_base(i, c), P_base(i, c + 1): a different cache line per lane (a CU takes about a
+  // cycle per line).  Where the column gather beside the solve has laid a pair down as rows (colbuf: pairs that are mirrored for
+  // the whole 64-index strip and do not straddle two column panels) it is read from there, coalesced and past the caches.
   double X[CU];
   if (live) {
+    const long row_ii = (long)ii * p_lds(ld), col_ii = p_col(ld, ii);
+    auto gather = [&](auto with_colbuf) {
+      constexpr bool CB = decltype(with_colbuf)::value;
 #pragma unroll
-    for (int a = 0; a < 3; ++a) X[a] = __builtin_nontemporal_load(Pb + p_index(ld, min(a, ii), max(a, ii)));
-    // A landmark's two positions are two ADJACENT state indices c, c + 1.  For the state indices i <= c the entries
-    // P(c, i), P(c + 1, i) are stored mirrored, as P_base(i, c), P_base(i, c + 1): side by side in row i.  Those column-
-    // direction gathers touch a different cache line per lane (a CU takes about a cycle per line: 42 of this kernel's 92 us
-    // at N = 2000 x 32 when every entry was its own 8-byte load), so a wave that lies entirely at or above the pair takes
-    // both with ONE 16-byte load per lane (8-byte aligned: column 3 + 2 idx is odd).  (Positions beyond the cadence's
-    // carry index 0: a coalesced read of row 0 that nothing uses.)
+      for (int a = 0; a < 3; ++a) X[a] = __builtin_nontemporal_load(Pb + (ii >= a ? (long)a * p_lds(ld) + col_ii : row_ii + a));
 #pragma unroll
-    for (int a = 3; a < CU; a += 2) {
-      const int c0 = o.C[a], c1 = o.C[a + 1];
+      for (int a = 3; a < CU; a += 2) {
+        const int c0 = o.C[a], c1 = o.C[a + 1];
 #ifdef CADP_SKIP_GATHER                                 /* diagnostic build: every gather reads the row direction */
-      X[a] = Pb[p_index(ld, min(c0, 2), ii)];
-      X[a + 1] = Pb[p_index(ld, min(c1, 2), ii)];
+        X[a] = Pb[p_index(ld, min(c0, 2), ii)];
+        X[a + 1] = Pb[p_index(ld, min(c1, 2), ii)];
 #else
-      if (c1 == c0 + 1 && i0 + 63 <= c0 && (c1 & (PPW - 1)) != 0) {   // (uniform; the pair does not straddle two column panels)
-        if (colbuf) {                                  // (uniform) gathered beside the solve, laid down as rows: two coalesced loads
-          const double* cb = colbuf + ((long)b * CAD_CU + a) * ld;   // (each entry is read exactly once: past the caches)
-          X[a] = __builtin_nontemporal_load(cb + ii);
-          X[a + 1] = __builtin_nontemporal_load(cb + ld + ii);
+        // entry (c, ii) for ii >= c, (ii, c) below it (positions beyond the cadence's carry index 0: row 0, which nothing uses)
+        const long u0 = (long)c0 * p_lds(ld) + col_ii, l0 = row_ii + p_col(ld, c0);
+        const long u1 = (long)c1 * p_lds(ld) + col_ii, l1 = row_ii + p_col(ld, c1);
+        const double* q0 = Pb + (ii >= c0 ? u0 : l0);
+        const double* q1 = Pb + (ii >= c1 ? u1 : l1);
+        if constexpr (CB) {
+          if (c1 == c0 + 1 && i0 + 63 <= c0 && (c1 & (PPW - 1)) != 0) {   // (uniform: an address, not a load, is chosen)
+            q0 = colbuf + ((long)b * CAD_CU + a) * ld + ii;
+            q1 = q0 + ld;
+          }
+          X[a] = __builtin_nontemporal_load(q0);       // (each entry is read exactly once)
+          X[a + 1] = __builtin_nontemporal_load(q1);
         } else {
-          const v2d_u v = *reinterpret_cast<const v2d_u*>(Pb + p_index(ld, ii, c0));
-          X[a] = v.x;
-          X[a + 1] = v.y;
+          X[a] = *q0;                                  // (without the column gather the mirrored pairs of neighbouring landmarks
+          X[a + 1] = *q1;                              //  share cache lines: through the caches)
         }
-      } else if (c1 <= i0) {                           // (uniform) both in the row direction: 512 contiguous bytes each, read once
-        X[a] = __builtin_nontemporal_load(Pb + p_index(ld, c0, ii));
-        X[a + 1] = __builtin_nontemporal_load(Pb + p_index(ld, c1, ii));
-      } else {
-        X[a] = Pb[p_index(ld, min(c0, ii), max(c0, ii))];
-        X[a + 1] = Pb[p_index(ld, min(c1, ii), max(c1, ii))];
-      }
 #endif
-    }
+      }
+    };
+    if (colbuf) gather(std::true_type{});
+    else gather(std::false_type{});
   } else {
 #pragma unroll
     for (int a = 0; a < CU; ++a) X[a] = 0.0;
   }
-  if (w0 < neff && busy) {                             // (uniform) some wave of this workgroup replays: stage the records
-    const double2* src = reinterpret_cast<const double2*>(o.rec);
-    double2* dst = reinterpret_cast<double2*>(sRec);
-    for (int e = G::rec_off(s0) / 2 + tid; e < G::REC / 2; e += NT) dst[e] = src[e];
-    if (tid < 16) dst[G::REC / 2 + tid] = make_double2(0.0, 0.0);
+  PSTAMP(1);
+  if (stage) {
+#pragma unroll
+    for (int q = 0; q < SQ; ++q)
+      if (e0s + q * NT < G::REC / 2) rdst[e0s + q * NT] = make_double2(stx[q], sty[q]);
+    for (int e = e0s + SQ * NT; e < G::REC / 2; e += NT) rdst[e] = rsrc[e];   // (one-wave workgroups: the rest, entry by entry)
+    if (tid < 16) rdst[G::REC / 2 + tid] = make_double2(0.0, 0.0);
     if (tid < CAD_SLOTS) {
-      sF[tid] = o.sfirst[tid];
-      sG[tid] = *reinterpret_cast<const double2*>(o.g[tid]);
+      sF[tid] = sf;
+      sG[tid] = make_double2(sgx, sgy);
     }
   }
+  PSTAMP(2);
   __syncthreads();
+  PSTAMP(3);
   if (i0 >= n) return;
   if (!live) {
     // beyond the active bound the rows and columns of P are exactly zero off the diagonal (and an idle trajectory appends
@@ -1098,6 +1152,11 @@ __global__ __launch_bounds__(64 * NW) void k_panels_cad(double* __restrict__ P, 
   // (the slots as a compile-time sequence: s, and with it every index of X and of the records, is a constant)
   auto slot = [&](auto sc) {
     constexpr int s = decltype(sc)::value;
+    if constexpr (s == 0) PSTAMP(4);
+    if constexpr (s == 1) PSTAMP(5);
+    if constexpr (s == 10) PSTAMP(6);
+    if constexpr (s == 20) PSTAMP(7);
+    if constexpr (s == 30) PSTAMP(8);
     if (s >= s0) {                                     // (uniform)
       predictions_before(s);
       constexpr int pa = G::pa(s), off = G::rec_off(s);
@@ -1157,6 +1216,7 @@ __global__ __launch_bounds__(64 * NW) void k_panels_cad(double* __restrict__ P, 
     }
   };
   static_for_slots(slot, std::make_integer_sequence<int, GM>{});
+  PSTAMP(9);
   predictions_before(GM);                              // steps behind the last landmark
   if (actw) {
     for (int k = 2 * nslots; k < nrp; ++k) {           // fewer ranks than the bank's busiest trajectory (and the k-tile pad): zeros
@@ -1171,6 +1231,14 @@ __global__ __launch_bounds__(64 * NW) void k_panels_cad(double* __restrict__ P, 
       for (int a = 0; a < 3; ++a) prow3[((long)b * 3 + a) * ld + i] = X[a];
     }
   }
+#ifdef CADP_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  PSTAMP(10);
+  if (NW == 4 && (blockIdx.x == 7 || blockIdx.x == 1) && (b == 5 || b == 20) && tid == 64 && nslots == GM)
+    printf("PST bx %d b %d: gather-issued %llu staged %llu barrier %llu slot0 %llu slot1 %llu slot10 %llu slot20 %llu slot30 %llu end-slots %llu drained %llu\n",
+           (int)blockIdx.x, b, pst_[1] - pst_[0], pst_[2] - pst_[0], pst_[3] - pst_[0], pst_[4] - pst_[0], pst_[5] - pst_[0], pst_[6] - pst_[0],
+           pst_[7] - pst_[0], pst_[8] - pst_[0], pst_[9] - pst_[0], pst_[10] - pst_[0]);
+#endif
   if (blockIdx.x == 0 && wave == 0) pose_epilogue(o, Pb, Vb, Wb, so, queue, b, ld, lane, nrp, tail_word, tail_target, flags, start_sigma);
 }
 
