@@ -1106,7 +1106,18 @@ __global__ __launch_bounds__(64 * NW) void k_panels_cad(double* __restrict__ P, 
 #pragma unroll
     for (int q = 0; q < SQ; ++q)
       if (e0s + q * NT < G::REC / 2) rdst[e0s + q * NT] = make_double2(stx[q], sty[q]);
-    for (int e = e0s + SQ * NT; e < G::REC / 2; e += NT) rdst[e] = rsrc[e];   // (one-wave workgroups: the rest, entry by entry)
+    for (int eb = e0s + SQ * NT; eb < G::REC / 2; eb += SQ * NT) {   // (one-wave workgroups: the rest, SQ requests at a time)
+      double tx[SQ], ty[SQ];
+#pragma unroll
+      for (int q = 0; q < SQ; ++q) {
+        const double2 t = rsrc[min(eb + q * NT, G::REC / 2 - 1)];
+        tx[q] = t.x;
+        ty[q] = t.y;
+      }
+#pragma unroll
+      for (int q = 0; q < SQ; ++q)
+        if (eb + q * NT < G::REC / 2) rdst[eb + q * NT] = make_double2(tx[q], ty[q]);
+    }
     if (tid < 16) rdst[G::REC / 2 + tid] = make_double2(0.0, 0.0);
     if (tid < CAD_SLOTS) {
       sF[tid] = sf;
@@ -1286,39 +1297,52 @@ __global__ __launch_bounds__(256) void k_panels_cad_ks(double* __restrict__ P, d
   const int ii = act ? i : n - 1;                      // idle lanes shadow the last state index (no stores)
   const bool actw = act && i >= 3;                     // the pose's state indices are the solve's
   const bool live = i0 < neff && (nslots > 0 || npred > 0);   // (uniform) this workgroup replays
+  // (as in k_panels_cad: the records are requested first, then the gather -- one independent load per entry at a selected
+  //  address --, and only then are the records written to LDS: one memory round trip for everything)
   double XP[3], XL[2 * LP];
   if (live) {
+    constexpr int SQ = 8;
+    const double2* src = reinterpret_cast<const double2*>(o.rec);
+    double2* dst = reinterpret_cast<double2*>(sRec);
+    const int e0s = G::rec_off(s0) / 2 + tid;
+    double stx[SQ], sty[SQ];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) XP[k] = Pb[p_index(ld, min(k, ii), max(k, ii))];
+    for (int q = 0; q < SQ; ++q) {
+      const double2 t = src[min(e0s + q * 256, G::REC / 2 - 1)];
+      stx[q] = t.x;
+      sty[q] = t.y;
+    }
+    int sf = 0;
+    double sgx = 0.0, sgy = 0.0;
+    if (tid < CAD_SLOTS) {
+      sf = o.sfirst[tid];
+      const double2 t = *reinterpret_cast<const double2*>(o.g[tid]);
+      sgx = t.x;
+      sgy = t.y;
+    }
+    const long row_ii = (long)ii * p_lds(ld), col_ii = p_col(ld, ii);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) XP[k] = Pb[ii >= k ? (long)k * p_lds(ld) + col_ii : row_ii + k];
 #pragma unroll
     for (int pp = 0; pp < LP; ++pp) {
       const int a = 3 + 8 * pp + 2 * wave;
       const int c0 = o.C[min(a, CU)], c1 = o.C[min(a + 1, CU)];   // (C[CU] = 0: a position beyond the cadence's)
-      if (c1 == c0 + 1 && i0 + 63 <= c0 && (c1 & (PPW - 1)) != 0) {   // (uniform) both mirrored: side by side in row i (see k_panels_cad)
-        if (colbuf && a < CU) {                        // (uniform) gathered beside the solve
-          const double* cb = colbuf + ((long)b * CAD_CU + a) * ld;
-          XL[2 * pp] = __builtin_nontemporal_load(cb + ii);
-          XL[2 * pp + 1] = __builtin_nontemporal_load(cb + ld + ii);
-        } else {
-          const v2d_u v = *reinterpret_cast<const v2d_u*>(Pb + p_index(ld, ii, c0));
-          XL[2 * pp] = v.x;
-          XL[2 * pp + 1] = v.y;
-        }
-      } else if (c1 <= i0) {                           // (uniform) both in the row direction: 512 contiguous bytes each, read once
-        XL[2 * pp] = __builtin_nontemporal_load(Pb + p_index(ld, c0, ii));
-        XL[2 * pp + 1] = __builtin_nontemporal_load(Pb + p_index(ld, c1, ii));
-      } else {
-        XL[2 * pp] = Pb[p_index(ld, min(c0, ii), max(c0, ii))];
-        XL[2 * pp + 1] = Pb[p_index(ld, min(c1, ii), max(c1, ii))];
+      const double* q0 = Pb + (ii >= c0 ? (long)c0 * p_lds(ld) + col_ii : row_ii + p_col(ld, c0));
+      const double* q1 = Pb + (ii >= c1 ? (long)c1 * p_lds(ld) + col_ii : row_ii + p_col(ld, c1));
+      if (colbuf && a < CU && c1 == c0 + 1 && i0 + 63 <= c0 && (c1 & (PPW - 1)) != 0) {   // (uniform) gathered beside the solve
+        q0 = colbuf + ((long)b * CAD_CU + a) * ld + ii;
+        q1 = q0 + ld;
       }
+      XL[2 * pp] = *q0;
+      XL[2 * pp + 1] = *q1;
     }
-    const double2* src = reinterpret_cast<const double2*>(o.rec);
-    double2* dst = reinterpret_cast<double2*>(sRec);
-    for (int e = G::rec_off(s0) / 2 + tid; e < G::REC / 2; e += 256) dst[e] = src[e];
+#pragma unroll
+    for (int q = 0; q < SQ; ++q)
+      if (e0s + q * 256 < G::REC / 2) dst[e0s + q * 256] = make_double2(stx[q], sty[q]);
     if (tid < 16) dst[G::REC / 2 + tid] = make_double2(0.0, 0.0);
     if (tid < CAD_SLOTS) {
-      sF[tid] = o.sfirst[tid];
-      sG[tid] = *reinterpret_cast<const double2*>(o.g[tid]);
+      sF[tid] = sf;
+      sG[tid] = make_double2(sgx, sgy);
     }
   }
   __syncthreads();
