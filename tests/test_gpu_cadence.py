@@ -12,6 +12,7 @@ measurement noise amplify a last-bit difference by four orders of magnitude; the
 reference-shaped dense NumPy path, pinned to the reference's golden vectors).
 """
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -629,6 +630,56 @@ def test_packed_cadences_with_wandering_landmark_counts(sd, N, B, steps, hi):
     assert max(need) <= -(-int(m.sum(axis=0).max()) // 40) + 1     # what the busiest trajectory needs at 40 per pass (+ the tail)
     check_against_per_step_and_oracle(sd, n, B, starts, means, lin, ang, idx, zr, zb, m, fused,
                                       oracle_for=None if B <= 4 else (0, B - 1))
+
+
+@pytest.mark.parametrize("case", range(int(os.environ.get("EKF_FUZZ_CASES", "10"))))   # (a soak: EKF_FUZZ_CASES=200)
+def test_random_streams_orders_pieces_and_options_against_the_oracle(sd, case):
+    """Everything at once, drawn from a seeded generator: a bank of 1 .. 4 trajectories of 20 .. 320 landmarks, 0 .. `hi`
+    landmarks per step and trajectory at scattered indices, dense starting covariances; the run's cadences in one of the three
+    orders (chained / look-ahead / plain) or on the per-step kernels; `stream_run` in one call or in random pieces, with or
+    without `run_end_flush`, a `flush()` or a download between pieces; the panel launch's shape forced or by size; the active
+    bound on or off.  Every trajectory against the oracle (the reference-shaped dense step) -- 1e-9 -- and no flag raised."""
+    rng = np.random.default_rng(52000 + case)
+    N, B = int(rng.integers(20, 321)), int(rng.integers(1, 5))
+    steps, hi = int(rng.integers(8, 61)), int(rng.choice([1, 3, 8, 16]))
+    n = 3 + 2 * N
+    means, lin, ang, idx, zr, zb, m = wandering_stream(N, B, steps, lambda k, b, r: r.integers(0, min(hi, N) + 1), 53000 + case)
+    starts = [dense_start(n, 54000 + 10 * case + t) for t in range(B)]
+    order = ("chain", "lookahead", "plain", "per_step")[int(rng.integers(0, 4))]
+    opts = [("small_state", 0), ("active_bound", int(rng.integers(0, 2)))]
+    opts += list(MODES[order]) if order != "per_step" else [("fused_cadence", 0)]
+    if rng.integers(0, 2):
+        opts.append(("panel_shape", int(rng.integers(1, 4))))
+    if rng.integers(0, 2):
+        opts.append(("run_end_flush", 1))
+    pieces = [steps]
+    if rng.integers(0, 2):
+        cuts = sorted(set(int(c) for c in rng.integers(1, steps, size=int(rng.integers(1, 6)))))
+        pieces = [b_ - a_ for a_, b_ in zip([0] + cuts, cuts + [steps])]
+    with sd.EkfSlam(n, batch=B) as f:
+        for name, value in opts:
+            f.set_option(name, value)
+        for b in range(B):
+            f.set_state(means[b], starts[b], b)
+        f.stream_upload(lin, ang, idx, zr, zb, m)
+        k = 0
+        for count in pieces:
+            f.stream_run(k, count)
+            k += count
+            what = int(rng.integers(0, 4))
+            if what == 0:
+                f.flush()
+            elif what == 1:
+                assert np.isfinite(f.mean(int(rng.integers(0, B)))).all()
+        out = [f.state(b) for b in range(B)]
+        assert [f.flags(b) for b in range(B)] == [0] * B, (order, opts, pieces)
+    cfg = orc.EkfConfig()
+    for b in range(B):
+        om, oP = means[b].copy(), starts[b].copy()
+        for k in range(steps):
+            mb = m[k, b]
+            om, oP = orc.ekf_step_dense(om, oP, lin[k, b], ang[k, b], idx[k, b, :mb], zr[k, b, :mb], zb[k, b, :mb], cfg)
+        assert orc.rel_fro(out[b][0], om) < TIGHT and orc.rel_fro(out[b][1], oP) < TIGHT, (order, opts, pieces, b)
 
 
 @pytest.mark.parametrize("N,B,steps", [(300, 3, 30), (1400, 24, 12), (2100, 2, 12)])
