@@ -357,6 +357,11 @@ def test_store_hazard_guard_is_in_the_shipped_machine_code(sd):
     assert not isa_lint.writes_vgpr("s_add_i32 s37, s60, s79", 76, 79)
     assert not isa_lint.writes_vgpr("v_add_u32_e32 v80, v78, v2", 76, 79)
     assert not isa_lint.writes_vgpr("buffer_store_dwordx4 v[76:79], v251, s[48:51], s39 offen nt", 76, 79)
+    # round 6: the fp64 DPP broadcasts of the fused cadence's panel launch (inline assembly the compiler's hazard recogniser does
+    # not look into): fed from LDS reads, never within two wait states of a VALU write of their source or five of a v_cmpx
+    dpps, bad_dpp = isa_lint.lint_dpp(sd.library_path())
+    assert dpps >= 6000, f"only {dpps} DPP operations found: did the panel launch change its down-date?"
+    assert not bad_dpp, "\n".join(bad_dpp[:20])
 
 
 def test_create_rejects_sizes_beyond_the_32_bit_offsets(sd):

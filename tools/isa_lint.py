@@ -10,6 +10,12 @@ machine code that actually ships: walking forward from every such store, no inst
 store's data tuple before at least WAIT_STATES = 2 wait states have gone by (`s_nop N` counts N + 1, any other
 instruction 1), and no branch may come before that either.
 
+The DPP hazards (round 6: `fnmac_row_bcast` in ekf_cadence.hip, v_fmac_f64_dpp ... row_newbcast written as inline assembly, which
+the compiler's hazard recogniser does not look into): a DPP operation that reads a VGPR through the DPP path needs 2 wait states
+behind a VALU instruction that wrote that VGPR, and 5 behind a VALU instruction that wrote EXEC (v_cmpx).  The kernel feeds its
+DPP operations from LDS reads, never from VALU results; this tool checks that nothing the compiler put in between (a copy, a
+v_cmpx) breaks that in the machine code that ships.
+
   python3 tools/isa_lint.py [path/to/libekfslam_hip.so]      exit status 1 on a violation
 """
 import os
@@ -123,6 +129,44 @@ def lint(lib_path):
     return stores, gaps, bad
 
 
+def is_valu(ins):
+    return ins.startswith("v_") and not ins.startswith(("v_readlane", "v_readfirstlane", "v_nop"))
+
+
+def lint_dpp(lib_path):
+    """Returns (DPP operations checked, violations as text): walking BACKWARD from every *_dpp instruction, no VALU instruction
+    within 2 wait states may have written its DPP source (the first source operand), none within 5 may have written EXEC; a
+    label boundary cannot be seen in this listing, so a branch TARGET in between is not modelled -- branches themselves count as
+    one wait state like any other instruction."""
+    checked = 0
+    bad = []
+    for name, ins in disassemble(lib_path):
+        for k, text in enumerate(ins):
+            op, _, rest = text.partition(" ")
+            if not op.endswith("_dpp"):
+                continue
+            ops = [t.strip() for t in rest.split(",")]
+            if len(ops) < 2:
+                continue
+            src = vgpr_range(ops[1].split()[0].lstrip("-|").rstrip("|"))
+            if src is None:
+                continue
+            checked += 1
+            waited, j = 0, k - 1
+            while j >= 0 and waited < 5:
+                prev = ins[j]
+                if is_valu(prev):
+                    if waited < 2 and writes_vgpr(prev, src[0], src[1]):
+                        bad.append(f"{name}: `{text}` reads what `{prev}` wrote {waited} wait state(s) earlier")
+                        break
+                    if prev.startswith("v_cmpx"):
+                        bad.append(f"{name}: `{text}` comes {waited} wait state(s) behind `{prev}` (EXEC)")
+                        break
+                waited += wait_states(prev)
+                j -= 1
+    return checked, bad
+
+
 if __name__ == "__main__":
     here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(here, "slam-duckietown_amd", "libekfslam_hip.so")
@@ -131,4 +175,8 @@ if __name__ == "__main__":
           f"(harmless: they only add wait states), {len(bad)} violations")
     for b in bad:
         print("  " + b)
-    sys.exit(1 if bad else 0)
+    nd, bad_d = lint_dpp(path)
+    print(f"{path}: {nd} DPP operations, {len(bad_d)} violations")
+    for b in bad_d:
+        print("  " + b)
+    sys.exit(1 if bad or bad_d else 0)
