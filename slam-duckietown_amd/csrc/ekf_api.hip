@@ -27,7 +27,7 @@ void launch_panels(hipStream_t, int, double*, double*, double*, const double*, d
 void launch_flush(hipStream_t, bool, double*, const double*, const double*, const double*, const int*,
                   const SolveOut*, int, long, int, int, int, int);
 void launch_flush_rs(hipStream_t, bool, double*, const double*, const double*, const double*, const int*,
-                     const SolveOut*, int, long, int, int, int, int, unsigned*, int, const int*);
+                     const SolveOut*, int, long, int, int, int, int, unsigned*, int, const int*, const CadOut*);
 int flush_rs_queue_words();
 void launch_predict_rc(hipStream_t, double*, const double*, double*, const int*, const SolveOut*, int, long,
                        int, int);
@@ -59,7 +59,7 @@ void launch_gather_cad(hipStream_t, const double*, const double*, const double*,
 long cadence_gbuf_doubles();
 void launch_panels_cad(hipStream_t, double*, double*, double*, const double*, double*, const int*, const CadOut*,
                        SolveOut*, unsigned*, int, long, int, int, int, const double*, double*, unsigned*, unsigned, unsigned, unsigned*,
-                       bool, unsigned, int);
+                       bool, unsigned, int, bool);
 bool panels_cad_latency_regime(int, int);
 }  // namespace ekf
 
@@ -186,6 +186,10 @@ struct ekf_handle : ekf::HostPlan {
   // spare (no measurable cost: 62.2 against 61.5 k at N = 2000 x 1, profiles/r06_chained_solves.txt), and no workgroup of a large
   // launch ever spins; 1 = small panel launches (each workgroup a CU to itself) are their own gate (panel_head_wait)
   int opt_panel_own_gate = 0;
+  // 1 = where a fused cadence's covariance pass follows its panel launch at once, in the row-slab form, the panel launch writes V
+  // only and the pass forms its W fragments from V and the records' S^-1 (half of the panel launch's stores); bit-identical
+  int opt_w_from_v = 1;
+  long w_from_v_passes = 0;       // statistics
   int opt_panel_shape = 0;        // diagnostics: 0 = the panel launch's shape by its size; 1 k_panels_cad_ks, 2 k_panels_cad<1>, 3 k_panels_cad<4> whatever the size
   int opt_panel_tform = 1;        // 1 = a chained cadence's panel launch in the latency regime takes the triangular-solve form (k_panels_cad_tf)
   int opt_run_end_flush = 0;      // 1 = ekf_stream_run applies what its last cadence left pending, so that the next call starts fused
@@ -242,7 +246,7 @@ static int fail(ekf_handle* h, int code, const std::string& msg) {
 }
 
 static int flush_pending(ekf_handle* h);
-static int flush_pending(ekf_handle* h, hipStream_t st);
+static int flush_pending(ekf_handle* h, hipStream_t st, const CadOut* wv = nullptr);
 static int materialize(ekf_handle* h, int b);
 
 #define HIP_TRY(h, expr)                                                                   \
@@ -768,7 +772,7 @@ static int prof_close(ekf_handle* h, ProfBracket* pb) {
 
 // Apply the pending low-rank update to P_base:  P_base += W V + diag(dacc)  (one pass over P), on stream `st` (the
 // handle's own unless the look-ahead of ekf_stream_run sends it to the second one).
-static int flush_pending(ekf_handle* h, hipStream_t st) {
+static int flush_pending(ekf_handle* h, hipStream_t st, const CadOut* wv) {
   if (h->pending_k == 0) return EKF_OK;
   if (!st) st = h->stream;
   const PassPlan p = plan_pass(h);
@@ -815,7 +819,7 @@ static int flush_pending(ekf_handle* h, hipStream_t st) {
   h->last_shares = shares ? h->shares_ok : 0;
   if (p.kernel == 2) {                                 // (the step before left the queue heads at zero)
     launch_flush_rs(st, p.streaming, h->dP, h->dV, h->dW, h->ddacc2[h->dcur], h->dn, h->dso, h->ld, h->pstride,
-                    h->batch, p.e_hi, p.nkt, p.rs_workgroups, h->dqueue, h->opt_pass_chunk, shares);
+                    h->batch, p.e_hi, p.nkt, p.rs_workgroups, h->dqueue, h->opt_pass_chunk, shares, p.kernel == 2 ? wv : nullptr);
   } else {
     launch_flush(st, p.streaming, h->dP, h->dV, h->dW, h->ddacc2[h->dcur], h->dn, h->dso, h->ld, h->pstride, h->batch,
                  p.e_hi, p.nkt, flush_rows_per_block(h, p.streaming, p.e_hi));
@@ -1036,6 +1040,14 @@ static int enqueue_cadence(ekf_handle* h, int c, bool presolved, bool* next_pres
     h->pending_k = pk;
   }
   const bool chain_next = beside && h->chain_run;
+  // ("w_from_v") the pass follows this panel launch at once, nothing else is pending, both take the forms that know how
+  bool wv = false;
+  if (h->opt_w_from_v && due && !beside && h->pending_k == 0 && ranks > 0 && !panels_cad_latency_regime(h->batch, n_hi) &&
+      h->opt_panel_shape != 1) {
+    h->pending_k = pend_after;
+    wv = plan_pass(h).kernel == 2;
+    h->pending_k = 0;
+  }
   hipStream_t pst = h->stream;                         // the panel launch's stream
   unsigned* psync = nullptr;
   unsigned head_sigma = 0u, tail_target = 0u;
@@ -1088,7 +1100,7 @@ static int enqueue_cadence(ekf_handle* h, int c, bool presolved, bool* next_pres
     launch_panels_cad(pst, h->dP, h->dV, h->dW, mu_in, mu_out, h->dn, dcad, h->dso, h->dqueue, h->ld,
                       h->pstride, h->batch, n_hi, nrp, h->colbuf_live ? h->dcolbuf : nullptr, prow_out, psync, head_sigma, tail_target, h->dflags,
                       chain_next && h->opt_panel_tform && !h->colbuf_live && panels_cad_latency_regime(h->batch, n_hi),
-                      chain_next ? h->sigma : 0u, h->opt_panel_shape);
+                      chain_next ? h->sigma : 0u, h->opt_panel_shape, wv);
     if (int rc2 = prof_close(h, &pb)) return rc2;
   }
   h->colbuf_live = false;
@@ -1124,7 +1136,10 @@ static int enqueue_cadence(ekf_handle* h, int c, bool presolved, bool* next_pres
     return EKF_OK;
   }
   if (!due) return EKF_OK;
-  if (!beside) return flush_pending(h);
+  if (!beside) {
+    if (wv) h->w_from_v_passes += 1;
+    return flush_pending(h, nullptr, wv ? dcad : nullptr);
+  }
   if (!h->dgbuf) HIP_TRY(h, hipMalloc(&h->dgbuf, sizeof(double) * cadence_gbuf_doubles() * h->batch));
   // ---- look-ahead: gather (stream) -> { pass (second stream) | solve of the next cadence (stream) } -> join ----
   const int kb = (h->pending_k + 3) & ~3;
@@ -1798,6 +1813,8 @@ extern "C" long ekf_debug_assoc_fallbacks(ekf_handle* h) { return h ? h->assoc_f
 extern "C" void ekf_debug_note_assoc_fallback(ekf_handle* h) { if (h) h->assoc_fallbacks += 1; }
 // (diagnostics section of the header) ... and how many of those had their block formed by k_chain_cad (chained solves)
 extern "C" long ekf_debug_chained(ekf_handle* h) { return h ? h->chained : -1; }
+// ... and covariance passes that formed their W fragments from V and the records ("w_from_v")
+extern "C" long ekf_debug_w_from_v(ekf_handle* h) { return h ? h->w_from_v_passes : -1; }
 // (diagnostics section of the header) launches of the small-state path so far
 extern "C" long ekf_debug_small_launches(ekf_handle* h) { return h ? h->small_launches : -1; }
 extern "C" long ekf_debug_fused_fetches(ekf_handle* h) { return h ? h->fused_fetches : -1; }
@@ -1941,6 +1958,11 @@ extern "C" int ekf_set_option(ekf_handle* h, const char* name, int value) {
   if (std::strcmp(name, "panel_own_gate") == 0) {
     if (value != 0 && value != 1) return fail(h, EKF_ERR_ARG, "panel_own_gate must be 0 or 1");
     h->opt_panel_own_gate = value;
+    return EKF_OK;
+  }
+  if (std::strcmp(name, "w_from_v") == 0) {
+    if (value != 0 && value != 1) return fail(h, EKF_ERR_ARG, "w_from_v must be 0 or 1");
+    h->opt_w_from_v = value;
     return EKF_OK;
   }
   if (std::strcmp(name, "panel_shape") == 0) {

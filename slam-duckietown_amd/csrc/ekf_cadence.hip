@@ -993,7 +993,9 @@ __global__ __launch_bounds__(64 * NW) void k_panels_cad(double* __restrict__ P, 
                                                         unsigned* __restrict__ queue, int ld, long pstride, int nrp,
                                                         const double* __restrict__ colbuf, double* __restrict__ prow3,
                                                         unsigned* __restrict__ sync, unsigned head_sigma, unsigned tail_target,
-                                                        unsigned* __restrict__ flags, unsigned start_sigma) {
+                                                        unsigned* __restrict__ flags, unsigned start_sigma, int skipw) {
+  // (`skipw`, "w_from_v": the covariance pass behind this launch forms its W fragments from V and the records' S^-1 -- W is
+  //  half of what this launch writes, and it is bound by what it writes; the pose's entries, pose_epilogue, are kept)
   using G = CadGeom;
   constexpr int CU = G::CU, GM = G::GM, NT = 64 * NW;
   const unsigned* tail_word = sync ? sync + SYNC_GATHER * SYNC_STRIDE : nullptr;
@@ -1134,7 +1136,7 @@ __global__ __launch_bounds__(64 * NW) void k_panels_cad(double* __restrict__ P, 
     if (actw) {
       for (int k = 0; k < nrp; ++k) {
         Vb[(long)k * ld + i] = 0.0;
-        Wb[wm_index(ld16, k, i)] = 0.0;
+        if (!skipw) Wb[wm_index(ld16, k, i)] = 0.0;
       }
       mu_out[(long)b * ld + i] = mu_in[(long)b * ld + i];
       if (prow3) {                                     // (chained runs) the pose rows as they stand: nothing of this wave changes
@@ -1201,8 +1203,10 @@ __global__ __launch_bounds__(64 * NW) void k_panels_cad(double* __restrict__ P, 
 #endif
         Vb[(long)kr * ld + i] = e0;
         Vb[(long)(kr + 1) * ld + i] = e1;
-        Wb[wm_index(ld16, kr, i)] = -f0;
-        Wb[wm_index(ld16, kr + 1, i)] = -f1;
+        if (!skipw) {                                  // (uniform)
+          Wb[wm_index(ld16, kr, i)] = -f0;
+          Wb[wm_index(ld16, kr + 1, i)] = -f1;
+        }
       }
       // x[a] -= K_s[C_u[a], :] . (H_s P_s)[:, i], what lives on (behind the last slot: the pose rows, for the predictions of
       // steps that observe nothing)
@@ -1232,7 +1236,7 @@ __global__ __launch_bounds__(64 * NW) void k_panels_cad(double* __restrict__ P, 
   if (actw) {
     for (int k = 2 * nslots; k < nrp; ++k) {           // fewer ranks than the bank's busiest trajectory (and the k-tile pad): zeros
       Vb[(long)k * ld + i] = 0.0;
-      Wb[wm_index(ld16, k, i)] = 0.0;
+      if (!skipw) Wb[wm_index(ld16, k, i)] = 0.0;
     }
     Pb[p_col(ld, i)] += d0;                            // entry (0, i)
     Pb[p_col(ld, i) + p_lds(ld)] += d1;                // entry (1, i)
@@ -2316,7 +2320,8 @@ void launch_snap_pose(hipStream_t st, const double* P, const int* nact, int ld, 
 void launch_panels_cad(hipStream_t st, double* P, double* V, double* W, const double* mu_in, double* mu_out,
                        const int* nact, const CadOut* co, SolveOut* so, unsigned* queue, int ld, long pstride, int batch,
                        int n_hi, int nrp, const double* colbuf, double* prow3, unsigned* sync, unsigned head_sigma, unsigned tail_target,
-                       unsigned* flags, bool tform, unsigned start_sigma, int shape) {
+                       unsigned* flags, bool tform, unsigned start_sigma, int shape, bool skipw) {
+  // (`skipw`: only the replay shapes 2 and 3 honour it -- the caller asks for it only where the launch takes one of them)
   // (chained cadences in the latency regime: the triangular-solve form, one 8-wave workgroup per 64 state indices)
   if (tform) {
     hipLaunchKernelGGL(k_panels_cad_tf, dim3((n_hi + 63) / 64, batch), dim3(64 * CAD_NW), 0, st, P, V, W, mu_in, mu_out, nact, co, so,
@@ -2333,10 +2338,10 @@ void launch_panels_cad(hipStream_t st, double* P, double* V, double* W, const do
                        nact, co, so, queue, ld, pstride, nrp, colbuf, prow3, sync, head_sigma, tail_target, flags, start_sigma);
   else if (shape == 2)
     hipLaunchKernelGGL((k_panels_cad<1>), dim3((n_hi + 63) / 64, batch), dim3(64), 0, st, P, V, W, mu_in, mu_out,
-                       nact, co, so, queue, ld, pstride, nrp, colbuf, prow3, sync, head_sigma, tail_target, flags, start_sigma);
+                       nact, co, so, queue, ld, pstride, nrp, colbuf, prow3, sync, head_sigma, tail_target, flags, start_sigma, skipw ? 1 : 0);
   else
     hipLaunchKernelGGL((k_panels_cad<4>), dim3((n_hi + 255) / 256, batch), dim3(256), 0, st, P, V, W, mu_in,
-                       mu_out, nact, co, so, queue, ld, pstride, nrp, colbuf, prow3, sync, head_sigma, tail_target, flags, start_sigma);
+                       mu_out, nact, co, so, queue, ld, pstride, nrp, colbuf, prow3, sync, head_sigma, tail_target, flags, start_sigma, skipw ? 1 : 0);
 }
 
 }  // namespace ekf

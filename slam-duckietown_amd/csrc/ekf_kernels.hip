@@ -1805,7 +1805,8 @@ __global__ __launch_bounds__(512, 2) void k_flush_rs(double* __restrict__ P, con
                                                      const int* __restrict__ nact,
                                                      const SolveOut* __restrict__ so, int ld, long pstride,
                                                      int nkt, int batch, int nrb, int nch, int cs_arg, int mode,
-                                                     unsigned* __restrict__ queue, const int* __restrict__ shares) {
+                                                     unsigned* __restrict__ queue, const int* __restrict__ shares,
+                                                     const CadOut* __restrict__ wv) {
   constexpr int RPW = NKT / 2;                         // ranks of a V strip each of the 8 waves stages
   __shared__ __attribute__((aligned(16))) double vbuf[2][NKT * 256];   // V strip as B fragments: [k-tile][col tile][lane]
   __shared__ __attribute__((aligned(16))) double img[8][16 * 64];      // per wave: 16 x 64 tile image (swizzled)
@@ -1982,10 +1983,37 @@ __global__ __launch_bounds__(512, 2) void k_flush_rs(double* __restrict__ P, con
       double vs[RPW];
       stage_load(0, I0_{}, IR_{}, vs);
       gload(0);
+      if (wv == nullptr) {                             // (uniform)
 #pragma unroll
-      for (int t = 0; t < NKT; ++t) {
-        const double x = ldb8(rsW, lane8, ((unsigned)t * ld16 + (unsigned)(i0w >> 4)) * 512u);
-        wf[t] = (t < nkt) ? x : 0.0;
+        for (int t = 0; t < NKT; ++t) {
+          const double x = ldb8(rsW, lane8, ((unsigned)t * ld16 + (unsigned)(i0w >> 4)) * 512u);
+          wf[t] = (t < nkt) ? x : 0.0;
+        }
+      } else {
+        // ("w_from_v", round 6) The pending ranks are those of ONE fused cadence whose panel launch wrote V only: W is
+        // redundant -- per landmark W[i][2s .. 2s+1] = -(V[2s][i], V[2s+1][i]) S_s^-1, with S_s^-1 in the cadence's records --
+        // and half of what that launch wrote.  This lane's fragment entry is rank k = 4t + lq: landmark s = 2t + (lq >> 1),
+        // column c = lq & 1 of S^-1; the same operations as the panel launch's f = fma(e0, S[0][c], e1 * S[1][c]), W = -f.
+        // The pose's state indices (rows 0..2, the solve's: CadOut::posevw) keep their stored entries.
+        const CadOut& oc = wv[b];
+        const int nsl = min(oc.nslots, CAD_SLOTS), s0c = CAD_SLOTS - nsl;
+        const __amdgpu_buffer_rsrc_t rsR = rs_rsrc(oc.rec);
+        const unsigned vlane = (unsigned)(2 * (lq >> 1)) * ld8 + (unsigned)li * 8u;
+        const unsigned cpart = (unsigned)(lq & 1) * 8u;
+#pragma unroll
+        for (int t = 0; t < NKT; ++t) {
+          const int sl = 2 * t + (lq >> 1), slot = min(s0c + sl, CAD_SLOTS - 1);
+          const unsigned roff = (unsigned)cad_rec_off(slot) * 8u + cpart;
+          const unsigned voff = ((unsigned)(4 * t) * (unsigned)ld + (unsigned)i0w) * 8u;
+          const double e0 = ldb8(rsV, vlane, voff), e1 = ldb8(rsV, vlane + ld8, voff);
+          const double sa = ldb8(rsR, roff, 80u), sb = ldb8(rsR, roff, 96u);
+          double w = -__builtin_fma(e0, sa, e1 * sb);
+          if (i0w == 0) {                              // (uniform) the wave that holds the pose rows
+            const double x = ldb8(rsW, lane8, (unsigned)t * ld16 * 512u);
+            w = li < 3 ? x : w;
+          }
+          wf[t] = (t < nkt && sl < nsl) ? w : 0.0;
+        }
       }
       stage_store(vbuf[0], I0_{}, IR_{}, vs);
       RS_STAMP(4);
@@ -2552,11 +2580,11 @@ void launch_flush(hipStream_t st, bool streaming, double* P, const double* V, co
 template <int NKT, bool NT, bool PAN>
 static void launch_flush_rs_t(hipStream_t st, double* P, const double* V, const double* W, const double* dacc,
                               const int* nact, const SolveOut* so, int ld, long pstride, int batch, int n_hi, int nkt,
-                              int workgroups, unsigned* queue, int chunk, const int* shares) {
+                              int workgroups, unsigned* queue, int chunk, const int* shares, const CadOut* wv) {
   const int nrb = (n_hi + RS_ROWS - 1) / RS_ROWS;
   if (shares) {                                        // equal static shares (mode 4): one per workgroup
     hipLaunchKernelGGL((k_flush_rs<NKT, NT, PAN>), dim3((unsigned)workgroups), dim3(512), 0, st, P, V, W, dacc, nact, so, ld,
-                       pstride, nkt, batch, nrb, 1, 0, 4, queue, shares);
+                       pstride, nkt, batch, nrb, 1, 0, 4, queue, shares, wv);
     return;
   }
   // Units (see the three modes at k_flush_rs's `pop`).  With an even number of trajectories per queue whole slabs taken
@@ -2597,20 +2625,20 @@ static void launch_flush_rs_t(hipStream_t st, double* P, const double* V, const 
   }
   const long units = (long)nrb * (mode == 0 ? nch : mode == 3 ? 2 : 1) * batch;   // (modes 1, 2: at least; only the grid size depends on it)
   hipLaunchKernelGGL((k_flush_rs<NKT, NT, PAN>), dim3((unsigned)std::min<long>(workgroups, units)), dim3(512), 0, st, P, V, W,
-                     dacc, nact, so, ld, pstride, nkt, batch, nrb, nch, cs, mode, queue, nullptr);
+                     dacc, nact, so, ld, pstride, nkt, batch, nrb, nch, cs, mode, queue, nullptr, wv);
 }
 
 void launch_flush_rs(hipStream_t st, bool streaming, double* P, const double* V, const double* W, const double* dacc,
                      const int* nact, const SolveOut* so, int ld, long pstride, int batch, int n_hi, int nkt,
-                     int workgroups, unsigned* queue, int chunk, const int* shares) {
+                     int workgroups, unsigned* queue, int chunk, const int* shares, const CadOut* wv) {
 #define EKF_FLUSH_RS(N)                                                                                   \
   do {                                                                                                    \
     if (ld > PPW) {                                                                                       \
-      if (streaming) launch_flush_rs_t<N, true, true>(st, P, V, W, dacc, nact, so, ld, pstride, batch, n_hi, nkt, workgroups, queue, chunk, shares); \
-      else launch_flush_rs_t<N, false, true>(st, P, V, W, dacc, nact, so, ld, pstride, batch, n_hi, nkt, workgroups, queue, chunk, shares);          \
+      if (streaming) launch_flush_rs_t<N, true, true>(st, P, V, W, dacc, nact, so, ld, pstride, batch, n_hi, nkt, workgroups, queue, chunk, shares, wv); \
+      else launch_flush_rs_t<N, false, true>(st, P, V, W, dacc, nact, so, ld, pstride, batch, n_hi, nkt, workgroups, queue, chunk, shares, wv);          \
     } else {                                                                                              \
-      if (streaming) launch_flush_rs_t<N, true, false>(st, P, V, W, dacc, nact, so, ld, pstride, batch, n_hi, nkt, workgroups, queue, chunk, shares); \
-      else launch_flush_rs_t<N, false, false>(st, P, V, W, dacc, nact, so, ld, pstride, batch, n_hi, nkt, workgroups, queue, chunk, shares);          \
+      if (streaming) launch_flush_rs_t<N, true, false>(st, P, V, W, dacc, nact, so, ld, pstride, batch, n_hi, nkt, workgroups, queue, chunk, shares, wv); \
+      else launch_flush_rs_t<N, false, false>(st, P, V, W, dacc, nact, so, ld, pstride, batch, n_hi, nkt, workgroups, queue, chunk, shares, wv);          \
     }                                                                                                     \
   } while (0)
   if (nkt <= 4) EKF_FLUSH_RS(4);

@@ -144,6 +144,7 @@ ABI = {
     "ekf_debug_lookaheads": (C.c_long, [C.c_void_p]),
     "ekf_debug_chained": (C.c_long, [C.c_void_p]),
     "ekf_debug_assoc_fallbacks": (C.c_long, [C.c_void_p]),
+    "ekf_debug_w_from_v": (C.c_long, [C.c_void_p]),
     "ekf_debug_note_assoc_fallback": (None, [C.c_void_p]),
     "ekf_debug_last_pass_shares": (C.c_int, [C.c_void_p]),
     "ekf_debug_small_launches": (C.c_long, [C.c_void_p]),

@@ -301,6 +301,35 @@ def test_forced_panel_shapes_agree_bit_for_bit(sd):
                 assert np.array_equal(res[0][b][0], res[shape][b][0]) and np.array_equal(res[0][b][1], res[shape][b][1]), (N, shape, b)
 
 
+def test_pass_forms_w_from_v_bit_identical(sd):
+    """`w_from_v` = 1 (the default): where a fused cadence's covariance pass follows its panel launch at once in the row-slab form, the panel
+    launch writes V only (W is half of its stores) and the pass forms its W fragments from V and the records' S^-1 with the
+    panel launch's own operations -- bit for bit the result of `w_from_v` = 0, the road taken counted.  N = 1300 x 30
+    (block-diagonal starts), N = 2100 x 9 with ragged landmark counts (dense starts)."""
+    lib = sd.load_library()
+    for N, B, steps, hi, diag in ((1300, 30, 9, 8, True), (2100, 9, 8, 13, False)):
+        n = 3 + 2 * N
+        means, lin, ang, idx, zr, zb, m = wandering_stream(N, B, steps, lambda k, b, rng: rng.integers(hi // 2, hi + 1), 6100 + N)
+        if diag:
+            starts = [np.concatenate([np.full(3, 0.1), np.full(2 * N, 1.0e4)]) for _ in range(B)]
+        else:
+            starts = [dense_start(n, 6200 + t) for t in range(B)]
+        res = {}
+        for wv in (0, 1):
+            with sd.EkfSlam(n, batch=B) as f:
+                f.set_option("active_bound", 0)
+                f.set_option("w_from_v", wv)
+                for b in range(B):
+                    (f.set_state_diag if diag else f.set_state)(means[b], starts[b], b)
+                f.run_stream(lin, ang, idx, zr, zb, m)
+                res[wv] = [f.state(b) for b in range(B)]
+                assert [f.flags(b) for b in range(B)] == [0] * B
+                took = lib.ekf_debug_w_from_v(f._h)
+                assert (took >= 1) if wv else (took == 0), (N, wv, took)
+        for b in range(B):
+            assert np.array_equal(res[0][b][0], res[1][b][0]) and np.array_equal(res[0][b][1], res[1][b][1]), (N, b)
+
+
 def lookaheads(sd, f):
     lib = sd.load_library()
     return lib.ekf_debug_lookaheads(f._h)
