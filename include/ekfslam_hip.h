@@ -219,7 +219,10 @@ int ekf_profile_read_class(ekf_handle *h, int cls, double *ms_total, long long *
  * state into PINNED host memory, e.g. from ekf_host_alloc: 1 = up to 40 MB a kernel mirrors the stored triangle straight into
  * the destination, no mirror pass and no copy engine; 2 = at every size; 0 = never: mirror pass + rectangle copy; same bytes),
  * "panel_shape" (diagnostics: 0 = a fused cadence's panel launch takes the shape its size selects, 1 .. 3 force the row-split
- * latency form / one wave per workgroup / four waves per workgroup; the same result bit for bit);
+ * latency form / one wave per workgroup / four waves per workgroup; the same result bit for bit),
+ * "w_from_v" (1, default: where a fused cadence's covariance pass follows its panel launch at once in the row-slab form, the
+ * panel launch writes V only and the pass forms its W fragments from V and the cadence's records -- W = -(V S^-1) per
+ * landmark is half of what that launch would write; the same result bit for bit; ekf_debug_snapshot's W view is then stale);
  * unknown names fail.
  * "fused_cadence", "lookahead" and "chain" (1 = where the next cadence's solve runs beside this one's pass -- banks of up to 40
  * trajectories whose pass leaves CUs free: every size with "chain" = 1, from "lookahead_min_mb" = 48 MB of covariance with the

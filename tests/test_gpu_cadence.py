@@ -305,9 +305,9 @@ def test_pass_forms_w_from_v_bit_identical(sd):
     """`w_from_v` = 1 (the default): where a fused cadence's covariance pass follows its panel launch at once in the row-slab form, the panel
     launch writes V only (W is half of its stores) and the pass forms its W fragments from V and the records' S^-1 with the
     panel launch's own operations -- bit for bit the result of `w_from_v` = 0, the road taken counted.  N = 1300 x 30
-    (block-diagonal starts), N = 2100 x 9 with ragged landmark counts (dense starts)."""
+    (block-diagonal starts, without and with the active bound), N = 2100 x 9 with ragged landmark counts (dense starts)."""
     lib = sd.load_library()
-    for N, B, steps, hi, diag in ((1300, 30, 9, 8, True), (2100, 9, 8, 13, False)):
+    for N, B, steps, hi, diag, bound in ((1300, 30, 9, 8, True, 0), (1300, 30, 9, 8, True, 1), (2100, 9, 8, 13, False, 0)):
         n = 3 + 2 * N
         means, lin, ang, idx, zr, zb, m = wandering_stream(N, B, steps, lambda k, b, rng: rng.integers(hi // 2, hi + 1), 6100 + N)
         if diag:
@@ -317,7 +317,7 @@ def test_pass_forms_w_from_v_bit_identical(sd):
         res = {}
         for wv in (0, 1):
             with sd.EkfSlam(n, batch=B) as f:
-                f.set_option("active_bound", 0)
+                f.set_option("active_bound", bound)
                 f.set_option("w_from_v", wv)
                 for b in range(B):
                     (f.set_state_diag if diag else f.set_state)(means[b], starts[b], b)
