@@ -1042,8 +1042,8 @@ static int enqueue_cadence(ekf_handle* h, int c, bool presolved, bool* next_pres
   const bool chain_next = beside && h->chain_run;
   // ("w_from_v") the pass follows this panel launch at once, nothing else is pending, both take the forms that know how
   bool wv = false;
-  if (h->opt_w_from_v && due && !beside && h->pending_k == 0 && ranks > 0 && !panels_cad_latency_regime(h->batch, n_hi) &&
-      h->opt_panel_shape != 1) {
+  if (h->opt_w_from_v && due && !beside && h->pending_k == 0 && ranks > 0 &&      // (... and the panel launch takes a replay shape)
+      (h->opt_panel_shape >= 2 || (h->opt_panel_shape == 0 && !panels_cad_latency_regime(h->batch, n_hi)))) {
     h->pending_k = pend_after;
     wv = plan_pass(h).kernel == 2;
     h->pending_k = 0;

@@ -666,8 +666,8 @@ def test_random_streams_orders_pieces_and_options_against_the_oracle(sd, case):
     """Everything at once, drawn from a seeded generator: a bank of 1 .. 4 trajectories of 20 .. 320 landmarks, 0 .. `hi`
     landmarks per step and trajectory at scattered indices, dense starting covariances; the run's cadences in one of the three
     orders (chained / look-ahead / plain) or on the per-step kernels; `stream_run` in one call or in random pieces, with or
-    without `run_end_flush`, a `flush()` or a download between pieces; the panel launch's shape forced or by size; the active
-    bound on or off.  Every trajectory against the oracle (the reference-shaped dense step) -- 1e-9 -- and no flag raised."""
+    without `run_end_flush`, a `flush()` or a download between pieces; the panel launch's shape forced or by size, the row-slab pass
+    forced (with W formed from V); the active bound on or off.  Every trajectory against the oracle (the reference-shaped dense step) -- 1e-9 -- and no flag raised."""
     rng = np.random.default_rng(52000 + case)
     N, B = int(rng.integers(20, 321)), int(rng.integers(1, 5))
     steps, hi = int(rng.integers(8, 61)), int(rng.choice([1, 3, 8, 16]))
@@ -679,6 +679,9 @@ def test_random_streams_orders_pieces_and_options_against_the_oracle(sd, case):
     opts += list(MODES[order]) if order != "per_step" else [("fused_cadence", 0)]
     if rng.integers(0, 2):
         opts.append(("panel_shape", int(rng.integers(1, 4))))
+    if rng.integers(0, 5) < 2:                            # the row-slab pass at any size: behind a replay shape of the panel launch
+        opts.append(("pass_kernel", 2))                   # it forms its W fragments from V ("w_from_v")
+        opts.append(("panel_shape", int(rng.integers(2, 4))))
     if rng.integers(0, 2):
         opts.append(("run_end_flush", 1))
     pieces = [steps]
@@ -702,6 +705,8 @@ def test_random_streams_orders_pieces_and_options_against_the_oracle(sd, case):
                 assert np.isfinite(f.mean(int(rng.integers(0, B)))).all()
         out = [f.state(b) for b in range(B)]
         assert [f.flags(b) for b in range(B)] == [0] * B, (order, opts, pieces)
+        if os.environ.get("EKF_FUZZ_VERBOSE"):
+            print("FUZZ", case, order, dict(opts), pieces, "cadences", cadences(sd, f), "w_from_v", sd.load_library().ekf_debug_w_from_v(f._h))
     cfg = orc.EkfConfig()
     for b in range(B):
         om, oP = means[b].copy(), starts[b].copy()
