@@ -253,6 +253,8 @@ long ekf_debug_lookaheads(ekf_handle *h);
 long ekf_debug_chained(ekf_handle *h);
 /* Covariance passes that formed their W fragments from V and the cadence's records (option "w_from_v"). */
 long ekf_debug_w_from_v(ekf_handle *h);
+/* ... and whether the last pass was one of them (the fourth template argument of k_flush_rs in a profiler's listing). */
+int ekf_debug_last_pass_wv(ekf_handle *h);
 /* Pieces of the longest static share the last row-slab pass used (0 = work queues / column strips; -1 = NULL handle). */
 int ekf_debug_last_pass_shares(ekf_handle *h);
 /* Launches of the small-state path; ekf_step_fetch calls served by the step's own launch; whole-state downloads written

@@ -230,6 +230,7 @@ struct ekf_handle : ekf::HostPlan {
   long fetch_retries = 0;         // statistics: hand-overs whose integrity trailer did not match (answered after a stream sync)
   int opt_zero_copy_inputs = 1;   // small-state online steps read their records from the pinned ring (no staged copy)
   int last_kernel = -1, last_nkt = 0, last_streaming = 0;   // what the last covariance pass launched
+  int last_wv = 0;                // ... and whether it formed its W fragments from V ("w_from_v")
   int last_shares = 0;            // ... and whether it ran on equal static shares (k_flush_rs, a few long trajectories)
   std::vector<unsigned> flags_host;
   unsigned* h_flags = nullptr;    // pinned: the sticky flags are read back with a stream-ordered copy
@@ -814,6 +815,7 @@ static int flush_pending(ekf_handle* h, hipStream_t st, const CadOut* wv) {
     HIP_TRY(h, hipEventRecord(e0, st));
   }
   h->last_kernel = p.kernel;
+  h->last_wv = (p.kernel == 2 && wv) ? 1 : 0;
   h->last_nkt = p.nkt;
   h->last_streaming = p.streaming ? 1 : 0;
   h->last_shares = shares ? h->shares_ok : 0;
@@ -1815,6 +1817,7 @@ extern "C" void ekf_debug_note_assoc_fallback(ekf_handle* h) { if (h) h->assoc_f
 extern "C" long ekf_debug_chained(ekf_handle* h) { return h ? h->chained : -1; }
 // ... and covariance passes that formed their W fragments from V and the records ("w_from_v")
 extern "C" long ekf_debug_w_from_v(ekf_handle* h) { return h ? h->w_from_v_passes : -1; }
+extern "C" int ekf_debug_last_pass_wv(ekf_handle* h) { return h ? h->last_wv : -1; }
 // (diagnostics section of the header) launches of the small-state path so far
 extern "C" long ekf_debug_small_launches(ekf_handle* h) { return h ? h->small_launches : -1; }
 extern "C" long ekf_debug_fused_fetches(ekf_handle* h) { return h ? h->fused_fetches : -1; }

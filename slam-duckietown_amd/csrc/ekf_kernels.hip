@@ -1798,7 +1798,7 @@ __device__ __forceinline__ void stb16(__amdgpu_buffer_rsrc_t rs, unsigned lane_b
 // PAN: the covariance lies in column panels (ld > 4096); otherwise the column offset of a strip is plain j * 8 -- the
 // panel arithmetic (a shift, a multiplication and a mask per tile, all scalar) is compiled out for the sizes that do not
 // need it: it cost the N = 2000 x 32 pass 5 - 10 us (profiles/r04_pass_drift.txt).
-template <int NKT, bool NT, bool PAN>
+template <int NKT, bool NT, bool PAN, bool WV>
 __global__ __launch_bounds__(512, 2) void k_flush_rs(double* __restrict__ P, const double* __restrict__ V,
                                                      const double* __restrict__ W,
                                                      const double* __restrict__ dacc,
@@ -1983,7 +1983,7 @@ __global__ __launch_bounds__(512, 2) void k_flush_rs(double* __restrict__ P, con
       double vs[RPW];
       stage_load(0, I0_{}, IR_{}, vs);
       gload(0);
-      if (wv == nullptr) {                             // (uniform)
+      if constexpr (!WV) {                             // (WV: an instantiation of its own -- the plain kernel's code is untouched)
 #pragma unroll
         for (int t = 0; t < NKT; ++t) {
           const double x = ldb8(rsW, lane8, ((unsigned)t * ld16 + (unsigned)(i0w >> 4)) * 512u);
@@ -2583,8 +2583,12 @@ static void launch_flush_rs_t(hipStream_t st, double* P, const double* V, const 
                               int workgroups, unsigned* queue, int chunk, const int* shares, const CadOut* wv) {
   const int nrb = (n_hi + RS_ROWS - 1) / RS_ROWS;
   if (shares) {                                        // equal static shares (mode 4): one per workgroup
-    hipLaunchKernelGGL((k_flush_rs<NKT, NT, PAN>), dim3((unsigned)workgroups), dim3(512), 0, st, P, V, W, dacc, nact, so, ld,
-                       pstride, nkt, batch, nrb, 1, 0, 4, queue, shares, wv);
+    if (wv)
+      hipLaunchKernelGGL((k_flush_rs<NKT, NT, PAN, true>), dim3((unsigned)workgroups), dim3(512), 0, st, P, V, W, dacc, nact, so, ld,
+                         pstride, nkt, batch, nrb, 1, 0, 4, queue, shares, wv);
+    else
+      hipLaunchKernelGGL((k_flush_rs<NKT, NT, PAN, false>), dim3((unsigned)workgroups), dim3(512), 0, st, P, V, W, dacc, nact, so, ld,
+                         pstride, nkt, batch, nrb, 1, 0, 4, queue, shares, wv);
     return;
   }
   // Units (see the three modes at k_flush_rs's `pop`).  With an even number of trajectories per queue whole slabs taken
@@ -2624,8 +2628,12 @@ static void launch_flush_rs_t(hipStream_t st, double* P, const double* V, const 
     }
   }
   const long units = (long)nrb * (mode == 0 ? nch : mode == 3 ? 2 : 1) * batch;   // (modes 1, 2: at least; only the grid size depends on it)
-  hipLaunchKernelGGL((k_flush_rs<NKT, NT, PAN>), dim3((unsigned)std::min<long>(workgroups, units)), dim3(512), 0, st, P, V, W,
-                     dacc, nact, so, ld, pstride, nkt, batch, nrb, nch, cs, mode, queue, nullptr, wv);
+  if (wv)
+    hipLaunchKernelGGL((k_flush_rs<NKT, NT, PAN, true>), dim3((unsigned)std::min<long>(workgroups, units)), dim3(512), 0, st, P, V, W,
+                       dacc, nact, so, ld, pstride, nkt, batch, nrb, nch, cs, mode, queue, nullptr, wv);
+  else
+    hipLaunchKernelGGL((k_flush_rs<NKT, NT, PAN, false>), dim3((unsigned)std::min<long>(workgroups, units)), dim3(512), 0, st, P, V, W,
+                       dacc, nact, so, ld, pstride, nkt, batch, nrb, nch, cs, mode, queue, nullptr, wv);
 }
 
 void launch_flush_rs(hipStream_t st, bool streaming, double* P, const double* V, const double* W, const double* dacc,

@@ -145,6 +145,7 @@ ABI = {
     "ekf_debug_chained": (C.c_long, [C.c_void_p]),
     "ekf_debug_assoc_fallbacks": (C.c_long, [C.c_void_p]),
     "ekf_debug_w_from_v": (C.c_long, [C.c_void_p]),
+    "ekf_debug_last_pass_wv": (C.c_int, [C.c_void_p]),
     "ekf_debug_note_assoc_fallback": (None, [C.c_void_p]),
     "ekf_debug_last_pass_shares": (C.c_int, [C.c_void_p]),
     "ekf_debug_small_launches": (C.c_long, [C.c_void_p]),
@@ -687,8 +688,8 @@ class EkfSlam:
         return int(self._lib.ekf_profile_passes(self._h))
 
     def last_pass(self) -> str:
-        """Name of the kernel the last covariance pass launched (e.g. ``ekf::k_flush_rs<20, true, false>``: k-tiles,
-        nontemporal, column-panel layout -- as rocprofv3 prints it), '' if none yet."""
+        """Name of the kernel the last covariance pass launched (e.g. ``ekf::k_flush_rs<20, true, false, true>``: k-tiles,
+        nontemporal, column-panel layout, W fragments formed from V -- as rocprofv3 prints it), '' if none yet."""
         k, t, st = C.c_int(), C.c_int(), C.c_int()
         self._check(self._lib.ekf_last_pass(self._h, C.byref(k), C.byref(t), C.byref(st)))
         if k.value < 0:
@@ -696,7 +697,8 @@ class EkfSlam:
         nt = "true" if st.value else "false"
         tiles = next(x for x in (4, 8, 12, 16, 20) if x >= t.value)
         if k.value == 2:
-            return f"ekf::k_flush_rs<{tiles}, {nt}, {'true' if self.n_max > 4096 else 'false'}>"
+            wv = "true" if self._lib.ekf_debug_last_pass_wv(self._h) == 1 else "false"
+            return f"ekf::k_flush_rs<{tiles}, {nt}, {'true' if self.n_max > 4096 else 'false'}, {wv}>"
         regs = {4: (4, 0), 8: (8, 0), 12: (12, 0), 16: (16, 0), 20: (15, 5)}[tiles]
         return f"ekf::k_flush<{regs[0]}, {regs[1]}, {nt}>"
 

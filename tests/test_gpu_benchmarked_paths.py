@@ -86,7 +86,7 @@ def test_config4_shard_n2000_x32_default_cadence(sd):
         # k-tiles (the third cadence -- the one-step tail -- is still pending here: its pass runs with the first download below)
         cad, covered, _, shares = debug_counters(sd, f)
         assert (cad, covered) == (3, 11)
-        assert f.last_pass() == "ekf::k_flush_rs<20, true, false>" and shares == 0
+        assert f.last_pass() == "ekf::k_flush_rs<20, true, false, true>" and shares == 0
         got = {}
         for b in range(B):
             mu, P = f.state(b)
@@ -138,7 +138,7 @@ def test_steady_state_leg_n2000_x32_as_benchmarked(sd):
             cad, covered, _, shares = debug_counters(sd, f)
             assert (cad, covered) == (steps * m // 40, steps)                # 54 cadences of 5 steps
             f.flush()
-            assert f.last_pass() == "ekf::k_flush_rs<20, true, false>" and shares == 0
+            assert f.last_pass() == "ekf::k_flush_rs<20, true, false, true>" and shares == 0
             got = {}
             for b in (0, 1, 2, 3, 16, 31):
                 mu, P = f.state(b)
@@ -292,7 +292,7 @@ def test_config5_n8000_dense_leg_as_benchmarked(sd):
         f.run_stream(lin, ang, idx, zr, zb)
         cad, covered, lookaheads, shares = debug_counters(sd, f)
         assert (cad, covered) == (3, 12) and lookaheads >= 1
-        assert f.last_pass() == "ekf::k_flush_rs<20, true, true>" and shares >= 1
+        assert f.last_pass() == "ekf::k_flush_rs<20, true, true, false>" and shares >= 1
         mu, P = f.state()
         assert f.flags() == 0
     assert np.array_equal(P, P.T)
